@@ -1,0 +1,83 @@
+"""ctypes binding of libcape_hip.so (the C-ABI declared in include/cape_hip.h).
+
+The product path has NO fallback: if the shared library is missing this module raises at
+import, and every compute entry point raises if no HIP device is present.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcape_hip.so")
+
+MAX_SRC = 8
+ACT = {"none": 0, "leaky": 1, "relu": 2, "tanh": 3}
+BIAS_NONE, BIAS_CHANNEL, BIAS_VERTEX = 0, 1, 2
+
+
+class CapeSrc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x_sample_stride", C.c_int64), ("ldx", C.c_int32), ("C", C.c_int32),
+        ("rowptr", C.c_void_p), ("colidx", C.c_void_p), ("vals", C.c_void_p),
+        ("w", C.c_void_p), ("w_rs", C.c_int64), ("w_cs", C.c_int64),
+        ("w2", C.c_void_p), ("w2_rs", C.c_int64), ("w2_cs", C.c_int64),
+    ]
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "cape_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C cape_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+_i32, _i64, _f32, _p = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+_SRCP = C.POINTER(CapeSrc)
+
+SIGNATURES = {
+    "cape_abi_version": (C.c_int, []),
+    "cape_csr_validate": (C.c_int, [_i32, _i32, _i64, _p, _p]),
+    "cape_gconv_fwd": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p, _i32, _i32, _p, _p]),
+    "cape_gconv_dw_workspace_bytes": (_i64, [_SRCP, _i32, _i32, _i32, _i32]),
+    "cape_gconv_dw": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p]),
+    "cape_spmm": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _f32, _p, _i64, _i32, _f32, _p, _i64, _i32,
+                            _i32, _i32, _i32, _p]),
+    "cape_bias_act_fwd": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p]),
+    "cape_act_bwd": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p]),
+    "cape_colsum_workspace_bytes": (_i64, [_i32, _i32, _i32]),
+    "cape_colsum": (C.c_int, [_p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _i64, _p]),
+    "cape_mask_mul": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
+    "cape_fill_cond": (C.c_int, [_p, _i32, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
+    "cape_reduce_cond": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "cape_groupnorm_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _f32, _i32, _i32, _p, _i64, _i32, _p,
+                                     _i32, _i32, _i32, _p]),
+    "cape_groupnorm_bwd": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _p, _i64, _i32, _p, _p, _i32, _i32,
+                                     _p, _i64, _i32, _p, _p, _p, _i32, _i32, _i32, _p]),
+    "cape_recon_edge_workspace_bytes": (_i64, [_i32, _i32, _i32]),
+    "cape_recon_edge_loss_fwd_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _f32,
+                                               _p, _p, _p, _i64, _p]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+_ERRORS = {-1: "CAPE_EINVAL (bad size / null pointer / unsupported combination)",
+           -2: "CAPE_EUNSORTED (CSR columns not strictly increasing)",
+           -3: "CAPE_ERANGE (CSR index out of range)",
+           -4: "CAPE_EWORKSPACE (workspace too small)"}
+
+
+class CapeHipError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        raise CapeHipError("%s failed: %s" % (what, _ERRORS.get(rc, "hipError_t %d" % rc)))
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise CapeHipError("cape_amd needs a HIP device (MI355X / gfx950); no CPU fallback exists")

@@ -1,0 +1,320 @@
+// Bandwidth-bound companions of the fused gather-GEMM (gfx950): standalone sparse operator
+// application, bias/activation and their gradients, column reductions, condition-channel
+// fill.  All kernels read/write [N, M, ld] fp32 views with channels contiguous and use
+// float4 accesses whenever the view is 16-byte aligned.
+#include "common.h"
+
+namespace {
+
+struct View {
+    float *p;
+    long long ss;
+    int ld;
+};
+struct CView {
+    const float *p;
+    long long ss;
+    int ld;
+};
+
+__host__ __device__ inline bool aligned4(const void *p, long long ss, int ld, int C) {
+    return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && ((ss & 3) == 0) && ((ld & 3) == 0) && ((C & 3) == 0);
+}
+
+// ---- spmm: y[n,r,:] = alpha * S x[n] + beta * z[n,r,:] ------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void spmm_kernel(CView x, const int *rp, const int *ci, const float *va,
+                                                   float alpha, CView z, float beta, View y, int N, int Mo, int C) {
+    const int W = VEC ? 4 : 1;
+    const int cq = (C + W - 1) / W;
+    const long long total = (long long)N * Mo * cq;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int q = (int)(i % cq);
+        const long long nr = i / cq;
+        const int r = (int)(nr % Mo);
+        const int n = (int)(nr / Mo);
+        const int c = q * W;
+        const float *xb = x.p + (long long)n * x.ss + c;
+        if (VEC) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int e1 = rp[r + 1];
+            for (int e = rp[r]; e < e1; ++e) {
+                const float v = va[e];
+                const float4 xv = *reinterpret_cast<const float4 *>(xb + (long long)ci[e] * x.ld);
+                acc.x = fmaf(v, xv.x, acc.x); acc.y = fmaf(v, xv.y, acc.y);
+                acc.z = fmaf(v, xv.z, acc.z); acc.w = fmaf(v, xv.w, acc.w);
+            }
+            acc.x *= alpha; acc.y *= alpha; acc.z *= alpha; acc.w *= alpha;
+            if (z.p) {
+                const float4 zv = *reinterpret_cast<const float4 *>(z.p + (long long)n * z.ss + (long long)r * z.ld + c);
+                acc.x = fmaf(beta, zv.x, acc.x); acc.y = fmaf(beta, zv.y, acc.y);
+                acc.z = fmaf(beta, zv.z, acc.z); acc.w = fmaf(beta, zv.w, acc.w);
+            }
+            *reinterpret_cast<float4 *>(y.p + (long long)n * y.ss + (long long)r * y.ld + c) = acc;
+        } else {
+            float acc = 0.f;
+            const int e1 = rp[r + 1];
+            for (int e = rp[r]; e < e1; ++e) acc = fmaf(va[e], xb[(long long)ci[e] * x.ld], acc);
+            acc *= alpha;
+            if (z.p) acc = fmaf(beta, z.p[(long long)n * z.ss + (long long)r * z.ld + c], acc);
+            y.p[(long long)n * y.ss + (long long)r * y.ld + c] = acc;
+        }
+    }
+}
+
+// ---- bias + activation ----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bias_act_kernel(CView x, const float *bias, int bias_mode, int act,
+                                                       View y, int N, int M, int C) {
+    const long long total = (long long)N * M * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long long nm = i / C;
+        const int m = (int)(nm % M);
+        const int n = (int)(nm / M);
+        float v = x.p[(long long)n * x.ss + (long long)m * x.ld + c];
+        if (bias_mode == CAPE_BIAS_CHANNEL) v += bias[c];
+        else if (bias_mode == CAPE_BIAS_VERTEX) v += bias[(long long)m * C + c];
+        y.p[(long long)n * y.ss + (long long)m * y.ld + c] = cape_act(v, act);
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void act_bwd_kernel(CView dy, CView y, int act, View dz, int N, int M, int C) {
+    const int W = VEC ? 4 : 1;
+    const int cq = C / W;
+    const long long total = (long long)N * M * cq;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % cq) * W;
+        const long long nm = i / cq;
+        const int m = (int)(nm % M);
+        const int n = (int)(nm / M);
+        if (VEC) {
+            const float4 g = *reinterpret_cast<const float4 *>(dy.p + (long long)n * dy.ss + (long long)m * dy.ld + c);
+            const float4 o = *reinterpret_cast<const float4 *>(y.p + (long long)n * y.ss + (long long)m * y.ld + c);
+            float4 r;
+            r.x = g.x * cape_act_grad_from_out(o.x, act);
+            r.y = g.y * cape_act_grad_from_out(o.y, act);
+            r.z = g.z * cape_act_grad_from_out(o.z, act);
+            r.w = g.w * cape_act_grad_from_out(o.w, act);
+            *reinterpret_cast<float4 *>(dz.p + (long long)n * dz.ss + (long long)m * dz.ld + c) = r;
+        } else {
+            const float g = dy.p[(long long)n * dy.ss + (long long)m * dy.ld + c];
+            const float o = y.p[(long long)n * y.ss + (long long)m * y.ld + c];
+            dz.p[(long long)n * dz.ss + (long long)m * dz.ld + c] = g * cape_act_grad_from_out(o, act);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mask_mul_kernel(CView dy, const unsigned *mask, View dz, int N, int M, int F) {
+    const int words = (F + 31) / 32;
+    const long long total = (long long)N * M * F;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int f = (int)(i % F);
+        const long long nm = i / F;
+        const int m = (int)(nm % M);
+        const int n = (int)(nm / M);
+        const unsigned w = mask[nm * words + (f >> 5)];
+        const float g = dy.p[(long long)n * dy.ss + (long long)m * dy.ld + f];
+        dz.p[(long long)n * dz.ss + (long long)m * dz.ld + f] = ((w >> (f & 31)) & 1u) ? g : 0.f;
+    }
+}
+
+// ---- column sums -----------------------------------------------------------------------------
+// stage 1: block b sums rows [b*RB, (b+1)*RB) of the flattened (n,m) row space -> part[b][c]
+constexpr int COLSUM_RB = 512;
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(CView x, int N, int M, int C, float *part) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const long long R = (long long)N * M;
+    const long long ra = (long long)blockIdx.x * COLSUM_RB;
+    const long long rb = (ra + COLSUM_RB < R) ? ra + COLSUM_RB : R;
+    for (int cbase = 0; cbase < C; cbase += 64) {
+        const int c = cbase + cl;
+        float s = 0.f;
+        if (c < C)
+            for (long long r = ra + rl; r < rb; r += 4) {
+                const long long n = r / M, m = r % M;
+                s += x.p[n * x.ss + m * x.ld + c];
+            }
+        red[rl][cl] = s;
+        __syncthreads();
+        if (rl == 0 && c < C) part[(long long)blockIdx.x * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float *part, int nblk, int C, int accumulate, float *out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(long long)b * C + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+__global__ __launch_bounds__(256) void sum_over_samples_kernel(CView x, int N, int M, int C, int accumulate, float *out) {
+    const long long total = (long long)M * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long long m = i / C;
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += x.p[(long long)n * x.ss + m * x.ld + c];
+        out[i] = accumulate ? out[i] + s : s;
+    }
+}
+
+// ---- condition channels ----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fill_cond_kernel(const float *cond, int ldc, const float *scale, View y,
+                                                        int N, int M, int C) {
+    const long long total = (long long)N * M * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long long nm = i / C;
+        const int m = (int)(nm % M);
+        const int n = (int)(nm / M);
+        float v = cond[(long long)n * ldc + c];
+        if (scale) v *= scale[m];
+        y.p[(long long)n * y.ss + (long long)m * y.ld + c] = v;
+    }
+}
+
+// dcond[n,c] (+)= sum_m scale[m] * dy[n,m,c]; one block per (n, 64-channel group)
+__global__ __launch_bounds__(256) void reduce_cond_kernel(CView dy, const float *scale, float *dcond, int ldc,
+                                                          int N, int M, int C, int accumulate) {
+    __shared__ float red[4][64];
+    const int cgroups = (C + 63) / 64;
+    const int n = blockIdx.x / cgroups, cg = blockIdx.x % cgroups;
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = cg * 64 + cl;
+    float s = 0.f;
+    if (c < C)
+        for (int m = rl; m < M; m += 4) {
+            const float v = dy.p[(long long)n * dy.ss + (long long)m * dy.ld + c];
+            s = scale ? fmaf(scale[m], v, s) : s + v;
+        }
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        float *d = dcond + (long long)n * ldc + c;
+        *d = accumulate ? *d + t : t;
+    }
+}
+
+inline int grid_for(long long total) {
+    long long b = (total + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int cape_spmm(const float *x, int64_t x_sample_stride, int32_t ldx, const int32_t *rowptr,
+                         const int32_t *colidx, const float *vals, float alpha, const float *z,
+                         int64_t z_sample_stride, int32_t ldz, float beta, float *y, int64_t y_sample_stride,
+                         int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
+    if (!x || !rowptr || !colidx || !vals || !y || N < 1 || Mo < 1 || C < 1 || ldx < C || ldy < C) return CAPE_EINVAL;
+    if (z && ldz < C) return CAPE_EINVAL;
+    CView xv{x, x_sample_stride, ldx}, zv{z, z_sample_stride, ldz};
+    View yv{y, y_sample_stride, ldy};
+    const bool vec = aligned4(x, x_sample_stride, ldx, C) && aligned4(y, y_sample_stride, ldy, C) &&
+                     (!z || aligned4(z, z_sample_stride, ldz, C));
+    hipStream_t st = (hipStream_t)stream;
+    if (vec) {
+        const long long total = (long long)N * Mo * (C / 4);
+        hipLaunchKernelGGL(spmm_kernel<true>, dim3(grid_for(total)), dim3(256), 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
+    } else {
+        const long long total = (long long)N * Mo * C;
+        hipLaunchKernelGGL(spmm_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
+    }
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}
+
+extern "C" int cape_bias_act_fwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *bias,
+                                 int32_t bias_mode, int32_t act, float *y, int64_t y_sample_stride, int32_t ldy,
+                                 int32_t N, int32_t M, int32_t C, void *stream) {
+    if (!x || !y || N < 1 || M < 1 || C < 1 || ldx < C || ldy < C) return CAPE_EINVAL;
+    if (bias_mode != CAPE_BIAS_NONE && !bias) return CAPE_EINVAL;
+    if (act < CAPE_ACT_NONE || act > CAPE_ACT_TANH) return CAPE_EINVAL;
+    CView xv{x, x_sample_stride, ldx};
+    View yv{y, y_sample_stride, ldy};
+    hipLaunchKernelGGL(bias_act_kernel, dim3(grid_for((long long)N * M * C)), dim3(256), 0, (hipStream_t)stream, xv, bias,
+                       bias_mode, act, yv, N, M, C);
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}
+
+extern "C" int cape_act_bwd(const float *dy, int64_t dy_sample_stride, int32_t lddy, const float *y,
+                            int64_t y_sample_stride, int32_t ldy, int32_t act, float *dz, int64_t dz_sample_stride,
+                            int32_t lddz, int32_t N, int32_t M, int32_t C, void *stream) {
+    if (!dy || !y || !dz || N < 1 || M < 1 || C < 1 || lddy < C || ldy < C || lddz < C) return CAPE_EINVAL;
+    if (act < CAPE_ACT_NONE || act > CAPE_ACT_TANH) return CAPE_EINVAL;
+    CView gv{dy, dy_sample_stride, lddy}, ov{y, y_sample_stride, ldy};
+    View zv{dz, dz_sample_stride, lddz};
+    const bool vec = aligned4(dy, dy_sample_stride, lddy, C) && aligned4(y, y_sample_stride, ldy, C) &&
+                     aligned4(dz, dz_sample_stride, lddz, C);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec) hipLaunchKernelGGL(act_bwd_kernel<true>, dim3(grid_for((long long)N * M * (C / 4))), dim3(256), 0, st, gv, ov, act, zv, N, M, C);
+    else hipLaunchKernelGGL(act_bwd_kernel<false>, dim3(grid_for((long long)N * M * C)), dim3(256), 0, st, gv, ov, act, zv, N, M, C);
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}
+
+extern "C" int64_t cape_colsum_workspace_bytes(int32_t N, int32_t M, int32_t C) {
+    if (N < 1 || M < 1 || C < 1) return CAPE_EINVAL;
+    const long long R = (long long)N * M;
+    const long long nblk = (R + COLSUM_RB - 1) / COLSUM_RB;
+    return nblk * C * (int64_t)sizeof(float);
+}
+
+extern "C" int cape_colsum(const float *x, int64_t x_sample_stride, int32_t ldx, int32_t N, int32_t M, int32_t C,
+                           int32_t per_vertex, int32_t accumulate, float *out, void *workspace,
+                           int64_t workspace_bytes, void *stream) {
+    if (!x || !out || N < 1 || M < 1 || C < 1 || ldx < C) return CAPE_EINVAL;
+    CView xv{x, x_sample_stride, ldx};
+    hipStream_t st = (hipStream_t)stream;
+    if (per_vertex) {
+        hipLaunchKernelGGL(sum_over_samples_kernel, dim3(grid_for((long long)M * C)), dim3(256), 0, st, xv, N, M, C, accumulate, out);
+        CAPE_LAUNCH_CHECK();
+        return CAPE_OK;
+    }
+    const long long R = (long long)N * M;
+    const int nblk = (int)((R + COLSUM_RB - 1) / COLSUM_RB);
+    if (!workspace || workspace_bytes < (int64_t)nblk * C * (int64_t)sizeof(float)) return CAPE_EWORKSPACE;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, xv, N, M, C, (float *)workspace);
+    CAPE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float *)workspace, nblk, C, accumulate, out);
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}
+
+extern "C" int cape_mask_mul(const float *dy, int64_t dy_sample_stride, int32_t lddy, const uint32_t *mask, float *dz,
+                             int64_t dz_sample_stride, int32_t lddz, int32_t N, int32_t M, int32_t F, void *stream) {
+    if (!dy || !mask || !dz || N < 1 || M < 1 || F < 1 || lddy < F || lddz < F) return CAPE_EINVAL;
+    CView gv{dy, dy_sample_stride, lddy};
+    View zv{dz, dz_sample_stride, lddz};
+    hipLaunchKernelGGL(mask_mul_kernel, dim3(grid_for((long long)N * M * F)), dim3(256), 0, (hipStream_t)stream, gv, mask, zv, N, M, F);
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}
+
+extern "C" int cape_fill_cond(const float *cond, int32_t ldc, const float *scale, float *y, int64_t y_sample_stride,
+                              int32_t ldy, int32_t N, int32_t M, int32_t C, void *stream) {
+    if (!cond || !y || N < 1 || M < 1 || C < 1 || ldc < C || ldy < C) return CAPE_EINVAL;
+    View yv{y, y_sample_stride, ldy};
+    hipLaunchKernelGGL(fill_cond_kernel, dim3(grid_for((long long)N * M * C)), dim3(256), 0, (hipStream_t)stream, cond, ldc, scale, yv, N, M, C);
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}
+
+extern "C" int cape_reduce_cond(const float *dy, int64_t dy_sample_stride, int32_t lddy, const float *scale, float *dcond,
+                                int32_t ldc, int32_t N, int32_t M, int32_t C, int32_t accumulate, void *stream) {
+    if (!dy || !dcond || N < 1 || M < 1 || C < 1 || lddy < C || ldc < C) return CAPE_EINVAL;
+    CView gv{dy, dy_sample_stride, lddy};
+    const int cgroups = (C + 63) / 64;
+    hipLaunchKernelGGL(reduce_cond_kernel, dim3(N * cgroups), dim3(256), 0, (hipStream_t)stream, gv, scale, dcond, ldc, N, M, C, accumulate);
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}

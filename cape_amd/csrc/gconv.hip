@@ -1,0 +1,569 @@
+// Fused gather-GEMM for the Chebyshev mesh convolution (gfx950 / CDNA4, fp32 MFMA).
+//
+//   y[n, r, :] = epilogue( sum_s  (S_s x_s[n])[r, :] @ B_s )
+//
+// S_s is a small CSR operator (a precomposed T_k(L~), T_k(L~)*U, D*T_k(L~) or a transpose of
+// one of those); the gathered A-tile [BM x 32] is built in LDS from coalesced float4 reads
+// of the [N, M, C] activations (neighbour rows come from L2: one mesh level of one sample is
+// <= 2.6 MB), the trailing dense contraction runs on v_mfma_f32_32x32x2_f32 (exact fp32).
+// This one kernel covers chebyshev5 (reference lib/models.py:69-103), the bias/activation
+// epilogues (:105-127), poolwT folded in as an operator (:129-152), res_block_affine in DUAL
+// mode (:776-793) and -- with transposed operators and weights -- their data gradients.
+// The weight-gradient kernel (contraction over vertices) lives below.
+#include "common.h"
+
+namespace {
+
+constexpr int KC = 32;   // contraction chunk staged per iteration
+
+struct SrcDev {
+    const float *x;
+    long long xs;
+    int ldx, C;
+    const int *rp;
+    const int *ci;
+    const float *va;
+    const float *w;
+    long long wrs, wcs;
+    const float *w2;
+    long long w2rs, w2cs;
+    int vec;   // 1: float4 gathers legal (ldx % 4 == 0, base 16B aligned)
+};
+
+struct GconvParams {
+    SrcDev s[CAPE_MAX_SRC];
+    int nsrc;
+    float *y;
+    long long ys;
+    int ldy;
+    int N, Mo, F;
+    const float *bias;
+    int bias_mode, act;
+    unsigned *mask;
+    int mask_words;
+    int row_tiles, col_tiles;
+};
+
+// ---- A-tile staging: gathered rows -> LDS [ROWS][KC+4] -----------------------------------
+template <int ROWS, int LDA>
+__device__ __forceinline__ void stage_gather(float *sA, const SrcDev &S, int n, int r0, int Mo,
+                                              int c0, int tid) {
+    const int q = tid & 7;        // float4 column of the 32-wide chunk
+    const int rl0 = tid >> 3;     // 0..31
+    const int c = c0 + 4 * q;
+    const float *xb = S.x + (long long)n * S.xs + c;
+    const int nvalid = S.C - c;   // channels available from c
+#pragma unroll
+    for (int pass = 0; pass < ROWS / 32; ++pass) {
+        const int rl = rl0 + 32 * pass;
+        const int r = r0 + rl;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < Mo && nvalid > 0) {
+            if (S.vec && nvalid >= 4) {
+                if (S.rp) {
+                    const int e1 = S.rp[r + 1];
+                    for (int e = S.rp[r]; e < e1; ++e) {
+                        const float v = S.va[e];
+                        const float4 xv = *reinterpret_cast<const float4 *>(xb + (long long)S.ci[e] * S.ldx);
+                        acc.x = fmaf(v, xv.x, acc.x);
+                        acc.y = fmaf(v, xv.y, acc.y);
+                        acc.z = fmaf(v, xv.z, acc.z);
+                        acc.w = fmaf(v, xv.w, acc.w);
+                    }
+                } else {
+                    acc = *reinterpret_cast<const float4 *>(xb + (long long)r * S.ldx);
+                }
+            } else {
+                float a[4] = {0.f, 0.f, 0.f, 0.f};
+                if (S.rp) {
+                    const int e1 = S.rp[r + 1];
+                    for (int e = S.rp[r]; e < e1; ++e) {
+                        const float v = S.va[e];
+                        const float *xr = xb + (long long)S.ci[e] * S.ldx;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (u < nvalid) a[u] = fmaf(v, xr[u], a[u]);
+                    }
+                } else {
+                    const float *xr = xb + (long long)r * S.ldx;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (u < nvalid) a[u] = xr[u];
+                }
+                acc = make_float4(a[0], a[1], a[2], a[3]);
+            }
+        }
+        *reinterpret_cast<float4 *>(&sA[rl * LDA + 4 * q]) = acc;
+    }
+}
+
+// ---- B-tile staging: weights [KC x BN] with arbitrary (row, col) strides -> LDS [KC][BN+4]
+template <int BN, int LDB>
+__device__ __forceinline__ void stage_weights(float *sB, const float *w, long long rs, long long cs,
+                                               int C, int F, int c0, int f0, int tid) {
+    const bool kmajor = (rs == 1 && cs != 1);   // contraction index contiguous in memory
+#pragma unroll 4
+    for (int idx = tid; idx < KC * BN; idx += 256) {
+        int kk, j;
+        if (kmajor) {
+            kk = idx & (KC - 1);
+            j = idx / KC;
+        } else {
+            j = idx % BN;
+            kk = idx / BN;
+        }
+        const int c = c0 + kk, f = f0 + j;
+        float v = 0.f;
+        if (c < C && f < F) v = w[c * rs + f * cs];
+        sB[kk * LDB + j] = v;
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool DUAL>
+__global__ __launch_bounds__(256) void gconv_fwd_kernel(GconvParams p) {
+    constexpr int LDA = KC + 4;
+    constexpr int LDB = BN + 4;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+
+    __shared__ __attribute__((aligned(16))) float smem[BM * LDA + (DUAL ? 2 : 1) * KC * LDB];
+    float *sA = smem;
+    float *sB = smem + BM * LDA;
+    float *sB2 = sB + KC * LDB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int li = lane & 31, lh = lane >> 5;
+
+    int n, t;
+    cape_map_block(blockIdx.x, p.N, p.row_tiles * p.col_tiles, n, t);
+    const int r0 = (t / p.col_tiles) * BM;
+    const int f0 = (t % p.col_tiles) * BN;
+
+    f32x16 acc[TM][TN];
+    f32x16 acc2[DUAL ? TM : 1][DUAL ? TN : 1];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                acc[a][b][g] = 0.f;
+                if (DUAL) acc2[a][b][g] = 0.f;
+            }
+
+    for (int si = 0; si < p.nsrc; ++si) {
+        const SrcDev &S = p.s[si];
+        const bool has2 = DUAL && (S.w2 != nullptr);
+        for (int c0 = 0; c0 < S.C; c0 += KC) {
+            __syncthreads();
+            stage_gather<BM, LDA>(sA, S, n, r0, p.Mo, c0, tid);
+            stage_weights<BN, LDB>(sB, S.w, S.wrs, S.wcs, S.C, p.F, c0, f0, tid);
+            if (has2) stage_weights<BN, LDB>(sB2, S.w2, S.w2rs, S.w2cs, S.C, p.F, c0, f0, tid);
+            __syncthreads();
+#pragma unroll
+            for (int kb = 0; kb < KC / 8; ++kb) {
+                // contraction index permutation: MFMA step t of this block of 8 uses physical
+                // index kb*8 + 4*lh + t for lane-half lh (same mapping for A and B).
+                float4 av[TM];
+                float bv[TN][4];
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+                    av[a] = *reinterpret_cast<const float4 *>(
+                        &sA[(wm * WTM + a * 32 + li) * LDA + kb * 8 + 4 * lh]);
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        bv[b][u] = sB[(kb * 8 + 4 * lh + u) * LDB + wn * WTN + b * 32 + li];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) {
+                        const float af = (u == 0) ? av[a].x : (u == 1) ? av[a].y : (u == 2) ? av[a].z : av[a].w;
+#pragma unroll
+                        for (int b = 0; b < TN; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bv[b][u], acc[a][b], 0, 0, 0);
+                    }
+                }
+                if (DUAL && has2) {
+                    float b2v[TN][4];
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            b2v[b][u] = sB2[(kb * 8 + 4 * lh + u) * LDB + wn * WTN + b * 32 + li];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                        for (int a = 0; a < TM; ++a) {
+                            const float af = (u == 0) ? av[a].x : (u == 1) ? av[a].y : (u == 2) ? av[a].z : av[a].w;
+#pragma unroll
+                            for (int b = 0; b < TN; ++b)
+                                acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, b2v[b][u], acc2[a][b], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: C layout of 32x32 MFMA: col = lane&31, row = (g&3) + 8*(g>>2) + 4*(lane>>5)
+    float *yb = p.y + (long long)n * p.ys;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int f = f0 + wn * WTN + b * 32 + li;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int r = r0 + wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                const bool ok = (r < p.Mo) && (f < p.F);
+                float v = acc[a][b][g];
+                if (DUAL) {
+                    const bool pos = ok && (v > 0.f);
+                    if (p.mask) {
+                        const unsigned long long bal = __ballot(pos);
+                        if (li == 0 && r < p.Mo && (f0 + wn * WTN + b * 32) < p.F) {
+                            const unsigned word = lh ? (unsigned)(bal >> 32) : (unsigned)bal;
+                            p.mask[((long long)n * p.Mo + r) * p.mask_words + ((f0 + wn * WTN + b * 32) >> 5)] = word;
+                        }
+                    }
+                    v = (v > 0.f ? v : 0.f) + acc2[a][b][g];
+                } else {
+                    if (ok) {
+                        if (p.bias_mode == CAPE_BIAS_CHANNEL) v += p.bias[f];
+                        else if (p.bias_mode == CAPE_BIAS_VERTEX) v += p.bias[(long long)r * p.F + f];
+                    }
+                    v = cape_act(v, p.act);
+                }
+                if (ok) yb[(long long)r * p.ldy + f] = v;
+            }
+        }
+    }
+}
+
+// =============================================================================================
+// weight gradient:  dW_s[c, f] = sum_{n, r} A_s[n, r, c] * dz[n, r, f]
+// Each workgroup owns one [CT x FT] tile of one source's dW and one (sample, row-range)
+// slice of the vertex dimension; partials go to the workspace and are summed in a fixed order
+// by dw_reduce_kernel (deterministic; no float atomics).
+// =============================================================================================
+struct DwParams {
+    SrcDev s[CAPE_MAX_SRC];
+    int nsrc;
+    const float *dz;
+    long long dzs;
+    int lddz, dzvec;
+    int N, Mo, F;
+    int ftiles;
+    int tile_off[CAPE_MAX_SRC + 1];   // first output tile of each source (c-tiles * ftiles)
+    long long part_off[CAPE_MAX_SRC + 1];   // element offset of each source inside one partial slab
+    int rsplit, rows_per_split;
+    float *ws;
+    long long slab;   // elements per split slab
+};
+
+template <int CT, int FT>
+__global__ __launch_bounds__(256) void gconv_dw_kernel(DwParams p) {
+    constexpr int RK = 32;
+    constexpr int LDA = CT + 4, LDB = FT + 4;
+    constexpr int WTM = CT / 2, WTN = FT / 2;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    __shared__ __attribute__((aligned(16))) float smem[RK * LDA + RK * LDB];
+    float *sA = smem;
+    float *sB = smem + RK * LDA;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int ntiles = p.tile_off[p.nsrc];
+    const int tile = blockIdx.x % ntiles;
+    const int split = blockIdx.x / ntiles;   // split = n * rsplit + rs
+    const int n = split / p.rsplit;
+    const int rs = split % p.rsplit;
+    int si = 0;
+    while (si + 1 < p.nsrc && tile >= p.tile_off[si + 1]) ++si;
+    const SrcDev &S = p.s[si];
+    const int lt = tile - p.tile_off[si];
+    const int c0 = (lt / p.ftiles) * CT;
+    const int f0 = (lt % p.ftiles) * FT;
+    const int ra = rs * p.rows_per_split;
+    const int rb = min(p.Mo, ra + p.rows_per_split);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+
+    const float *dzb = p.dz + (long long)n * p.dzs;
+    const float *xb = S.x + (long long)n * S.xs;
+
+    for (int rbase = ra; rbase < rb; rbase += RK) {
+        __syncthreads();
+        // A chunk: RK gathered rows x CT channels
+        for (int idx = tid; idx < RK * (CT / 4); idx += 256) {
+            const int rl = idx / (CT / 4), q = idx % (CT / 4);
+            const int r = rbase + rl;
+            const int c = c0 + 4 * q;
+            const int nvalid = S.C - c;
+            float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < rb && nvalid > 0) {
+                if (S.vec && nvalid >= 4) {
+                    if (S.rp) {
+                        const int e1 = S.rp[r + 1];
+                        for (int e = S.rp[r]; e < e1; ++e) {
+                            const float v = S.va[e];
+                            const float4 xv = *reinterpret_cast<const float4 *>(xb + (long long)S.ci[e] * S.ldx + c);
+                            v4.x = fmaf(v, xv.x, v4.x);
+                            v4.y = fmaf(v, xv.y, v4.y);
+                            v4.z = fmaf(v, xv.z, v4.z);
+                            v4.w = fmaf(v, xv.w, v4.w);
+                        }
+                    } else {
+                        v4 = *reinterpret_cast<const float4 *>(xb + (long long)r * S.ldx + c);
+                    }
+                } else {
+                    float a[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (S.rp) {
+                        const int e1 = S.rp[r + 1];
+                        for (int e = S.rp[r]; e < e1; ++e) {
+                            const float v = S.va[e];
+                            const float *xr = xb + (long long)S.ci[e] * S.ldx + c;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (u < nvalid) a[u] = fmaf(v, xr[u], a[u]);
+                        }
+                    } else {
+                        const float *xr = xb + (long long)r * S.ldx + c;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (u < nvalid) a[u] = xr[u];
+                    }
+                    v4 = make_float4(a[0], a[1], a[2], a[3]);
+                }
+            }
+            *reinterpret_cast<float4 *>(&sA[rl * LDA + 4 * q]) = v4;
+        }
+        // B chunk: RK rows of dz x FT channels
+        for (int idx = tid; idx < RK * (FT / 4); idx += 256) {
+            const int rl = idx / (FT / 4), q = idx % (FT / 4);
+            const int r = rbase + rl;
+            const int f = f0 + 4 * q;
+            const int nvalid = p.F - f;
+            float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < rb && nvalid > 0) {
+                const float *zr = dzb + (long long)r * p.lddz + f;
+                if (p.dzvec && nvalid >= 4) {
+                    v4 = *reinterpret_cast<const float4 *>(zr);
+                } else {
+                    float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (u < nvalid) a[u] = zr[u];
+                    v4 = make_float4(a[0], a[1], a[2], a[3]);
+                }
+            }
+            *reinterpret_cast<float4 *>(&sB[rl * LDB + 4 * q]) = v4;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < RK / 8; ++kb) {
+            float av[TM][4], bv[TN][4];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) av[a][u] = sA[(kb * 8 + 4 * lh + u) * LDA + wm * WTM + a * 32 + li];
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bv[b][u] = sB[(kb * 8 + 4 * lh + u) * LDB + wn * WTN + b * 32 + li];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][u], bv[b][u], acc[a][b], 0, 0, 0);
+        }
+    }
+
+    // partial slab layout: [split][part_off[si] + c*F + f]
+    float *out = p.ws + (long long)split * p.slab + p.part_off[si];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int f = f0 + wn * WTN + b * 32 + li;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int c = c0 + wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                if (c < S.C && f < p.F) out[(long long)c * p.F + f] = acc[a][b][g];
+            }
+        }
+}
+
+struct DwReduceParams {
+    float *w[CAPE_MAX_SRC];
+    long long wrs[CAPE_MAX_SRC], wcs[CAPE_MAX_SRC];
+    long long part_off[CAPE_MAX_SRC + 1];
+    int nsrc, F, nsplit, accumulate;
+    const float *ws;
+    long long slab;
+};
+
+__global__ __launch_bounds__(256) void dw_reduce_kernel(DwReduceParams p) {
+    const long long total = p.part_off[p.nsrc];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        int si = 0;
+        while (si + 1 < p.nsrc && i >= p.part_off[si + 1]) ++si;
+        const long long loc = i - p.part_off[si];
+        const long long c = loc / p.F, f = loc % p.F;
+        float sum = 0.f;
+        for (int sp = 0; sp < p.nsplit; ++sp) sum += p.ws[(long long)sp * p.slab + i];
+        float *dst = p.w[si] + c * p.wrs[si] + f * p.wcs[si];
+        *dst = p.accumulate ? (*dst + sum) : sum;
+    }
+}
+
+inline int fill_src(SrcDev &d, const cape_src_t &s) {
+    if (!s.x || s.C <= 0 || s.ldx < s.C) return CAPE_EINVAL;
+    if (s.rowptr && (!s.colidx || !s.vals)) return CAPE_EINVAL;
+    d.x = s.x; d.xs = s.x_sample_stride; d.ldx = s.ldx; d.C = s.C;
+    d.rp = s.rowptr; d.ci = s.colidx; d.va = s.vals;
+    d.w = s.w; d.wrs = s.w_rs; d.wcs = s.w_cs;
+    d.w2 = s.w2; d.w2rs = s.w2_rs; d.w2cs = s.w2_cs;
+    d.vec = ((s.ldx & 3) == 0) && ((s.x_sample_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(s.x) & 15) == 0);
+    return CAPE_OK;
+}
+
+struct DwPlan {
+    int ct, ft, ctiles[CAPE_MAX_SRC], ftiles, ntiles, rsplit, rows_per_split;
+    long long slab;
+};
+
+inline void plan_dw(const cape_src_t *srcs, int nsrc, int N, int Mo, int F, DwPlan &pl) {
+    int maxC = 0;
+    for (int i = 0; i < nsrc; ++i) maxC = srcs[i].C > maxC ? srcs[i].C : maxC;
+    pl.ct = (maxC <= 64) ? 64 : 128;
+    pl.ft = (F <= 64) ? 64 : 128;
+    pl.ftiles = (F + pl.ft - 1) / pl.ft;
+    pl.ntiles = 0;
+    pl.slab = 0;
+    for (int i = 0; i < nsrc; ++i) {
+        pl.ctiles[i] = (srcs[i].C + pl.ct - 1) / pl.ct;
+        pl.ntiles += pl.ctiles[i] * pl.ftiles;
+        pl.slab += (long long)srcs[i].C * F;
+    }
+    // aim for >= ~1024 workgroups, at least 64 rows (2 chunks) per split
+    int want = (1024 + pl.ntiles * N - 1) / (pl.ntiles * N);
+    if (want < 1) want = 1;
+    int maxsplit = (Mo + 63) / 64;
+    if (want > maxsplit) want = maxsplit;
+    int rows = (Mo + want - 1) / want;
+    rows = ((rows + 31) / 32) * 32;
+    pl.rows_per_split = rows;
+    pl.rsplit = (Mo + rows - 1) / rows;
+}
+
+}  // namespace
+
+extern "C" int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, int64_t y_sample_stride,
+                              int32_t ldy, int32_t N, int32_t Mo, int32_t F, const float *bias,
+                              int32_t bias_mode, int32_t act, uint32_t *mask_out, void *stream) {
+    if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || !y || N < 1 || Mo < 1 || F < 1 || ldy < F) return CAPE_EINVAL;
+    if (bias_mode != CAPE_BIAS_NONE && !bias) return CAPE_EINVAL;
+    if (act < CAPE_ACT_NONE || act > CAPE_ACT_TANH) return CAPE_EINVAL;
+    GconvParams p;
+    bool dual = false;
+    for (int i = 0; i < nsrc; ++i) {
+        if (!srcs[i].w) return CAPE_EINVAL;
+        int rc = fill_src(p.s[i], srcs[i]);
+        if (rc) return rc;
+        dual = dual || (srcs[i].w2 != nullptr);
+    }
+    if (mask_out && !dual) return CAPE_EINVAL;
+    if (dual && (bias_mode != CAPE_BIAS_NONE || act != CAPE_ACT_NONE)) return CAPE_EINVAL;
+    p.nsrc = nsrc; p.y = y; p.ys = y_sample_stride; p.ldy = ldy;
+    p.N = N; p.Mo = Mo; p.F = F;
+    p.bias = bias; p.bias_mode = bias ? bias_mode : CAPE_BIAS_NONE; p.act = act;
+    p.mask = mask_out; p.mask_words = (F + 31) / 32;
+    const int BM = 128;
+    const int BN = (F <= 32) ? 32 : (F <= 64) ? 64 : 128;
+    p.row_tiles = (Mo + BM - 1) / BM;
+    p.col_tiles = (F + BN - 1) / BN;
+    dim3 grid((unsigned)(N * p.row_tiles * p.col_tiles)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (!dual) {
+        if (BN == 32) hipLaunchKernelGGL((gconv_fwd_kernel<128, 32, 4, 1, false>), grid, block, 0, st, p);
+        else if (BN == 64) hipLaunchKernelGGL((gconv_fwd_kernel<128, 64, 4, 1, false>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gconv_fwd_kernel<128, 128, 2, 2, false>), grid, block, 0, st, p);
+    } else {
+        if (BN == 32) hipLaunchKernelGGL((gconv_fwd_kernel<128, 32, 4, 1, true>), grid, block, 0, st, p);
+        else if (BN == 64) hipLaunchKernelGGL((gconv_fwd_kernel<128, 64, 4, 1, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gconv_fwd_kernel<128, 128, 2, 2, true>), grid, block, 0, st, p);
+    }
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}
+
+extern "C" int64_t cape_gconv_dw_workspace_bytes(const cape_src_t *srcs, int32_t nsrc, int32_t N,
+                                                 int32_t Mo, int32_t F) {
+    if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || N < 1 || Mo < 1 || F < 1) return CAPE_EINVAL;
+    DwPlan pl;
+    plan_dw(srcs, nsrc, N, Mo, F, pl);
+    return (int64_t)pl.slab * N * pl.rsplit * (int64_t)sizeof(float);
+}
+
+extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *dz,
+                             int64_t dz_sample_stride, int32_t lddz, int32_t N, int32_t Mo, int32_t F,
+                             int32_t accumulate, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || !dz || N < 1 || Mo < 1 || F < 1 || lddz < F || !workspace)
+        return CAPE_EINVAL;
+    DwPlan pl;
+    plan_dw(srcs, nsrc, N, Mo, F, pl);
+    const long long need = pl.slab * N * pl.rsplit * (long long)sizeof(float);
+    if (workspace_bytes < need) return CAPE_EWORKSPACE;
+    DwParams p;
+    DwReduceParams rp;
+    p.nsrc = nsrc; rp.nsrc = nsrc;
+    int toff = 0;
+    long long poff = 0;
+    for (int i = 0; i < nsrc; ++i) {
+        if (!srcs[i].w) return CAPE_EINVAL;
+        int rc = fill_src(p.s[i], srcs[i]);
+        if (rc) return rc;
+        p.tile_off[i] = toff; p.part_off[i] = poff; rp.part_off[i] = poff;
+        toff += pl.ctiles[i] * pl.ftiles;
+        poff += (long long)srcs[i].C * F;
+        rp.w[i] = const_cast<float *>(srcs[i].w); rp.wrs[i] = srcs[i].w_rs; rp.wcs[i] = srcs[i].w_cs;
+    }
+    p.tile_off[nsrc] = toff; p.part_off[nsrc] = poff; rp.part_off[nsrc] = poff;
+    p.dz = dz; p.dzs = dz_sample_stride; p.lddz = lddz;
+    p.dzvec = ((lddz & 3) == 0) && ((dz_sample_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dz) & 15) == 0);
+    p.N = N; p.Mo = Mo; p.F = F; p.ftiles = pl.ftiles;
+    p.rsplit = pl.rsplit; p.rows_per_split = pl.rows_per_split;
+    p.ws = (float *)workspace; p.slab = pl.slab;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)(pl.ntiles * N * pl.rsplit)), block(256);
+    if (pl.ct == 64 && pl.ft == 64) hipLaunchKernelGGL((gconv_dw_kernel<64, 64>), grid, block, 0, st, p);
+    else if (pl.ct == 64) hipLaunchKernelGGL((gconv_dw_kernel<64, 128>), grid, block, 0, st, p);
+    else if (pl.ft == 64) hipLaunchKernelGGL((gconv_dw_kernel<128, 64>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((gconv_dw_kernel<128, 128>), grid, block, 0, st, p);
+    CAPE_LAUNCH_CHECK();
+    rp.F = F; rp.nsplit = N * pl.rsplit; rp.accumulate = accumulate; rp.ws = (const float *)workspace; rp.slab = pl.slab;
+    long long total = poff;
+    int rblocks = (int)((total + 255) / 256);
+    if (rblocks > 2048) rblocks = 2048;
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3(rblocks), dim3(256), 0, st, rp);
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}

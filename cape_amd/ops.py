@@ -1,0 +1,512 @@
+"""Graph operators of the CAPE hot path on MI355X: thin torch.autograd wrappers around the
+C-ABI kernels of libcape_hip.so.
+
+Names follow the reference's operator plug-points (lib/models.py:58-62: ``chebyshev5``,
+``poolwT``, ``b1leakyrelu`` / ``b1relu`` / ``b1tanh`` / ``b2relu``); PyTorch supplies device
+memory, streams and the autograd tape only -- all arithmetic on [N, M, C] mesh activations
+happens in the HIP kernels.  Activations are fp32 ``[N, M, C]`` *views* of buffers whose row
+stride is padded to a multiple of 4 floats (16-byte aligned rows for float4 gathers).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, CapeSrc, check
+from .graph import ConvOperators, HostCSR
+
+_ACT_OF = {"b1leakyrelu": ("leaky", _lib.BIAS_CHANNEL), "b1relu": ("relu", _lib.BIAS_CHANNEL),
+           "b1tanh": ("tanh", _lib.BIAS_CHANNEL), "b2relu": ("relu", _lib.BIAS_VERTEX)}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _pad4(c):
+    return (int(c) + 3) // 4 * 4
+
+
+def alloc_act(N, M, Cn, device, zero=False):
+    """[N, M, C] view of a fresh [N, M, pad4(C)] buffer."""
+    ld = _pad4(Cn)
+    buf = (torch.zeros if zero else torch.empty)((N, M, ld), device=device, dtype=torch.float32)
+    return buf[:, :, :Cn] if ld != Cn else buf
+
+
+def as_act(t):
+    """Make ``t`` [N, M, C] usable by the kernels (unit channel stride, fp32, on device)."""
+    assert t.dim() == 3 and t.dtype == torch.float32 and t.is_cuda
+    if t.stride(2) != 1 and t.shape[2] != 1:
+        t = t.contiguous()
+    if t.shape[1] > 1 and t.stride(1) < t.shape[2]:
+        t = t.contiguous()
+    return t
+
+
+def _v(t):
+    """(ptr, sample_stride, ld) of an activation view."""
+    ld = t.stride(1) if t.shape[1] > 1 else max(t.shape[2], t.stride(1))
+    ss = t.stride(0) if t.shape[0] > 1 else t.shape[1] * ld
+    return C.c_void_p(t.data_ptr()), int(ss), int(ld)
+
+
+def _ptr(t, offset_elems=0):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr() + 4 * int(offset_elems))
+
+
+class DeviceCSR(object):
+    def __init__(self, host, device):
+        assert isinstance(host, HostCSR)
+        self.shape = host.shape
+        self.identity = host.identity
+        self.nnz = host.nnz
+        if host.identity:
+            self.rowptr = self.colidx = self.vals = None
+        else:
+            rc = lib.cape_csr_validate(host.shape[0], host.shape[1], host.nnz,
+                                       host.rowptr.ctypes.data_as(C.c_void_p),
+                                       host.colidx.ctypes.data_as(C.c_void_p))
+            check(rc, "cape_csr_validate")
+        # identity operators still keep real arrays for the standalone spmm path
+        self.rowptr_t = torch.from_numpy(host.rowptr).to(device)
+        self.colidx_t = torch.from_numpy(host.colidx).to(device)
+        self.vals_t = torch.from_numpy(host.vals).to(device)
+        if not host.identity:
+            self.rowptr, self.colidx, self.vals = self.rowptr_t, self.colidx_t, self.vals_t
+
+
+class DeviceConvOps(object):
+    """Device copy of graph.ConvOperators."""
+
+    def __init__(self, host, device):
+        assert isinstance(host, ConvOperators)
+        self.K, self.fused = host.K, host.fused
+        self.Mi, self.Mo = host.Mi, host.Mo
+        if host.fused:
+            self.fwd = [DeviceCSR(h, device) for h in host.fwd]
+            self.bwd = [DeviceCSR(h, device) for h in host.bwd]
+        else:
+            self.Lt = DeviceCSR(host.Lt, device)
+            self.LtT = DeviceCSR(host.LtT, device)
+        self.host = host
+
+
+def _mk_srcs(entries):
+    """entries: list of dict(x=view, csr=DeviceCSR|None, C=int, w=(tensor, off, rs, cs), w2=... or None)."""
+    arr = (CapeSrc * len(entries))()
+    for s, e in zip(arr, entries):
+        x = e["x"]
+        p, ss, ld = _v(x)
+        s.x, s.x_sample_stride, s.ldx, s.C = p, ss, ld, int(e.get("C", x.shape[2]))
+        csr = e.get("csr")
+        if csr is not None and not csr.identity:
+            s.rowptr, s.colidx, s.vals = csr.rowptr.data_ptr(), csr.colidx.data_ptr(), csr.vals.data_ptr()
+        else:
+            s.rowptr = s.colidx = s.vals = None
+        wt, off, rs, cs = e["w"]
+        s.w, s.w_rs, s.w_cs = wt.data_ptr() + 4 * int(off), int(rs), int(cs)
+        if e.get("w2") is not None:
+            wt2, off2, rs2, cs2 = e["w2"]
+            s.w2, s.w2_rs, s.w2_cs = wt2.data_ptr() + 4 * int(off2), int(rs2), int(cs2)
+        else:
+            s.w2, s.w2_rs, s.w2_cs = None, 0, 0
+    return arr
+
+
+# --------------------------------------------------------------------------------------------
+# raw kernel wrappers (no autograd)
+# --------------------------------------------------------------------------------------------
+def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=None):
+    _lib.require_gpu()
+    arr = _mk_srcs(entries)
+    N, Mo, F = y.shape
+    p, ss, ld = _v(y)
+    rc = lib.cape_gconv_fwd(arr, len(entries), p, ss, ld, N, Mo, F, _ptr(bias),
+                            bias_mode if bias is not None else _lib.BIAS_NONE, _lib.ACT[act],
+                            _ptr(mask), _stream())
+    check(rc, "cape_gconv_fwd")
+    return y
+
+
+def gconv_dw(entries, dz, accumulate=False):
+    """entries' ``w`` fields name the gradient blocks to write."""
+    _lib.require_gpu()
+    arr = _mk_srcs(entries)
+    N, Mo, F = dz.shape
+    need = lib.cape_gconv_dw_workspace_bytes(arr, len(entries), N, Mo, F)
+    if need < 0:
+        check(int(need), "cape_gconv_dw_workspace_bytes")
+    ws = torch.empty((need + 3) // 4, device=dz.device, dtype=torch.float32)
+    p, ss, ld = _v(dz)
+    rc = lib.cape_gconv_dw(arr, len(entries), p, ss, ld, N, Mo, F, 1 if accumulate else 0,
+                           C.c_void_p(ws.data_ptr()), need, _stream())
+    check(rc, "cape_gconv_dw")
+
+
+def spmm(x, csr, y=None, alpha=1.0, z=None, beta=0.0):
+    _lib.require_gpu()
+    N, Mi, Cn = x.shape
+    Mo = csr.shape[0]
+    if y is None:
+        y = alloc_act(N, Mo, Cn, x.device)
+    xp, xs, xl = _v(x)
+    yp, ys, yl = _v(y)
+    if z is not None:
+        zp, zs, zl = _v(z)
+    else:
+        zp, zs, zl = None, 0, 0
+    rc = lib.cape_spmm(xp, xs, xl, C.c_void_p(csr.rowptr_t.data_ptr()), C.c_void_p(csr.colidx_t.data_ptr()),
+                       C.c_void_p(csr.vals_t.data_ptr()), float(alpha), zp, zs, zl, float(beta),
+                       yp, ys, yl, N, Mo, Cn, _stream())
+    check(rc, "cape_spmm")
+    return y
+
+
+def bias_act_fwd(x, bias, bias_mode, act, y=None):
+    _lib.require_gpu()
+    N, M, Cn = x.shape
+    if y is None:
+        y = alloc_act(N, M, Cn, x.device)
+    xp, xs, xl = _v(x)
+    yp, ys, yl = _v(y)
+    rc = lib.cape_bias_act_fwd(xp, xs, xl, _ptr(bias), bias_mode if bias is not None else 0, _lib.ACT[act],
+                               yp, ys, yl, N, M, Cn, _stream())
+    check(rc, "cape_bias_act_fwd")
+    return y
+
+
+def act_bwd(dy, y, act, dz=None):
+    _lib.require_gpu()
+    N, M, Cn = dy.shape
+    if dz is None:
+        dz = alloc_act(N, M, Cn, dy.device)
+    gp, gs, gl = _v(dy)
+    yp, ys, yl = _v(y)
+    zp, zs, zl = _v(dz)
+    rc = lib.cape_act_bwd(gp, gs, gl, yp, ys, yl, _lib.ACT[act], zp, zs, zl, N, M, Cn, _stream())
+    check(rc, "cape_act_bwd")
+    return dz
+
+
+def colsum(x, out, per_vertex=False, accumulate=False):
+    _lib.require_gpu()
+    N, M, Cn = x.shape
+    xp, xs, xl = _v(x)
+    if per_vertex:
+        ws, need = None, 0
+    else:
+        need = lib.cape_colsum_workspace_bytes(N, M, Cn)
+        ws = torch.empty((need + 3) // 4, device=x.device, dtype=torch.float32)
+    rc = lib.cape_colsum(xp, xs, xl, N, M, Cn, 1 if per_vertex else 0, 1 if accumulate else 0,
+                         C.c_void_p(out.data_ptr()), _ptr(ws), need, _stream())
+    check(rc, "cape_colsum")
+    return out
+
+
+def mask_mul(dy, mask, dz=None):
+    _lib.require_gpu()
+    N, M, F = dy.shape
+    if dz is None:
+        dz = alloc_act(N, M, F, dy.device)
+    gp, gs, gl = _v(dy)
+    zp, zs, zl = _v(dz)
+    rc = lib.cape_mask_mul(gp, gs, gl, C.c_void_p(mask.data_ptr()), zp, zs, zl, N, M, F, _stream())
+    check(rc, "cape_mask_mul")
+    return dz
+
+
+def fill_cond(cond, y, scale=None):
+    _lib.require_gpu()
+    N, M, Cn = y.shape
+    assert cond.shape == (N, Cn) and cond.stride(1) == 1
+    yp, ys, yl = _v(y)
+    rc = lib.cape_fill_cond(C.c_void_p(cond.data_ptr()), cond.stride(0) if N > 1 else Cn, _ptr(scale), yp, ys, yl,
+                            N, M, Cn, _stream())
+    check(rc, "cape_fill_cond")
+    return y
+
+
+def reduce_cond(dy, scale=None, out=None, accumulate=False):
+    _lib.require_gpu()
+    N, M, Cn = dy.shape
+    if out is None:
+        out = torch.empty((N, Cn), device=dy.device, dtype=torch.float32)
+    gp, gs, gl = _v(dy)
+    rc = lib.cape_reduce_cond(gp, gs, gl, _ptr(scale), C.c_void_p(out.data_ptr()), out.stride(0) if N > 1 else Cn,
+                              N, M, Cn, 1 if accumulate else 0, _stream())
+    check(rc, "cape_reduce_cond")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# autograd operators
+# --------------------------------------------------------------------------------------------
+class ChebConvFn(torch.autograd.Function):
+    """y = [ epilogue( sum_k (S_k x) W_k ) | cond tiled over vertices ]
+
+    * plain mode  (W_aff None): epilogue = act(. + bias)            -- chebyshev5 + b1*/b2relu
+      (+ poolwT folded into S_k), reference lib/models.py:69-127,154-171,796-810
+    * affine mode (W_aff given): relu(sum_k (S_k x) W_k) + (S_0 x) W_aff -- res_block_affine,
+      lib/models.py:776-793 (unpool folded into S_k)
+    ``cond`` [N, Cc] is appended as Cc vertex-constant channels (fit_cond_dim + concat, :813-832).
+    """
+
+    @staticmethod
+    def forward(ctx, x, W, bias, W_aff, cond, ops, act, bias_mode):
+        x = as_act(x)
+        N, Mi, Cin = x.shape
+        K, Fout = ops.K, W.shape[1]
+        assert ops.fused and W.shape[0] == Cin * K and Mi == ops.Mi
+        assert W.is_contiguous() and (W_aff is None or W_aff.is_contiguous())
+        Cc = 0 if cond is None else cond.shape[1]
+        yfull = alloc_act(N, ops.Mo, Fout + Cc, x.device)
+        y = yfull[:, :, :Fout]
+        entries = []
+        for k in range(K):
+            e = dict(x=x, csr=ops.fwd[k], w=(W, k * Fout, K * Fout, 1))
+            if W_aff is not None and k == 0:
+                e["w2"] = (W_aff, 0, Fout, 1)
+            entries.append(e)
+        mask = None
+        if W_aff is not None:
+            assert W_aff.shape == (Cin, Fout)
+            mask = torch.empty((N, ops.Mo, (Fout + 31) // 32), device=x.device, dtype=torch.int32)
+            gconv_fwd(entries, y, mask=mask)
+        else:
+            gconv_fwd(entries, y, bias=bias, bias_mode=bias_mode, act=act)
+        if Cc:
+            fill_cond(cond.contiguous(), yfull[:, :, Fout:])
+        ctx.ops, ctx.act, ctx.bias_mode, ctx.Fout, ctx.Cc = ops, act, bias_mode, Fout, Cc
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, W, W_aff, mask, yfull if (act != "none" and W_aff is None) else None)
+        return yfull
+
+    @staticmethod
+    def backward(ctx, gfull):
+        x, W, W_aff, mask, ysaved = ctx.saved_tensors
+        ops, act, Fout, Cc = ctx.ops, ctx.act, ctx.Fout, ctx.Cc
+        K = ops.K
+        N, Mi, Cin = x.shape
+        gfull = as_act(gfull)
+        g = gfull[:, :, :Fout]
+        need_x, need_w, need_b, need_wa, need_c = (ctx.needs_input_grad[i] for i in range(5))
+        dW = dB = dWa = dcond = dx = None
+        if W_aff is not None:
+            dz = mask_mul(g, mask)          # gradient through relu of the graph-conv branch
+        elif act != "none":
+            dz = act_bwd(g, ysaved[:, :, :Fout], act)
+        else:
+            dz = g
+        if need_b and ctx.has_bias:
+            if ctx.bias_mode == _lib.BIAS_VERTEX:
+                dB = torch.empty((1, ops.Mo, Fout), device=x.device, dtype=torch.float32)
+                colsum(dz, dB, per_vertex=True)
+            else:
+                dB = torch.empty((1, 1, Fout), device=x.device, dtype=torch.float32)
+                colsum(dz, dB)
+        if need_w:
+            dW = torch.empty_like(W)
+            gconv_dw([dict(x=x, csr=ops.fwd[k], w=(dW, k * Fout, K * Fout, 1)) for k in range(K)], dz)
+        if W_aff is not None and need_wa:
+            dWa = torch.empty_like(W_aff)
+            gconv_dw([dict(x=x, csr=ops.fwd[0], w=(dWa, 0, Fout, 1))], g)
+        if need_x:
+            dx = alloc_act(N, Mi, Cin, x.device)
+            entries = [dict(x=dz, csr=ops.bwd[k], w=(W, k * Fout, 1, K * Fout)) for k in range(K)]
+            if W_aff is not None:
+                entries.append(dict(x=g, csr=ops.bwd[0], w=(W_aff, 0, 1, Fout)))
+            gconv_fwd(entries, dx)
+        if Cc and need_c:
+            dcond = reduce_cond(gfull[:, :, Fout:])
+        return dx, dW, dB, dWa, dcond, None, None, None
+
+
+class ChebConvRecurrenceFn(torch.autograd.Function):
+    """General-K chebyshev5 (lib/models.py:69-103) by the explicit recurrence
+    x_k = 2 L~ x_{k-1} - x_{k-2} with standalone sparse applications; used above FUSE_MAX_K."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, ops, act, bias_mode):
+        x = as_act(x)
+        N, M, Cin = x.shape
+        K, Fout = ops.K, W.shape[1]
+        xs = [x, spmm(x, ops.Lt)]
+        for k in range(2, K):
+            xs.append(spmm(xs[-1], ops.Lt, alpha=2.0, z=xs[-2], beta=-1.0))
+        y = alloc_act(N, M, Fout, x.device)
+        gconv_fwd([dict(x=xs[k], csr=None, w=(W, k * Fout, K * Fout, 1)) for k in range(K)], y,
+                  bias=bias, bias_mode=bias_mode, act=act)
+        ctx.ops, ctx.act, ctx.bias_mode, ctx.has_bias = ops, act, bias_mode, bias is not None
+        ctx.save_for_backward(W, y, *xs)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        W, y = ctx.saved_tensors[:2]
+        xs = ctx.saved_tensors[2:]
+        ops, act = ctx.ops, ctx.act
+        K, Fout = ops.K, W.shape[1]
+        N, M, Cin = xs[0].shape
+        g = as_act(g)
+        dz = act_bwd(g, y, act) if act != "none" else g
+        dW = dB = dx = None
+        if ctx.needs_input_grad[2] and ctx.has_bias:
+            if ctx.bias_mode == _lib.BIAS_VERTEX:
+                dB = torch.empty((1, M, Fout), device=g.device, dtype=torch.float32)
+                colsum(dz, dB, per_vertex=True)
+            else:
+                dB = torch.empty((1, 1, Fout), device=g.device, dtype=torch.float32)
+                colsum(dz, dB)
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty_like(W)
+            gconv_dw([dict(x=xs[k], csr=None, w=(dW, k * Fout, K * Fout, 1)) for k in range(K)], dz)
+        if ctx.needs_input_grad[0]:
+            # G_k = dz W_k^T, then Clenshaw for sum_k T_k(L~)^T G_k
+            G = []
+            for k in range(K):
+                gk = alloc_act(N, M, Cin, g.device)
+                gconv_fwd([dict(x=dz, csr=None, w=(W, k * Fout, 1, K * Fout))], gk)
+                G.append(gk)
+            b1 = b2 = None   # b_{k+1}, b_{k+2}
+            for k in range(K - 1, 0, -1):
+                if b1 is None:
+                    bk = G[k]
+                else:
+                    bk = spmm(b1, ops.LtT, alpha=2.0, z=G[k], beta=1.0)
+                    if b2 is not None:
+                        bk.sub_(b2)
+                b1, b2 = bk, b1
+            dx = spmm(b1, ops.LtT, alpha=1.0, z=G[0], beta=1.0) if b1 is not None else G[0]
+            if b2 is not None:
+                dx.sub_(b2)
+        return dx, dW, dB, None, None, None
+
+
+class SparseOpFn(torch.autograd.Function):
+    """y[n] = P x[n]  -- poolwT (lib/models.py:129-152) as a standalone operator."""
+
+    @staticmethod
+    def forward(ctx, x, fwd_csr, bwd_csr):
+        ctx.bwd_csr = bwd_csr
+        return spmm(as_act(x), fwd_csr)
+
+    @staticmethod
+    def backward(ctx, g):
+        return spmm(as_act(g), ctx.bwd_csr), None, None
+
+
+class ConcatCondFn(torch.autograd.Function):
+    """[x | cond tiled over vertices]  (fit_cond_dim + tf.concat, lib/models.py:533-536,663-666)."""
+
+    @staticmethod
+    def forward(ctx, x, cond):
+        N, M, Cx = x.shape
+        Cc = cond.shape[1]
+        out = alloc_act(N, M, Cx + Cc, x.device, zero=False)
+        out[:, :, :Cx].copy_(x)
+        fill_cond(cond.contiguous(), out[:, :, Cx:])
+        ctx.Cx = Cx
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = as_act(g)
+        dx = g[:, :, :ctx.Cx] if ctx.needs_input_grad[0] else None
+        dc = reduce_cond(g[:, :, ctx.Cx:]) if ctx.needs_input_grad[1] else None
+        return dx, dc
+
+
+class GroupNormFn(torch.autograd.Function):
+    """gn(norm_type='group') optionally fused with the following tf.nn.relu
+    (lib/models.py:681-712, 751-760)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, G, eps, relu):
+        _lib.require_gpu()
+        x = as_act(x)
+        N, V, Cn = x.shape
+        y = alloc_act(N, V, Cn, x.device)
+        stats = torch.empty((N, G, 2), device=x.device, dtype=torch.float32)
+        xp, xs, xl = _v(x)
+        yp, ys, yl = _v(y)
+        rc = lib.cape_groupnorm_fwd(xp, xs, xl, _ptr(gamma), _ptr(beta), float(eps), int(G), int(relu), yp, ys, yl,
+                                    _ptr(stats), N, V, Cn, _stream())
+        check(rc, "cape_groupnorm_fwd")
+        ctx.G, ctx.relu = G, relu
+        ctx.save_for_backward(x, y, gamma, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, gamma, stats = ctx.saved_tensors
+        g = as_act(g)
+        N, V, Cn = x.shape
+        dx = alloc_act(N, V, Cn, x.device)
+        dgp = torch.empty((N, Cn), device=x.device, dtype=torch.float32)
+        dbp = torch.empty((N, Cn), device=x.device, dtype=torch.float32)
+        gst = torch.empty((N, ctx.G, 2), device=x.device, dtype=torch.float32)
+        xp, xs, xl = _v(x)
+        yp, ys, yl = _v(y)
+        gp, gs, gl = _v(g)
+        dp, ds, dl = _v(dx)
+        rc = lib.cape_groupnorm_bwd(xp, xs, xl, yp, ys, yl, gp, gs, gl, _ptr(gamma), _ptr(stats), int(ctx.G),
+                                    int(ctx.relu), dp, ds, dl, _ptr(dgp), _ptr(dbp), _ptr(gst), N, V, Cn, _stream())
+        check(rc, "cape_groupnorm_bwd")
+        return dx, dgp.sum(0), dbp.sum(0), None, None, None
+
+
+class ReconEdgeLossFn(torch.autograd.Function):
+    """total = w_recon * mean|pred-gt| + w_edge * edge_loss  (lib/models.py:357-375,
+    lib/losses.py:9-25).  Returns (total, recon, edge); only ``total`` is differentiable."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, verts_ref, edges, vptr, vidx, w_recon, w_edge):
+        _lib.require_gpu()
+        pred, gt = pred.contiguous(), gt.contiguous()
+        N, M, _ = pred.shape
+        E = edges.shape[0]
+        need = lib.cape_recon_edge_workspace_bytes(N, M, E)
+        ws = torch.empty((need + 3) // 4, device=pred.device, dtype=torch.float32)
+        out = torch.empty(2, device=pred.device, dtype=torch.float32)
+        dpred = torch.empty_like(pred)
+        rc = lib.cape_recon_edge_loss_fwd_bwd(_ptr(pred), _ptr(gt), _ptr(verts_ref), _ptr(edges), _ptr(vptr), _ptr(vidx),
+                                              N, M, E, float(w_recon), float(w_edge), _ptr(out), _ptr(dpred), _ptr(ws),
+                                              need, _stream())
+        check(rc, "cape_recon_edge_loss_fwd_bwd")
+        ctx.save_for_backward(dpred)
+        total = w_recon * out[0] + w_edge * out[1]
+        ctx.mark_non_differentiable(out)
+        return total, out
+
+    @staticmethod
+    def backward(ctx, gtotal, _gout):
+        (dpred,) = ctx.saved_tensors
+        return dpred * gtotal, None, None, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------------
+# functional front-ends with the reference's operator names
+# --------------------------------------------------------------------------------------------
+def chebyshev5(x, W, ops, bias=None, activation=None, cond=None, W_affine=None):
+    """Graph convolution (lib/models.py:69-103) with optional fused bias+activation
+    (``activation`` in b1leakyrelu/b1relu/b1tanh/b2relu), affine branch and condition concat."""
+    if activation is None:
+        act, bmode = "none", (_lib.BIAS_NONE if bias is None else
+                              (_lib.BIAS_VERTEX if bias.shape[1] > 1 else _lib.BIAS_CHANNEL))
+    else:
+        act, bmode = _ACT_OF[activation]
+    if ops.fused:
+        return ChebConvFn.apply(x, W, bias, W_affine, cond, ops, act, bmode)
+    assert W_affine is None
+    y = ChebConvRecurrenceFn.apply(x, W, bias, ops, act, bmode)
+    if cond is not None:
+        y = ConcatCondFn.apply(y, cond)
+    return y
+
+
+def poolwT(x, fwd_csr, bwd_csr):
+    return SparseOpFn.apply(x, fwd_csr, bwd_csr)

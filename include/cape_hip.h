@@ -1,0 +1,197 @@
+/*
+ * cape_hip.h -- C-ABI of libcape_hip.so: the MI355X (gfx950) implementation of CAPE's
+ * Chebyshev mesh-convolution hot path.
+ *
+ * Every entry point is extern "C", takes caller-owned DEVICE pointers + explicit sizes +
+ * a hipStream_t (passed as void*), performs no allocation and no synchronisation, keeps
+ * no global mutable state and returns 0 on success, a negative CAPE_E* code for argument
+ * errors or a positive hipError_t for launch errors.  Results are deterministic (no
+ * floating-point atomics).  Tensors are fp32, row-major [N, M, ld] with channels
+ * contiguous (ld >= C is the row stride in elements), i.e. the reference's [N, M, F]
+ * placeholder layout (reference lib/models.py:272-282) without its [M, F*N] shuffles
+ * (lib/models.py:81-83, 97-99, 147-151).
+ *
+ * Reference interfaces replaced (paths relative to the reference checkout):
+ *   cape_gconv_fwd      lib/models.py:69-103  chebyshev5   (tf.sparse_tensor_dense_matmul x(K-1)
+ *                                                           + tf.matmul), fused with
+ *                       lib/models.py:105-127 b1leakyrelu / b1relu / b1tanh / b2relu,
+ *                       lib/models.py:129-152 poolwT       (pool folded in as output-row CSR,
+ *                                                           unpool folded in as input CSR),
+ *                       lib/models.py:776-793 res_block_affine (DUAL accumulator mode),
+ *                       lib/models.py:611-616 per-vertex output bias;
+ *                       and, with transposed operators/weights, the data gradient that
+ *                       tf.gradients (lib/models.py:460,465) derives for those ops.
+ *   cape_gconv_dw       the weight gradient of the same ops (tf.gradients, :460).
+ *   cape_spmm           lib/models.py:91,94,149 SparseTensorDenseMatMul as a standalone op
+ *                       (general-K Chebyshev recurrence, non-selection pool matrices).
+ *   cape_bias_act_fwd / cape_act_bwd / cape_colsum
+ *                       lib/models.py:105-127 standalone and their gradients.
+ *   cape_mask_mul       gradient of tf.nn.relu in res_block_affine (lib/models.py:785).
+ *   cape_fill_cond      lib/models.py:813-832 fit_cond_dim + tf.concat (:535,593,608,665).
+ *   cape_groupnorm_fwd / cape_groupnorm_bwd
+ *                       lib/models.py:681-712 gn (norm_type='group') and its gradient.
+ *   cape_recon_edge_loss_fwd_bwd
+ *                       lib/models.py:357-375 L1 reconstruction + lib/losses.py:9-25 edge loss
+ *                       and their gradients w.r.t. the prediction.
+ *   cape_csr_validate   host-side structural check of an operator before upload.
+ */
+#ifndef CAPE_HIP_H
+#define CAPE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAPE_ABI_VERSION 1
+#define CAPE_MAX_SRC 8
+
+/* error codes (negative = argument error; positive values are hipError_t) */
+#define CAPE_OK 0
+#define CAPE_EINVAL (-1)       /* bad size / null pointer / unsupported combination */
+#define CAPE_EUNSORTED (-2)    /* CSR column indices not strictly increasing in a row */
+#define CAPE_ERANGE (-3)       /* CSR index out of range / rowptr not monotone */
+#define CAPE_EWORKSPACE (-4)   /* workspace too small */
+
+/* activation selectors (lib/models.py:105-127) */
+#define CAPE_ACT_NONE 0
+#define CAPE_ACT_LEAKY 1       /* tf.nn.leaky_relu, alpha = 0.2 */
+#define CAPE_ACT_RELU 2
+#define CAPE_ACT_TANH 3
+
+/* bias selectors */
+#define CAPE_BIAS_NONE 0
+#define CAPE_BIAS_CHANNEL 1    /* [1,1,F]  (b1*)                */
+#define CAPE_BIAS_VERTEX 2     /* [1,M,F]  (b2relu, :615 output) */
+
+/*
+ * One operand ("source") of the fused gather-GEMM:
+ *   A[n, r, c] = sum_e vals[e] * x[n, colidx[e], c]   e in [rowptr[r], rowptr[r+1])
+ *              = x[n, r, c]                            when rowptr == NULL (identity)
+ *   acc1[n, r, f] += sum_c A[n, r, c] * w [c*w_rs  + f*w_cs ]
+ *   acc2[n, r, f] += sum_c A[n, r, c] * w2[c*w2_rs + f*w2_cs]   (only if w2 != NULL)
+ * For the forward Chebyshev term k of a layer with reference weight W[Fin*K, Fout]
+ * (row index fin*K + k, lib/models.py:97-101):  w = W + k*Fout, w_rs = K*Fout, w_cs = 1.
+ * For its data gradient: x = dZ, CSR = transposed operator, w = W + k*Fout, w_rs = 1,
+ * w_cs = K*Fout.
+ */
+typedef struct cape_src {
+    const float *x;          /* device [N, Mi, ldx] (pointer may include a channel offset) */
+    int64_t x_sample_stride; /* elements between consecutive samples                       */
+    int32_t ldx;             /* row stride in elements                                     */
+    int32_t C;               /* channels contracted from this source                       */
+    const int32_t *rowptr;   /* device, Mo+1 entries, or NULL for identity                 */
+    const int32_t *colidx;   /* device, nnz                                                */
+    const float *vals;       /* device, nnz                                                */
+    const float *w;          /* device weight block 1                                      */
+    int64_t w_rs, w_cs;
+    const float *w2;         /* device weight block 2 (DUAL mode) or NULL                  */
+    int64_t w2_rs, w2_cs;
+} cape_src_t;
+
+int cape_abi_version(void);
+
+/* Host-side structural check of a CSR operator (host pointers). */
+int cape_csr_validate(int32_t rows, int32_t cols, int64_t nnz, const int32_t *rowptr,
+                      const int32_t *colidx);
+
+/*
+ * Fused gather-GEMM forward.
+ *   single mode (mask_out == NULL, no source has w2):
+ *        y[n,r,f] = act(acc1 + bias)
+ *   DUAL mode (at least one source has w2)  -- res_block_affine, lib/models.py:776-793:
+ *        y[n,r,f] = relu(acc1) + acc2 ; if mask_out != NULL bit (f%32) of
+ *        mask_out[(n*Mo + r)*ceil(F/32) + f/32] = (acc1 > 0)
+ * bias: NULL or [F] (CAPE_BIAS_CHANNEL) or [Mo,F] (CAPE_BIAS_VERTEX).
+ */
+int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, int64_t y_sample_stride,
+                   int32_t ldy, int32_t N, int32_t Mo, int32_t F, const float *bias,
+                   int32_t bias_mode, int32_t act, uint32_t *mask_out, void *stream);
+
+/*
+ * Weight gradient of the fused gather-GEMM:
+ *   dW_s[c*w_rs + f*w_cs] (+)= sum_{n,r} A_s[n,r,c] * dz[n,r,f]
+ * for every source s (w is the *output* gradient block here and is written, w2 is ignored).
+ * accumulate != 0 adds to the existing contents.  Uses a caller-provided workspace of at
+ * least cape_gconv_dw_workspace_bytes(...) bytes.
+ */
+int64_t cape_gconv_dw_workspace_bytes(const cape_src_t *srcs, int32_t nsrc, int32_t N,
+                                      int32_t Mo, int32_t F);
+int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *dz,
+                  int64_t dz_sample_stride, int32_t lddz, int32_t N, int32_t Mo, int32_t F,
+                  int32_t accumulate, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* y[n,r,:] = alpha * sum_e vals[e]*x[n,colidx[e],:] + beta * z[n,r,:]   (z may be NULL, may alias y) */
+int cape_spmm(const float *x, int64_t x_sample_stride, int32_t ldx, const int32_t *rowptr,
+              const int32_t *colidx, const float *vals, float alpha, const float *z,
+              int64_t z_sample_stride, int32_t ldz, float beta, float *y,
+              int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t C,
+              void *stream);
+
+/* y = act(x + bias) over [N, M, C] views (y may alias x). */
+int cape_bias_act_fwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *bias,
+                      int32_t bias_mode, int32_t act, float *y, int64_t y_sample_stride,
+                      int32_t ldy, int32_t N, int32_t M, int32_t C, void *stream);
+
+/* dz = dy * act'(.) evaluated from the activation OUTPUT y (dz may alias dy). */
+int cape_act_bwd(const float *dy, int64_t dy_sample_stride, int32_t lddy, const float *y,
+                 int64_t y_sample_stride, int32_t ldy, int32_t act, float *dz,
+                 int64_t dz_sample_stride, int32_t lddz, int32_t N, int32_t M, int32_t C,
+                 void *stream);
+
+/* out[c] (+)= sum_{n (if reduce_n), m} x[n,m,c];  reduce_n=0 gives out[m,c] = sum_n (vertex bias grad). */
+int64_t cape_colsum_workspace_bytes(int32_t N, int32_t M, int32_t C);
+int cape_colsum(const float *x, int64_t x_sample_stride, int32_t ldx, int32_t N, int32_t M,
+                int32_t C, int32_t per_vertex, int32_t accumulate, float *out, void *workspace,
+                int64_t workspace_bytes, void *stream);
+
+/* dgc[n,r,f] = dy[n,r,f] if mask bit set else 0 (gradient through the relu of the affine block). */
+int cape_mask_mul(const float *dy, int64_t dy_sample_stride, int32_t lddy, const uint32_t *mask,
+                  float *dz, int64_t dz_sample_stride, int32_t lddz, int32_t N, int32_t M,
+                  int32_t F, void *stream);
+
+/* y[n,m,c] = scale[m] * cond[n,c]  (scale NULL = 1): the tiled condition channels. */
+int cape_fill_cond(const float *cond, int32_t ldc, const float *scale, float *y,
+                   int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t M, int32_t C,
+                   void *stream);
+
+/* dcond[n,c] (+)= sum_m scale[m] * dy[n,m,c] */
+int cape_reduce_cond(const float *dy, int64_t dy_sample_stride, int32_t lddy, const float *scale,
+                     float *dcond, int32_t ldc, int32_t N, int32_t M, int32_t C,
+                     int32_t accumulate, void *stream);
+
+/* Group norm over [N, V, C] (G groups of C/G channels, population variance, eps),
+ * optional fused ReLU; stats = [N, G, 2] (mean, rstd) saved for backward. */
+int cape_groupnorm_fwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *gamma,
+                       const float *beta, float eps, int32_t G, int32_t relu, float *y,
+                       int64_t y_sample_stride, int32_t ldy, float *stats, int32_t N, int32_t V,
+                       int32_t C, void *stream);
+/* dx plus per-sample partial parameter gradients dgamma_partial/dbeta_partial [N, C] (the caller
+ * sums them over N); y is the forward OUTPUT (only read when relu != 0, may be NULL otherwise);
+ * gstats is a [N, G, 2] scratch buffer. */
+int cape_groupnorm_bwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *y,
+                       int64_t y_sample_stride, int32_t ldy, const float *dy,
+                       int64_t dy_sample_stride, int32_t lddy, const float *gamma,
+                       const float *stats, int32_t G, int32_t relu, float *dx,
+                       int64_t dx_sample_stride, int32_t lddx, float *dgamma_partial,
+                       float *dbeta_partial, float *gstats, int32_t N, int32_t V, int32_t C,
+                       void *stream);
+
+/*
+ * L1 reconstruction + edge loss (lib/models.py:357-375, lib/losses.py:9-25) and gradient:
+ *   loss_out[0] = mean |pred - gt| ; loss_out[1] = mean_e || (p_i - p_j) - (g_i - g_j) ||
+ *   dpred = w_recon * d(recon)/dpred + w_edge * d(edge)/dpred      (dpred may be NULL)
+ * edges: device int32 [E,2].  workspace >= cape_recon_edge_workspace_bytes(N, M, E).
+ */
+int64_t cape_recon_edge_workspace_bytes(int32_t N, int32_t M, int32_t E);
+int cape_recon_edge_loss_fwd_bwd(const float *pred, const float *gt, const float *verts_ref,
+                                 const int32_t *edges, const int32_t *vert_edge_ptr,
+                                 const int32_t *vert_edge_idx, int32_t N, int32_t M, int32_t E,
+                                 float w_recon, float w_edge, float *loss_out, float *dpred,
+                                 void *workspace, int64_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAPE_HIP_H */
