@@ -510,3 +510,33 @@ def chebyshev5(x, W, ops, bias=None, activation=None, cond=None, W_affine=None):
 
 def poolwT(x, fwd_csr, bwd_csr):
     return SparseOpFn.apply(x, fwd_csr, bwd_csr)
+
+
+class BiasActFn(torch.autograd.Function):
+    """Standalone act(x + bias): b1leakyrelu / b1relu / b1tanh / b2relu (lib/models.py:105-127),
+    used where the activation cannot be fused into the producing conv (encoder res_block)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, act, bias_mode):
+        x = as_act(x)
+        y = bias_act_fwd(x, bias, bias_mode, act)
+        ctx.act, ctx.bias_mode = act, bias_mode
+        ctx.save_for_backward(y)
+        ctx.bshape = None if bias is None else tuple(bias.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = as_act(g)
+        dz = act_bwd(g, y, ctx.act) if ctx.act != "none" else g
+        dB = None
+        if ctx.bshape is not None and ctx.needs_input_grad[1]:
+            dB = torch.empty(ctx.bshape, device=g.device, dtype=torch.float32)
+            colsum(dz, dB, per_vertex=(ctx.bias_mode == _lib.BIAS_VERTEX))
+        return dz, dB, None, None
+
+
+def brelu(x, bias, activation):
+    act, bmode = _ACT_OF[activation]
+    return BiasActFn.apply(x, bias, act, bmode)

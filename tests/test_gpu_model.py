@@ -1,0 +1,157 @@
+"""Full-network GPU parity: cape_amd.models.CAPE (HIP kernels through the C-ABI) against the CPU
+oracle (numpy fp64 restatement of reference lib/models.py + torch autograd twin) with identical,
+name-keyed weights and inputs.
+
+Tolerances (fp32 path): per-vertex L2 error of the reconstruction <= 1e-4 x the largest
+per-vertex L2 norm of the fp64 oracle output; latent codes / logits 1e-4 relative (max-norm);
+parameter gradients are judged against the noise of the SAME graph evaluated by the oracle in fp32
+on the CPU in the reference's op order (the stand-in for the TF1 CPU path): (leaky-)ReLU units that
+sit at ~0 flip sign in ANY fp32 evaluation and move individual gradients by 1e-3..1e-2 of their
+largest entry (decoder/fc1, every relu after a group-norm), differently per implementation.  Per
+variable: max-norm error <= max(1e-3, 4 x e32_var, 2 x worst e32 over variables); globally: the
+relative L2 error over ALL gradient entries <= 4 x that of the fp32 CPU evaluation.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def vertex_err(a, ref):
+    a = np.asarray(a, np.float64).reshape(-1, ref.shape[-1])
+    r = np.asarray(ref, np.float64).reshape(-1, ref.shape[-1])
+    return np.sqrt(((a - r) ** 2).sum(-1)).max() / max(np.sqrt((r * r).sum(-1)).max(), 1e-30)
+
+
+def rel_err(a, ref):
+    a, r = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    return np.abs(a - r).max() / max(np.abs(r).max(), 1e-30)
+
+
+def _inputs(N, nz, seed=0):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((N, 6890, 3))
+    gt = x + 0.1 * rng.standard_normal((N, 6890, 3))
+    xd = rng.standard_normal((N, 6890, 3))
+    cond = 0.5 * rng.standard_normal((N, 126))
+    cond_d = 0.5 * rng.standard_normal((N, 126))
+    clo = np.eye(4)[np.arange(N) % 4]
+    clo_d = np.eye(4)[(np.arange(N) + 1) % 4]
+    eps = rng.standard_normal((N, nz))
+    return x, gt, xd, cond, cond_d, clo, clo_d, eps
+
+
+def _twin(cfg, mesh_ops, N, overrides=None, tdtype=torch.float64):
+    from oracle.configs import cape_params
+    from oracle.torch_twin import TwinCAPE
+    P = cape_params(cfg, N)
+    P.update(overrides or {})
+    m = mesh_ops
+    pack = m["pack"]
+    return P, TwinCAPE(m["L"], m["D"], m["U"], m["L_d"], m["D_d"], p=m["p"], dtype=np.float64, tdtype=tdtype,
+                       verts_ref=pack["template_verts"], vpe=pack["edges_smpl"], **P)
+
+
+def _build(cfg, mesh_ops, N, overrides=None):
+    from cape_amd.models import CAPE
+    P, twin = _twin(cfg, mesh_ops, N, overrides)
+    m = mesh_ops
+    model = CAPE(L=m["L"], D=m["D"], U=m["U"], L_d=m["L_d"], D_d=m["D_d"], p=m["p"], **P)
+    model.build_graph(model.input_num_verts, model.nn_input_channel, phase='train')
+    return P, twin, model
+
+
+def _run_twin(twin, x, gt, xd, cond, cond_d, clo, clo_d, eps):
+    y, y2 = twin.cond_embeddings(cond, clo)
+    xh, zm, zl = twin.generator(x, y, y2, eps)
+    yd, y2d = twin.cond_embeddings(cond_d, clo_d)
+    d_fake = twin.discriminator(xh, y, y2)
+    d_real = twin.discriminator(xd, yd, y2d)
+    ls = twin.losses(xh, gt, zm, zl, d_real, d_fake)
+    return xh, zm, zl, d_real, d_fake, ls
+
+
+CONFIGS = [
+    ("affine_nz64", None),
+    ("cmr_nz18", None),
+    # encoder res_block (:715-741) + plain udn decoder (:173-191) + conditioned encoder, tanh
+    ("affine_nz18", dict(use_res_block=True, use_res_block_dec=False, cond_encoder=True, activation='b1tanh',
+                         F=[16, 16, 32, 32, 64, 64, 128, 128], reduce_dim=32, loss='l2')),
+]
+
+
+@pytest.mark.parametrize("cfg,overrides", CONFIGS, ids=["affine_nz64", "cmr_nz18", "resblock_udn_tanh"])
+def test_full_model_forward_backward(cfg, overrides, mesh_ops):
+    N = 2
+    P, twin, model = _build(cfg, mesh_ops, N, overrides)
+    x, gt, xd, cond, cond_d, clo, clo_d, eps = _inputs(N, P["nz"])
+    xh, zm, zl, d_real, d_fake, ls = _run_twin(twin, x, gt, xd, cond, cond_d, clo, clo_d, eps)
+    # same variable set (names + shapes) as the restated reference graph, then identical values
+    assert set(model._vars) == set(twin.vs.vars), set(model._vars) ^ set(twin.vs.vars)
+    model.load_variables(twin.vs.vars)
+
+    dev = model.device
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    out = model.forward_losses(t(x), t(cond), t(clo), t(gt), t(xd), t(cond_d), t(clo_d), eps=t(eps))
+    assert vertex_err(out['prediction'].detach().cpu().numpy(), xh.detach().numpy()) < 1e-4
+    assert rel_err(out['z_mean'].detach().cpu().numpy(), zm.detach().numpy()) < 1e-4
+    assert rel_err(out['z_logvar'].detach().cpu().numpy(), zl.detach().numpy()) < 1e-4
+    for k in ('recon', 'latent', 'edge', 'gan_g', 'gan_d', 'loss_g', 'loss_d'):
+        assert abs(float(out[k]) - float(ls[k])) < 1e-4 * max(abs(float(ls[k])), 1e-3), k
+
+    # gradients: loss_g w.r.t. generator+condition variables, loss_d w.r.t. discriminator variables
+    g_names, d_names = model._g_names, model._d_names
+    tg = torch.autograd.grad(ls['loss_g'], [twin.params[n] for n in g_names], retain_graph=True, allow_unused=True)
+    td = torch.autograd.grad(ls['loss_d'], [twin.params[n] for n in d_names], allow_unused=True)
+    hg = torch.autograd.grad(out['loss_g'], [model._vars[n] for n in g_names], retain_graph=True, allow_unused=True)
+    hd = torch.autograd.grad(out['loss_d'], [model._vars[n] for n in d_names], allow_unused=True)
+    # calibrator: the same graph in fp32 on the CPU, reference op order
+    _, twin32 = _twin(cfg, mesh_ops, N, overrides, tdtype=torch.float32)
+    ls32 = _run_twin(twin32, x, gt, xd, cond, cond_d, clo, clo_d, eps)[-1]
+    cg = torch.autograd.grad(ls32['loss_g'], [twin32.params[n] for n in g_names], retain_graph=True, allow_unused=True)
+    cd = torch.autograd.grad(ls32['loss_d'], [twin32.params[n] for n in d_names], allow_unused=True)
+    rows, num, den, num32 = [], 0.0, 0.0, 0.0
+    for names, tgr, hgr, cgr in ((g_names, tg, hg, cg), (d_names, td, hd, cd)):
+        for n, a, b, c in zip(names, tgr, hgr, cgr):
+            if a is None:
+                assert b is None or float(b.abs().max()) == 0.0, n
+                continue
+            a64, b64, c64 = a.numpy(), b.cpu().numpy().astype(np.float64), c.numpy().astype(np.float64)
+            rows.append((n, rel_err(b64, a64), rel_err(c64, a64)))
+            num += ((b64 - a64) ** 2).sum()
+            num32 += ((c64 - a64) ** 2).sum()
+            den += (a64 ** 2).sum()
+    noise = max(r[2] for r in rows)          # worst variable of the fp32 CPU evaluation (ReLU-flip noise level)
+    for n, e, e32 in rows:
+        assert e < max(1e-3, 4 * e32, 2 * noise), (n, e, e32, noise)
+    gl, gl32 = np.sqrt(num / den), np.sqrt(num32 / den)
+    print("gradient error: worst var %.3g (fp32 CPU worst %.3g); global L2 %.3g (fp32 CPU %.3g)"
+          % (max(r[1] for r in rows), noise, gl, gl32))
+    assert gl < max(1e-5, 4 * gl32), (gl, gl32)
+
+
+def test_encode_decode_api_padding(mesh_ops):
+    """numpy-in / numpy-out drivers with zero padding to batch_size (reference :931-1174)."""
+    N = 4
+    P, twin, model = _build("affine_nz64", mesh_ops, N)
+    x, gt, xd, cond, cond_d, clo, clo_d, eps = _inputs(6, P["nz"], seed=3)     # 6 = 4 + 2 (ragged last batch)
+    _run_twin(twin, x[:1], gt[:1], xd[:1], cond[:1], cond_d[:1], clo[:1], clo_d[:1], eps[:1])   # materialise all variables
+    y, y2 = twin.cond_embeddings(cond, clo)
+    zm, zl = twin.encoder(x, y, y2)
+    model.load_variables(twin.vs.vars)
+    hz, hl, hy, hy2 = model.encode(x, cond, clo)
+    assert hz.shape == (6, P["nz"]) and hy.shape == (6, P["nz_cond"]) and hy2.shape == (6, P["nz_cond2"])
+    assert rel_err(hz, zm.detach().numpy()) < 1e-4 and rel_err(hl, zl.detach().numpy()) < 1e-4
+    assert rel_err(hy, y.detach().numpy()) < 1e-5
+    c1, c2 = model.encode_only_condition(cond, clo)
+    assert np.allclose(c1, hy) and np.allclose(c2, hy2)
+    # decode with ONE condition row broadcast over several z (demos.py:392-395)
+    z_total = np.concatenate([zm.detach().numpy()[:5], np.repeat(hy[:1], 5, 0), np.repeat(hy2[:1], 5, 0)], 1)
+    rec = model.decode(z_total, cond=hy[:1], cond2=hy2[:1])
+    ref = twin.decoder_cond_vert(z_total, np.repeat(hy[:1], 5, 0), np.repeat(hy2[:1], 5, 0)).detach().numpy()
+    assert rec.shape == (5, 6890, 3) and vertex_err(rec, ref) < 1e-4
+    # predict with labels: loss averaging over the zero-padded last batch (:1083-1086)
+    preds, lr_, ll_, le_ = model.predict(x, cond, clo, labels=gt)
+    assert preds.shape == (6, 6890, 3) and np.isfinite([lr_, ll_, le_]).all()
+    assert model.predict(x[:3], cond[:3], clo[:3]).shape == (3, 6890, 3)
