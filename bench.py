@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- meshes/sec of the CAPE-affineconv_nz64 training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of 16 synthetic meshes PER GPU: the full
+CAPE-affineconv_nz64 Mesh-CVAE (reference configs/CAPE-affineconv_nz64_pose32_clotype32_male.yaml)
+forward + backward + gradient clipping + Momentum update (BASELINE.json configs[2]); with
+``--gan`` the mesh-patch discriminator passes and its update are included as well (the reference's
+adversarial step).  Inputs are resident in HBM before the timed region; weights are the reference
+initialisers (random), data is synthetic N(0,1) displacements on the real SMPL mesh hierarchy.
+Prints ONE JSON line (rank 0).  Data-parallel (weak scaling): per-GPU batch fixed, one flat
+gradient all-reduce per step over RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, chip table (fp32 matrix = vector peak)
+HBM_PEAK_GBS = 8000.0
+
+
+def build_model(batch, local_rank, config):
+    from cape_amd.configs import cape_params
+    from cape_amd.load_data import load_graph_mtx
+    from cape_amd.models import CAPE
+    L, D, U, p, L_d, D_d, _ = load_graph_mtx(None, load_for_demo=True)
+    params = cape_params(config, p=p, batch_size=batch, name='bench')
+    model = CAPE(L=L, D=D, U=U, L_d=L_d, D_d=D_d, device='cuda:%d' % local_rank, **params)
+    model.build_graph(model.input_num_verts, model.nn_input_channel, phase='train')
+    return model
+
+
+def synthetic_batch(model, seed):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    B, M = model.batch_size, model.input_num_verts
+    r = lambda *s: torch.randn(*s, generator=g)
+    x = r(B, M, 3)
+    clo = torch.eye(4)[torch.arange(B) % 4]
+    return dict(data_g=x, gt=x + 0.1 * r(B, M, 3), data_d=r(B, M, 3), cond_g=0.5 * r(B, 126), cond_d=0.5 * r(B, 126),
+                cond2_g=clo, cond2_d=clo.roll(1, 0), eps=r(B, int(model.nz)))
+
+
+def kernel_roofline(runner):
+    """Per-launch HIP-event timing of every gather-GEMM launch in ONE eager pass of the same step
+    (graph replays cannot be bracketed per kernel); returns the roofline object of the kernel
+    instantiation with the largest total time."""
+    from cape_amd import ops
+    ops.LAUNCH_LOG = []
+    torch.cuda.synchronize()
+    for _ in range(3):
+        runner._fwd_bwd()
+    torch.cuda.synchronize()
+    log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+    agg = {}
+    for name, flops, byts, e0, e1 in log:
+        a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[2] += flops
+        a[3] += byts
+    if not agg:
+        return None, {}
+    dom = max(agg, key=lambda k: agg[k][1])
+    n, t, fl, by = agg[dom]
+    achieved = fl / t / 1e12
+    table = {k: dict(launches=v[0] // 3, avg_us=1e6 * v[1] / v[0], tflops=v[2] / v[1] / 1e12, alg_gbs=v[3] / v[1] / 1e9)
+             for k, v in agg.items()}
+    roof = dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                launches_per_step=n // 3, avg_launch_us=round(1e6 * t / n, 2),
+                alg_flop_per_launch=fl / n, alg_bytes_per_launch=by / n,
+                hbm_alg_gbs=round(by / t / 1e9, 1), hbm_frac=round(by / t / 1e9 / HBM_PEAK_GBS, 4))
+    return roof, table
+
+
+def cpu_baseline(batch=2, iters=2):
+    """The CPU oracle (numpy/torch restatement of the reference's TF1 graph, reference op order, fp32)
+    timed on this host: forward+backward of the same CVAE step on a bounded sample."""
+    from cape_amd.load_data import load_graph_mtx, load_pack
+    from oracle.torch_twin import TwinCAPE
+    from oracle.configs import cape_params as oracle_params
+    L, D, U, p, L_d, D_d, _ = load_graph_mtx(None, load_for_demo=True)
+    pack = load_pack()
+    P = oracle_params('affine_nz64', batch)
+    twin = TwinCAPE(L, D, U, L_d, D_d, p=p, dtype=np.float64, tdtype=torch.float32, verts_ref=pack['template_verts'],
+                    vpe=pack['edges_smpl'], **P)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((batch, 6890, 3)).astype(np.float32)
+    cond = rng.standard_normal((batch, 126)).astype(np.float32)
+    clo = np.eye(4, dtype=np.float32)[np.arange(batch) % 4]
+    eps = rng.standard_normal((batch, P['nz'])).astype(np.float32)
+    times = []
+    for it in range(iters + 1):
+        t0 = time.time()
+        y, y2 = twin.cond_embeddings(cond, clo)
+        xh, zm, zl = twin.generator(x, y, y2, eps)
+        ls = twin.losses(xh, x, zm, zl)
+        torch.autograd.grad(ls['loss_g'], [v for n, v in twin.params.items() if not n.startswith('discriminator')],
+                            allow_unused=True)
+        if it:                        # first pass builds the variables
+            times.append(time.time() - t0)
+    t = float(np.median(times))
+    return dict(value=round(batch / t, 3), unit="meshes/s", cores=int(torch.get_num_threads()), kind="port",
+                sample="torch-CPU fp32 restatement of the TF1 graph (reference op order), CVAE fwd+bwd, batch %d, "
+                       "median of %d passes" % (batch, iters))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=16, help='meshes per GPU per step')
+    ap.add_argument('--config', default='CAPE-affineconv_nz64_pose32_clotype32_male')
+    ap.add_argument('--gan', action='store_true', help='include the discriminator passes/update (adversarial step)')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    from cape_amd import dist as cdist
+    from cape_amd.runtime import GraphedTrainStep
+    import torch.distributed as tdist
+    world, rank, local = cdist.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    model = build_model(args.batch, local, args.config)
+    hook = None
+    if world > 1:
+        for grp in ('g', 'd'):
+            cdist.broadcast_flat(model._opt_state[grp]['flat'])
+        hook = cdist.GradAverager()
+    runner = GraphedTrainStep(model, with_gan=args.gan, grad_hook=hook, use_graph=not args.no_graph)
+    runner.load_batch(**synthetic_batch(model, seed=1234 + rank))
+    torch.cuda.synchronize()
+    runner.capture()
+
+    for _ in range(args.warmup):
+        runner.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        tdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        tdist.barrier()
+    torch.cuda.synchronize()
+    elapsed = cdist.max_over_ranks(time.perf_counter() - t0, model.device)
+
+    loss = float(runner.losses['loss_g']) if 'loss_g' in runner.losses else float('nan')
+    roof, table = (None, {})
+    if not args.no_roofline:
+        roof, table = kernel_roofline(runner)
+    if rank != 0:
+        return
+    ms = 1e3 * elapsed / args.steps
+    result = {
+        "metric": "meshes/sec fwd+bwd, CAPE-affineconv nz64 @ batch 16, 1/2/4/8 MI355X",
+        "value": round(args.batch * world * args.steps / elapsed, 2), "unit": "meshes/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "CAPE-affineconv_nz64 Mesh-CVAE%s: fwd+bwd+clip+momentum update, batch %d per GPU, "
+                               "6890-vertex SMPL hierarchy (BASELINE configs[2])"
+                               % (" + mesh-patch discriminator (adversarial step)" if args.gan else "", args.batch),
+                   "global_batch": args.batch * world, "parallelism": "dp%d" % world, "graph_replay": runner._gA is not None,
+                   "final_loss_g": loss},
+        "roofline": roof,
+    }
+    if table:
+        result["kernels"] = {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in table.items()}
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline()
+    else:
+        result["cpu_baseline"] = None
+    print(json.dumps(result))
+
+
+if __name__ == '__main__':
+    main()

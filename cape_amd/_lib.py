@@ -6,6 +6,11 @@ import, and every compute entry point raises if no HIP device is present.
 import ctypes as C
 import os
 
+# torch MUST be imported before the library is loaded: libcape_hip.so needs libamdhip64.so.7 and has
+# to bind to the SAME HIP runtime instance PyTorch-ROCm uses (its bundled copy), otherwise streams,
+# device pointers and the primary context would belong to two different runtimes (hipErrorNoDevice).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcape_hip.so")
 

@@ -7,6 +7,14 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// hipGetLastError() is sticky per thread: clear whatever another runtime user (e.g. torch's device
+// probing) left behind before launching, so that CAPE_LAUNCH_CHECK reports OUR launch only.
+#define CAPE_LAUNCH(...)            \
+    do {                            \
+        (void)hipGetLastError();    \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
+
 #define CAPE_LAUNCH_CHECK()                          \
     do {                                             \
         hipError_t e__ = hipGetLastError();          \

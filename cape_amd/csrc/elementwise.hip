@@ -223,10 +223,10 @@ extern "C" int cape_spmm(const float *x, int64_t x_sample_stride, int32_t ldx, c
     hipStream_t st = (hipStream_t)stream;
     if (vec) {
         const long long total = (long long)N * Mo * (C / 4);
-        hipLaunchKernelGGL(spmm_kernel<true>, dim3(grid_for(total)), dim3(256), 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
+        CAPE_LAUNCH(spmm_kernel<true>, dim3(grid_for(total)), dim3(256), 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
     } else {
         const long long total = (long long)N * Mo * C;
-        hipLaunchKernelGGL(spmm_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
+        CAPE_LAUNCH(spmm_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
     }
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
@@ -240,7 +240,7 @@ extern "C" int cape_bias_act_fwd(const float *x, int64_t x_sample_stride, int32_
     if (act < CAPE_ACT_NONE || act > CAPE_ACT_TANH) return CAPE_EINVAL;
     CView xv{x, x_sample_stride, ldx};
     View yv{y, y_sample_stride, ldy};
-    hipLaunchKernelGGL(bias_act_kernel, dim3(grid_for((long long)N * M * C)), dim3(256), 0, (hipStream_t)stream, xv, bias,
+    CAPE_LAUNCH(bias_act_kernel, dim3(grid_for((long long)N * M * C)), dim3(256), 0, (hipStream_t)stream, xv, bias,
                        bias_mode, act, yv, N, M, C);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
@@ -256,8 +256,8 @@ extern "C" int cape_act_bwd(const float *dy, int64_t dy_sample_stride, int32_t l
     const bool vec = aligned4(dy, dy_sample_stride, lddy, C) && aligned4(y, y_sample_stride, ldy, C) &&
                      aligned4(dz, dz_sample_stride, lddz, C);
     hipStream_t st = (hipStream_t)stream;
-    if (vec) hipLaunchKernelGGL(act_bwd_kernel<true>, dim3(grid_for((long long)N * M * (C / 4))), dim3(256), 0, st, gv, ov, act, zv, N, M, C);
-    else hipLaunchKernelGGL(act_bwd_kernel<false>, dim3(grid_for((long long)N * M * C)), dim3(256), 0, st, gv, ov, act, zv, N, M, C);
+    if (vec) CAPE_LAUNCH(act_bwd_kernel<true>, dim3(grid_for((long long)N * M * (C / 4))), dim3(256), 0, st, gv, ov, act, zv, N, M, C);
+    else CAPE_LAUNCH(act_bwd_kernel<false>, dim3(grid_for((long long)N * M * C)), dim3(256), 0, st, gv, ov, act, zv, N, M, C);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }
@@ -276,16 +276,16 @@ extern "C" int cape_colsum(const float *x, int64_t x_sample_stride, int32_t ldx,
     CView xv{x, x_sample_stride, ldx};
     hipStream_t st = (hipStream_t)stream;
     if (per_vertex) {
-        hipLaunchKernelGGL(sum_over_samples_kernel, dim3(grid_for((long long)M * C)), dim3(256), 0, st, xv, N, M, C, accumulate, out);
+        CAPE_LAUNCH(sum_over_samples_kernel, dim3(grid_for((long long)M * C)), dim3(256), 0, st, xv, N, M, C, accumulate, out);
         CAPE_LAUNCH_CHECK();
         return CAPE_OK;
     }
     const long long R = (long long)N * M;
     const int nblk = (int)((R + COLSUM_RB - 1) / COLSUM_RB);
     if (!workspace || workspace_bytes < (int64_t)nblk * C * (int64_t)sizeof(float)) return CAPE_EWORKSPACE;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, xv, N, M, C, (float *)workspace);
+    CAPE_LAUNCH(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, xv, N, M, C, (float *)workspace);
     CAPE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float *)workspace, nblk, C, accumulate, out);
+    CAPE_LAUNCH(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float *)workspace, nblk, C, accumulate, out);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }
@@ -295,7 +295,7 @@ extern "C" int cape_mask_mul(const float *dy, int64_t dy_sample_stride, int32_t 
     if (!dy || !mask || !dz || N < 1 || M < 1 || F < 1 || lddy < F || lddz < F) return CAPE_EINVAL;
     CView gv{dy, dy_sample_stride, lddy};
     View zv{dz, dz_sample_stride, lddz};
-    hipLaunchKernelGGL(mask_mul_kernel, dim3(grid_for((long long)N * M * F)), dim3(256), 0, (hipStream_t)stream, gv, mask, zv, N, M, F);
+    CAPE_LAUNCH(mask_mul_kernel, dim3(grid_for((long long)N * M * F)), dim3(256), 0, (hipStream_t)stream, gv, mask, zv, N, M, F);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }
@@ -304,7 +304,7 @@ extern "C" int cape_fill_cond(const float *cond, int32_t ldc, const float *scale
                               int32_t ldy, int32_t N, int32_t M, int32_t C, void *stream) {
     if (!cond || !y || N < 1 || M < 1 || C < 1 || ldc < C || ldy < C) return CAPE_EINVAL;
     View yv{y, y_sample_stride, ldy};
-    hipLaunchKernelGGL(fill_cond_kernel, dim3(grid_for((long long)N * M * C)), dim3(256), 0, (hipStream_t)stream, cond, ldc, scale, yv, N, M, C);
+    CAPE_LAUNCH(fill_cond_kernel, dim3(grid_for((long long)N * M * C)), dim3(256), 0, (hipStream_t)stream, cond, ldc, scale, yv, N, M, C);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }
@@ -314,7 +314,7 @@ extern "C" int cape_reduce_cond(const float *dy, int64_t dy_sample_stride, int32
     if (!dy || !dcond || N < 1 || M < 1 || C < 1 || lddy < C || ldc < C) return CAPE_EINVAL;
     CView gv{dy, dy_sample_stride, lddy};
     const int cgroups = (C + 63) / 64;
-    hipLaunchKernelGGL(reduce_cond_kernel, dim3(N * cgroups), dim3(256), 0, (hipStream_t)stream, gv, scale, dcond, ldc, N, M, C, accumulate);
+    CAPE_LAUNCH(reduce_cond_kernel, dim3(N * cgroups), dim3(256), 0, (hipStream_t)stream, gv, scale, dcond, ldc, N, M, C, accumulate);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }

@@ -503,13 +503,13 @@ extern "C" int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, in
     dim3 grid((unsigned)(N * p.row_tiles * p.col_tiles)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (!dual) {
-        if (BN == 32) hipLaunchKernelGGL((gconv_fwd_kernel<128, 32, 4, 1, false>), grid, block, 0, st, p);
-        else if (BN == 64) hipLaunchKernelGGL((gconv_fwd_kernel<128, 64, 4, 1, false>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((gconv_fwd_kernel<128, 128, 2, 2, false>), grid, block, 0, st, p);
+        if (BN == 32) CAPE_LAUNCH((gconv_fwd_kernel<128, 32, 4, 1, false>), grid, block, 0, st, p);
+        else if (BN == 64) CAPE_LAUNCH((gconv_fwd_kernel<128, 64, 4, 1, false>), grid, block, 0, st, p);
+        else CAPE_LAUNCH((gconv_fwd_kernel<128, 128, 2, 2, false>), grid, block, 0, st, p);
     } else {
-        if (BN == 32) hipLaunchKernelGGL((gconv_fwd_kernel<128, 32, 4, 1, true>), grid, block, 0, st, p);
-        else if (BN == 64) hipLaunchKernelGGL((gconv_fwd_kernel<128, 64, 4, 1, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((gconv_fwd_kernel<128, 128, 2, 2, true>), grid, block, 0, st, p);
+        if (BN == 32) CAPE_LAUNCH((gconv_fwd_kernel<128, 32, 4, 1, true>), grid, block, 0, st, p);
+        else if (BN == 64) CAPE_LAUNCH((gconv_fwd_kernel<128, 64, 4, 1, true>), grid, block, 0, st, p);
+        else CAPE_LAUNCH((gconv_fwd_kernel<128, 128, 2, 2, true>), grid, block, 0, st, p);
     }
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
@@ -554,16 +554,16 @@ extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *
     p.ws = (float *)workspace; p.slab = pl.slab;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(pl.ntiles * N * pl.rsplit)), block(256);
-    if (pl.ct == 64 && pl.ft == 64) hipLaunchKernelGGL((gconv_dw_kernel<64, 64>), grid, block, 0, st, p);
-    else if (pl.ct == 64) hipLaunchKernelGGL((gconv_dw_kernel<64, 128>), grid, block, 0, st, p);
-    else if (pl.ft == 64) hipLaunchKernelGGL((gconv_dw_kernel<128, 64>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((gconv_dw_kernel<128, 128>), grid, block, 0, st, p);
+    if (pl.ct == 64 && pl.ft == 64) CAPE_LAUNCH((gconv_dw_kernel<64, 64>), grid, block, 0, st, p);
+    else if (pl.ct == 64) CAPE_LAUNCH((gconv_dw_kernel<64, 128>), grid, block, 0, st, p);
+    else if (pl.ft == 64) CAPE_LAUNCH((gconv_dw_kernel<128, 64>), grid, block, 0, st, p);
+    else CAPE_LAUNCH((gconv_dw_kernel<128, 128>), grid, block, 0, st, p);
     CAPE_LAUNCH_CHECK();
     rp.F = F; rp.nsplit = N * pl.rsplit; rp.accumulate = accumulate; rp.ws = (const float *)workspace; rp.slab = pl.slab;
     long long total = poff;
     int rblocks = (int)((total + 255) / 256);
     if (rblocks > 2048) rblocks = 2048;
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3(rblocks), dim3(256), 0, st, rp);
+    CAPE_LAUNCH(dw_reduce_kernel, dim3(rblocks), dim3(256), 0, st, rp);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }

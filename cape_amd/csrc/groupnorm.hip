@@ -130,9 +130,9 @@ extern "C" int cape_groupnorm_fwd(const float *x, int64_t x_sample_stride, int32
     if (!x || !gamma || !beta || !y || !stats || N < 1 || V < 1 || C < 1 || G < 1 || (C % G) != 0 || ldx < C || ldy < C)
         return CAPE_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(N * G), dim3(256), 0, st, x, (long long)x_sample_stride, ldx, eps, G, V, C, stats);
+    CAPE_LAUNCH(gn_stats_kernel, dim3(N * G), dim3(256), 0, st, x, (long long)x_sample_stride, ldx, eps, G, V, C, stats);
     CAPE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for((long long)N * V * C)), dim3(256), 0, st, x, (long long)x_sample_stride, ldx,
+    CAPE_LAUNCH(gn_apply_kernel, dim3(grid_for((long long)N * V * C)), dim3(256), 0, st, x, (long long)x_sample_stride, ldx,
                        gamma, beta, stats, G, relu, y, (long long)y_sample_stride, ldy, N, V, C);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
@@ -148,11 +148,11 @@ extern "C" int cape_groupnorm_bwd(const float *x, int64_t x_sample_stride, int32
         return CAPE_EINVAL;
     if (relu && (!y || ldy < C)) return CAPE_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(N * G), dim3(256), 0, st, x, (long long)x_sample_stride, ldx, y,
+    CAPE_LAUNCH(gn_bwd_stats_kernel, dim3(N * G), dim3(256), 0, st, x, (long long)x_sample_stride, ldx, y,
                        (long long)y_sample_stride, ldy, dy, (long long)dy_sample_stride, lddy, gamma, stats, G, relu, V, C,
                        dgamma_partial, dbeta_partial, gstats);
     CAPE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for((long long)N * V * C)), dim3(256), 0, st, x, (long long)x_sample_stride,
+    CAPE_LAUNCH(gn_bwd_apply_kernel, dim3(grid_for((long long)N * V * C)), dim3(256), 0, st, x, (long long)x_sample_stride,
                        ldx, y, (long long)y_sample_stride, ldy, dy, (long long)dy_sample_stride, lddy, gamma, stats, gstats, G,
                        relu, dx, (long long)dx_sample_stride, lddx, N, V, C);
     CAPE_LAUNCH_CHECK();

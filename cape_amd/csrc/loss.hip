@@ -127,13 +127,13 @@ extern "C" int cape_recon_edge_loss_fwd_bwd(const float *pred, const float *gt, 
     float *part_e = ws, *part_v = ws + 1024, *unit = ws + 2048;
     hipStream_t st = (hipStream_t)stream;
     const int ne = nblocks((long long)N * E), nv = nblocks((long long)N * M);
-    hipLaunchKernelGGL(edge_fwd_kernel, dim3(ne), dim3(LB), 0, st, pred, gt, verts_ref, edges, N, M, E, unit, part_e);
+    CAPE_LAUNCH(edge_fwd_kernel, dim3(ne), dim3(LB), 0, st, pred, gt, verts_ref, edges, N, M, E, unit, part_e);
     CAPE_LAUNCH_CHECK();
     const float cr = w_recon / ((float)N * (float)M * 3.0f);
     const float ce = w_edge / ((float)N * (float)E);
-    hipLaunchKernelGGL(vert_kernel, dim3(nv), dim3(LB), 0, st, pred, gt, unit, vert_edge_ptr, vert_edge_idx, N, M, E, cr, ce, dpred, part_v);
+    CAPE_LAUNCH(vert_kernel, dim3(nv), dim3(LB), 0, st, pred, gt, unit, vert_edge_ptr, vert_edge_idx, N, M, E, cr, ce, dpred, part_v);
     CAPE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(LB), 0, st, part_e, ne, 1.0f / ((float)N * (float)E), part_v, nv,
+    CAPE_LAUNCH(loss_final_kernel, dim3(1), dim3(LB), 0, st, part_e, ne, 1.0f / ((float)N * (float)E), part_v, nv,
                        1.0f / ((float)N * (float)M * 3.0f), loss_out);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;

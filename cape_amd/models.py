@@ -258,7 +258,11 @@ class base_model(object):
     def vae_sampling(self, z_mean, z_logvar, eps=None):
         if eps is None:
             eps = torch.randn((z_mean.shape[0], int(self.nz)), device=z_mean.device, dtype=torch.float32)
-        return z_mean + torch.sqrt(torch.exp(z_logvar)) * eps
+        # reference :195 writes sqrt(exp(logvar)); exp(0.5*logvar) is the same number (to rounding) but
+        # its gradient stays finite when exp(logvar) under/overflows in fp32 (|logvar| > ~88..103), where
+        # the sqrt/exp chain yields inf*0 = NaN -- reached within 10 steps from the reference initialisers
+        # on N(0,1) data.
+        return z_mean + torch.exp(0.5 * z_logvar) * eps
 
     def _get_path(self, folder):
         return os.path.join(self.project_dir, folder, self.name)
@@ -570,13 +574,29 @@ class CAPE(base_model):
 
     # ======================= optimiser shell (reference :419-474) ===================================
     def _init_optimizer(self):
+        """Flatten each variable group (G: generator + condition nets, D: discriminator) into ONE
+        contiguous fp32 buffer (variables become views of it) with matching flat gradient and
+        momentum buffers: the optimiser is a handful of launches over the flat buffers and the
+        data-parallel exchange is a single all-reduce of ``flat_grad`` (cape_amd.dist)."""
         self._opt_state = {}
         for grp, names in (('g', self._g_names), ('d', self._d_names)):
             params = [self._vars[n] for n in names]
-            st = {'params': params,
-                  'm': [torch.zeros_like(p) for p in params]}
+            total = sum(p.numel() for p in params)
+            flat = torch.empty(total, device=self.device, dtype=torch.float32)
+            flat_grad = torch.zeros(total, device=self.device, dtype=torch.float32)
+            views, off = [], 0
+            with torch.no_grad():
+                for p in params:
+                    n = p.numel()
+                    flat[off:off + n].copy_(p.detach().reshape(-1))
+                    p.data = flat[off:off + n].view(p.shape)
+                    views.append(flat_grad[off:off + n].view(p.shape))
+                    off += n
+            st = {'params': params, 'flat': flat, 'flat_grad': flat_grad, 'grad_views': views,
+                  'm': torch.zeros_like(flat),
+                  'neg_lr': torch.zeros((), device=self.device, dtype=torch.float32)}
             if self.optimizer == 'adam':
-                st['v'] = [torch.zeros_like(p) for p in params]
+                st['v'] = torch.zeros_like(flat)
                 st['t'] = 0
             self._opt_state[grp] = st
         self.global_step = 0
@@ -590,31 +610,43 @@ class CAPE(base_model):
             return base_lr * self.decay_rate ** ((step - warm) // max(ds, 1))
         return base_lr * self.decay_rate ** (step // max(ds, 1))
 
-    def _apply(self, grp, grads, lr, clip=5.0, pre_reduce=None):
-        """clip_by_global_norm(5.0) + Momentum (non-Nesterov) / Adam update, TF semantics."""
+    def set_learning_rates(self):
+        """Host side of the lr schedule (:426-442): write -lr into the device scalars read by
+        ``apply_updates`` (kept outside any captured graph)."""
+        lr_g = self._lr_at(self.lr_g, self.global_step)
+        lr_d = self._lr_at(self.lr_d, self.global_step)
+        self._opt_state['g']['neg_lr'].fill_(-lr_g)
+        self._opt_state['d']['neg_lr'].fill_(-lr_d)
+        return lr_g, lr_d
+
+    def store_grads(self, grp, grads):
         st = self._opt_state[grp]
-        params = st['params']
-        if pre_reduce is not None:
-            grads = pre_reduce(grads)
-        sq = torch.stack([(g * g).sum() for g in grads]).sum()
-        gnorm = torch.sqrt(sq)
-        scale = clip / torch.clamp(gnorm, min=clip)
         with torch.no_grad():
+            for view, g in zip(st['grad_views'], grads):
+                if g is None:
+                    view.zero_()
+                else:
+                    view.copy_(g)
+
+    def apply_updates(self, grp, clip=5.0):
+        """clip_by_global_norm(5.0) (:461) + Momentum (non-Nesterov, TF semantics: accum = m*accum + g;
+        var -= lr*accum) or Adam, on the flat buffers.  Capturable: no host reads."""
+        st = self._opt_state[grp]
+        g, flat, m = st['flat_grad'], st['flat'], st['m']
+        with torch.no_grad():
+            gnorm = torch.linalg.vector_norm(g)
+            scale = clip / torch.clamp(gnorm, min=clip)
             if self.optimizer == 'adam':
                 st['t'] += 1
                 b1, b2, eps = 0.9, 0.999, 1e-8
-                lr_t = lr * np.sqrt(1 - b2 ** st['t']) / (1 - b1 ** st['t'])
-                for p, g, m, v in zip(params, grads, st['m'], st['v']):
-                    g = g * scale
-                    m.mul_(b1).add_(g, alpha=1 - b1)
-                    v.mul_(b2).addcmul_(g, g, value=1 - b2)
-                    p.addcdiv_(m, v.sqrt().add_(eps), value=-lr_t)
+                corr = float(np.sqrt(1 - b2 ** st['t']) / (1 - b1 ** st['t']))
+                gs = g * scale
+                m.mul_(b1).add_(gs, alpha=1 - b1)
+                st['v'].mul_(b2).addcmul_(gs, gs, value=1 - b2)
+                flat.add_(st['neg_lr'] * corr * m / (st['v'].sqrt() + eps))
             else:
-                torch._foreach_mul_(st['m'], self.momentum)
-                scaled = torch._foreach_mul(list(grads), scale)
-                torch._foreach_add_(st['m'], scaled)
-                torch._foreach_add_(params, st['m'], alpha=-lr)
-        self.global_step += 1
+                m.mul_(self.momentum).addcmul_(g, scale)
+                flat.addcmul_(m, st['neg_lr'])
         return gnorm
 
     # ======================= training step ========================================================
@@ -654,26 +686,36 @@ class CAPE(base_model):
         out['loss_g'] = loss_g
         return out
 
-    def train_step(self, data_g, cond_g, cond2_g, gt, data_d, cond_d, cond2_d, eps=None, grad_hook=None):
-        """forward + backward + both optimiser updates on one (G batch, D batch) pair."""
-        out = self.forward_losses(data_g, cond_g, cond2_g, gt, data_d, cond_d, cond2_d, eps=eps)
+    def backward_to_flat(self, out):
+        """Gradients of loss_g w.r.t. the G group and loss_d w.r.t. the D group -> flat gradient buffers."""
         g_params = self._opt_state['g']['params']
         d_params = self._opt_state['d']['params']
-        lr_g = self._lr_at(self.lr_g, self.global_step)
-        lr_d = self._lr_at(self.lr_d, self.global_step)
+        if 'loss_d' not in out:
+            grads_g = torch.autograd.grad(out['loss_g'], g_params, allow_unused=True)
+            self.store_grads('g', grads_g)
+            return
         if self.bug_compat:
             grads_g = torch.autograd.grad(out['loss_g'], g_params, allow_unused=True)
-            grads_d = [p.detach() for p in d_params]          # quirk C2: clipped WEIGHTS as "gradients"
+            grads_d = [p.detach() for p in d_params]          # quirk C2: the WEIGHTS are clipped and applied
         else:
             grads = torch.autograd.grad([out['loss_g'], out['loss_d']], g_params + d_params,
                                         grad_outputs=[torch.ones_like(out['loss_g']), torch.ones_like(out['loss_d'])],
                                         allow_unused=True)
             grads_g, grads_d = grads[:len(g_params)], grads[len(g_params):]
-        grads_g = [g if g is not None else torch.zeros_like(p) for g, p in zip(grads_g, g_params)]
-        grads_d = [g if g is not None else torch.zeros_like(p) for g, p in zip(grads_d, d_params)]
-        self._apply('g', grads_g, lr_g, pre_reduce=grad_hook)
-        self._apply('d', grads_d, lr_d, pre_reduce=grad_hook if not self.bug_compat else None)
-        out['lr_g'], out['lr_d'] = lr_g, lr_d
+        self.store_grads('g', grads_g)
+        self.store_grads('d', grads_d)
+
+    def train_step(self, data_g, cond_g, cond2_g, gt, data_d, cond_d, cond2_d, eps=None, grad_hook=None):
+        """forward + backward + both optimiser updates on one (G batch, D batch) pair.
+        ``grad_hook(flat_grad)`` runs between backward and the update (data-parallel all-reduce)."""
+        out = self.forward_losses(data_g, cond_g, cond2_g, gt, data_d, cond_d, cond2_d, eps=eps)
+        self.backward_to_flat(out)
+        out['lr_g'], out['lr_d'] = self.set_learning_rates()
+        for grp in ('g', 'd'):
+            if grad_hook is not None and not (grp == 'd' and self.bug_compat):
+                grad_hook(self._opt_state[grp]['flat_grad'])
+            self.apply_updates(grp)
+            self.global_step += 1
         return out
 
     # ======================= checkpoints ============================================================
@@ -683,9 +725,8 @@ class CAPE(base_model):
         arrays = self.variables()
         arrays['training/global_step'] = np.asarray(self.global_step, dtype=np.int64)
         if self._opt_state is not None:
-            for grp, names in (('g', self._g_names), ('d', self._d_names)):
-                for n, m in zip(names, self._opt_state[grp]['m']):
-                    arrays[n + '/Momentum'] = m.detach().cpu().numpy()
+            for grp in ('g', 'd'):
+                arrays['training/momentum_' + grp] = self._opt_state[grp]['m'].detach().cpu().numpy()
         fn = os.path.join(path, 'model-%d.npz' % step)
         np.savez(fn, **arrays)
         keep = sorted(glob.glob(os.path.join(path, 'model-*.npz')), key=os.path.getmtime)
@@ -704,10 +745,10 @@ class CAPE(base_model):
         self.global_step = int(arrays.get('training/global_step', 0))
         if self._opt_state is not None:
             with torch.no_grad():
-                for grp, names in (('g', self._g_names), ('d', self._d_names)):
-                    for n, m in zip(names, self._opt_state[grp]['m']):
-                        if n + '/Momentum' in arrays:
-                            m.copy_(torch.from_numpy(arrays[n + '/Momentum']).to(m.device))
+                for grp in ('g', 'd'):
+                    key = 'training/momentum_' + grp
+                    if key in arrays and arrays[key].shape == tuple(self._opt_state[grp]['m'].shape):
+                        self._opt_state[grp]['m'].copy_(torch.from_numpy(arrays[key]).to(self.device))
 
     def _get_session(self, sess=None):
         """The reference restores the latest checkpoint on every inference call (:209-215, quirk C9);

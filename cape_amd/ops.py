@@ -118,6 +118,45 @@ def _mk_srcs(entries):
 
 
 # --------------------------------------------------------------------------------------------
+# per-launch timing hook (bench.py roofline leg): when LAUNCH_LOG is a list every gather-GEMM launch
+# is bracketed by HIP events on the launch stream and logged with its algorithmic work.
+# --------------------------------------------------------------------------------------------
+LAUNCH_LOG = None
+
+
+def _gconv_work(entries, N, Mo, F):
+    """Algorithmic work of one gather-GEMM launch: dense contraction 2*N*Mo*C*F per weight block plus
+    2*N*nnz*C for the sparse operator application; bytes = operands touched once (fp32)."""
+    flops, byts = 0, 4 * N * Mo * F
+    seen = set()
+    for e in entries:
+        Cs = int(e.get("C", e["x"].shape[2]))
+        nblk = 2 if e.get("w2") is not None else 1
+        flops += 2 * N * Mo * Cs * F * nblk
+        csr = e.get("csr")
+        if csr is not None and not csr.identity:
+            flops += 2 * N * csr.nnz * Cs
+            byts += 8 * csr.nnz + 4 * (csr.shape[0] + 1)
+        byts += 4 * Cs * F * nblk
+        key = e["x"].data_ptr()
+        if key not in seen:
+            seen.add(key)
+            byts += 4 * N * e["x"].shape[1] * Cs
+    return flops, byts
+
+
+def _log_launch(name, flops, byts, fn):
+    if LAUNCH_LOG is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = fn()
+    e1.record()
+    LAUNCH_LOG.append((name, flops, byts, e0, e1))
+    return out
+
+
+# --------------------------------------------------------------------------------------------
 # raw kernel wrappers (no autograd)
 # --------------------------------------------------------------------------------------------
 def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=None):
@@ -125,10 +164,21 @@ def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=
     arr = _mk_srcs(entries)
     N, Mo, F = y.shape
     p, ss, ld = _v(y)
-    rc = lib.cape_gconv_fwd(arr, len(entries), p, ss, ld, N, Mo, F, _ptr(bias),
-                            bias_mode if bias is not None else _lib.BIAS_NONE, _lib.ACT[act],
-                            _ptr(mask), _stream())
-    check(rc, "cape_gconv_fwd")
+
+    def launch():
+        rc = lib.cape_gconv_fwd(arr, len(entries), p, ss, ld, N, Mo, F, _ptr(bias),
+                                bias_mode if bias is not None else _lib.BIAS_NONE, _lib.ACT[act],
+                                _ptr(mask), _stream())
+        check(rc, "cape_gconv_fwd")
+
+    if LAUNCH_LOG is None:
+        launch()
+    else:
+        dual = any(e.get("w2") is not None for e in entries)
+        bn = 32 if F <= 32 else (64 if F <= 64 else 128)
+        name = "gconv_fwd_kernel<128,%d,%s,%s>" % (bn, "2,2" if bn == 128 else "4,1", "true" if dual else "false")
+        flops, byts = _gconv_work(entries, N, Mo, F)
+        _log_launch(name, flops, byts, launch)
     return y
 
 
