@@ -11,6 +11,12 @@
 // mode (:776-793) and -- with transposed operators and weights -- their data gradients.
 // The weight-gradient kernel (contraction over vertices) lives below.
 #include "common.h"
+#ifndef CAPE_EXP
+#define CAPE_EXP 0
+#endif
+#ifndef CAPE_SPEC
+#define CAPE_SPEC 0
+#endif
 
 namespace {
 
@@ -53,25 +59,51 @@ __device__ __forceinline__ void stage_gather(float *sA, const SrcDev &S, int n, 
     const int c = c0 + 4 * q;
     const float *xb = S.x + (long long)n * S.xs + c;
     const int nvalid = S.C - c;   // channels available from c
+    constexpr int P = ROWS / 32;
+    if (!S.rp && S.vec && nvalid >= 4) {
+        // plain source, aligned: issue every load of the chunk before the first LDS store
+        float4 v[P];
 #pragma unroll
-    for (int pass = 0; pass < ROWS / 32; ++pass) {
+        for (int pass = 0; pass < P; ++pass) {
+            const int r = r0 + rl0 + 32 * pass;
+            // unconditional load from a clamped (always valid) row, zeroed by a select afterwards:
+            // a branch around each load would make hipcc wait vmcnt(0) per load (serialised round trips)
+            const int rc = r < Mo ? r : Mo - 1;
+            v[pass] = *reinterpret_cast<const float4 *>(xb + (long long)rc * S.ldx);
+        }
+#pragma unroll
+        for (int pass = 0; pass < P; ++pass) {
+            const bool ok = (r0 + rl0 + 32 * pass) < Mo;
+            float4 o = v[pass];
+            o.x = ok ? o.x : 0.f; o.y = ok ? o.y : 0.f; o.z = ok ? o.z : 0.f; o.w = ok ? o.w : 0.f;
+            *reinterpret_cast<float4 *>(&sA[(rl0 + 32 * pass) * LDA + 4 * q]) = o;
+        }
+        return;
+    }
+#pragma unroll
+    for (int pass = 0; pass < P; ++pass) {
         const int rl = rl0 + 32 * pass;
         const int r = r0 + rl;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < Mo && nvalid > 0) {
             if (S.vec && nvalid >= 4) {
-                if (S.rp) {
-                    const int e1 = S.rp[r + 1];
-                    for (int e = S.rp[r]; e < e1; ++e) {
-                        const float v = S.va[e];
-                        const float4 xv = *reinterpret_cast<const float4 *>(xb + (long long)S.ci[e] * S.ldx);
-                        acc.x = fmaf(v, xv.x, acc.x);
-                        acc.y = fmaf(v, xv.y, acc.y);
-                        acc.z = fmaf(v, xv.z, acc.z);
-                        acc.w = fmaf(v, xv.w, acc.w);
-                    }
-                } else {
-                    acc = *reinterpret_cast<const float4 *>(xb + (long long)r * S.ldx);
+                // gathered source: two row entries in flight per step
+                const int e1 = S.rp[r + 1];
+                int e = S.rp[r];
+                for (; e + 1 < e1; e += 2) {
+                    const float v0 = S.va[e], v1 = S.va[e + 1];
+                    const float4 x0 = *reinterpret_cast<const float4 *>(xb + (long long)S.ci[e] * S.ldx);
+                    const float4 x1 = *reinterpret_cast<const float4 *>(xb + (long long)S.ci[e + 1] * S.ldx);
+                    acc.x = fmaf(v0, x0.x, acc.x); acc.y = fmaf(v0, x0.y, acc.y);
+                    acc.z = fmaf(v0, x0.z, acc.z); acc.w = fmaf(v0, x0.w, acc.w);
+                    acc.x = fmaf(v1, x1.x, acc.x); acc.y = fmaf(v1, x1.y, acc.y);
+                    acc.z = fmaf(v1, x1.z, acc.z); acc.w = fmaf(v1, x1.w, acc.w);
+                }
+                if (e < e1) {
+                    const float v0 = S.va[e];
+                    const float4 x0 = *reinterpret_cast<const float4 *>(xb + (long long)S.ci[e] * S.ldx);
+                    acc.x = fmaf(v0, x0.x, acc.x); acc.y = fmaf(v0, x0.y, acc.y);
+                    acc.z = fmaf(v0, x0.z, acc.z); acc.w = fmaf(v0, x0.w, acc.w);
                 }
             } else {
                 float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -98,43 +130,101 @@ __device__ __forceinline__ void stage_gather(float *sA, const SrcDev &S, int n, 
 }
 
 // ---- B-tile staging: weights [KC x BN] with arbitrary (row, col) strides -> LDS [KC][BN+4]
-template <int BN, int LDB>
+// NT = number of staging threads (the loader half of the workgroup)
+template <int BN, int LDB, int NT>
 __device__ __forceinline__ void stage_weights(float *sB, const float *w, long long rs, long long cs,
                                                int C, int F, int c0, int f0, int tid) {
-    const bool kmajor = (rs == 1 && cs != 1);   // contraction index contiguous in memory
-#pragma unroll 4
-    for (int idx = tid; idx < KC * BN; idx += 256) {
-        int kk, j;
-        if (kmajor) {
-            kk = idx & (KC - 1);
-            j = idx / KC;
-        } else {
-            j = idx % BN;
-            kk = idx / BN;
+    if (cs == 1 && ((rs & 3) == 0) && ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0)) {
+        // output index contiguous in memory (forward weights): float4 along f
+        constexpr int NL = (KC * (BN / 4) + NT - 1) / NT;
+        float4 v[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = tid + i * NT;
+            const int j4 = idx % (BN / 4), kk = idx / (BN / 4);
+            const int c = c0 + kk, f = f0 + 4 * j4;
+            const int cc = c < C ? c : C - 1, fc = f < F ? f : 0;      // clamped, always valid
+            v[i] = *reinterpret_cast<const float4 *>(w + cc * rs + fc);
         }
-        const int c = c0 + kk, f = f0 + j;
-        float v = 0.f;
-        if (c < C && f < F) v = w[c * rs + f * cs];
-        sB[kk * LDB + j] = v;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = tid + i * NT;
+            const int j4 = idx % (BN / 4), kk = idx / (BN / 4);
+            const bool ok = (c0 + kk < C) && (f0 + 4 * j4 < F);
+            float4 o = v[i];
+            o.x = ok ? o.x : 0.f; o.y = ok ? o.y : 0.f; o.z = ok ? o.z : 0.f; o.w = ok ? o.w : 0.f;
+            if (idx < KC * (BN / 4)) *reinterpret_cast<float4 *>(&sB[kk * LDB + 4 * j4]) = o;
+        }
+    } else if (rs == 1 && ((cs & 3) == 0) && ((C & 3) == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0)) {
+        // contraction index contiguous in memory (transposed weights, data gradient): float4 along c
+        constexpr int NL = ((KC / 4) * BN + NT - 1) / NT;
+        float4 v[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = tid + i * NT;
+            const int k4 = idx % (KC / 4), j = idx / (KC / 4);
+            const int c = c0 + 4 * k4, f = f0 + j;
+            const int cc = c < C ? c : 0, fc = f < F ? f : F - 1;      // clamped, always valid
+            v[i] = *reinterpret_cast<const float4 *>(w + cc + fc * cs);
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int idx = tid + i * NT;
+            const int k4 = idx % (KC / 4), j = idx / (KC / 4);
+            const bool ok = (c0 + 4 * k4 < C) && (f0 + j < F);
+            if (idx < (KC / 4) * BN) {
+                sB[(4 * k4 + 0) * LDB + j] = ok ? v[i].x : 0.f;
+                sB[(4 * k4 + 1) * LDB + j] = ok ? v[i].y : 0.f;
+                sB[(4 * k4 + 2) * LDB + j] = ok ? v[i].z : 0.f;
+                sB[(4 * k4 + 3) * LDB + j] = ok ? v[i].w : 0.f;
+            }
+        }
+    } else {
+        const bool kmajor = (rs == 1 && cs != 1);
+#pragma unroll 4
+        for (int idx = tid; idx < KC * BN; idx += NT) {
+            int kk, j;
+            if (kmajor) {
+                kk = idx & (KC - 1);
+                j = idx / KC;
+            } else {
+                j = idx % BN;
+                kk = idx / BN;
+            }
+            const int c = c0 + kk, f = f0 + j;
+            float v = 0.f;
+            if (c < C && f < F) v = w[c * rs + f * cs];
+            sB[kk * LDB + j] = v;
+        }
     }
 }
 
+// Workgroup = 8 waves with SPLIT ROLES (CDNA4: MFMA and VALU/VMEM are separate pipes that co-issue
+// from different waves of a SIMD): waves 0-3 only read LDS tiles and issue v_mfma_f32_32x32x2_f32,
+// waves 4-7 only gather/stage the NEXT [BM x 32] A chunk and [32 x BN] weight chunk into the other
+// LDS buffer.  One barrier per chunk hands the buffers over; the MFMA waves never wait on global
+// memory, the loader waves are free to sit on L2 latency.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool DUAL>
-__global__ __launch_bounds__(256) void gconv_fwd_kernel(GconvParams p) {
+__global__ __launch_bounds__(CAPE_SPEC ? 512 : 256) void gconv_fwd_kernel(GconvParams p) {
     constexpr int LDA = KC + 4;
     constexpr int LDB = BN + 4;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    constexpr int A_SZ = BM * LDA, B_SZ = KC * LDB;
+    constexpr int BUF_SZ = A_SZ + (DUAL ? 2 : 1) * B_SZ;
+    static_assert(WAVES_M * WAVES_N == 4, "4 MFMA waves per workgroup");
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
 
-    __shared__ __attribute__((aligned(16))) float smem[BM * LDA + (DUAL ? 2 : 1) * KC * LDB];
-    float *sA = smem;
-    float *sB = smem + BM * LDA;
-    float *sB2 = sB + KC * LDB;
+    __shared__ __attribute__((aligned(16))) float smem[(CAPE_SPEC ? 2 : 1) * BUF_SZ];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+#if CAPE_SPEC
+    const bool loader = tid >= 256;
+#else
+    const bool loader = false;
+#endif
+    const int ltid = tid & 255;
+    const int lane = tid & 63, wave = (tid >> 6) & 3;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int li = lane & 31, lh = lane >> 5;
 
@@ -155,19 +245,34 @@ __global__ __launch_bounds__(256) void gconv_fwd_kernel(GconvParams p) {
                 if (DUAL) acc2[a][b][g] = 0.f;
             }
 
-    for (int si = 0; si < p.nsrc; ++si) {
-        const SrcDev &S = p.s[si];
-        const bool has2 = DUAL && (S.w2 != nullptr);
-        for (int c0 = 0; c0 < S.C; c0 += KC) {
-            __syncthreads();
-            stage_gather<BM, LDA>(sA, S, n, r0, p.Mo, c0, tid);
-            stage_weights<BN, LDB>(sB, S.w, S.wrs, S.wcs, S.C, p.F, c0, f0, tid);
-            if (has2) stage_weights<BN, LDB>(sB2, S.w2, S.w2rs, S.w2cs, S.C, p.F, c0, f0, tid);
-            __syncthreads();
+    int total = 0;
+    for (int si = 0; si < p.nsrc; ++si) total += (p.s[si].C + KC - 1) / KC;
+
+    // loader cursor (source, channel offset) of the NEXT chunk to stage; consumer cursor of the
+    // chunk being multiplied (only its source's w2 flag matters)
+    int l_si = 0, l_c0 = 0;
+    int c_si = 0, c_c0 = 0;
+
+    auto stage = [&](int buf) {
+        const SrcDev &S = p.s[l_si];
+        float *sA = smem + buf * BUF_SZ;
+        float *sB = sA + A_SZ;
+        stage_gather<BM, LDA>(sA, S, n, r0, p.Mo, l_c0, ltid);
+        stage_weights<BN, LDB, 256>(sB, S.w, S.wrs, S.wcs, S.C, p.F, l_c0, f0, ltid);
+        if (DUAL && S.w2) stage_weights<BN, LDB, 256>(sB + B_SZ, S.w2, S.w2rs, S.w2cs, S.C, p.F, l_c0, f0, ltid);
+        l_c0 += KC;
+        if (l_c0 >= S.C) { l_c0 = 0; ++l_si; }
+    };
+
+    auto compute = [&](int buf) {
+            const float *sA = smem + buf * BUF_SZ;
+            const float *sB = sA + A_SZ;
+            const float *sB2 = sB + B_SZ;
+            const bool has2 = DUAL && (p.s[c_si].w2 != nullptr);
 #pragma unroll
             for (int kb = 0; kb < KC / 8; ++kb) {
-                // contraction index permutation: MFMA step t of this block of 8 uses physical
-                // index kb*8 + 4*lh + t for lane-half lh (same mapping for A and B).
+                // contraction index permutation: MFMA step u of this block of 8 uses physical
+                // index kb*8 + 4*lh + u for lane-half lh (same mapping for A and B).
                 float4 av[TM];
                 float bv[TN][4];
 #pragma unroll
@@ -208,8 +313,30 @@ __global__ __launch_bounds__(256) void gconv_fwd_kernel(GconvParams p) {
                     }
                 }
             }
+            c_c0 += KC;
+            if (c_c0 >= p.s[c_si].C) { c_c0 = 0; ++c_si; }
+    };
+
+#if CAPE_SPEC
+    if (loader) stage(0);
+    __syncthreads();
+    for (int it = 0; it < total; ++it) {
+        if (loader) {
+            if (it + 1 < total) stage((it + 1) & 1);
+        } else {
+            compute(it & 1);
         }
+        __syncthreads();
     }
+#else
+    for (int it = 0; it < total; ++it) {
+        __syncthreads();
+        stage(0);
+        __syncthreads();
+        compute(0);
+    }
+#endif
+    if (loader) return;
 
     // ---- epilogue: C layout of 32x32 MFMA: col = lane&31, row = (g&3) + 8*(g>>2) + 4*(lane>>5)
     float *yb = p.y + (long long)n * p.ys;
@@ -500,7 +627,7 @@ extern "C" int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, in
     const int BN = (F <= 32) ? 32 : (F <= 64) ? 64 : 128;
     p.row_tiles = (Mo + BM - 1) / BM;
     p.col_tiles = (F + BN - 1) / BN;
-    dim3 grid((unsigned)(N * p.row_tiles * p.col_tiles)), block(256);
+    dim3 grid((unsigned)(N * p.row_tiles * p.col_tiles)), block(CAPE_SPEC ? 512 : 256);
     hipStream_t st = (hipStream_t)stream;
     if (!dual) {
         if (BN == 32) CAPE_LAUNCH((gconv_fwd_kernel<128, 32, 4, 1, false>), grid, block, 0, st, p);

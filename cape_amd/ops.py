@@ -16,6 +16,10 @@ from . import _lib
 from ._lib import lib, CapeSrc, check
 from .graph import ConvOperators, HostCSR
 
+# "twopass": sparse operators applied by the streaming spmm kernel, dense contraction as a plain GEMM
+# "fused":   sparse operators gathered inside the GEMM kernel's A-tile staging (one launch per layer)
+MODE = "twopass"
+
 _ACT_OF = {"b1leakyrelu": ("leaky", _lib.BIAS_CHANNEL), "b1relu": ("relu", _lib.BIAS_CHANNEL),
            "b1tanh": ("tanh", _lib.BIAS_CHANNEL), "b2relu": ("relu", _lib.BIAS_VERTEX)}
 
@@ -375,6 +379,109 @@ class ChebConvFn(torch.autograd.Function):
         return dx, dW, dB, dWa, dcond, None, None, None
 
 
+class ChebConvTwoPassFn(torch.autograd.Function):
+    """Same operator as ChebConvFn, evaluated in two passes: the sparse operators S_k are applied by
+    the streaming ``cape_spmm`` kernel (X_k = S_k x materialised once, kept for the weight gradient),
+    and the dense contraction runs as a plain multi-source GEMM (no gather in the MFMA kernel's
+    staging).  The data gradient applies S_k^T either before or after the W_k^T contraction,
+    whichever side has fewer rows / channels."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, W_aff, cond, ops, act, bias_mode):
+        x = as_act(x)
+        N, Mi, Cin = x.shape
+        K, Fout = ops.K, W.shape[1]
+        assert ops.fused and W.shape[0] == Cin * K and Mi == ops.Mi
+        Cc = 0 if cond is None else cond.shape[1]
+        yfull = alloc_act(N, ops.Mo, Fout + Cc, x.device)
+        y = yfull[:, :, :Fout]
+        xs = [x if ops.fwd[k].identity else spmm(x, ops.fwd[k]) for k in range(K)]
+        entries = []
+        for k in range(K):
+            e = dict(x=xs[k], csr=None, w=(W, k * Fout, K * Fout, 1))
+            if W_aff is not None and k == 0:
+                e["w2"] = (W_aff, 0, Fout, 1)
+            entries.append(e)
+        mask = None
+        if W_aff is not None:
+            mask = torch.empty((N, ops.Mo, (Fout + 31) // 32), device=x.device, dtype=torch.int32)
+            gconv_fwd(entries, y, mask=mask)
+        else:
+            gconv_fwd(entries, y, bias=bias, bias_mode=bias_mode, act=act)
+        if Cc:
+            fill_cond(cond.contiguous(), yfull[:, :, Fout:])
+        ctx.ops, ctx.act, ctx.bias_mode, ctx.Fout, ctx.Cc = ops, act, bias_mode, Fout, Cc
+        ctx.has_bias = bias is not None
+        ctx.xshape = (N, Mi, Cin)
+        ctx.save_for_backward(W, W_aff, mask, yfull if (act != "none" and W_aff is None) else None, *xs)
+        return yfull
+
+    @staticmethod
+    def backward(ctx, gfull):
+        W, W_aff, mask, ysaved = ctx.saved_tensors[:4]
+        xs = ctx.saved_tensors[4:]
+        ops, act, Fout, Cc = ctx.ops, ctx.act, ctx.Fout, ctx.Cc
+        K = ops.K
+        N, Mi, Cin = ctx.xshape
+        Mo = ops.Mo
+        dev = W.device
+        gfull = as_act(gfull)
+        g = gfull[:, :, :Fout]
+        need_x, need_w, need_b, need_wa, need_c = (ctx.needs_input_grad[i] for i in range(5))
+        dW = dB = dWa = dcond = dx = None
+        if W_aff is not None:
+            dz = mask_mul(g, mask)
+        elif act != "none":
+            dz = act_bwd(g, ysaved[:, :, :Fout], act)
+        else:
+            dz = g
+        if need_b and ctx.has_bias:
+            if ctx.bias_mode == _lib.BIAS_VERTEX:
+                dB = torch.empty((1, Mo, Fout), device=dev, dtype=torch.float32)
+                colsum(dz, dB, per_vertex=True)
+            else:
+                dB = torch.empty((1, 1, Fout), device=dev, dtype=torch.float32)
+                colsum(dz, dB)
+        if need_w:
+            dW = torch.empty_like(W)
+            gconv_dw([dict(x=xs[k], csr=None, w=(dW, k * Fout, K * Fout, 1)) for k in range(K)], dz)
+        if W_aff is not None and need_wa:
+            dWa = torch.empty_like(W_aff)
+            gconv_dw([dict(x=xs[0], csr=None, w=(dWa, 0, Fout, 1))], g)
+        if need_x:
+            # transposed weight blocks with the output index contiguous: Wt[k][f][c] = W[c*K+k][f]
+            Wt = W.view(Cin, K, Fout).permute(1, 2, 0).contiguous()
+            Wat = W_aff.t().contiguous() if W_aff is not None else None
+            contract_first = (Mo < Mi) or (Mo == Mi and Cin < Fout)
+            if contract_first:
+                # G_k = dz W_k^T at the Mo output rows, then dx = sum_k S_k^T G_k
+                dx = None
+                for k in range(K):
+                    ent = [dict(x=dz, csr=None, w=(Wt, k * Fout * Cin, Cin, 1))]
+                    if W_aff is not None and k == 0:
+                        ent.append(dict(x=g, csr=None, w=(Wat, 0, Cin, 1)))
+                    Gk = alloc_act(N, Mo, Cin, dev)
+                    gconv_fwd(ent, Gk)
+                    if ops.bwd[k].identity:
+                        dx = Gk if dx is None else dx.add_(Gk)
+                    else:
+                        dx = spmm(Gk, ops.bwd[k]) if dx is None else spmm(Gk, ops.bwd[k], z=dx, beta=1.0, y=dx)
+            else:
+                # T_k = S_k^T dz at the Mi input rows, then one GEMM over all sources
+                ent = []
+                for k in range(K):
+                    Tk = dz if ops.bwd[k].identity else spmm(dz, ops.bwd[k])
+                    ent.append(dict(x=Tk, csr=None, w=(Wt, k * Fout * Cin, Cin, 1)))
+                if W_aff is not None:
+                    Ta = g if ops.bwd[0].identity else spmm(g, ops.bwd[0])
+                    ent.append(dict(x=Ta, csr=None, w=(Wat, 0, Cin, 1)))
+                dx = alloc_act(N, Mi, Cin, dev)
+                gconv_fwd(ent, dx)
+        if Cc and need_c:
+            dcond = reduce_cond(gfull[:, :, Fout:])
+        return dx, dW, dB, dWa, dcond, None, None, None
+
+
 class ChebConvRecurrenceFn(torch.autograd.Function):
     """General-K chebyshev5 (lib/models.py:69-103) by the explicit recurrence
     x_k = 2 L~ x_{k-1} - x_{k-2} with standalone sparse applications; used above FUSE_MAX_K."""
@@ -550,7 +657,8 @@ def chebyshev5(x, W, ops, bias=None, activation=None, cond=None, W_affine=None):
     else:
         act, bmode = _ACT_OF[activation]
     if ops.fused:
-        return ChebConvFn.apply(x, W, bias, W_affine, cond, ops, act, bmode)
+        fn = ChebConvTwoPassFn if MODE == "twopass" else ChebConvFn
+        return fn.apply(x, W, bias, W_affine, cond, ops, act, bmode)
     assert W_affine is None
     y = ChebConvRecurrenceFn.apply(x, W, bias, ops, act, bmode)
     if cond is not None:

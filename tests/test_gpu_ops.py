@@ -68,9 +68,11 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("mode", ["twopass", "fused"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_cheb_conv_fwd_bwd(case, mesh_ops, dev):
+def test_cheb_conv_fwd_bwd(case, mode, mesh_ops, dev, monkeypatch):
     from cape_amd import ops
+    monkeypatch.setattr(ops, "MODE", mode)
     from cape_amd.graph import ConvOperators
     name, level, N, Cin, Fout, K, act, bias_kind, pool_i, unpool_i, Cc, affine = case
     if isinstance(level, str):
