@@ -28,6 +28,10 @@ class CapeSrc(C.Structure):
     ]
 
 
+class CapeRank(C.Structure):
+    _fields_ = [("R", C.c_int32), ("rowscale", C.c_void_p), ("coef", C.c_void_p), ("to_acc2", C.c_uint32)]
+
+
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         "cape_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -41,7 +45,10 @@ _SRCP = C.POINTER(CapeSrc)
 SIGNATURES = {
     "cape_abi_version": (C.c_int, []),
     "cape_csr_validate": (C.c_int, [_i32, _i32, _i64, _p, _p]),
-    "cape_gconv_fwd": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p, _i32, _i32, _p, _p]),
+    "cape_gconv_fwd": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p, _i32, _i32, _p,
+                                 C.POINTER(CapeRank), _p]),
+    "cape_rowscale_reduce_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
+    "cape_rowscale_reduce": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _i32, _i32, _p, _p, _i64, _p]),
     "cape_gconv_dw_workspace_bytes": (_i64, [_SRCP, _i32, _i32, _i32, _i32]),
     "cape_gconv_dw": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p, _i64, _p]),
     "cape_spmm": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _f32, _p, _i64, _i32, _f32, _p, _i64, _i32,

@@ -121,7 +121,34 @@ __global__ __launch_bounds__(256) void mask_mul_kernel(CView dy, const unsigned 
 
 // ---- column sums -----------------------------------------------------------------------------
 // stage 1: block b sums rows [b*RB, (b+1)*RB) of the flattened (n,m) row space -> part[b][c]
-constexpr int COLSUM_RB = 512;
+constexpr int COLSUM_RB = 128;
+
+// aligned fast path (C % 4 == 0, C <= 256): thread = (float4 column, row lane)
+__global__ __launch_bounds__(256) void colsum_partial_vec_kernel(CView x, int N, int M, int C, float *part) {
+    __shared__ float4 red[256];
+    const int c4n = C >> 2;
+    const int lanes = 256 / c4n;               // row lanes
+    const int q = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+    const long long R = (long long)N * M;
+    const long long ra = (long long)blockIdx.x * COLSUM_RB;
+    const long long rb = (ra + COLSUM_RB < R) ? ra + COLSUM_RB : R;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rl < lanes)
+        for (long long r = ra + rl; r < rb; r += lanes) {
+            const long long n = r / M, m = r % M;
+            const float4 v = *reinterpret_cast<const float4 *>(x.p + n * x.ss + m * x.ld + 4 * q);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0) {
+        for (int l = 1; l < lanes; ++l) {
+            const float4 v = red[l * c4n + q];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(part + (long long)blockIdx.x * C + 4 * q) = s;
+    }
+}
 
 __global__ __launch_bounds__(256) void colsum_partial_kernel(CView x, int N, int M, int C, float *part) {
     __shared__ float red[4][64];
@@ -144,12 +171,20 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(CView x, int N, int
     }
 }
 
+// stage 2: block = 64 columns x 4 partial lanes
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float *part, int nblk, int C, int accumulate, float *out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(long long)b * C + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < C)
+        for (int b = pl; b < nblk; b += 4) s += part[(long long)b * C + c];
+    red[pl][cl] = s;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 __global__ __launch_bounds__(256) void sum_over_samples_kernel(CView x, int N, int M, int C, int accumulate, float *out) {
@@ -199,6 +234,56 @@ __global__ __launch_bounds__(256) void reduce_cond_kernel(CView dy, const float 
         float *d = dcond + (long long)n * ldc + c;
         *d = accumulate ? *d + t : t;
     }
+}
+
+// ---- out[n, j, f] = sum_r rowscale[j, r] * dz[n, r, f]   (gradient of the rank-1 condition terms)
+constexpr int RSR_RB = 128;   // rows per block
+constexpr int RSR_MAXR = 4;
+
+// stage 1: block = (sample n, row chunk), thread = (column, row lane); part[n][chunk][j][f]
+__global__ __launch_bounds__(256) void rowscale_partial_kernel(CView dz, const float *rowscale, int R, int N, int Mo, int F,
+                                                               float *part, int chunks) {
+    __shared__ float red[RSR_MAXR][256];
+    const int n = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+    const int ra = ch * RSR_RB, rb = min(Mo, ra + RSR_RB);
+    for (int fbase = 0; fbase < F; fbase += 64) {
+        const int fl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+        const int f = fbase + fl;
+        float acc[RSR_MAXR] = {0.f, 0.f, 0.f, 0.f};
+        if (f < F)
+            for (int r = ra + rl; r < rb; r += 4) {
+                const float v = dz.p[(long long)n * dz.ss + (long long)r * dz.ld + f];
+#pragma unroll
+                for (int j = 0; j < RSR_MAXR; ++j)
+                    if (j < R) acc[j] = fmaf(rowscale[(long long)j * Mo + r], v, acc[j]);
+            }
+#pragma unroll
+        for (int j = 0; j < RSR_MAXR; ++j) red[j][threadIdx.x] = acc[j];
+        __syncthreads();
+        if (rl == 0 && f < F) {
+#pragma unroll
+            for (int j = 0; j < RSR_MAXR; ++j)
+                if (j < R)
+                    part[(((long long)n * chunks + ch) * R + j) * F + f] =
+                        (red[j][fl] + red[j][64 + fl]) + (red[j][128 + fl] + red[j][192 + fl]);
+        }
+        __syncthreads();
+    }
+}
+
+// stage 2: out[n][j][f] = sum_chunk part[n][chunk][j][f]; block = 64 (j,f) elements x 4 chunk lanes
+__global__ __launch_bounds__(256) void rowscale_final_kernel(const float *part, int chunks, int RF, int N, float *out) {
+    __shared__ float red[4][64];
+    const int el = threadIdx.x & 63, cl = threadIdx.x >> 6;
+    const int blocks_per_n = (RF + 63) / 64;
+    const int n = blockIdx.x / blocks_per_n;
+    const int e = (blockIdx.x % blocks_per_n) * 64 + el;
+    float s = 0.f;
+    if (e < RF)
+        for (int c = cl; c < chunks; c += 4) s += part[((long long)n * chunks + c) * RF + e];
+    red[cl][el] = s;
+    __syncthreads();
+    if (cl == 0 && e < RF) out[(long long)n * RF + e] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
 }
 
 inline int grid_for(long long total) {
@@ -283,9 +368,12 @@ extern "C" int cape_colsum(const float *x, int64_t x_sample_stride, int32_t ldx,
     const long long R = (long long)N * M;
     const int nblk = (int)((R + COLSUM_RB - 1) / COLSUM_RB);
     if (!workspace || workspace_bytes < (int64_t)nblk * C * (int64_t)sizeof(float)) return CAPE_EWORKSPACE;
-    CAPE_LAUNCH(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, xv, N, M, C, (float *)workspace);
+    if (aligned4(x, x_sample_stride, ldx, C) && C <= 256 && (256 % (C / 4)) == 0)
+        CAPE_LAUNCH(colsum_partial_vec_kernel, dim3(nblk), dim3(256), 0, st, xv, N, M, C, (float *)workspace);
+    else
+        CAPE_LAUNCH(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, xv, N, M, C, (float *)workspace);
     CAPE_LAUNCH_CHECK();
-    CAPE_LAUNCH(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float *)workspace, nblk, C, accumulate, out);
+    CAPE_LAUNCH(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, (const float *)workspace, nblk, C, accumulate, out);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }
@@ -315,6 +403,28 @@ extern "C" int cape_reduce_cond(const float *dy, int64_t dy_sample_stride, int32
     CView gv{dy, dy_sample_stride, lddy};
     const int cgroups = (C + 63) / 64;
     CAPE_LAUNCH(reduce_cond_kernel, dim3(N * cgroups), dim3(256), 0, (hipStream_t)stream, gv, scale, dcond, ldc, N, M, C, accumulate);
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}
+
+extern "C" int64_t cape_rowscale_reduce_workspace_bytes(int32_t N, int32_t Mo, int32_t F, int32_t R) {
+    if (N < 1 || Mo < 1 || F < 1 || R < 1 || R > RSR_MAXR) return CAPE_EINVAL;
+    const long long chunks = (Mo + RSR_RB - 1) / RSR_RB;
+    return (int64_t)N * chunks * R * F * (int64_t)sizeof(float);
+}
+
+extern "C" int cape_rowscale_reduce(const float *dz, int64_t dz_sample_stride, int32_t lddz, const float *rowscale, int32_t R,
+                                    int32_t N, int32_t Mo, int32_t F, float *out, void *workspace, int64_t workspace_bytes,
+                                    void *stream) {
+    if (!dz || !rowscale || !out || !workspace || N < 1 || Mo < 1 || F < 1 || R < 1 || R > RSR_MAXR || lddz < F) return CAPE_EINVAL;
+    if (workspace_bytes < cape_rowscale_reduce_workspace_bytes(N, Mo, F, R)) return CAPE_EWORKSPACE;
+    const int chunks = (Mo + RSR_RB - 1) / RSR_RB;
+    CView zv{dz, dz_sample_stride, lddz};
+    hipStream_t st = (hipStream_t)stream;
+    CAPE_LAUNCH(rowscale_partial_kernel, dim3(N * chunks), dim3(256), 0, st, zv, rowscale, R, N, Mo, F, (float *)workspace, chunks);
+    CAPE_LAUNCH_CHECK();
+    const int RF = R * F;
+    CAPE_LAUNCH(rowscale_final_kernel, dim3(N * ((RF + 63) / 64)), dim3(256), 0, st, (const float *)workspace, chunks, RF, N, out);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }

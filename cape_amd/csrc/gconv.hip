@@ -48,6 +48,10 @@ struct GconvParams {
     unsigned *mask;
     int mask_words;
     int row_tiles, col_tiles;
+    int rankR;
+    const float *rowscale;
+    const float *coef;
+    unsigned rank_to2;
 };
 
 // ---- A-tile staging: gathered rows -> LDS [ROWS][KC+4] -----------------------------------
@@ -205,7 +209,7 @@ __device__ __forceinline__ void stage_weights(float *sB, const float *w, long lo
 // LDS buffer.  One barrier per chunk hands the buffers over; the MFMA waves never wait on global
 // memory, the loader waves are free to sit on L2 latency.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool DUAL>
-__global__ __launch_bounds__(CAPE_SPEC ? 512 : 256) void gconv_fwd_kernel(GconvParams p) {
+__global__ __launch_bounds__(CAPE_SPEC ? 512 : 256, (DUAL && BN == 128) ? 1 : 4) void gconv_fwd_kernel(GconvParams p) {
     constexpr int LDA = KC + 4;
     constexpr int LDB = BN + 4;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -345,11 +349,25 @@ __global__ __launch_bounds__(CAPE_SPEC ? 512 : 256) void gconv_fwd_kernel(GconvP
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int f = f0 + wn * WTN + b * 32 + li;
+            float coef[CAPE_MAX_SRC];
+#pragma unroll
+            for (int j = 0; j < CAPE_MAX_SRC; ++j)
+                coef[j] = (j < p.rankR && f < p.F) ? p.coef[((long long)n * p.rankR + j) * p.F + f] : 0.f;
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int r = r0 + wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
                 const bool ok = (r < p.Mo) && (f < p.F);
                 float v = acc[a][b][g];
+                float v2add = 0.f;
+                if (p.rankR > 0 && r < p.Mo) {
+#pragma unroll
+                    for (int j = 0; j < CAPE_MAX_SRC; ++j)
+                        if (j < p.rankR) {
+                            const float t = p.rowscale[(long long)j * p.Mo + r] * coef[j];
+                            if (DUAL && ((p.rank_to2 >> j) & 1u)) v2add += t;
+                            else v += t;
+                        }
+                }
                 if (DUAL) {
                     const bool pos = ok && (v > 0.f);
                     if (p.mask) {
@@ -359,7 +377,7 @@ __global__ __launch_bounds__(CAPE_SPEC ? 512 : 256) void gconv_fwd_kernel(GconvP
                             p.mask[((long long)n * p.Mo + r) * p.mask_words + ((f0 + wn * WTN + b * 32) >> 5)] = word;
                         }
                     }
-                    v = (v > 0.f ? v : 0.f) + acc2[a][b][g];
+                    v = (v > 0.f ? v : 0.f) + acc2[a][b][g] + v2add;
                 } else {
                     if (ok) {
                         if (p.bias_mode == CAPE_BIAS_CHANNEL) v += p.bias[f];
@@ -395,7 +413,7 @@ struct DwParams {
 };
 
 template <int CT, int FT>
-__global__ __launch_bounds__(256) void gconv_dw_kernel(DwParams p) {
+__global__ __launch_bounds__(256, 4) void gconv_dw_kernel(DwParams p) {
     constexpr int RK = 32;
     constexpr int LDA = CT + 4, LDB = FT + 4;
     constexpr int WTM = CT / 2, WTN = FT / 2;
@@ -436,7 +454,29 @@ __global__ __launch_bounds__(256) void gconv_dw_kernel(DwParams p) {
 
     for (int rbase = ra; rbase < rb; rbase += RK) {
         __syncthreads();
-        // A chunk: RK gathered rows x CT channels
+        // A chunk: RK (gathered) rows x CT channels
+        if (!S.rp && S.vec && (c0 + CT <= S.C)) {
+            // plain aligned source, full channel tile: all loads first, clamped rows + select
+            constexpr int NA = RK * (CT / 4) / 256;
+            float4 va4[NA];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int idx = tid + i * 256;
+                const int rl = idx / (CT / 4), q = idx % (CT / 4);
+                const int r = rbase + rl;
+                const int rc = r < rb ? r : rb - 1;
+                va4[i] = *reinterpret_cast<const float4 *>(xb + (long long)rc * S.ldx + c0 + 4 * q);
+            }
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int idx = tid + i * 256;
+                const int rl = idx / (CT / 4), q = idx % (CT / 4);
+                const bool ok = (rbase + rl) < rb;
+                float4 o = va4[i];
+                o.x = ok ? o.x : 0.f; o.y = ok ? o.y : 0.f; o.z = ok ? o.z : 0.f; o.w = ok ? o.w : 0.f;
+                *reinterpret_cast<float4 *>(&sA[rl * LDA + 4 * q]) = o;
+            }
+        } else
         for (int idx = tid; idx < RK * (CT / 4); idx += 256) {
             const int rl = idx / (CT / 4), q = idx % (CT / 4);
             const int r = rbase + rl;
@@ -481,6 +521,27 @@ __global__ __launch_bounds__(256) void gconv_dw_kernel(DwParams p) {
             *reinterpret_cast<float4 *>(&sA[rl * LDA + 4 * q]) = v4;
         }
         // B chunk: RK rows of dz x FT channels
+        if (p.dzvec && (f0 + FT <= p.F)) {
+            constexpr int NB = RK * (FT / 4) / 256;
+            float4 vb4[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int idx = tid + i * 256;
+                const int rl = idx / (FT / 4), q = idx % (FT / 4);
+                const int r = rbase + rl;
+                const int rc = r < rb ? r : rb - 1;
+                vb4[i] = *reinterpret_cast<const float4 *>(dzb + (long long)rc * p.lddz + f0 + 4 * q);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int idx = tid + i * 256;
+                const int rl = idx / (FT / 4), q = idx % (FT / 4);
+                const bool ok = (rbase + rl) < rb;
+                float4 o = vb4[i];
+                o.x = ok ? o.x : 0.f; o.y = ok ? o.y : 0.f; o.z = ok ? o.z : 0.f; o.w = ok ? o.w : 0.f;
+                *reinterpret_cast<float4 *>(&sB[rl * LDB + 4 * q]) = o;
+            }
+        } else
         for (int idx = tid; idx < RK * (FT / 4); idx += 256) {
             const int rl = idx / (FT / 4), q = idx % (FT / 4);
             const int r = rbase + rl;
@@ -547,17 +608,25 @@ struct DwReduceParams {
     long long slab;
 };
 
+// block = 64 consecutive output elements x 4 split lanes; fixed summation order (deterministic)
 __global__ __launch_bounds__(256) void dw_reduce_kernel(DwReduceParams p) {
+    __shared__ float red[4][64];
     const long long total = p.part_off[p.nsrc];
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + el;
+    float sum = 0.f;
+    if (i < total)
+        for (int sp = sl; sp < p.nsplit; sp += 4) sum += p.ws[(long long)sp * p.slab + i];
+    red[sl][el] = sum;
+    __syncthreads();
+    if (sl == 0 && i < total) {
         int si = 0;
         while (si + 1 < p.nsrc && i >= p.part_off[si + 1]) ++si;
         const long long loc = i - p.part_off[si];
         const long long c = loc / p.F, f = loc % p.F;
-        float sum = 0.f;
-        for (int sp = 0; sp < p.nsplit; ++sp) sum += p.ws[(long long)sp * p.slab + i];
+        const float t = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
         float *dst = p.w[si] + c * p.wrs[si] + f * p.wcs[si];
-        *dst = p.accumulate ? (*dst + sum) : sum;
+        *dst = p.accumulate ? (*dst + t) : t;
     }
 }
 
@@ -591,7 +660,7 @@ inline void plan_dw(const cape_src_t *srcs, int nsrc, int N, int Mo, int F, DwPl
         pl.slab += (long long)srcs[i].C * F;
     }
     // aim for >= ~1024 workgroups, at least 64 rows (2 chunks) per split
-    int want = (1024 + pl.ntiles * N - 1) / (pl.ntiles * N);
+    int want = (768 + pl.ntiles * N - 1) / (pl.ntiles * N);
     if (want < 1) want = 1;
     int maxsplit = (Mo + 63) / 64;
     if (want > maxsplit) want = maxsplit;
@@ -605,7 +674,8 @@ inline void plan_dw(const cape_src_t *srcs, int nsrc, int N, int Mo, int F, DwPl
 
 extern "C" int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, int64_t y_sample_stride,
                               int32_t ldy, int32_t N, int32_t Mo, int32_t F, const float *bias,
-                              int32_t bias_mode, int32_t act, uint32_t *mask_out, void *stream) {
+                              int32_t bias_mode, int32_t act, uint32_t *mask_out, const cape_rank_t *rank,
+                              void *stream) {
     if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || !y || N < 1 || Mo < 1 || F < 1 || ldy < F) return CAPE_EINVAL;
     if (bias_mode != CAPE_BIAS_NONE && !bias) return CAPE_EINVAL;
     if (act < CAPE_ACT_NONE || act > CAPE_ACT_TANH) return CAPE_EINVAL;
@@ -623,6 +693,12 @@ extern "C" int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, in
     p.N = N; p.Mo = Mo; p.F = F;
     p.bias = bias; p.bias_mode = bias ? bias_mode : CAPE_BIAS_NONE; p.act = act;
     p.mask = mask_out; p.mask_words = (F + 31) / 32;
+    p.rankR = 0; p.rowscale = nullptr; p.coef = nullptr; p.rank_to2 = 0;
+    if (rank && rank->R > 0) {
+        if (rank->R > CAPE_MAX_SRC || !rank->rowscale || !rank->coef) return CAPE_EINVAL;
+        if (rank->to_acc2 && !dual) return CAPE_EINVAL;
+        p.rankR = rank->R; p.rowscale = rank->rowscale; p.coef = rank->coef; p.rank_to2 = rank->to_acc2;
+    }
     const int BM = 128;
     const int BN = (F <= 32) ? 32 : (F <= 64) ? 64 : 128;
     p.row_tiles = (Mo + BM - 1) / BM;
@@ -688,8 +764,7 @@ extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *
     CAPE_LAUNCH_CHECK();
     rp.F = F; rp.nsplit = N * pl.rsplit; rp.accumulate = accumulate; rp.ws = (const float *)workspace; rp.slab = pl.slab;
     long long total = poff;
-    int rblocks = (int)((total + 255) / 256);
-    if (rblocks > 2048) rblocks = 2048;
+    int rblocks = (int)((total + 63) / 64);
     CAPE_LAUNCH(dw_reduce_kernel, dim3(rblocks), dim3(256), 0, st, rp);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;

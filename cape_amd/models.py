@@ -186,11 +186,13 @@ class base_model(object):
 
     # ---- the reference's named operators (plug-points) --------------------------------------------
     def chebyshev5(self, x, L, Fout, K, activation=None, bias=None, pool=None, unpool=None, cond=None,
-                   W_affine=None):
-        """Graph conv (reference :69-103); optional fusions are keyword-only extensions."""
-        W = self._weight_variable([x.shape[-1] * K, Fout])
+                   W_affine=None, cond_in=None):
+        """Graph conv (reference :69-103); optional fusions are keyword-only extensions.  ``cond_in``
+        = vertex-constant input channels appended after x's channels (never materialised)."""
+        Cin = x.shape[-1] + (0 if cond_in is None else cond_in.shape[1])
+        W = self._weight_variable([Cin * K, Fout])
         return ops.chebyshev5(x, W, self._conv_ops(L, K, unpool=unpool, pool=pool), bias=bias,
-                              activation=activation, cond=cond, W_affine=W_affine)
+                              activation=activation, cond=cond, W_affine=W_affine, cond_in=cond_in)
 
     def _brelu_named(self, x, kind):
         shape = [1, x.shape[1], x.shape[2]] if kind == 'b2relu' else [1, 1, x.shape[2]]
@@ -219,28 +221,26 @@ class base_model(object):
         return (self.filter.__func__ is base_model.chebyshev5 and self.pool.__func__ is base_model.poolwT
                 and self.unpool.__func__ is base_model.poolwT and self._activation_name in _ACTIVATIONS)
 
-    def _conv_act_pool(self, x, L, Fout, K, D, cond=None):
+    def _conv_act_pool(self, x, L, Fout, K, D, cond_in=None):
         """conv -> bias+act -> pool (cnp / cnp_d bodies, reference :154-171, :796-810)."""
-        N, M, _ = x.shape
         kind = self._activation_name
         if self._fusable():
             host = self._conv_ops(L, K, pool=D).host
             if host.pool_fused and host.fused and kind != 'b2relu':
                 b = self._bias_variable([1, 1, Fout])
-                return self.chebyshev5(x, L, Fout, K, activation=kind, bias=b, pool=D, cond=cond)
+                return self.chebyshev5(x, L, Fout, K, activation=kind, bias=b, pool=D, cond_in=cond_in)
+        if cond_in is not None:
+            x = ops.ConcatCondFn.apply(x, cond_in)
         x = self.filter(x, L, Fout, K)
         x = self.brelu(x)
-        x = self.pool(x, D)
-        if cond is not None:
-            x = ops.ConcatCondFn.apply(x, cond)
-        return x
+        return self.pool(x, D)
 
-    def cnp(self, x, i, name):
+    def cnp(self, x, i, name, cond_in=None):
         with self.variable_scope(name):
             return self._conv_act_pool(x, self.Laplacian[i], self.out_channels[i], self.poly_order[i],
-                                       self.Downsample_mtx[i])
+                                       self.Downsample_mtx[i], cond_in=cond_in)
 
-    def udn(self, x, out_channels, i, name, cond=None):
+    def udn(self, x, out_channels, i, name, cond_in=None):
         """unpool -> conv -> bias+act (reference :173-191), unpool folded into the conv operators."""
         with self.variable_scope(name):
             L, Fout, K = self.Laplacian[-i - 2], out_channels[-i - 1], self.poly_order[-i - 1]
@@ -248,12 +248,11 @@ class base_model(object):
             kind = self._activation_name
             if self._fusable() and K <= 3 and kind != 'b2relu':
                 b = self._bias_variable([1, 1, Fout])
-                return self.chebyshev5(x, L, Fout, K, activation=kind, bias=b, unpool=U, cond=cond)
+                return self.chebyshev5(x, L, Fout, K, activation=kind, bias=b, unpool=U, cond_in=cond_in)
+            if cond_in is not None:
+                x = ops.ConcatCondFn.apply(x, cond_in)
             x = self.unpool(x, U)
-            x = self.brelu(self.filter(x, L, Fout, K))
-            if cond is not None:
-                x = ops.ConcatCondFn.apply(x, cond)
-            return x
+            return self.brelu(self.filter(x, L, Fout, K))
 
     def vae_sampling(self, z_mean, z_logvar, eps=None):
         if eps is None:
@@ -399,43 +398,45 @@ class CAPE(base_model):
                 x = ops.ConcatCondFn.apply(x, cond)
             return x
 
-    def res_block_affine(self, x, i, name, cond=None):
-        """unpool -> relu(K-conv) + 1x1 affine conv (reference :776-793): ONE fused launch."""
+    def res_block_affine(self, x, i, name, cond_in=None):
+        """unpool -> relu(K-conv) + 1x1 affine conv (reference :776-793): ONE fused launch; the
+        condition channels of the input enter as rank-1 terms."""
         Lm, Fh, K = self.Laplacian[-i - 2], self.out_channels[-i - 1] // 2, self.poly_order[-i - 1]
         U = self.Upsample_mtx[-i - 1]
         with self.variable_scope(name):
             if self._fusable() and K <= 3:
+                Cin = x.shape[-1] + (0 if cond_in is None else cond_in.shape[1])
                 with self.variable_scope('affine'):
-                    Wa = self._weight_variable([x.shape[-1], Fh])
+                    Wa = self._weight_variable([Cin, Fh])
                 with self.variable_scope('graph_conv'):
-                    return self.chebyshev5(x, Lm, Fh, K, unpool=U, cond=cond, W_affine=Wa)
+                    return self.chebyshev5(x, Lm, Fh, K, unpool=U, W_affine=Wa, cond_in=cond_in)
+            if cond_in is not None:
+                x = ops.ConcatCondFn.apply(x, cond_in)
             x = self.unpool(x, U)
             with self.variable_scope('graph_conv'):
                 x_gc = torch.relu(self.filter(x, Lm, Fh, K))
             with self.variable_scope('affine'):
                 x_aff = self.filter(x, Lm, Fh, 1)
-            x = x_aff + x_gc
-            if cond is not None:
-                x = ops.ConcatCondFn.apply(x, cond)
-            return x
+            return x_aff + x_gc
 
-    def cnp_d(self, x, i, name):
+    def cnp_d(self, x, i, name, cond_in=None):
         with self.variable_scope(name):
             return self._conv_act_pool(x, self.Laplacian_d[i], self.out_channels[i], self.poly_order_d[i],
-                                       self.Downsample_mtx_d[i])
+                                       self.Downsample_mtx_d[i], cond_in=cond_in)
 
     def fit_cond_dim(self, x, y):
         return y.reshape(x.shape[0], 1, y.shape[-1]).expand(x.shape[0], x.shape[1], y.shape[-1])
 
     def encoder(self, x, y, y2, use_res_block=False, use_cond=True):
-        if use_cond:
-            x = ops.ConcatCondFn.apply(x, torch.cat([y, y2], 1))
+        cond_in = torch.cat([y, y2], 1) if use_cond else None
+        if cond_in is not None and use_res_block:
+            x, cond_in = ops.ConcatCondFn.apply(x, cond_in), None      # res_block reads its input twice
         with self.variable_scope('encoder'):
             for i in range(len(self.out_channels)):
                 if use_res_block:
                     x = self.res_block(x, i, 'encoder_resblock{}'.format(i + 1))
                 else:
-                    x = self.cnp(x, i, 'encoder_conv{}'.format(i + 1))
+                    x = self.cnp(x, i, 'encoder_conv{}'.format(i + 1), cond_in=cond_in if i == 0 else None)
             if self.reduce_dim > 0:
                 with self.variable_scope('1x1-conv'):
                     x = self.filter(x, self.Laplacian[-1], self.out_channels[-1] // self.reduce_rate, K=1)
@@ -449,6 +450,9 @@ class CAPE(base_model):
     def decoder_cond_vert(self, x, y, y2, use_res_block=False):
         N = x.shape[0]
         cond = torch.cat([y, y2], 1)
+        # the GraphCMR block group-normalises over the concatenated [features | condition] channels, so it
+        # needs the condition materialised; every other consumer takes it as rank-1 ``cond_in`` terms.
+        materialise = bool(use_res_block and not self.affine) or not self._fusable()
         with self.variable_scope('decoder'):
             with self.variable_scope('fc1'):
                 out_nodes = int(self.p[-1] * self.out_channels[-1]) // self.reduce_rate
@@ -457,25 +461,33 @@ class CAPE(base_model):
             if self.reduce_dim > 0:
                 with self.variable_scope('1x1-conv'):
                     if self._fusable():
-                        x = self.chebyshev5(x, self.Laplacian[-1], self.out_channels[-1], 1, cond=cond)
+                        x = self.chebyshev5(x, self.Laplacian[-1], self.out_channels[-1], 1,
+                                            cond=cond if materialise else None)
                     else:
                         x = ops.ConcatCondFn.apply(self.filter(x, self.Laplacian[-1], self.out_channels[-1], K=1), cond)
-            else:
+            elif materialise:
                 x = ops.ConcatCondFn.apply(x, cond)
             for i in range(len(self.out_channels)):
                 if use_res_block:
                     if not self.affine:
                         x = self.res_block_decoder(x, i, 'decoder_resblock_cmr{}'.format(i + 1), cond=cond)
                     else:
-                        x = self.res_block_affine(x, i, 'decoder_resblock_affine{}'.format(i + 1), cond=cond)
+                        x = self.res_block_affine(x, i, 'decoder_resblock_affine{}'.format(i + 1),
+                                                  cond_in=None if materialise else cond)
+                        if materialise:
+                            x = ops.ConcatCondFn.apply(x, cond)
                 else:
-                    x = self.udn(x, self.out_channels, i, 'decoder_conv{}'.format(i + 1), cond=cond)
+                    x = self.udn(x, self.out_channels, i, 'decoder_conv{}'.format(i + 1),
+                                 cond_in=None if materialise else cond)
+                    if materialise:
+                        x = ops.ConcatCondFn.apply(x, cond)
             with self.variable_scope('outputs'):
                 M = self.Laplacian[0].shape[0]
                 Fo = int(self.nn_input_channel)
                 b = self._bias_variable([1, M, Fo])      # one bias per vertex per channel (:615)
                 if self._fusable():
-                    x = self.chebyshev5(x, self.Laplacian[0], Fo, self.poly_order[0], bias=b)
+                    x = self.chebyshev5(x, self.Laplacian[0], Fo, self.poly_order[0], bias=b,
+                                        cond_in=None if materialise else cond)
                 else:
                     x = self.filter(x, self.Laplacian[0], Fo, self.poly_order[0]) + b
         return x
@@ -489,11 +501,11 @@ class CAPE(base_model):
         return x_hat, z_mean, z_logvar
 
     def discriminator(self, x, y, y2):
-        x = ops.ConcatCondFn.apply(x, torch.cat([y, y2], 1))
+        cond = torch.cat([y, y2], 1)
         with self.variable_scope('discriminator'):
             with self.variable_scope('shared'):
                 for i in range(len(self.Downsample_mtx_d)):
-                    x = self.cnp_d(x, i, 'conv{}'.format(i + 1))
+                    x = self.cnp_d(x, i, 'conv{}'.format(i + 1), cond_in=cond if i == 0 else None)
             with self.variable_scope('prediction_map'):
                 # poly_order[-1] (=2), not poly_order_d: reference quirk C3 (:676), kept for
                 # checkpoint-shape compatibility

@@ -93,6 +93,10 @@ class DeviceConvOps(object):
         if host.fused:
             self.fwd = [DeviceCSR(h, device) for h in host.fwd]
             self.bwd = [DeviceCSR(h, device) for h in host.bwd]
+            # row sums S_k 1 (rank-1 handling of vertex-constant condition channels); the last row
+            # repeats S_0 1 for the affine (K=1) branch of res_block_affine
+            rs = host.cond_row_terms()
+            self.rowscale = torch.from_numpy(np.stack(rs + [rs[0]]).astype(np.float32)).to(device).contiguous()
         else:
             self.Lt = DeviceCSR(host.Lt, device)
             self.LtT = DeviceCSR(host.LtT, device)
@@ -163,16 +167,23 @@ def _log_launch(name, flops, byts, fn):
 # --------------------------------------------------------------------------------------------
 # raw kernel wrappers (no autograd)
 # --------------------------------------------------------------------------------------------
-def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=None):
+def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=None, rank=None):
+    """rank = (rowscale [R,Mo], coef [N,R,F], to_acc2 bitmask) or None."""
     _lib.require_gpu()
     arr = _mk_srcs(entries)
     N, Mo, F = y.shape
     p, ss, ld = _v(y)
+    rk = None
+    if rank is not None:
+        rowscale, coef, to2 = rank
+        assert coef.is_contiguous() and rowscale.is_contiguous() and coef.shape[0] == N and coef.shape[2] == F
+        assert rowscale.shape[1] == Mo and rowscale.shape[0] >= coef.shape[1]
+        rk = _lib.CapeRank(int(coef.shape[1]), rowscale.data_ptr(), coef.data_ptr(), int(to2))
 
     def launch():
         rc = lib.cape_gconv_fwd(arr, len(entries), p, ss, ld, N, Mo, F, _ptr(bias),
                                 bias_mode if bias is not None else _lib.BIAS_NONE, _lib.ACT[act],
-                                _ptr(mask), _stream())
+                                _ptr(mask), C.byref(rk) if rk is not None else None, _stream())
         check(rc, "cape_gconv_fwd")
 
     if LAUNCH_LOG is None:
@@ -296,141 +307,97 @@ def reduce_cond(dy, scale=None, out=None, accumulate=False):
     return out
 
 
+def rowscale_reduce(dz, rowscale, R):
+    """out[n, j, f] = sum_r rowscale[j, r] * dz[n, r, f]  for j < R."""
+    _lib.require_gpu()
+    N, Mo, F = dz.shape
+    out = torch.empty((N, R, F), device=dz.device, dtype=torch.float32)
+    need = lib.cape_rowscale_reduce_workspace_bytes(N, Mo, F, R)
+    ws = torch.empty((need + 3) // 4, device=dz.device, dtype=torch.float32)
+    p, ss, ld = _v(dz)
+    rc = lib.cape_rowscale_reduce(p, ss, ld, C.c_void_p(rowscale.data_ptr()), R, N, Mo, F, _ptr(out), _ptr(ws), need,
+                                  _stream())
+    check(rc, "cape_rowscale_reduce")
+    return out
+
+
 # --------------------------------------------------------------------------------------------
 # autograd operators
 # --------------------------------------------------------------------------------------------
 class ChebConvFn(torch.autograd.Function):
-    """y = [ epilogue( sum_k (S_k x) W_k ) | cond tiled over vertices ]
+    """y = [ epilogue( sum_k (S_k [x | cond_in 1^T]) W_k ) | cond_out tiled over vertices ]
 
     * plain mode  (W_aff None): epilogue = act(. + bias)            -- chebyshev5 + b1*/b2relu
       (+ poolwT folded into S_k), reference lib/models.py:69-127,154-171,796-810
     * affine mode (W_aff given): relu(sum_k (S_k x) W_k) + (S_0 x) W_aff -- res_block_affine,
       lib/models.py:776-793 (unpool folded into S_k)
-    ``cond`` [N, Cc] is appended as Cc vertex-constant channels (fit_cond_dim + concat, :813-832).
+    ``cond_in`` [N, Cc] stands for Cc vertex-constant INPUT channels appended after x's channels
+    (fit_cond_dim + tf.concat, :591-594, :606-609, :663-666): they are never materialised -- their
+    contribution is the rank-1 update (S_k 1)(cond_in W_k[cond rows]) added in the GEMM epilogue.
+    ``cond_out`` [N, Cc'] is appended to the OUTPUT as materialised channels (only where a consumer
+    needs the concatenated tensor, e.g. group-norm blocks).
+    ``mode``: "fused"  = S_k gathered inside the GEMM kernel's A-tile staging (one launch);
+              "twopass" = X_k = S_k x by the streaming spmm kernel, then a plain multi-source GEMM.
     """
 
     @staticmethod
-    def forward(ctx, x, W, bias, W_aff, cond, ops, act, bias_mode):
+    def forward(ctx, x, W, bias, W_aff, cond_in, cond_out, ops, act, bias_mode, mode):
         x = as_act(x)
-        N, Mi, Cin = x.shape
+        N, Mi, Ch = x.shape
         K, Fout = ops.K, W.shape[1]
-        assert ops.fused and W.shape[0] == Cin * K and Mi == ops.Mi
-        assert W.is_contiguous() and (W_aff is None or W_aff.is_contiguous())
-        Cc = 0 if cond is None else cond.shape[1]
-        yfull = alloc_act(N, ops.Mo, Fout + Cc, x.device)
+        Cc = 0 if cond_in is None else cond_in.shape[1]
+        assert ops.fused and W.shape[0] == (Ch + Cc) * K and Mi == ops.Mi
+        assert W.is_contiguous() and (W_aff is None or (W_aff.is_contiguous() and W_aff.shape == (Ch + Cc, Fout)))
+        Co = 0 if cond_out is None else cond_out.shape[1]
+        yfull = alloc_act(N, ops.Mo, Fout + Co, x.device)
         y = yfull[:, :, :Fout]
+        twopass = (mode == "twopass")
+        xs = [x if (ops.fwd[k].identity or not twopass) else spmm(x, ops.fwd[k]) for k in range(K)]
         entries = []
         for k in range(K):
-            e = dict(x=x, csr=ops.fwd[k], w=(W, k * Fout, K * Fout, 1))
+            e = dict(x=xs[k], csr=None if twopass else ops.fwd[k], w=(W, k * Fout, K * Fout, 1))
             if W_aff is not None and k == 0:
                 e["w2"] = (W_aff, 0, Fout, 1)
             entries.append(e)
+        rank = None
+        if Cc:
+            cond_in = cond_in.contiguous()
+            coef = torch.mm(cond_in, W[Ch * K:].view(Cc, K * Fout)).view(N, K, Fout)
+            to2 = 0
+            if W_aff is not None:
+                coef = torch.cat([coef, torch.mm(cond_in, W_aff[Ch:]).view(N, 1, Fout)], dim=1)
+                to2 = 1 << K
+                rowscale = ops.rowscale                      # [K+1, Mo], last row = S_0 1
+            else:
+                rowscale = ops.rowscale[:K]
+            rank = (rowscale.contiguous(), coef.contiguous(), to2)
         mask = None
         if W_aff is not None:
-            assert W_aff.shape == (Cin, Fout)
             mask = torch.empty((N, ops.Mo, (Fout + 31) // 32), device=x.device, dtype=torch.int32)
-            gconv_fwd(entries, y, mask=mask)
+            gconv_fwd(entries, y, mask=mask, rank=rank)
         else:
-            gconv_fwd(entries, y, bias=bias, bias_mode=bias_mode, act=act)
-        if Cc:
-            fill_cond(cond.contiguous(), yfull[:, :, Fout:])
-        ctx.ops, ctx.act, ctx.bias_mode, ctx.Fout, ctx.Cc = ops, act, bias_mode, Fout, Cc
-        ctx.has_bias = bias is not None
-        ctx.save_for_backward(x, W, W_aff, mask, yfull if (act != "none" and W_aff is None) else None)
+            gconv_fwd(entries, y, bias=bias, bias_mode=bias_mode, act=act, rank=rank)
+        if Co:
+            fill_cond(cond_out.contiguous(), yfull[:, :, Fout:])
+        ctx.ops, ctx.act, ctx.bias_mode, ctx.Fout, ctx.Co, ctx.Cc = ops, act, bias_mode, Fout, Co, Cc
+        ctx.has_bias, ctx.twopass, ctx.xshape = bias is not None, twopass, (N, Mi, Ch)
+        ctx.save_for_backward(W, W_aff, mask, yfull if (act != "none" and W_aff is None) else None, cond_in, *xs)
         return yfull
 
     @staticmethod
     def backward(ctx, gfull):
-        x, W, W_aff, mask, ysaved = ctx.saved_tensors
-        ops, act, Fout, Cc = ctx.ops, ctx.act, ctx.Fout, ctx.Cc
-        K = ops.K
-        N, Mi, Cin = x.shape
+        W, W_aff, mask, ysaved, cond_in = ctx.saved_tensors[:5]
+        xs = ctx.saved_tensors[5:]
+        ops, act, Fout, Co, Cc = ctx.ops, ctx.act, ctx.Fout, ctx.Co, ctx.Cc
+        K, twopass = ops.K, ctx.twopass
+        N, Mi, Ch = ctx.xshape
+        Mo, dev = ops.Mo, W.device
         gfull = as_act(gfull)
         g = gfull[:, :, :Fout]
-        need_x, need_w, need_b, need_wa, need_c = (ctx.needs_input_grad[i] for i in range(5))
-        dW = dB = dWa = dcond = dx = None
+        need_x, need_w, need_b, need_wa, need_ci, need_co = (ctx.needs_input_grad[i] for i in range(6))
+        dW = dB = dWa = dci = dco = dx = None
         if W_aff is not None:
             dz = mask_mul(g, mask)          # gradient through relu of the graph-conv branch
-        elif act != "none":
-            dz = act_bwd(g, ysaved[:, :, :Fout], act)
-        else:
-            dz = g
-        if need_b and ctx.has_bias:
-            if ctx.bias_mode == _lib.BIAS_VERTEX:
-                dB = torch.empty((1, ops.Mo, Fout), device=x.device, dtype=torch.float32)
-                colsum(dz, dB, per_vertex=True)
-            else:
-                dB = torch.empty((1, 1, Fout), device=x.device, dtype=torch.float32)
-                colsum(dz, dB)
-        if need_w:
-            dW = torch.empty_like(W)
-            gconv_dw([dict(x=x, csr=ops.fwd[k], w=(dW, k * Fout, K * Fout, 1)) for k in range(K)], dz)
-        if W_aff is not None and need_wa:
-            dWa = torch.empty_like(W_aff)
-            gconv_dw([dict(x=x, csr=ops.fwd[0], w=(dWa, 0, Fout, 1))], g)
-        if need_x:
-            dx = alloc_act(N, Mi, Cin, x.device)
-            entries = [dict(x=dz, csr=ops.bwd[k], w=(W, k * Fout, 1, K * Fout)) for k in range(K)]
-            if W_aff is not None:
-                entries.append(dict(x=g, csr=ops.bwd[0], w=(W_aff, 0, 1, Fout)))
-            gconv_fwd(entries, dx)
-        if Cc and need_c:
-            dcond = reduce_cond(gfull[:, :, Fout:])
-        return dx, dW, dB, dWa, dcond, None, None, None
-
-
-class ChebConvTwoPassFn(torch.autograd.Function):
-    """Same operator as ChebConvFn, evaluated in two passes: the sparse operators S_k are applied by
-    the streaming ``cape_spmm`` kernel (X_k = S_k x materialised once, kept for the weight gradient),
-    and the dense contraction runs as a plain multi-source GEMM (no gather in the MFMA kernel's
-    staging).  The data gradient applies S_k^T either before or after the W_k^T contraction,
-    whichever side has fewer rows / channels."""
-
-    @staticmethod
-    def forward(ctx, x, W, bias, W_aff, cond, ops, act, bias_mode):
-        x = as_act(x)
-        N, Mi, Cin = x.shape
-        K, Fout = ops.K, W.shape[1]
-        assert ops.fused and W.shape[0] == Cin * K and Mi == ops.Mi
-        Cc = 0 if cond is None else cond.shape[1]
-        yfull = alloc_act(N, ops.Mo, Fout + Cc, x.device)
-        y = yfull[:, :, :Fout]
-        xs = [x if ops.fwd[k].identity else spmm(x, ops.fwd[k]) for k in range(K)]
-        entries = []
-        for k in range(K):
-            e = dict(x=xs[k], csr=None, w=(W, k * Fout, K * Fout, 1))
-            if W_aff is not None and k == 0:
-                e["w2"] = (W_aff, 0, Fout, 1)
-            entries.append(e)
-        mask = None
-        if W_aff is not None:
-            mask = torch.empty((N, ops.Mo, (Fout + 31) // 32), device=x.device, dtype=torch.int32)
-            gconv_fwd(entries, y, mask=mask)
-        else:
-            gconv_fwd(entries, y, bias=bias, bias_mode=bias_mode, act=act)
-        if Cc:
-            fill_cond(cond.contiguous(), yfull[:, :, Fout:])
-        ctx.ops, ctx.act, ctx.bias_mode, ctx.Fout, ctx.Cc = ops, act, bias_mode, Fout, Cc
-        ctx.has_bias = bias is not None
-        ctx.xshape = (N, Mi, Cin)
-        ctx.save_for_backward(W, W_aff, mask, yfull if (act != "none" and W_aff is None) else None, *xs)
-        return yfull
-
-    @staticmethod
-    def backward(ctx, gfull):
-        W, W_aff, mask, ysaved = ctx.saved_tensors[:4]
-        xs = ctx.saved_tensors[4:]
-        ops, act, Fout, Cc = ctx.ops, ctx.act, ctx.Fout, ctx.Cc
-        K = ops.K
-        N, Mi, Cin = ctx.xshape
-        Mo = ops.Mo
-        dev = W.device
-        gfull = as_act(gfull)
-        g = gfull[:, :, :Fout]
-        need_x, need_w, need_b, need_wa, need_c = (ctx.needs_input_grad[i] for i in range(5))
-        dW = dB = dWa = dcond = dx = None
-        if W_aff is not None:
-            dz = mask_mul(g, mask)
         elif act != "none":
             dz = act_bwd(g, ysaved[:, :, :Fout], act)
         else:
@@ -442,44 +409,72 @@ class ChebConvTwoPassFn(torch.autograd.Function):
             else:
                 dB = torch.empty((1, 1, Fout), device=dev, dtype=torch.float32)
                 colsum(dz, dB)
+        csr_of = (lambda k: None) if twopass else (lambda k: ops.fwd[k])
         if need_w:
             dW = torch.empty_like(W)
-            gconv_dw([dict(x=xs[k], csr=None, w=(dW, k * Fout, K * Fout, 1)) for k in range(K)], dz)
+            gconv_dw([dict(x=xs[k], csr=csr_of(k), w=(dW, k * Fout, K * Fout, 1)) for k in range(K)], dz)
         if W_aff is not None and need_wa:
             dWa = torch.empty_like(W_aff)
-            gconv_dw([dict(x=xs[0], csr=None, w=(dWa, 0, Fout, 1))], g)
+            gconv_dw([dict(x=xs[0], csr=csr_of(0), w=(dWa, 0, Fout, 1))], g)
+        if Cc:
+            # rank-1 condition terms: dcoef[n,k,f] = sum_r (S_k 1)[r] dz[n,r,f]
+            dcoef = rowscale_reduce(dz, ops.rowscale, K).view(N, K * Fout)
+            Wc = W[Ch * K:].view(Cc, K * Fout)
+            if need_w:
+                torch.mm(cond_in.t(), dcoef, out=dW[Ch * K:].view(Cc, K * Fout))
+            if need_ci:
+                dci = torch.mm(dcoef, Wc.t())
+            if W_aff is not None:
+                dca = rowscale_reduce(g, ops.rowscale, 1).view(N, Fout)
+                if need_wa:
+                    torch.mm(cond_in.t(), dca, out=dWa[Ch:])
+                if need_ci:
+                    dci = dci + torch.mm(dca, W_aff[Ch:].t())
         if need_x:
-            # transposed weight blocks with the output index contiguous: Wt[k][f][c] = W[c*K+k][f]
-            Wt = W.view(Cin, K, Fout).permute(1, 2, 0).contiguous()
-            Wat = W_aff.t().contiguous() if W_aff is not None else None
-            contract_first = (Mo < Mi) or (Mo == Mi and Cin < Fout)
-            if contract_first:
-                # G_k = dz W_k^T at the Mo output rows, then dx = sum_k S_k^T G_k
-                dx = None
-                for k in range(K):
-                    ent = [dict(x=dz, csr=None, w=(Wt, k * Fout * Cin, Cin, 1))]
-                    if W_aff is not None and k == 0:
-                        ent.append(dict(x=g, csr=None, w=(Wat, 0, Cin, 1)))
-                    Gk = alloc_act(N, Mo, Cin, dev)
-                    gconv_fwd(ent, Gk)
-                    if ops.bwd[k].identity:
-                        dx = Gk if dx is None else dx.add_(Gk)
-                    else:
-                        dx = spmm(Gk, ops.bwd[k]) if dx is None else spmm(Gk, ops.bwd[k], z=dx, beta=1.0, y=dx)
-            else:
-                # T_k = S_k^T dz at the Mi input rows, then one GEMM over all sources
-                ent = []
-                for k in range(K):
-                    Tk = dz if ops.bwd[k].identity else spmm(dz, ops.bwd[k])
-                    ent.append(dict(x=Tk, csr=None, w=(Wt, k * Fout * Cin, Cin, 1)))
+            dx = alloc_act(N, Mi, Ch, dev)
+            if not twopass:
+                entries = [dict(x=dz, csr=ops.bwd[k], w=(W, k * Fout, 1, K * Fout), C=Fout) for k in range(K)]
+                # only the first Ch "output" columns (x channels) of W^T are produced: F of this launch = Ch
                 if W_aff is not None:
-                    Ta = g if ops.bwd[0].identity else spmm(g, ops.bwd[0])
-                    ent.append(dict(x=Ta, csr=None, w=(Wat, 0, Cin, 1)))
-                dx = alloc_act(N, Mi, Cin, dev)
-                gconv_fwd(ent, dx)
-        if Cc and need_c:
-            dcond = reduce_cond(gfull[:, :, Fout:])
-        return dx, dW, dB, dWa, dcond, None, None, None
+                    entries.append(dict(x=g, csr=ops.bwd[0], w=(W_aff, 0, 1, Fout)))
+                gconv_fwd(entries, dx)
+            else:
+                # transposed weight blocks with the output index contiguous: Wt[k][f][c] = W[c*K+k][f]
+                Wt = W[:Ch * K].view(Ch, K, Fout).permute(1, 2, 0).contiguous()
+                Wat = W_aff[:Ch].t().contiguous() if W_aff is not None else None
+                contract_first = (Mo < Mi) or (Mo == Mi and Ch < Fout)
+                if contract_first:
+                    # G_k = dz W_k^T at the Mo output rows, then dx = sum_k S_k^T G_k
+                    first = True
+                    for k in range(K):
+                        ent = [dict(x=dz, csr=None, w=(Wt, k * Fout * Ch, Ch, 1))]
+                        if W_aff is not None and k == 0:
+                            ent.append(dict(x=g, csr=None, w=(Wat, 0, Ch, 1)))
+                        if ops.bwd[k].identity and first:
+                            gconv_fwd(ent, dx)
+                        else:
+                            Gk = alloc_act(N, Mo, Ch, dev)
+                            gconv_fwd(ent, Gk)
+                            if ops.bwd[k].identity:
+                                dx.add_(Gk)
+                            elif first:
+                                spmm(Gk, ops.bwd[k], y=dx)
+                            else:
+                                spmm(Gk, ops.bwd[k], z=dx, beta=1.0, y=dx)
+                        first = False
+                else:
+                    # T_k = S_k^T dz at the Mi input rows, then one GEMM over all sources
+                    ent = []
+                    for k in range(K):
+                        Tk = dz if ops.bwd[k].identity else spmm(dz, ops.bwd[k])
+                        ent.append(dict(x=Tk, csr=None, w=(Wt, k * Fout * Ch, Ch, 1)))
+                    if W_aff is not None:
+                        Ta = g if ops.bwd[0].identity else spmm(g, ops.bwd[0])
+                        ent.append(dict(x=Ta, csr=None, w=(Wat, 0, Ch, 1)))
+                    gconv_fwd(ent, dx)
+        if Co and need_co:
+            dco = reduce_cond(gfull[:, :, Fout:])
+        return dx, dW, dB, dWa, dci, dco, None, None, None, None
 
 
 class ChebConvRecurrenceFn(torch.autograd.Function):
@@ -648,18 +643,20 @@ class ReconEdgeLossFn(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------
 # functional front-ends with the reference's operator names
 # --------------------------------------------------------------------------------------------
-def chebyshev5(x, W, ops, bias=None, activation=None, cond=None, W_affine=None):
+def chebyshev5(x, W, ops, bias=None, activation=None, cond=None, W_affine=None, cond_in=None):
     """Graph convolution (lib/models.py:69-103) with optional fused bias+activation
-    (``activation`` in b1leakyrelu/b1relu/b1tanh/b2relu), affine branch and condition concat."""
+    (``activation`` in b1leakyrelu/b1relu/b1tanh/b2relu), affine branch, rank-1 input condition
+    (``cond_in``) and materialised output condition concat (``cond``)."""
     if activation is None:
         act, bmode = "none", (_lib.BIAS_NONE if bias is None else
                               (_lib.BIAS_VERTEX if bias.shape[1] > 1 else _lib.BIAS_CHANNEL))
     else:
         act, bmode = _ACT_OF[activation]
     if ops.fused:
-        fn = ChebConvTwoPassFn if MODE == "twopass" else ChebConvFn
-        return fn.apply(x, W, bias, W_affine, cond, ops, act, bmode)
+        return ChebConvFn.apply(x, W, bias, W_affine, cond_in, cond, ops, act, bmode, MODE)
     assert W_affine is None
+    if cond_in is not None:
+        x = ConcatCondFn.apply(x, cond_in)
     y = ChebConvRecurrenceFn.apply(x, W, bias, ops, act, bmode)
     if cond is not None:
         y = ConcatCondFn.apply(y, cond)

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CAPE_ABI_VERSION 1
+#define CAPE_ABI_VERSION 2
 #define CAPE_MAX_SRC 8
 
 /* error codes (negative = argument error; positive values are hipError_t) */
@@ -90,6 +90,20 @@ typedef struct cape_src {
     int64_t w2_rs, w2_cs;
 } cape_src_t;
 
+/*
+ * Rank-1 epilogue terms of the fused gather-GEMM: vertex-constant input channels (the tiled
+ * condition vector, lib/models.py:813-832 fit_cond_dim + tf.concat at :593,608,665) need no
+ * per-vertex contraction because S_k (1 c^T) = (S_k 1) c^T.  Their contribution to the
+ * pre-activation is   sum_j rowscale[j, r] * coef[n, j, f]   with rowscale_j = S_k 1 (row sums of the
+ * operator) and coef_j = cond @ W_k[cond rows] (a tiny dense product done by the caller).
+ */
+typedef struct cape_rank {
+    int32_t R;             /* number of terms, 0..CAPE_MAX_SRC                                  */
+    const float *rowscale; /* device [R, Mo]                                                    */
+    const float *coef;     /* device [N, R, F]                                                  */
+    uint32_t to_acc2;      /* bit j set: term j goes to the second accumulator (DUAL mode)      */
+} cape_rank_t;
+
 int cape_abi_version(void);
 
 /* Host-side structural check of a CSR operator (host pointers). */
@@ -104,10 +118,21 @@ int cape_csr_validate(int32_t rows, int32_t cols, int64_t nnz, const int32_t *ro
  *        y[n,r,f] = relu(acc1) + acc2 ; if mask_out != NULL bit (f%32) of
  *        mask_out[(n*Mo + r)*ceil(F/32) + f/32] = (acc1 > 0)
  * bias: NULL or [F] (CAPE_BIAS_CHANNEL) or [Mo,F] (CAPE_BIAS_VERTEX).
+ * rank: NULL or rank-1 terms added to the accumulators before the epilogue.
  */
 int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, int64_t y_sample_stride,
                    int32_t ldy, int32_t N, int32_t Mo, int32_t F, const float *bias,
-                   int32_t bias_mode, int32_t act, uint32_t *mask_out, void *stream);
+                   int32_t bias_mode, int32_t act, uint32_t *mask_out, const cape_rank_t *rank,
+                   void *stream);
+
+/*
+ * Gradient of the rank-1 terms w.r.t. coef:  out[n, j, f] = sum_r rowscale[j, r] * dz[n, r, f]
+ * (deterministic two-stage reduction; workspace >= cape_rowscale_reduce_workspace_bytes).
+ */
+int64_t cape_rowscale_reduce_workspace_bytes(int32_t N, int32_t Mo, int32_t F, int32_t R);
+int cape_rowscale_reduce(const float *dz, int64_t dz_sample_stride, int32_t lddz,
+                         const float *rowscale, int32_t R, int32_t N, int32_t Mo, int32_t F,
+                         float *out, void *workspace, int64_t workspace_bytes, void *stream);
 
 /*
  * Weight gradient of the fused gather-GEMM:

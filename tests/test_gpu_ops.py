@@ -34,8 +34,10 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _twin_conv(x, L, W, K, bias, act, pool=None, unpool=None, cond=None, W_aff=None):
+def _twin_conv(x, L, W, K, bias, act, pool=None, unpool=None, cond=None, W_aff=None, cond_in=None):
     from oracle import torch_twin as tt
+    if cond_in is not None:
+        x = torch.cat([x, tt.fit_cond_dim(x, cond_in)], -1)
     if unpool is not None:
         x = tt.poolwT(x, unpool)
     y = tt.chebyshev5(x, L, W, K)
@@ -65,6 +67,13 @@ CASES = [
     ("tanh_b2",          6, 2, 32, 48, 2, "b1tanh", "channel", None, None, 0, False),
     ("b2relu",           6, 2, 32, 40, 2, "b2relu", "vertex", None, None, 5, False),
     ("k6_recurrence",    0, 2, 16, 32, 6, "b1leakyrelu", "channel", None, None, 0, False),
+    # vertex-constant input channels (cond_in: Cin = feature channels, +64 / +35 condition channels)
+    ("affine_blk7_cin",  1, 2, 64, 32, 2, None, None, None, 1, -64, True),
+    ("affine_blk2_cin",  6, 2, 256, 256, 2, None, None, None, 6, -64, True),
+    ("disc_conv1_cin",  "d0", 2, 3, 64, 3, "b1leakyrelu", "channel", "d0", None, -64, False),
+    ("out_conv_cin",     0, 2, 32, 3, 2, None, "vertex", None, None, -64, False),
+    ("udn_cin_tanh",     3, 2, 128, 64, 2, "b1tanh", "channel", None, 3, -35, False),
+    ("k6_recurrence_cin", 0, 2, 16, 32, 6, "b1leakyrelu", "channel", None, None, -8, False),
 ]
 
 
@@ -87,9 +96,12 @@ def test_cheb_conv_fwd_bwd(case, mode, mesh_ops, dev, monkeypatch):
     rng = np.random.default_rng(zlib.crc32(name.encode()))
     Mi = unpool.shape[1] if unpool is not None else L.shape[0]
     Mo = pool.shape[0] if pool is not None else L.shape[0]
+    Cci = -Cc if Cc < 0 else 0          # negative entry = input-side condition channels
+    Cc = max(Cc, 0)
     x = rng.standard_normal((N, Mi, Cin))
-    W = 0.1 * rng.standard_normal((Cin * K, Fout))
-    W_aff = 0.1 * rng.standard_normal((Cin, Fout)) if affine else None
+    W = 0.1 * rng.standard_normal(((Cin + Cci) * K, Fout))
+    W_aff = 0.1 * rng.standard_normal((Cin + Cci, Fout)) if affine else None
+    cond_in = rng.standard_normal((N, Cci)) if Cci else None
     if bias_kind == "channel":
         b = 0.1 * rng.standard_normal((1, 1, Fout))
     elif bias_kind == "vertex":
@@ -101,16 +113,16 @@ def test_cheb_conv_fwd_bwd(case, mode, mesh_ops, dev, monkeypatch):
 
     # ---- oracle (torch twin, fp64) ----
     t = lambda a: None if a is None else torch.tensor(a, dtype=torch.float64, requires_grad=True)
-    tx, tW, tWa, tb, tc = t(x), t(W), t(W_aff), t(b), t(cond)
-    ty = _twin_conv(tx, L, tW, K, tb, act, pool=pool, unpool=unpool, cond=tc, W_aff=tWa)
+    tx, tW, tWa, tb, tc, tci = t(x), t(W), t(W_aff), t(b), t(cond), t(cond_in)
+    ty = _twin_conv(tx, L, tW, K, tb, act, pool=pool, unpool=unpool, cond=tc, W_aff=tWa, cond_in=tci)
     ty.backward(torch.tensor(gy, dtype=torch.float64))
 
     # ---- HIP path ----
     g = lambda a: None if a is None else torch.tensor(a, dtype=torch.float32, device=dev, requires_grad=True)
-    hx, hW, hWa, hb, hc = g(x), g(W), g(W_aff), g(b), g(cond)
+    hx, hW, hWa, hb, hc, hci = g(x), g(W), g(W_aff), g(b), g(cond), g(cond_in)
     dops = ops.DeviceConvOps(ConvOperators(L, K, unpool=unpool, pool=pool), dev)
     assert dops.Mo == Mo and dops.Mi == Mi
-    hy = ops.chebyshev5(hx, hW, dops, bias=hb, activation=act, cond=hc, W_affine=hWa)
+    hy = ops.chebyshev5(hx, hW, dops, bias=hb, activation=act, cond=hc, W_affine=hWa, cond_in=hci)
     assert tuple(hy.shape) == (N, Mo, Fout + Cc)
     hy.backward(torch.tensor(gy, dtype=torch.float32, device=dev))
     torch.cuda.synchronize()
@@ -124,6 +136,8 @@ def test_cheb_conv_fwd_bwd(case, mode, mesh_ops, dev, monkeypatch):
         assert mat_err(hb.grad.cpu().numpy(), tb.grad.numpy()) < TOL, "dbias"
     if Cc:
         assert mat_err(hc.grad.cpu().numpy(), tc.grad.numpy()) < TOL, "dcond"
+    if Cci:
+        assert mat_err(hci.grad.cpu().numpy(), tci.grad.numpy()) < TOL, "dcond_in"
 
 
 def test_spmm_and_sparse_op(mesh_ops, dev):
