@@ -17,6 +17,9 @@
 #ifndef CAPE_SPEC
 #define CAPE_SPEC 0
 #endif
+#ifndef CAPE_PIPE
+#define CAPE_PIPE 0
+#endif
 
 namespace {
 
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(CAPE_SPEC ? 512 : 256, (DUAL && BN == 128) ? 1 : 4)
     static_assert(WAVES_M * WAVES_N == 4, "4 MFMA waves per workgroup");
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
 
-    __shared__ __attribute__((aligned(16))) float smem[(CAPE_SPEC ? 2 : 1) * BUF_SZ];
+    __shared__ __attribute__((aligned(16))) float smem[((CAPE_SPEC || CAPE_PIPE) ? 2 : 1) * BUF_SZ];
 
     const int tid = threadIdx.x;
 #if CAPE_SPEC
@@ -332,12 +335,106 @@ __global__ __launch_bounds__(CAPE_SPEC ? 512 : 256, (DUAL && BN == 128) ? 1 : 4)
         }
         __syncthreads();
     }
-#else
+#elif !CAPE_PIPE
+    // All 4 waves stage, then multiply; 3-4 resident workgroups per CU overlap each other's staging
+    // and MFMA phases (measured faster on MI355X than both the loader/MFMA wave split above and the
+    // register-prefetch pipeline below, which cost occupancy).
     for (int it = 0; it < total; ++it) {
         __syncthreads();
         stage(0);
         __syncthreads();
         compute(0);
+    }
+#else
+    // Software pipeline (all 4 waves stage AND multiply): the global loads of chunk it+1 are issued
+    // into registers before the MFMAs of chunk it and written to the other LDS buffer after them --
+    // one barrier per chunk, HBM/L2 latency hidden behind 64 MFMAs per wave.  Plain aligned sources
+    // with output-contiguous weights take this path; anything else (gathered / unaligned / strided
+    // weights) is staged synchronously after the multiply.
+    constexpr int P = BM / 32;
+    constexpr int NLB = (KC * (BN / 4)) / 256;
+    float4 ra[P], rb[NLB], rb2[DUAL ? NLB : 1];
+    const int q = ltid & 7, rl0 = ltid >> 3;
+    auto is_fast = [&](int si) -> bool {
+        const SrcDev &S = p.s[si];
+        const bool wfast = (S.wcs == 1) && ((S.wrs & 3) == 0) && ((p.F & 3) == 0) && ((reinterpret_cast<uintptr_t>(S.w) & 15) == 0);
+        const bool w2fast = !(DUAL && S.w2) || ((S.w2cs == 1) && ((S.w2rs & 3) == 0) && ((reinterpret_cast<uintptr_t>(S.w2) & 15) == 0));
+        return (S.rp == nullptr) && S.vec && ((S.C & 3) == 0) && wfast && w2fast;
+    };
+    auto load_regs = [&](int si, int c0) {
+        const SrcDev &S = p.s[si];
+        const int c = c0 + 4 * q;
+        const int cc = c < S.C ? c : 0;
+        const float *xb = S.x + (long long)n * S.xs + cc;
+#pragma unroll
+        for (int pass = 0; pass < P; ++pass) {
+            const int r = r0 + rl0 + 32 * pass;
+            const int rc = r < p.Mo ? r : p.Mo - 1;
+            ra[pass] = *reinterpret_cast<const float4 *>(xb + (long long)rc * S.ldx);
+        }
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) {
+            const int idx = ltid + i * 256;
+            const int j4 = idx % (BN / 4), kk = idx / (BN / 4);
+            const int cw = c0 + kk, f = f0 + 4 * j4;
+            const int cwc = cw < S.C ? cw : S.C - 1, fc = f < p.F ? f : 0;
+            rb[i] = *reinterpret_cast<const float4 *>(S.w + cwc * S.wrs + fc);
+            if (DUAL && S.w2) rb2[i] = *reinterpret_cast<const float4 *>(S.w2 + cwc * S.w2rs + fc);
+        }
+    };
+    auto store_regs = [&](int buf, int si, int c0) {
+        const SrcDev &S = p.s[si];
+        float *sA = smem + buf * BUF_SZ;
+        float *sB = sA + A_SZ;
+        const bool cok = (c0 + 4 * q) < S.C;
+#pragma unroll
+        for (int pass = 0; pass < P; ++pass) {
+            const bool ok = cok && ((r0 + rl0 + 32 * pass) < p.Mo);
+            float4 o = ra[pass];
+            o.x = ok ? o.x : 0.f; o.y = ok ? o.y : 0.f; o.z = ok ? o.z : 0.f; o.w = ok ? o.w : 0.f;
+            *reinterpret_cast<float4 *>(&sA[(rl0 + 32 * pass) * LDA + 4 * q]) = o;
+        }
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) {
+            const int idx = ltid + i * 256;
+            const int j4 = idx % (BN / 4), kk = idx / (BN / 4);
+            const bool ok = (c0 + kk < S.C) && (f0 + 4 * j4 < p.F);
+            float4 o = rb[i];
+            o.x = ok ? o.x : 0.f; o.y = ok ? o.y : 0.f; o.z = ok ? o.z : 0.f; o.w = ok ? o.w : 0.f;
+            *reinterpret_cast<float4 *>(&sB[kk * LDB + 4 * j4]) = o;
+            if (DUAL && S.w2) {
+                float4 o2 = rb2[i];
+                o2.x = ok ? o2.x : 0.f; o2.y = ok ? o2.y : 0.f; o2.z = ok ? o2.z : 0.f; o2.w = ok ? o2.w : 0.f;
+                *reinterpret_cast<float4 *>(&sB[B_SZ + kk * LDB + 4 * j4]) = o2;
+            }
+        }
+    };
+    // prologue: chunk 0 -> buffer 0
+    if (is_fast(0)) {
+        load_regs(0, 0);
+        store_regs(0, 0, 0);
+        l_c0 += KC;
+        if (l_c0 >= p.s[l_si].C) { l_c0 = 0; ++l_si; }
+    } else {
+        stage(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < total; ++it) {
+        const bool more = (it + 1 < total);
+        const bool fast = more && is_fast(l_si);
+        const int n_si = l_si, n_c0 = l_c0;
+        if (fast) load_regs(n_si, n_c0);
+        compute(it & 1);
+        if (more) {
+            if (fast) {
+                store_regs((it + 1) & 1, n_si, n_c0);
+                l_c0 += KC;
+                if (l_c0 >= p.s[l_si].C) { l_c0 = 0; ++l_si; }
+            } else {
+                stage((it + 1) & 1);
+            }
+        }
+        __syncthreads();
     }
 #endif
     if (loader) return;
@@ -700,7 +797,7 @@ extern "C" int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, in
         p.rankR = rank->R; p.rowscale = rank->rowscale; p.coef = rank->coef; p.rank_to2 = rank->to_acc2;
     }
     const int BM = 128;
-    const int BN = (F <= 32) ? 32 : (F <= 64) ? 64 : 128;
+    const int BN = (F <= 32) ? 32 : (F <= 64 || dual) ? 64 : 128;
     p.row_tiles = (Mo + BM - 1) / BM;
     p.col_tiles = (F + BN - 1) / BN;
     dim3 grid((unsigned)(N * p.row_tiles * p.col_tiles)), block(CAPE_SPEC ? 512 : 256);
