@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ref_*.npz by executing the REFERENCE's own lib/models.py (graph assembly,
+layer order, indices, weight layouts, variable names) on the numpy TF1 shim in
+oracle/tf1_numpy_shim.  Runs only where /root/reference exists (the build container); the committed
+.npz files are what the tests and the GPU box use.  TEST INFRASTRUCTURE ONLY.
+
+What this pins: everything the reference does in Python.  What it cannot pin: TensorFlow 1.13's C++
+kernels, which the shim replaces by numpy ops with the documented semantics (float64 compute).
+"""
+import copy
+import os
+import sys
+import zlib
+
+sys.dont_write_bytecode = True            # never write __pycache__ into the read-only reference tree
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("CAPE_REFERENCE", "/root/reference")
+sys.path.insert(0, os.path.join(HERE, "tf1_numpy_shim"))
+sys.path.insert(1, REF)
+sys.path.insert(2, os.path.dirname(HERE))
+
+import numpy as np                         # noqa: E402
+import tensorflow as tf                    # noqa: E402  (the shim)
+from lib import models                     # noqa: E402  (the reference's model code)
+from lib.load_data import load_graph_mtx   # noqa: E402  (the reference's loader)
+from lib.utils import filter_cloth_pose    # noqa: E402
+
+from oracle.configs import cape_params     # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def inputs(N, nz, seed):
+    from oracle.golden_inputs import golden_inputs
+    rot = np.load(os.path.join(REF, "data", "demo_data", "demo_pose_params.npz"))["rot"]
+    d = golden_inputs(N, nz, seed, rot)
+    # cross-check our filter_cloth_pose restatement against the reference's (lib/utils.py:38-62)
+    assert np.array_equal(d["cond"], np.tile(filter_cloth_pose(rot), (N // 6 + 1, 1))[:N].astype(np.float32))
+    return d
+
+
+def run(tag, cfg, overrides, N, seed):
+    tf.shim_reset()
+    # the reference targets numpy < 1.16.3 where np.load unpickled object arrays by default
+    _np_load = np.load
+    np.load = lambda *a, **k: _np_load(*a, **dict(k, allow_pickle=True))
+    try:
+        L, D, U, p, L_ds2, D_ds2, U_ds2 = load_graph_mtx(REF, load_for_demo=True)  # run_simple_demo.py:14
+    finally:
+        np.load = _np_load
+    params = cape_params(cfg, N)
+    params.update(overrides or {})
+    params["p"] = p
+    nz = params["nz"]
+    inp = inputs(N, nz, seed)
+    tf.shim_configure(seed=params["seed"], compute_dtype=np.float64, eps=inp["eps"])
+    ref_params = copy.deepcopy(params)
+    for k in ("lr", "num_epochs", "decay_rate", "decay_steps", "momentum", "optimizer"):
+        ref_params.setdefault(k, None)
+    model = models.CAPE(L=L, D=D, U=U, L_d=L_ds2, D_d=D_ds2, **ref_params)          # run_simple_demo.py:45
+    model.build_graph(model.input_num_verts, model.nn_input_channel, phase='demo')  # run_simple_demo.py:47
+    sess = tf.Session(graph=model.graph)
+    feed = {model.ph_data_g: inp["x"], model.ph_cond_g: inp["cond"], model.ph_cond2_g: inp["clo"],
+            model.ph_gt: inp["gt"], model.ph_data_d: inp["xd"], model.ph_cond_d: inp["cond_d"],
+            model.ph_cond2_d: inp["clo_d"], model.is_train: False}
+    names = ["op_prediction", "z_mean", "z_logvar", "recon_loss", "latent_loss", "edge_loss", "loss_g", "loss_d",
+             "op_loss_g", "op_loss_d", "fc_regularization_g", "op_vae_mean", "op_vae_var", "op_cond_latent",
+             "op_cond2_latent", "y_latent_g", "y2_latent_g"]
+    vals = sess.run([getattr(model, n) for n in names], feed)
+    out = {"out_" + n: np.asarray(v, dtype=np.float64) for n, v in zip(names, vals)}
+    out64 = dict(out)
+    # decoder-only path used by demos.py:392-395 (model.decode)
+    z_total = np.concatenate([out["out_op_vae_mean"], out["out_op_cond_latent"], out["out_op_cond2_latent"]], 1)
+    out["out_op_decoder"] = np.asarray(sess.run(model.op_decoder, {
+        model.ph_z_total: z_total, model.ph_y_latent: out["out_op_cond_latent"],
+        model.ph_y2_latent: out["out_op_cond2_latent"], model.is_train: False}), dtype=np.float64)
+    # big tensors are stored as float32 (6e-8 resolution); inputs are regenerated from the seed
+    for k in ("out_op_prediction", "out_op_decoder"):
+        out[k] = out[k].astype(np.float32)
+    out["meta_N"], out["meta_nz"], out["meta_seed"] = np.int64(N), np.int64(nz), np.int64(seed)
+    # variable inventory: names, shapes and checksums of the weights the reference graph created
+    var = tf.shim_variables()
+    vn = sorted(var)
+    out["var_names"] = np.array(vn)
+    out["var_shapes"] = np.array([",".join(str(s) for s in var[n].shape) for n in vn])
+    out["var_sums"] = np.array([float(np.asarray(var[n], np.float64).sum()) for n in vn])
+    out["var_crc"] = np.array([zlib.crc32(np.ascontiguousarray(var[n], dtype=np.float32).tobytes()) for n in vn], dtype=np.int64)
+    out["config"] = np.array(repr(dict(cfg=cfg, overrides=overrides, N=N, seed=seed)))
+    fn = os.path.join(OUT, "ref_%s.npz" % tag)
+    np.savez_compressed(fn, **out)
+    print(tag, "->", fn, os.path.getsize(fn), "bytes;", len(vn), "variables; prediction mean|.|",
+          float(np.abs(out["out_op_prediction"]).mean()))
+
+
+CASES = [
+    ("affine_nz64", "affine_nz64", None, 2, 11),
+    ("cmr_nz18", "cmr_nz18", None, 2, 12),
+    ("resblock_udn_tanh", "affine_nz18", dict(use_res_block=True, use_res_block_dec=False, cond_encoder=True,
+                                             activation='b1tanh', F=[16, 16, 32, 32, 64, 64, 128, 128],
+                                             reduce_dim=32, loss='l2'), 2, 13),
+]
+
+def main():
+    for case in CASES:
+        run(*case)
+
+
+if __name__ == "__main__":
+    import threading
+    sys.setrecursionlimit(100000)          # the lazy graph is evaluated recursively (GN decoder is deep)
+    threading.stack_size(512 * 1024 * 1024)
+    t = threading.Thread(target=main)
+    t.start()
+    t.join()

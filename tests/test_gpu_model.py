@@ -155,3 +155,37 @@ def test_encode_decode_api_padding(mesh_ops):
     preds, lr_, ll_, le_ = model.predict(x, cond, clo, labels=gt)
     assert preds.shape == (6, 6890, 3) and np.isfinite([lr_, ll_, le_]).all()
     assert model.predict(x[:3], cond[:3], clo[:3]).shape == (3, 6890, 3)
+
+
+@pytest.mark.parametrize("tag", ["affine_nz64", "cmr_nz18", "resblock_udn_tanh"])
+def test_model_matches_reference_golden(tag, mesh_ops):
+    """HIP path vs the golden vectors produced by the reference's own lib/models.py code (run on the
+    numpy TF1 shim by oracle/make_golden.py): same named weights, same inputs."""
+    from test_oracle_golden import load_case, build_oracle
+    from oracle.golden_inputs import golden_inputs
+    from cape_amd.models import CAPE
+    g, meta = load_case(tag)
+    P, orc = build_oracle(meta, mesh_ops)
+    inp = golden_inputs(meta["N"], P["nz"], meta["seed"], mesh_ops["pack"]["demo_rot"])
+    y, y2 = orc.cond_embeddings(inp["cond"], inp["clo"])            # materialises the name-keyed weights
+    xh, _, _ = orc.generator(inp["x"], y, y2, inp["eps"])
+    orc.discriminator(xh, y, y2)
+    m = mesh_ops
+    model = CAPE(L=m["L"], D=m["D"], U=m["U"], L_d=m["L_d"], D_d=m["D_d"], p=m["p"], **P)
+    model.build_graph(model.input_num_verts, model.nn_input_channel, phase='demo')
+    assert sorted(model._vars) == [str(n) for n in g["var_names"]]
+    model.load_variables(orc.vs.vars)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=model.device)
+    with torch.no_grad():
+        out = model.forward_losses(t(inp["x"]), t(inp["cond"]), t(inp["clo"]), t(inp["gt"]), t(inp["xd"]),
+                                   t(inp["cond_d"]), t(inp["clo_d"]), eps=t(inp["eps"]))
+    assert vertex_err(out['prediction'].cpu().numpy(), g["out_op_prediction"].astype(np.float64)) < 1e-4
+    assert rel_err(out['z_mean'].cpu().numpy(), g["out_z_mean"]) < 1e-4
+    assert rel_err(out['z_logvar'].cpu().numpy(), g["out_z_logvar"]) < 1e-4
+    for key, name in (("recon", "recon_loss"), ("latent", "latent_loss"), ("edge", "edge_loss"),
+                      ("gan_g", "loss_g"), ("gan_d", "loss_d"), ("loss_g", "op_loss_g"), ("loss_d", "op_loss_d")):
+        assert abs(float(out[key]) - float(g["out_" + name])) < 1e-4 * max(abs(float(g["out_" + name])), 1e-3), key
+    # decode() driver (numpy in/out) vs the reference's op_decoder
+    zt = np.concatenate([g["out_op_vae_mean"], g["out_op_cond_latent"], g["out_op_cond2_latent"]], 1)
+    rec = model.decode(zt, cond=g["out_op_cond_latent"], cond2=g["out_op_cond2_latent"])
+    assert vertex_err(rec, g["out_op_decoder"].astype(np.float64)) < 1e-4

@@ -1,0 +1,114 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/cape_hip.h declares,
+host-side operator algebra, loaders, config assembly, and the loud-failure rule (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_match_header():
+    hdr = open(os.path.join(ROOT, "include", "cape_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|int64_t)\s+(cape_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 18
+    lib = ctypes.CDLL(os.path.join(ROOT, "cape_amd", "libcape_hip.so"))
+    for name in declared:
+        assert hasattr(lib, name), "missing export %s" % name
+    from cape_amd import _lib
+    assert set(_lib.SIGNATURES) == declared
+    assert _lib.lib.cape_abi_version() == int(re.search(r"#define CAPE_ABI_VERSION (\d+)", hdr).group(1))
+
+
+def test_csr_validate_error_codes():
+    from cape_amd._lib import lib
+    rp = np.array([0, 1, 3], dtype=np.int32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert lib.cape_csr_validate(2, 2, 3, p(rp), p(np.array([0, 0, 1], dtype=np.int32))) == 0
+    assert lib.cape_csr_validate(2, 2, 3, p(rp), p(np.array([0, 1, 0], dtype=np.int32))) == -2      # unsorted
+    assert lib.cape_csr_validate(2, 2, 3, p(rp), p(np.array([0, 0, 5], dtype=np.int32))) == -3      # range
+    assert lib.cape_csr_validate(2, 2, 3, None, None) == -1
+
+
+def test_compute_entry_points_fail_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cape_amd import _lib
+    with pytest.raises(_lib.CapeHipError):
+        _lib.require_gpu()
+    from cape_amd.configs import cape_params
+    from cape_amd.load_data import load_graph_mtx
+    from cape_amd.models import CAPE
+    L, D, U, p, Ld, Dd, _ = load_graph_mtx(None, True)
+    with pytest.raises((RuntimeError, AssertionError, _lib.CapeHipError)):
+        CAPE(L=L, D=D, U=U, L_d=Ld, D_d=Dd, **cape_params(p=p, batch_size=2)).build_graph(6890, 3, 'demo')
+
+
+def test_laplacian_and_rescale_semantics(mesh_ops):
+    from cape_amd import mesh_sampling as ms
+    from oracle import cape_oracle as co
+    for L in mesh_ops["L"][::2] + mesh_ops["L_d"]:
+        assert L.dtype == np.float32 and sp.isspmatrix_csr(L)
+        Lt = ms.rescale_L(sp.csr_matrix(L), 2)
+        Lo = co.rescale_L(sp.csr_matrix(L), 2)
+        assert (Lt != Lo).nnz == 0
+        assert abs(Lt - Lt.T).max() == 0 and Lt.diagonal().max() == 0          # symmetric, zero diagonal
+        assert Lt.has_sorted_indices
+
+
+def test_operator_composition(mesh_ops):
+    from cape_amd.graph import ConvOperators, is_identity, is_row_selection
+    L, D, U = mesh_ops["L"], mesh_ops["D"], mesh_ops["U"]
+    assert is_identity(D[0]) and is_row_selection(D[1]) and not is_identity(D[1])
+    rng = np.random.default_rng(0)
+    # encoder layer with pooling: S_k = D T_k(L~)
+    ops = ConvOperators(L[1], 2, pool=D[1])
+    x = rng.standard_normal((6890, 5))
+    Lt = sp.csr_matrix(L[1], dtype=np.float64) - sp.identity(6890)
+    want = [D[1].astype(np.float64) @ x, D[1].astype(np.float64) @ (Lt @ x)]
+    for k in range(2):
+        got = ops.fwd[k].to_scipy().astype(np.float64) @ x
+        assert np.abs(got - want[k]).max() < 1e-6
+        assert np.abs(ops.bwd[k].to_scipy().toarray() - ops.fwd[k].to_scipy().toarray().T).max() == 0
+    # decoder layer with unpooling: S_k = T_k(L~) U ; identity-level U prunes to an exact identity
+    ops = ConvOperators(L[0], 2, unpool=U[0])
+    assert ops.fwd[0].identity and ops.Mi == 6890
+    ops = ConvOperators(L[1], 3, unpool=U[1])
+    assert (ops.Mi, ops.Mo) == (3445, 6890) and len(ops.fwd) == 3 and not ops.fwd[0].identity
+    xs = rng.standard_normal((3445, 4))
+    Um = U[1].astype(np.float64)
+    T2 = 2 * (Lt @ (Lt @ (Um @ xs))) - Um @ xs
+    assert np.abs(ops.fwd[2].to_scipy().astype(np.float64) @ xs - T2).max() < 1e-5
+    # rank-1 condition terms: S_k 1
+    rs = ops.cond_row_terms()
+    assert np.abs(rs[1] - np.asarray((Lt @ Um).sum(axis=1)).ravel()).max() < 1e-5
+    # K above FUSE_MAX_K falls back to the explicit recurrence
+    assert not ConvOperators(L[0], 6).fused
+
+
+def test_load_graph_mtx_and_configs(mesh_ops):
+    from cape_amd.configs import cape_params
+    from cape_amd.load_data import filter_cloth_pose, load_graph_mtx
+    assert mesh_ops["p"] == [6890, 6890, 3445, 3445, 1723, 1723, 862, 862, 862]
+    L3 = load_graph_mtx(None, load_for_demo=False)
+    assert len(L3) == 3 and [m.shape[0] for m in L3[0]] == [6890, 3445, 1723, 862, 431]
+    rot = mesh_ops["pack"]["demo_rot"]
+    assert filter_cloth_pose(rot).shape == (6, 126) and filter_cloth_pose(rot[:, :72]).shape == (6, 42)
+    P = cape_params('CAPE-affineconv_nz64_pose32_clotype32_male', p=mesh_ops["p"])
+    assert P["F"] == [64, 64, 128, 128, 256, 256, 512, 512] and P["K"] == [2] * 8 and P["affine"] and P["nz"] == 64
+    assert cape_params('CAPE_nz18_pose24_clotype8_male')["affine"] is False
+
+
+def test_vertex_edge_table(mesh_ops):
+    from cape_amd.graph import vertex_edge_table
+    edges = mesh_ops["pack"]["edges_smpl"]
+    ptr, idx = vertex_edge_table(edges, 6890)
+    assert ptr[-1] == 2 * len(edges) and len(idx) == 2 * len(edges)
+    v = 1234
+    inc = idx[ptr[v]:ptr[v + 1]]
+    for code in inc:
+        assert edges[code >> 1][code & 1] == v
