@@ -1,0 +1,105 @@
+"""API conformance on the GPU: replay the call sequences of the reference's entry scripts against
+cape_amd.models.CAPE -- run_simple_demo.py:14-49 + demos.py:367-407 (demo) and main.py:50-109 +
+demos.py:47-90 (train -> test) -- with synthetic BodyData-shaped inputs."""
+import copy
+import os
+import types
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _args_dict():
+    # config_parser.py defaults overridden by configs/CAPE-affineconv_nz64_pose32_clotype32_male.yaml
+    return dict(config='configs/x.yaml', name='dropin_test', num_conv_layers=8, ds_factor=2, K=2, Kd=3, nf=64, nz=64,
+                nz_cond=32, nz_cond2=32, n_layer_cond=1, activation='b1leakyrelu', use_res_block=0, use_res_block_dec=1,
+                cond_encoder=0, reduce_dim=64, affine=1, pose_type='rot', optim_condnet=1, batch_size=4, num_epochs=1,
+                lr=8e-3, lr_scaler=1e-1, decay_every=2, lr_warmup=1, seed=123, restart=1, optimizer='sgd', loss='l1',
+                loss_mask='', dataset='dataset_male_4clotypes', regularization=2e-3, lambda_recon=1.0, lambda_edge=1.0,
+                lambda_latent=8e-4, lambda_gan=0.1, mode='demo', gender='male', smpl_model_folder='body_models',
+                demo_n_sample=3, save_obj=0, vis_demo=0)
+
+
+def _params(args_dict, p, decay_steps=1):
+    # main.py:50-84 / run_simple_demo.py:17-43 verbatim in structure
+    args = types.SimpleNamespace(**args_dict)
+    params = copy.deepcopy(args_dict)
+    params['restart'] = bool(args.restart)
+    params['use_res_block'], params['use_res_block_dec'] = bool(args.use_res_block), bool(args.use_res_block_dec)
+    params['nn_input_channel'] = 3
+    params['K'] = [2] * args.num_conv_layers
+    params['Kd'] = args.Kd
+    params['p'] = p
+    params['n_layer_cond'] = args.n_layer_cond
+    params['cond_encoder'] = bool(args.cond_encoder)
+    params['reduce_dim'] = args.reduce_dim
+    params['affine'] = bool(args.affine)
+    params['optimizer'] = args.optimizer
+    params['lr_warmup'] = bool(args.lr_warmup)
+    params['optim_condnet'] = bool(args.optim_condnet)
+    params['decay_steps'] = decay_steps
+    params['cond_dim'] = 126
+    params['cond2_dim'] = 4
+    nf = args.nf
+    params['F'] = [nf, nf, 2 * nf, 2 * nf, 4 * nf, 4 * nf, 8 * nf, 8 * nf]
+    for key in ['demo_n_sample', 'mode', 'dataset', 'num_conv_layers', 'ds_factor', 'nf', 'config', 'pose_type',
+                'decay_every', 'gender', 'save_obj', 'vis_demo', 'smpl_model_folder']:
+        params.pop(key)
+    return params
+
+
+def test_train_then_demo_sequences(tmp_path, mesh_ops):
+    from cape_amd import models
+    from cape_amd.load_data import load_graph_mtx, filter_cloth_pose
+    L, D, U, p, L_ds2, D_ds2, U_ds2 = load_graph_mtx(None, load_for_demo=True)          # run_simple_demo.py:14
+    ad = _args_dict()
+    rng = np.random.default_rng(0)
+    n_train, n_val = 8, 4
+    data = types.SimpleNamespace(
+        vertices_train=rng.standard_normal((n_train, 6890, 3)).astype(np.float32),
+        cond1_train=rng.standard_normal((n_train, 126)).astype(np.float32),
+        cond2_train=np.eye(4, dtype=np.float32)[rng.integers(0, 4, n_train)],
+        vertices_val=rng.standard_normal((n_val, 6890, 3)).astype(np.float32),
+        cond1_val=rng.standard_normal((n_val, 126)).astype(np.float32),
+        cond2_val=np.eye(4, dtype=np.float32)[rng.integers(0, 4, n_val)])
+
+    # ---- main.py:87-92 (train) ----
+    params = _params(ad, p, decay_steps=ad['decay_every'] * n_train / ad['batch_size'])
+    model = models.CAPE(L=L, D=D, U=U, L_d=L_ds2, D_d=D_ds2, project_dir=str(tmp_path), **params)
+    assert (model.input_num_verts, model.nn_input_channel, model.nz, model.batch_size) == (6890, 3, 64, 4)
+    model.build_graph(model.input_num_verts, model.nn_input_channel, phase='train')
+    loss, t_step = model.fit(data)
+    assert len(loss) == 1 and np.isfinite(loss[0]) and t_step > 0
+    assert os.path.exists(os.path.join(str(tmp_path), 'checkpoints', 'dropin_test'))
+
+    # ---- main.py:95-100 -> demos.py:63-84 (test): a NEW model object restores the checkpoint ----
+    model2 = models.CAPE(L=L, D=D, U=U, L_d=L_ds2, D_d=D_ds2, project_dir=str(tmp_path), **params)
+    model2.build_graph(model2.input_num_verts, model2.nn_input_channel, phase='demo')
+    preds, lr_, ll_, le_ = model2.predict(data.vertices_val, data.cond1_val, data.cond2_val, labels=data.vertices_val)
+    assert preds.shape == (n_val, 6890, 3) and np.isfinite(preds).all() and np.isfinite([lr_, ll_, le_]).all()
+    string, *_ = model2.evaluate(data.vertices_val, data.cond1_val, data.cond2_val, data.vertices_val, model2)
+    assert string.startswith('recon loss:')
+
+    # ---- run_simple_demo.py:48-49 -> demos.py:367-407 (sample_vary_clotype) ----
+    clotype = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    rot = filter_cloth_pose(mesh_ops["pack"]["demo_rot"])[0]
+    rot_repeated = np.repeat(rot[np.newaxis, :], len(clotype), axis=0)
+    pose_emb, clotype_emb = model2.encode_only_condition(rot_repeated, clotype)
+    assert pose_emb.shape == (4, 32) and clotype_emb.shape == (4, 32)
+    pose_emb = pose_emb[0]
+    z_samples = np.random.normal(loc=0.0, scale=1.0, size=(ad['demo_n_sample'], model2.nz))
+    for i in range(len(clotype)):
+        z_sample_c = np.array([np.concatenate([s.reshape(1, -1), pose_emb.reshape(1, -1), clotype_emb[i].reshape(1, -1)],
+                                              axis=1) for s in z_samples]).reshape(ad['demo_n_sample'], -1)
+        predictions = model2.decode(z_sample_c, cond=pose_emb.reshape(1, -1), cond2=clotype_emb[i].reshape(1, -1))
+        assert predictions.shape == (3, 6890, 3) and np.isfinite(predictions).all()
+    # a model without any checkpoint refuses to run inference, like the reference's Saver.restore would
+    orphan = models.CAPE(L=L, D=D, U=U, L_d=L_ds2, D_d=D_ds2, project_dir=str(tmp_path), **dict(params, name='nothing_here'))
+    orphan.build_graph(6890, 3, phase='demo')
+    with pytest.raises(ValueError):
+        orphan.encode_only_condition(rot_repeated, clotype)
+    # operator plug-points are resolved by name; unknown names fail like getattr in the reference
+    with pytest.raises(AttributeError):
+        models.CAPE(L=L, D=D, U=U, L_d=L_ds2, D_d=D_ds2, **dict(params, filter='no_such_filter'))
