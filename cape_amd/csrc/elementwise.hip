@@ -123,30 +123,34 @@ __global__ __launch_bounds__(256) void mask_mul_kernel(CView dy, const unsigned 
 // stage 1: block b sums rows [b*RB, (b+1)*RB) of the flattened (n,m) row space -> part[b][c]
 constexpr int COLSUM_RB = 128;
 
-// aligned fast path (C % 4 == 0, C <= 256): thread = (float4 column, row lane)
+// aligned fast path (C % 4 == 0): thread = (float4 column, row lane); column groups of <= 256 floats
 __global__ __launch_bounds__(256) void colsum_partial_vec_kernel(CView x, int N, int M, int C, float *part) {
     __shared__ float4 red[256];
-    const int c4n = C >> 2;
-    const int lanes = 256 / c4n;               // row lanes
-    const int q = threadIdx.x % c4n, rl = threadIdx.x / c4n;
     const long long R = (long long)N * M;
     const long long ra = (long long)blockIdx.x * COLSUM_RB;
     const long long rb = (ra + COLSUM_RB < R) ? ra + COLSUM_RB : R;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (rl < lanes)
-        for (long long r = ra + rl; r < rb; r += lanes) {
-            const long long n = r / M, m = r % M;
-            const float4 v = *reinterpret_cast<const float4 *>(x.p + n * x.ss + m * x.ld + 4 * q);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    for (int cbase = 0; cbase < C; cbase += 256) {
+        const int cw = min(256, C - cbase);
+        const int c4n = cw >> 2;
+        const int lanes = 256 / c4n;               // row lanes
+        const int q = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rl < lanes)
+            for (long long r = ra + rl; r < rb; r += lanes) {
+                const long long n = r / M, m = r % M;
+                const float4 v = *reinterpret_cast<const float4 *>(x.p + n * x.ss + m * x.ld + cbase + 4 * q);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (rl == 0) {
+            for (int l = 1; l < lanes; ++l) {
+                const float4 v = red[l * c4n + q];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            *reinterpret_cast<float4 *>(part + (long long)blockIdx.x * C + cbase + 4 * q) = s;
         }
-    red[threadIdx.x] = s;
-    __syncthreads();
-    if (rl == 0) {
-        for (int l = 1; l < lanes; ++l) {
-            const float4 v = red[l * c4n + q];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-        *reinterpret_cast<float4 *>(part + (long long)blockIdx.x * C + 4 * q) = s;
+        __syncthreads();
     }
 }
 
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(256) void reduce_cond_kernel(CView dy, const float 
 }
 
 // ---- out[n, j, f] = sum_r rowscale[j, r] * dz[n, r, f]   (gradient of the rank-1 condition terms)
-constexpr int RSR_RB = 128;   // rows per block
+constexpr int RSR_RB = 32;    // rows per block
 constexpr int RSR_MAXR = 4;
 
 // stage 1: block = (sample n, row chunk), thread = (column, row lane); part[n][chunk][j][f]
@@ -368,7 +372,7 @@ extern "C" int cape_colsum(const float *x, int64_t x_sample_stride, int32_t ldx,
     const long long R = (long long)N * M;
     const int nblk = (int)((R + COLSUM_RB - 1) / COLSUM_RB);
     if (!workspace || workspace_bytes < (int64_t)nblk * C * (int64_t)sizeof(float)) return CAPE_EWORKSPACE;
-    if (aligned4(x, x_sample_stride, ldx, C) && C <= 256 && (256 % (C / 4)) == 0)
+    if (aligned4(x, x_sample_stride, ldx, C) && (C >= 256 ? (C % 256) == 0 : (256 % (C / 4)) == 0))
         CAPE_LAUNCH(colsum_partial_vec_kernel, dim3(nblk), dim3(256), 0, st, xv, N, M, C, (float *)workspace);
     else
         CAPE_LAUNCH(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, xv, N, M, C, (float *)workspace);

@@ -98,6 +98,7 @@ class base_model(object):
         self._ops_cache = {}
         self._csr_cache = {}
         self._init_rng = np.random.default_rng(seed)
+        self._grad_views = {}      # TF variable name -> view of the flat gradient bucket (train phase)
 
     # ---- data assets ---------------------------------------------------------------------------
     def _load_template(self):
@@ -163,7 +164,7 @@ class base_model(object):
         with self.variable_scope('dense'):
             k = self._get_variable('kernel', (x.shape[-1], units), 'fc_kernel')
             b = self._get_variable('bias', (units,), 'fc_bias')
-        y = torch.addmm(b, x, k)
+        y = ops.dense_splitk(x, k, b, grad_buf=self._grad_views.get('/'.join(self._scope + ['dense', 'kernel'])))
         if activation == 'leaky_relu':
             y = torch.nn.functional.leaky_relu(y, 0.2)
         return y
@@ -191,8 +192,13 @@ class base_model(object):
         = vertex-constant input channels appended after x's channels (never materialised)."""
         Cin = x.shape[-1] + (0 if cond_in is None else cond_in.shape[1])
         W = self._weight_variable([Cin * K, Fout])
+        gW = self._grad_views.get('/'.join(self._scope + ['weights']))
+        gWa = None
+        if W_affine is not None:
+            gWa = self._grad_views.get('/'.join(self._scope[:-1] + ['affine', 'weights']))
         return ops.chebyshev5(x, W, self._conv_ops(L, K, unpool=unpool, pool=pool), bias=bias,
-                              activation=activation, cond=cond, W_affine=W_affine, cond_in=cond_in)
+                              activation=activation, cond=cond, W_affine=W_affine, cond_in=cond_in,
+                              grad_bufs=(gW, gWa))
 
     def _brelu_named(self, x, kind):
         shape = [1, x.shape[1], x.shape[2]] if kind == 'b2relu' else [1, 1, x.shape[2]]
@@ -604,6 +610,12 @@ class CAPE(base_model):
                     p.data = flat[off:off + n].view(p.shape)
                     views.append(flat_grad[off:off + n].view(p.shape))
                     off += n
+            if grp == 'g':
+                # generator/condition variables are used exactly once per step, so their gradient kernels
+                # may write the bucket directly; discriminator variables are shared by the real and the
+                # fake pass (two contributions that autograd must add) and keep private gradient tensors.
+                for nm, view in zip(names, views):
+                    self._grad_views[nm] = view
             st = {'params': params, 'flat': flat, 'flat_grad': flat_grad, 'grad_views': views,
                   'm': torch.zeros_like(flat),
                   'neg_lr': torch.zeros((), device=self.device, dtype=torch.float32)}
@@ -637,7 +649,7 @@ class CAPE(base_model):
             for view, g in zip(st['grad_views'], grads):
                 if g is None:
                     view.zero_()
-                else:
+                elif g.data_ptr() != view.data_ptr():      # kernels may already have written the bucket
                     view.copy_(g)
 
     def apply_updates(self, grp, clip=5.0):

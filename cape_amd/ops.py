@@ -324,6 +324,14 @@ def rowscale_reduce(dz, rowscale, R):
 # --------------------------------------------------------------------------------------------
 # autograd operators
 # --------------------------------------------------------------------------------------------
+def _grad_buffer(W, view=None):
+    """Destination of a weight gradient: the caller-provided view of the flat gradient bucket (the
+    kernels then write straight into the bucket and the per-variable copy disappears) or a fresh tensor."""
+    if view is not None and view.shape == W.shape and view.is_contiguous():
+        return view
+    return torch.empty_like(W)
+
+
 class ChebConvFn(torch.autograd.Function):
     """y = [ epilogue( sum_k (S_k [x | cond_in 1^T]) W_k ) | cond_out tiled over vertices ]
 
@@ -341,7 +349,7 @@ class ChebConvFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, W, bias, W_aff, cond_in, cond_out, ops, act, bias_mode, mode):
+    def forward(ctx, x, W, bias, W_aff, cond_in, cond_out, ops, act, bias_mode, mode, gW=None, gWa=None):
         x = as_act(x)
         N, Mi, Ch = x.shape
         K, Fout = ops.K, W.shape[1]
@@ -381,6 +389,7 @@ class ChebConvFn(torch.autograd.Function):
             fill_cond(cond_out.contiguous(), yfull[:, :, Fout:])
         ctx.ops, ctx.act, ctx.bias_mode, ctx.Fout, ctx.Co, ctx.Cc = ops, act, bias_mode, Fout, Co, Cc
         ctx.has_bias, ctx.twopass, ctx.xshape = bias is not None, twopass, (N, Mi, Ch)
+        ctx.gW, ctx.gWa = gW, gWa
         ctx.save_for_backward(W, W_aff, mask, yfull if (act != "none" and W_aff is None) else None, cond_in, *xs)
         return yfull
 
@@ -411,10 +420,10 @@ class ChebConvFn(torch.autograd.Function):
                 colsum(dz, dB)
         csr_of = (lambda k: None) if twopass else (lambda k: ops.fwd[k])
         if need_w:
-            dW = torch.empty_like(W)
+            dW = _grad_buffer(W, ctx.gW)
             gconv_dw([dict(x=xs[k], csr=csr_of(k), w=(dW, k * Fout, K * Fout, 1)) for k in range(K)], dz)
         if W_aff is not None and need_wa:
-            dWa = torch.empty_like(W_aff)
+            dWa = _grad_buffer(W_aff, ctx.gWa)
             gconv_dw([dict(x=xs[0], csr=csr_of(0), w=(dWa, 0, Fout, 1))], g)
         if Cc:
             # rank-1 condition terms: dcoef[n,k,f] = sum_r (S_k 1)[r] dz[n,r,f]
@@ -439,17 +448,20 @@ class ChebConvFn(torch.autograd.Function):
                     entries.append(dict(x=g, csr=ops.bwd[0], w=(W_aff, 0, 1, Fout)))
                 gconv_fwd(entries, dx)
             else:
-                # transposed weight blocks with the output index contiguous: Wt[k][f][c] = W[c*K+k][f]
+                # transposed weight blocks with the output index contiguous, Wt[k][f][c] = W[c*K+k][f]: one
+                # small copy per layer; staging the W^T blocks in place through strides (row stride 1,
+                # column stride K*Fout) measured 1.5x slower in the GEMM (scattered LDS writes)
                 Wt = W[:Ch * K].view(Ch, K, Fout).permute(1, 2, 0).contiguous()
-                Wat = W_aff[:Ch].t().contiguous() if W_aff is not None else None
+                wT = lambda k: (Wt, k * Fout * Ch, Ch, 1)
+                waT = (W_aff[:Ch].t().contiguous(), 0, Ch, 1) if W_aff is not None else None
                 contract_first = (Mo < Mi) or (Mo == Mi and Ch < Fout)
                 if contract_first:
                     # G_k = dz W_k^T at the Mo output rows, then dx = sum_k S_k^T G_k
                     first = True
                     for k in range(K):
-                        ent = [dict(x=dz, csr=None, w=(Wt, k * Fout * Ch, Ch, 1))]
+                        ent = [dict(x=dz, csr=None, w=wT(k))]
                         if W_aff is not None and k == 0:
-                            ent.append(dict(x=g, csr=None, w=(Wat, 0, Ch, 1)))
+                            ent.append(dict(x=g, csr=None, w=waT))
                         if ops.bwd[k].identity and first:
                             gconv_fwd(ent, dx)
                         else:
@@ -467,14 +479,14 @@ class ChebConvFn(torch.autograd.Function):
                     ent = []
                     for k in range(K):
                         Tk = dz if ops.bwd[k].identity else spmm(dz, ops.bwd[k])
-                        ent.append(dict(x=Tk, csr=None, w=(Wt, k * Fout * Ch, Ch, 1)))
+                        ent.append(dict(x=Tk, csr=None, w=wT(k)))
                     if W_aff is not None:
                         Ta = g if ops.bwd[0].identity else spmm(g, ops.bwd[0])
-                        ent.append(dict(x=Ta, csr=None, w=(Wat, 0, Ch, 1)))
+                        ent.append(dict(x=Ta, csr=None, w=waT))
                     gconv_fwd(ent, dx)
         if Co and need_co:
             dco = reduce_cond(gfull[:, :, Fout:])
-        return dx, dW, dB, dWa, dci, dco, None, None, None, None
+        return dx, dW, dB, dWa, dci, dco, None, None, None, None, None, None
 
 
 class ChebConvRecurrenceFn(torch.autograd.Function):
@@ -643,7 +655,7 @@ class ReconEdgeLossFn(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------
 # functional front-ends with the reference's operator names
 # --------------------------------------------------------------------------------------------
-def chebyshev5(x, W, ops, bias=None, activation=None, cond=None, W_affine=None, cond_in=None):
+def chebyshev5(x, W, ops, bias=None, activation=None, cond=None, W_affine=None, cond_in=None, grad_bufs=(None, None)):
     """Graph convolution (lib/models.py:69-103) with optional fused bias+activation
     (``activation`` in b1leakyrelu/b1relu/b1tanh/b2relu), affine branch, rank-1 input condition
     (``cond_in``) and materialised output condition concat (``cond``)."""
@@ -653,7 +665,7 @@ def chebyshev5(x, W, ops, bias=None, activation=None, cond=None, W_affine=None, 
     else:
         act, bmode = _ACT_OF[activation]
     if ops.fused:
-        return ChebConvFn.apply(x, W, bias, W_affine, cond_in, cond, ops, act, bmode, MODE)
+        return ChebConvFn.apply(x, W, bias, W_affine, cond_in, cond, ops, act, bmode, MODE, grad_bufs[0], grad_bufs[1])
     assert W_affine is None
     if cond_in is not None:
         x = ConcatCondFn.apply(x, cond_in)
@@ -695,3 +707,75 @@ class BiasActFn(torch.autograd.Function):
 def brelu(x, bias, activation):
     act, bmode = _ACT_OF[activation]
     return BiasActFn.apply(x, bias, act, bmode)
+
+
+class _SplitKMatmulFn(torch.autograd.Function):
+    """y = x @ W for a skinny x ([16, in]) and a very long contraction (in = 55168 = 862 vertices x 64
+    channels, the encoder's fc_mean/fc_var and -- transposed -- the decoder fc1 data gradient): rocBLAS
+    picks a single-wave-of-tiles kernel without split-K (160 us); batching the contraction into S chunks
+    fills the chip.  Plumbing around rocBLAS, not a custom kernel (the FCs are a 'next' row)."""
+
+    @staticmethod
+    def forward(ctx, x, W, S, gW=None):
+        ctx.S, ctx.gW = S, gW
+        ctx.save_for_backward(x, W)
+        return _splitk_mm(x, W, S)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        dx = dW = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(g, W.t())
+        if ctx.needs_input_grad[1]:
+            dW = _grad_buffer(W, ctx.gW)
+            torch.mm(x.t(), g, out=dW)
+        return dx, dW, None, None
+
+
+def _splitk_mm(x, W, S):
+    n, kin = x.shape
+    kc = kin // S
+    parts = torch.bmm(x.view(n, S, kc).transpose(0, 1), W.view(S, kc, W.shape[1]))     # [S, n, out]
+    return parts.sum(0)
+
+
+class _WideMatmulFn(torch.autograd.Function):
+    """y = x @ W with a very wide output (decoder fc1: 128 -> 55168): the data gradient g @ W^T has the
+    long contraction and takes the split path."""
+
+    @staticmethod
+    def forward(ctx, x, W, S, gW=None):
+        ctx.S, ctx.gW = S, gW
+        ctx.save_for_backward(x, W)
+        return torch.mm(x, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        dx = dW = None
+        if ctx.needs_input_grad[0]:
+            n, kout = g.shape
+            S, kc = ctx.S, kout // ctx.S
+            parts = torch.bmm(g.view(n, S, kc).transpose(0, 1), W.view(W.shape[0], S, kc).permute(1, 2, 0))
+            dx = parts.sum(0)
+        if ctx.needs_input_grad[1]:
+            dW = _grad_buffer(W, ctx.gW)
+            torch.mm(x.t(), g, out=dW)
+        return dx, dW, None, None
+
+
+def dense_splitk(x, kernel, bias, min_long=8192, grad_buf=None):
+    """tf.layers.dense: x @ kernel + bias, with split contraction for the 55168-long sides."""
+    kin, kout = kernel.shape
+
+    def splits(n):
+        for S in (64, 32, 16, 8):
+            if n % S == 0:
+                return S
+        return 0
+    if kin >= min_long and splits(kin) and x.shape[0] <= 64:
+        return _SplitKMatmulFn.apply(x, kernel, splits(kin), grad_buf) + bias
+    if kout >= min_long and splits(kout) and x.shape[0] <= 64:
+        return _WideMatmulFn.apply(x, kernel, splits(kout), grad_buf) + bias
+    return torch.addmm(bias, x, kernel)
