@@ -11,6 +11,7 @@
 // mode (:776-793) and -- with transposed operators and weights -- their data gradients.
 // The weight-gradient kernel (contraction over vertices) lives below.
 #include "common.h"
+#include <stdlib.h>
 #ifndef CAPE_EXP
 #define CAPE_EXP 0
 #endif
@@ -212,7 +213,7 @@ __device__ __forceinline__ void stage_weights(float *sB, const float *w, long lo
 // LDS buffer.  One barrier per chunk hands the buffers over; the MFMA waves never wait on global
 // memory, the loader waves are free to sit on L2 latency.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool DUAL>
-__global__ __launch_bounds__(CAPE_SPEC ? 512 : 256, (DUAL && BN == 128) ? 1 : 4) void gconv_fwd_kernel(GconvParams p) {
+__global__ __launch_bounds__(CAPE_SPEC ? 512 : 256, (DUAL && BN == 128 && BM == 128) ? 1 : 4) void gconv_fwd_kernel(GconvParams p) {
     constexpr int LDA = KC + 4;
     constexpr int LDB = BN + 4;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -796,20 +797,28 @@ extern "C" int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, in
         if (rank->to_acc2 && !dual) return CAPE_EINVAL;
         p.rankR = rank->R; p.rowscale = rank->rowscale; p.coef = rank->coef; p.rank_to2 = rank->to_acc2;
     }
-    const int BM = 128;
-    const int BN = (F <= 32) ? 32 : (F <= 64 || dual) ? 64 : 128;
-    p.row_tiles = (Mo + BM - 1) / BM;
+    int BM = 128;
+    static const int dual_wide = getenv("CAPE_DUAL_WIDE") ? atoi(getenv("CAPE_DUAL_WIDE")) : 1;
+    const bool dualw = dual && dual_wide && F > 64;      // DUAL: 64x128 tiles (two accumulator sets = 64 AGPRs)
+    const int BN = (F <= 32) ? 32 : (F <= 64 || (dual && !dualw)) ? 64 : 128;
+    if (dualw) BM = 64;
     p.col_tiles = (F + BN - 1) / BN;
+    // small meshes: 128-row tiles leave <= 2 workgroups per CU (no overlap partner while staging);
+    // 64-row tiles double the resident workgroups at the price of re-reading the weight tile
+    static const int bm64_below = getenv("CAPE_BM64_BELOW") ? atoi(getenv("CAPE_BM64_BELOW")) : 640;
+    if (!dual && BN == 128 && (long long)N * ((Mo + 127) / 128) * p.col_tiles < bm64_below) BM = 64;
+    p.row_tiles = (Mo + BM - 1) / BM;
     dim3 grid((unsigned)(N * p.row_tiles * p.col_tiles)), block(CAPE_SPEC ? 512 : 256);
     hipStream_t st = (hipStream_t)stream;
     if (!dual) {
         if (BN == 32) CAPE_LAUNCH((gconv_fwd_kernel<128, 32, 4, 1, false>), grid, block, 0, st, p);
         else if (BN == 64) CAPE_LAUNCH((gconv_fwd_kernel<128, 64, 4, 1, false>), grid, block, 0, st, p);
+        else if (BM == 64) CAPE_LAUNCH((gconv_fwd_kernel<64, 128, 2, 2, false>), grid, block, 0, st, p);
         else CAPE_LAUNCH((gconv_fwd_kernel<128, 128, 2, 2, false>), grid, block, 0, st, p);
     } else {
         if (BN == 32) CAPE_LAUNCH((gconv_fwd_kernel<128, 32, 4, 1, true>), grid, block, 0, st, p);
         else if (BN == 64) CAPE_LAUNCH((gconv_fwd_kernel<128, 64, 4, 1, true>), grid, block, 0, st, p);
-        else CAPE_LAUNCH((gconv_fwd_kernel<128, 128, 2, 2, true>), grid, block, 0, st, p);
+        else CAPE_LAUNCH((gconv_fwd_kernel<64, 128, 2, 2, true>), grid, block, 0, st, p);
     }
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;

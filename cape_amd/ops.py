@@ -190,7 +190,7 @@ def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=
         launch()
     else:
         dual = any(e.get("w2") is not None for e in entries)
-        bn = 32 if F <= 32 else (64 if (F <= 64 or dual) else 128)
+        bn = 32 if F <= 32 else (64 if F <= 64 else 128)
         name = "gconv_fwd_kernel<128,%d,%s,%s>" % (bn, "2,2" if bn == 128 else "4,1", "true" if dual else "false")
         flops, byts = _gconv_work(entries, N, Mo, F)
         _log_launch(name, flops, byts, launch)
