@@ -506,6 +506,7 @@ struct DwParams {
     int tile_off[CAPE_MAX_SRC + 1];   // first output tile of each source (c-tiles * ftiles)
     long long part_off[CAPE_MAX_SRC + 1];   // element offset of each source inside one partial slab
     int rsplit, rows_per_split;
+    int ngroups, samples_per_group;
     float *ws;
     long long slab;   // elements per split slab
 };
@@ -527,9 +528,11 @@ __global__ __launch_bounds__(256, 4) void gconv_dw_kernel(DwParams p) {
 
     const int ntiles = p.tile_off[p.nsrc];
     const int tile = blockIdx.x % ntiles;
-    const int split = blockIdx.x / ntiles;   // split = n * rsplit + rs
-    const int n = split / p.rsplit;
+    const int split = blockIdx.x / ntiles;   // split = group * rsplit + rs
+    const int grp = split / p.rsplit;
     const int rs = split % p.rsplit;
+    const int n_begin = grp * p.samples_per_group;
+    const int n_end = min(p.N, n_begin + p.samples_per_group);
     int si = 0;
     while (si + 1 < p.nsrc && tile >= p.tile_off[si + 1]) ++si;
     const SrcDev &S = p.s[si];
@@ -547,6 +550,7 @@ __global__ __launch_bounds__(256, 4) void gconv_dw_kernel(DwParams p) {
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
 
+    for (int n = n_begin; n < n_end; ++n) {
     const float *dzb = p.dz + (long long)n * p.dzs;
     const float *xb = S.x + (long long)n * S.xs;
 
@@ -681,6 +685,7 @@ __global__ __launch_bounds__(256, 4) void gconv_dw_kernel(DwParams p) {
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][u], bv[b][u], acc[a][b], 0, 0, 0);
         }
     }
+    }   // samples of this group
 
     // partial slab layout: [split][part_off[si] + c*F + f]
     float *out = p.ws + (long long)split * p.slab + p.part_off[si];
@@ -740,7 +745,7 @@ inline int fill_src(SrcDev &d, const cape_src_t &s) {
 }
 
 struct DwPlan {
-    int ct, ft, ctiles[CAPE_MAX_SRC], ftiles, ntiles, rsplit, rows_per_split;
+    int ct, ft, ctiles[CAPE_MAX_SRC], ftiles, ntiles, rsplit, rows_per_split, ngroups, samples_per_group;
     long long slab;
 };
 
@@ -757,15 +762,20 @@ inline void plan_dw(const cape_src_t *srcs, int nsrc, int N, int Mo, int F, DwPl
         pl.ntiles += pl.ctiles[i] * pl.ftiles;
         pl.slab += (long long)srcs[i].C * F;
     }
-    // aim for >= ~1024 workgroups, at least 64 rows (2 chunks) per split
-    int want = (768 + pl.ntiles * N - 1) / (pl.ntiles * N);
-    if (want < 1) want = 1;
-    int maxsplit = (Mo + 63) / 64;
-    if (want > maxsplit) want = maxsplit;
-    int rows = (Mo + want - 1) / want;
+    // aim for ~512 workgroups: split the vertex dimension down to 128 rows, then the batch into groups
+    int S = (512 + pl.ntiles - 1) / pl.ntiles;
+    if (S < 1) S = 1;
+    int maxr = (Mo + 127) / 128;
+    int rsplit = S < maxr ? S : maxr;
+    int rows = (Mo + rsplit - 1) / rsplit;
     rows = ((rows + 31) / 32) * 32;
     pl.rows_per_split = rows;
     pl.rsplit = (Mo + rows - 1) / rows;
+    int ngroups = (S + pl.rsplit - 1) / pl.rsplit;
+    if (ngroups > N) ngroups = N;
+    if (ngroups < 1) ngroups = 1;
+    pl.samples_per_group = (N + ngroups - 1) / ngroups;
+    pl.ngroups = (N + pl.samples_per_group - 1) / pl.samples_per_group;
 }
 
 }  // namespace
@@ -798,7 +808,7 @@ extern "C" int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, in
         p.rankR = rank->R; p.rowscale = rank->rowscale; p.coef = rank->coef; p.rank_to2 = rank->to_acc2;
     }
     int BM = 128;
-    static const int dual_wide = getenv("CAPE_DUAL_WIDE") ? atoi(getenv("CAPE_DUAL_WIDE")) : 1;
+    static const int dual_wide = getenv("CAPE_DUAL_WIDE") ? atoi(getenv("CAPE_DUAL_WIDE")) : 0;
     const bool dualw = dual && dual_wide && F > 64;      // DUAL: 64x128 tiles (two accumulator sets = 64 AGPRs)
     const int BN = (F <= 32) ? 32 : (F <= 64 || (dual && !dualw)) ? 64 : 128;
     if (dualw) BM = 64;
@@ -829,7 +839,7 @@ extern "C" int64_t cape_gconv_dw_workspace_bytes(const cape_src_t *srcs, int32_t
     if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || N < 1 || Mo < 1 || F < 1) return CAPE_EINVAL;
     DwPlan pl;
     plan_dw(srcs, nsrc, N, Mo, F, pl);
-    return (int64_t)pl.slab * N * pl.rsplit * (int64_t)sizeof(float);
+    return (int64_t)pl.slab * pl.ngroups * pl.rsplit * (int64_t)sizeof(float);
 }
 
 extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *dz,
@@ -839,7 +849,7 @@ extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *
         return CAPE_EINVAL;
     DwPlan pl;
     plan_dw(srcs, nsrc, N, Mo, F, pl);
-    const long long need = pl.slab * N * pl.rsplit * (long long)sizeof(float);
+    const long long need = pl.slab * pl.ngroups * pl.rsplit * (long long)sizeof(float);
     if (workspace_bytes < need) return CAPE_EWORKSPACE;
     DwParams p;
     DwReduceParams rp;
@@ -860,15 +870,16 @@ extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *
     p.dzvec = ((lddz & 3) == 0) && ((dz_sample_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dz) & 15) == 0);
     p.N = N; p.Mo = Mo; p.F = F; p.ftiles = pl.ftiles;
     p.rsplit = pl.rsplit; p.rows_per_split = pl.rows_per_split;
+    p.ngroups = pl.ngroups; p.samples_per_group = pl.samples_per_group;
     p.ws = (float *)workspace; p.slab = pl.slab;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)(pl.ntiles * N * pl.rsplit)), block(256);
+    dim3 grid((unsigned)(pl.ntiles * pl.ngroups * pl.rsplit)), block(256);
     if (pl.ct == 64 && pl.ft == 64) CAPE_LAUNCH((gconv_dw_kernel<64, 64>), grid, block, 0, st, p);
     else if (pl.ct == 64) CAPE_LAUNCH((gconv_dw_kernel<64, 128>), grid, block, 0, st, p);
     else if (pl.ft == 64) CAPE_LAUNCH((gconv_dw_kernel<128, 64>), grid, block, 0, st, p);
     else CAPE_LAUNCH((gconv_dw_kernel<128, 128>), grid, block, 0, st, p);
     CAPE_LAUNCH_CHECK();
-    rp.F = F; rp.nsplit = N * pl.rsplit; rp.accumulate = accumulate; rp.ws = (const float *)workspace; rp.slab = pl.slab;
+    rp.F = F; rp.nsplit = pl.ngroups * pl.rsplit; rp.accumulate = accumulate; rp.ws = (const float *)workspace; rp.slab = pl.slab;
     long long total = poff;
     int rblocks = (int)((total + 63) / 64);
     CAPE_LAUNCH(dw_reduce_kernel, dim3(rblocks), dim3(256), 0, st, rp);
