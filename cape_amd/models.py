@@ -599,8 +599,12 @@ class CAPE(base_model):
         self._opt_state = {}
         for grp, names in (('g', self._g_names), ('d', self._d_names)):
             params = [self._vars[n] for n in names]
-            total = sum(p.numel() for p in params)
-            flat = torch.empty(total, device=self.device, dtype=torch.float32)
+            # every variable starts on a 256-byte boundary of the bucket: the kernels' float4 weight
+            # staging needs 16-byte aligned blocks (an unaligned base silently takes the scalar path, 2x
+            # slower); the padding stays zero in parameters, gradients and momentum.
+            al = lambda n: (n + 63) // 64 * 64
+            total = sum(al(p.numel()) for p in params)
+            flat = torch.zeros(total, device=self.device, dtype=torch.float32)
             flat_grad = torch.zeros(total, device=self.device, dtype=torch.float32)
             views, off = [], 0
             with torch.no_grad():
@@ -609,7 +613,7 @@ class CAPE(base_model):
                     flat[off:off + n].copy_(p.detach().reshape(-1))
                     p.data = flat[off:off + n].view(p.shape)
                     views.append(flat_grad[off:off + n].view(p.shape))
-                    off += n
+                    off += al(n)
             if grp == 'g':
                 # generator/condition variables are used exactly once per step, so their gradient kernels
                 # may write the bucket directly; discriminator variables are shared by the real and the
