@@ -290,6 +290,155 @@ __global__ __launch_bounds__(256) void rowscale_final_kernel(const float *part, 
     if (cl == 0 && e < RF) out[(long long)n * RF + e] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
 }
 
+// ---- fused backward preparation: dz, bias gradient and rank-1 term gradients in one pass over g ----
+constexpr int BP_RB = 128;                  // rows per block
+constexpr int BP_MAXT = RSR_MAXR + 2;       // reduction terms: [0]=sum dz, [1..R]=rowscale_j*dz, [R+1]=rowscale_rg*g
+
+__global__ __launch_bounds__(256) void bwd_prep_kernel(CView g, CView y, int act, const unsigned *mask, View dz,
+                                                       const float *rowscale, int R, int rg, int want_bias, int want_g,
+                                                       int N, int Mo, int F, float *part, int chunks) {
+    __shared__ float red[BP_MAXT][256];
+    const int n = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+    const int ra = ch * BP_RB, rb = min(Mo, ra + BP_RB);
+    const int words = (F + 31) / 32;
+    const int T = R + 2;
+    const int fl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    for (int fbase = 0; fbase < F; fbase += 64) {
+        const int f = fbase + fl;
+        float acc[BP_MAXT];
+#pragma unroll
+        for (int j = 0; j < BP_MAXT; ++j) acc[j] = 0.f;
+        if (f < F)
+            for (int r = ra + rl; r < rb; r += 4) {
+                const float gv = g.p[(long long)n * g.ss + (long long)r * g.ld + f];
+                float d;
+                if (mask) d = ((mask[((long long)n * Mo + r) * words + (f >> 5)] >> (f & 31)) & 1u) ? gv : 0.f;
+                else if (act != CAPE_ACT_NONE) d = gv * cape_act_grad_from_out(y.p[(long long)n * y.ss + (long long)r * y.ld + f], act);
+                else d = gv;
+                dz.p[(long long)n * dz.ss + (long long)r * dz.ld + f] = d;
+                acc[0] += d;
+#pragma unroll
+                for (int j = 0; j < RSR_MAXR; ++j)
+                    if (j < R) acc[1 + j] = fmaf(rowscale[(long long)j * Mo + r], d, acc[1 + j]);
+                if (want_g) acc[BP_MAXT - 1] = fmaf(rowscale[(long long)rg * Mo + r], gv, acc[BP_MAXT - 1]);
+            }
+#pragma unroll
+        for (int j = 0; j < BP_MAXT; ++j) red[j][threadIdx.x] = acc[j];
+        __syncthreads();
+        if (rl == 0 && f < F) {
+            float *pp = part + ((long long)n * chunks + ch) * T * F;
+            if (want_bias) pp[f] = (red[0][fl] + red[0][64 + fl]) + (red[0][128 + fl] + red[0][192 + fl]);
+#pragma unroll
+            for (int j = 0; j < RSR_MAXR; ++j)
+                if (j < R) pp[(1 + j) * F + f] = (red[1 + j][fl] + red[1 + j][64 + fl]) + (red[1 + j][128 + fl] + red[1 + j][192 + fl]);
+            if (want_g) pp[(R + 1) * F + f] = (red[BP_MAXT - 1][fl] + red[BP_MAXT - 1][64 + fl]) +
+                                              (red[BP_MAXT - 1][128 + fl] + red[BP_MAXT - 1][192 + fl]);
+        }
+        __syncthreads();
+    }
+}
+
+// float4 variant (F % 4 == 0, 16-byte aligned views, F <= 1024): thread = (float4 column, row lane)
+__global__ __launch_bounds__(256) void bwd_prep_vec_kernel(CView g, CView y, int act, const unsigned *mask, View dz,
+                                                           const float *rowscale, int R, int rg, int want_bias, int want_g,
+                                                           int N, int Mo, int F, float *part, int chunks) {
+    __shared__ float4 red[256];
+    const int n = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+    const int ra = ch * BP_RB, rb = min(Mo, ra + BP_RB);
+    const int words = (F + 31) / 32;
+    const int T = R + 2;
+    float *pp = part + ((long long)n * chunks + ch) * T * F;
+    for (int fbase = 0; fbase < F; fbase += 256) {
+        const int fw = min(256, F - fbase);
+        const int c4n = fw >> 2;
+        const int lanes = 256 / c4n;
+        const int q = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+        const int f = fbase + 4 * q;
+        float4 acc[BP_MAXT];
+#pragma unroll
+        for (int j = 0; j < BP_MAXT; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rl < lanes)
+            for (int r = ra + rl; r < rb; r += lanes) {
+                const float4 gv = *reinterpret_cast<const float4 *>(g.p + (long long)n * g.ss + (long long)r * g.ld + f);
+                float4 d = gv;
+                if (mask) {
+                    const unsigned w = mask[((long long)n * Mo + r) * words + (f >> 5)] >> (f & 31);
+                    d.x = (w & 1u) ? gv.x : 0.f; d.y = (w & 2u) ? gv.y : 0.f; d.z = (w & 4u) ? gv.z : 0.f; d.w = (w & 8u) ? gv.w : 0.f;
+                } else if (act != CAPE_ACT_NONE) {
+                    const float4 o = *reinterpret_cast<const float4 *>(y.p + (long long)n * y.ss + (long long)r * y.ld + f);
+                    d.x = gv.x * cape_act_grad_from_out(o.x, act); d.y = gv.y * cape_act_grad_from_out(o.y, act);
+                    d.z = gv.z * cape_act_grad_from_out(o.z, act); d.w = gv.w * cape_act_grad_from_out(o.w, act);
+                }
+                *reinterpret_cast<float4 *>(dz.p + (long long)n * dz.ss + (long long)r * dz.ld + f) = d;
+                acc[0].x += d.x; acc[0].y += d.y; acc[0].z += d.z; acc[0].w += d.w;
+#pragma unroll
+                for (int j = 0; j < RSR_MAXR; ++j)
+                    if (j < R) {
+                        const float sv = rowscale[(long long)j * Mo + r];
+                        acc[1 + j].x = fmaf(sv, d.x, acc[1 + j].x); acc[1 + j].y = fmaf(sv, d.y, acc[1 + j].y);
+                        acc[1 + j].z = fmaf(sv, d.z, acc[1 + j].z); acc[1 + j].w = fmaf(sv, d.w, acc[1 + j].w);
+                    }
+                if (want_g) {
+                    const float sv = rowscale[(long long)rg * Mo + r];
+                    acc[BP_MAXT - 1].x = fmaf(sv, gv.x, acc[BP_MAXT - 1].x); acc[BP_MAXT - 1].y = fmaf(sv, gv.y, acc[BP_MAXT - 1].y);
+                    acc[BP_MAXT - 1].z = fmaf(sv, gv.z, acc[BP_MAXT - 1].z); acc[BP_MAXT - 1].w = fmaf(sv, gv.w, acc[BP_MAXT - 1].w);
+                }
+            }
+        // reduce the row lanes term by term through LDS
+#pragma unroll
+        for (int j = 0; j < BP_MAXT; ++j) {
+            const bool used = (j == 0 && want_bias) || (j >= 1 && j <= R) || (j == BP_MAXT - 1 && want_g);
+            if (!used) continue;
+            red[threadIdx.x] = acc[j];
+            __syncthreads();
+            if (rl == 0) {
+                float4 t = acc[j];
+                for (int l = 1; l < lanes; ++l) {
+                    const float4 v = red[l * c4n + q];
+                    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+                }
+                const int trow = (j == BP_MAXT - 1) ? (R + 1) : j;
+                *reinterpret_cast<float4 *>(pp + (long long)trow * F + f) = t;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// stage 2: block = (term t, 64 columns) x 4 lanes.  t = 0: dbias[f] = sum over (n, chunk);
+// t = 1..R: dcoef[n, t-1, f] = sum over chunks; t = R+1: dcoef_g[n, f] = sum over chunks.
+__global__ __launch_bounds__(256) void bwd_prep_final_kernel(const float *part, int chunks, int N, int F, int R, float *dbias,
+                                                             float *dcoef, float *dcoef_g) {
+    __shared__ float red[4][64];
+    const int T = R + 2;
+    const int fblocks = (F + 63) / 64;
+    const int fl = threadIdx.x & 63, ln = threadIdx.x >> 6;
+    int b = blockIdx.x;
+    const int fb = b % fblocks; b /= fblocks;
+    const int f = fb * 64 + fl;
+    // block order: [bias blocks: fblocks] then for each n: (R+1) * fblocks
+    float s = 0.f;
+    float *dst = nullptr;
+    if (b == 0) {            // bias
+        if (dbias && f < F) {
+            for (long long i = ln; i < (long long)N * chunks; i += 4) s += part[i * T * F + f];
+            dst = dbias + f;
+        }
+    } else {
+        const int idx = b - 1;
+        const int n = idx / (R + 1), t = 1 + idx % (R + 1);
+        float *out = (t <= R) ? (dcoef ? dcoef + ((long long)n * R + (t - 1)) * F : nullptr)
+                              : (dcoef_g ? dcoef_g + (long long)n * F : nullptr);
+        if (out && f < F) {
+            for (int c = ln; c < chunks; c += 4) s += part[(((long long)n * chunks + c) * T + t) * F + f];
+            dst = out + f;
+        }
+    }
+    red[ln][fl] = s;
+    __syncthreads();
+    if (ln == 0 && dst) *dst = (red[0][fl] + red[1][fl]) + (red[2][fl] + red[3][fl]);
+}
+
 inline int grid_for(long long total) {
     long long b = (total + 255) / 256;
     if (b > 4096) b = 4096;
@@ -430,5 +579,44 @@ extern "C" int cape_rowscale_reduce(const float *dz, int64_t dz_sample_stride, i
     const int RF = R * F;
     CAPE_LAUNCH(rowscale_final_kernel, dim3(N * ((RF + 63) / 64)), dim3(256), 0, st, (const float *)workspace, chunks, RF, N, out);
     CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}
+
+extern "C" int64_t cape_bwd_prep_workspace_bytes(int32_t N, int32_t Mo, int32_t F, int32_t R) {
+    if (N < 1 || Mo < 1 || F < 1 || R < 0 || R > RSR_MAXR) return CAPE_EINVAL;
+    const long long chunks = (Mo + BP_RB - 1) / BP_RB;
+    return (int64_t)N * chunks * (R + 2) * F * (int64_t)sizeof(float);
+}
+
+extern "C" int cape_bwd_prep(const float *g, int64_t g_sample_stride, int32_t ldg, const float *y, int64_t y_sample_stride,
+                             int32_t ldy, int32_t act, const uint32_t *mask, float *dz, int64_t dz_sample_stride, int32_t lddz,
+                             float *dbias, const float *rowscale, int32_t R, float *dcoef, int32_t rg, float *dcoef_g, int32_t N,
+                             int32_t Mo, int32_t F, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!g || !dz || !workspace || N < 1 || Mo < 1 || F < 1 || ldg < F || lddz < F || R < 0 || R > RSR_MAXR) return CAPE_EINVAL;
+    if (act < CAPE_ACT_NONE || act > CAPE_ACT_TANH) return CAPE_EINVAL;
+    if (!mask && act != CAPE_ACT_NONE && (!y || ldy < F)) return CAPE_EINVAL;
+    if ((R > 0 || dcoef_g) && !rowscale) return CAPE_EINVAL;
+    if (R > 0 && !dcoef) return CAPE_EINVAL;
+    if (workspace_bytes < cape_bwd_prep_workspace_bytes(N, Mo, F, R)) return CAPE_EWORKSPACE;
+    const int chunks = (Mo + BP_RB - 1) / BP_RB;
+    CView gv{g, g_sample_stride, ldg}, yv{y, y_sample_stride, ldy};
+    View zv{dz, dz_sample_stride, lddz};
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = aligned4(g, g_sample_stride, ldg, F) && aligned4(dz, dz_sample_stride, lddz, F) &&
+                     (mask || act == CAPE_ACT_NONE || aligned4(y, y_sample_stride, ldy, F)) &&
+                     (F >= 256 ? (F % 256) == 0 : (256 % (F / 4)) == 0) && ((F & 31) == 0 || !mask);
+    if (vec)
+        CAPE_LAUNCH(bwd_prep_vec_kernel, dim3(N * chunks), dim3(256), 0, st, gv, yv, act, mask, zv, rowscale, R, rg, dbias ? 1 : 0,
+                    dcoef_g ? 1 : 0, N, Mo, F, (float *)workspace, chunks);
+    else
+        CAPE_LAUNCH(bwd_prep_kernel, dim3(N * chunks), dim3(256), 0, st, gv, yv, act, mask, zv, rowscale, R, rg, dbias ? 1 : 0,
+                    dcoef_g ? 1 : 0, N, Mo, F, (float *)workspace, chunks);
+    CAPE_LAUNCH_CHECK();
+    if (dbias || R > 0 || dcoef_g) {
+        const int fblocks = (F + 63) / 64;
+        const int nblk = fblocks * (1 + N * (R + 1));
+        CAPE_LAUNCH(bwd_prep_final_kernel, dim3(nblk), dim3(256), 0, st, (const float *)workspace, chunks, N, F, R, dbias, dcoef, dcoef_g);
+        CAPE_LAUNCH_CHECK();
+    }
     return CAPE_OK;
 }

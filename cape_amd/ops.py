@@ -307,6 +307,30 @@ def reduce_cond(dy, scale=None, out=None, accumulate=False):
     return out
 
 
+def bwd_prep(g, y=None, act="none", mask=None, want_bias=False, rowscale=None, R=0, rg=None):
+    """One pass over g: returns (dz, dbias [F] or None, dcoef [N,R,F] or None, dcoef_g [N,F] or None)."""
+    _lib.require_gpu()
+    N, Mo, F = g.shape
+    dev = g.device
+    dz = alloc_act(N, Mo, F, dev)
+    dbias = torch.empty(F, device=dev, dtype=torch.float32) if want_bias else None
+    dcoef = torch.empty((N, R, F), device=dev, dtype=torch.float32) if R else None
+    dcoef_g = torch.empty((N, F), device=dev, dtype=torch.float32) if rg is not None else None
+    need = lib.cape_bwd_prep_workspace_bytes(N, Mo, F, R)
+    ws = torch.empty((need + 3) // 4, device=dev, dtype=torch.float32)
+    gp, gs, gl = _v(g)
+    zp, zs, zl = _v(dz)
+    if y is not None and mask is None and act != "none":
+        yp, ys, yl = _v(y)
+    else:
+        yp, ys, yl = None, 0, 0
+    rc = lib.cape_bwd_prep(gp, gs, gl, yp, ys, yl, _lib.ACT[act] if mask is None else 0, _ptr(mask), zp, zs, zl,
+                           _ptr(dbias), _ptr(rowscale), R, _ptr(dcoef), 0 if rg is None else int(rg), _ptr(dcoef_g),
+                           N, Mo, F, _ptr(ws), need, _stream())
+    check(rc, "cape_bwd_prep")
+    return dz, dbias, dcoef, dcoef_g
+
+
 def rowscale_reduce(dz, rowscale, R):
     """out[n, j, f] = sum_r rowscale[j, r] * dz[n, r, f]  for j < R."""
     _lib.require_gpu()
@@ -405,19 +429,22 @@ class ChebConvFn(torch.autograd.Function):
         g = gfull[:, :, :Fout]
         need_x, need_w, need_b, need_wa, need_ci, need_co = (ctx.needs_input_grad[i] for i in range(6))
         dW = dB = dWa = dci = dco = dx = None
-        if W_aff is not None:
-            dz = mask_mul(g, mask)          # gradient through relu of the graph-conv branch
-        elif act != "none":
-            dz = act_bwd(g, ysaved[:, :, :Fout], act)
+        # one pass over g: dz (activation / ReLU-mask gradient), channel-bias gradient and the rank-1
+        # condition-term gradients
+        chan_bias = need_b and ctx.has_bias and ctx.bias_mode != _lib.BIAS_VERTEX
+        plain = (W_aff is None and act == "none" and not chan_bias and not Cc)
+        if plain:
+            dz, dbv, dcoef, dca = g, None, None, None
         else:
-            dz = g
+            dz, dbv, dcoef, dca = bwd_prep(g, y=None if ysaved is None else ysaved[:, :, :Fout], act=act, mask=mask,
+                                           want_bias=chan_bias, rowscale=ops.rowscale if Cc else None,
+                                           R=K if Cc else 0, rg=(K if (Cc and W_aff is not None) else None))
         if need_b and ctx.has_bias:
             if ctx.bias_mode == _lib.BIAS_VERTEX:
                 dB = torch.empty((1, Mo, Fout), device=dev, dtype=torch.float32)
                 colsum(dz, dB, per_vertex=True)
             else:
-                dB = torch.empty((1, 1, Fout), device=dev, dtype=torch.float32)
-                colsum(dz, dB)
+                dB = dbv.view(1, 1, Fout)
         csr_of = (lambda k: None) if twopass else (lambda k: ops.fwd[k])
         if need_w:
             dW = _grad_buffer(W, ctx.gW)
@@ -426,15 +453,14 @@ class ChebConvFn(torch.autograd.Function):
             dWa = _grad_buffer(W_aff, ctx.gWa)
             gconv_dw([dict(x=xs[0], csr=csr_of(0), w=(dWa, 0, Fout, 1))], g)
         if Cc:
-            # rank-1 condition terms: dcoef[n,k,f] = sum_r (S_k 1)[r] dz[n,r,f]
-            dcoef = rowscale_reduce(dz, ops.rowscale, K).view(N, K * Fout)
+            # rank-1 condition terms: dcoef[n,k,f] = sum_r (S_k 1)[r] dz[n,r,f]  (from bwd_prep)
+            dcoef = dcoef.view(N, K * Fout)
             Wc = W[Ch * K:].view(Cc, K * Fout)
             if need_w:
                 torch.mm(cond_in.t(), dcoef, out=dW[Ch * K:].view(Cc, K * Fout))
             if need_ci:
                 dci = torch.mm(dcoef, Wc.t())
             if W_aff is not None:
-                dca = rowscale_reduce(g, ops.rowscale, 1).view(N, Fout)
                 if need_wa:
                     torch.mm(cond_in.t(), dca, out=dWa[Ch:])
                 if need_ci:

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CAPE_ABI_VERSION 2
+#define CAPE_ABI_VERSION 3
 #define CAPE_MAX_SRC 8
 
 /* error codes (negative = argument error; positive values are hipError_t) */
@@ -146,6 +146,24 @@ int64_t cape_gconv_dw_workspace_bytes(const cape_src_t *srcs, int32_t nsrc, int3
 int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *dz,
                   int64_t dz_sample_stride, int32_t lddz, int32_t N, int32_t Mo, int32_t F,
                   int32_t accumulate, void *workspace, int64_t workspace_bytes, void *stream);
+
+/*
+ * One pass over the incoming gradient g [N, Mo, F] that produces everything the backward of a conv
+ * layer needs besides the GEMMs (replaces cape_act_bwd / cape_mask_mul + cape_colsum +
+ * cape_rowscale_reduce, i.e. 3-7 launches and as many passes over g):
+ *   dz[n,r,f]      = g * act'(y)            (y = activation OUTPUT; act = CAPE_ACT_*)            or
+ *                  = g if mask bit else 0   (mask != NULL: ReLU of res_block_affine, lib/models.py:785)
+ *   dbias[f]       = sum_{n,r} dz           (dbias != NULL; channel bias of lib/models.py:105-121)
+ *   dcoef[n,j,f]   = sum_r rowscale[j,r] * dz[n,r,f]   j < R      (rank-1 condition terms)
+ *   dcoef_g[n,f]   = sum_r rowscale[rg,r] * g[n,r,f]              (dcoef_g != NULL: affine branch)
+ * dz may alias g.  Deterministic two-stage reductions; workspace >= cape_bwd_prep_workspace_bytes.
+ */
+int64_t cape_bwd_prep_workspace_bytes(int32_t N, int32_t Mo, int32_t F, int32_t R);
+int cape_bwd_prep(const float *g, int64_t g_sample_stride, int32_t ldg, const float *y,
+                  int64_t y_sample_stride, int32_t ldy, int32_t act, const uint32_t *mask, float *dz,
+                  int64_t dz_sample_stride, int32_t lddz, float *dbias, const float *rowscale,
+                  int32_t R, float *dcoef, int32_t rg, float *dcoef_g, int32_t N, int32_t Mo,
+                  int32_t F, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* y[n,r,:] = alpha * sum_e vals[e]*x[n,colidx[e],:] + beta * z[n,r,:]   (z may be NULL, may alias y) */
 int cape_spmm(const float *x, int64_t x_sample_stride, int32_t ldx, const int32_t *rowptr,
