@@ -125,6 +125,7 @@ def main():
     ap.add_argument('--config', default='CAPE-affineconv_nz64_pose32_clotype32_male')
     ap.add_argument('--gan', action='store_true', help='include the discriminator passes/update (adversarial step)')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--side-stream', action='store_true', help='issue weight-gradient kernels on a parallel graph branch (measured slower)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -132,7 +133,10 @@ def main():
     from cape_amd import dist as cdist
     from cape_amd.runtime import GraphedTrainStep
     import torch.distributed as tdist
-    world, rank, local = cdist.init_from_env()
+    # CAPE_DIST_BACKEND=gloo + CAPE_FORCE_DEVICE=0 let the N>1 code path be exercised on a 1-GPU box
+    world, rank, local = cdist.init_from_env(backend=os.environ.get("CAPE_DIST_BACKEND"))
+    if "CAPE_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["CAPE_FORCE_DEVICE"])
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local)
@@ -142,7 +146,8 @@ def main():
         for grp in ('g', 'd'):
             cdist.broadcast_flat(model._opt_state[grp]['flat'])
         hook = cdist.GradAverager()
-    runner = GraphedTrainStep(model, with_gan=args.gan, grad_hook=hook, use_graph=not args.no_graph)
+    runner = GraphedTrainStep(model, with_gan=args.gan, grad_hook=hook, use_graph=not args.no_graph,
+                              side_stream=args.side_stream)
     runner.load_batch(**synthetic_batch(model, seed=1234 + rank))
     torch.cuda.synchronize()
     runner.capture()

@@ -720,6 +720,7 @@ class CAPE(base_model):
         d_params = self._opt_state['d']['params']
         if 'loss_d' not in out:
             grads_g = torch.autograd.grad(out['loss_g'], g_params, allow_unused=True)
+            ops.join_side_stream()
             self.store_grads('g', grads_g)
             return
         if self.bug_compat:
@@ -730,6 +731,7 @@ class CAPE(base_model):
                                         grad_outputs=[torch.ones_like(out['loss_g']), torch.ones_like(out['loss_d'])],
                                         allow_unused=True)
             grads_g, grads_d = grads[:len(g_params)], grads[len(g_params):]
+        ops.join_side_stream()
         self.store_grads('g', grads_g)
         self.store_grads('d', grads_d)
 

@@ -348,6 +348,42 @@ def rowscale_reduce(dz, rowscale, R):
 # --------------------------------------------------------------------------------------------
 # autograd operators
 # --------------------------------------------------------------------------------------------
+# Weight-gradient side stream.  The weight gradients (dW GEMM + split reduction) of a layer depend only on
+# dz and the saved inputs and are consumed by the optimiser; the data-gradient chain is the critical path
+# of the backward pass.  When SIDE_STREAM is set (by the training-step runner) the weight-gradient kernels
+# are issued on it -- inside a captured HIP graph this becomes a parallel branch that fills the CUs the
+# small fine-level kernels and the tile-quantised deep-level GEMMs leave idle.  join_side_stream() must be
+# called before the gradients are read.
+SIDE_STREAM = None
+
+
+class _on_side_stream(object):
+    def __init__(self, *tensors):
+        self.tensors = tensors
+
+    def __enter__(self):
+        self.side = SIDE_STREAM
+        if self.side is None:
+            return self
+        self.main = torch.cuda.current_stream()
+        self.side.wait_stream(self.main)
+        for t in self.tensors:
+            if t is not None:
+                t.record_stream(self.side)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.side is not None:
+            self.ctx.__exit__(*a)
+
+
+def join_side_stream():
+    if SIDE_STREAM is not None:
+        torch.cuda.current_stream().wait_stream(SIDE_STREAM)
+
+
 def _grad_buffer(W, view=None):
     """Destination of a weight gradient: the caller-provided view of the flat gradient bucket (the
     kernels then write straight into the bucket and the per-variable copy disappears) or a fresh tensor."""
@@ -448,10 +484,16 @@ class ChebConvFn(torch.autograd.Function):
         csr_of = (lambda k: None) if twopass else (lambda k: ops.fwd[k])
         if need_w:
             dW = _grad_buffer(W, ctx.gW)
-            gconv_dw([dict(x=xs[k], csr=csr_of(k), w=(dW, k * Fout, K * Fout, 1)) for k in range(K)], dz)
         if W_aff is not None and need_wa:
             dWa = _grad_buffer(W_aff, ctx.gWa)
-            gconv_dw([dict(x=xs[0], csr=csr_of(0), w=(dWa, 0, Fout, 1))], g)
+        with _on_side_stream(dz, g, dW, dWa, *xs):
+            if need_w:
+                gconv_dw([dict(x=xs[k], csr=csr_of(k), w=(dW, k * Fout, K * Fout, 1)) for k in range(K)], dz)
+            if W_aff is not None and need_wa:
+                gconv_dw([dict(x=xs[0], csr=csr_of(0), w=(dWa, 0, Fout, 1))], g)
+        if SIDE_STREAM is not None and Cc and (need_w or need_wa):
+            # the rank-1 rows of dW / dWa are written on the main stream below: order them after the kernels
+            torch.cuda.current_stream().wait_stream(SIDE_STREAM)
         if Cc:
             # rank-1 condition terms: dcoef[n,k,f] = sum_r (S_k 1)[r] dz[n,r,f]  (from bwd_prep)
             dcoef = dcoef.view(N, K * Fout)

@@ -11,8 +11,9 @@ import torch
 
 
 class GraphedTrainStep(object):
-    def __init__(self, model, with_gan=False, grad_hook=None, use_graph=True):
+    def __init__(self, model, with_gan=False, grad_hook=None, use_graph=True, side_stream=False):
         self.model, self.with_gan, self.grad_hook = model, with_gan, grad_hook
+        self.side = torch.cuda.Stream(device=model.device) if side_stream else None
         self.use_graph = use_graph and model.optimizer != "adam"   # Adam keeps a host-side step counter
         B, d = model.batch_size, model.device
         M, Cn = model.input_num_verts, model.nn_input_channel
@@ -29,6 +30,14 @@ class GraphedTrainStep(object):
 
     # ---- the two halves of a step -------------------------------------------------------------------
     def _fwd_bwd(self):
+        from . import ops
+        ops.SIDE_STREAM = self.side
+        try:
+            self._fwd_bwd_inner()
+        finally:
+            ops.SIDE_STREAM = None
+
+    def _fwd_bwd_inner(self):
         m, b = self.model, self.buf
         if self.with_gan:
             out = m.forward_losses(b['data_g'], b['cond_g'], b['cond2_g'], b['gt'], b['data_d'], b['cond_d'],
