@@ -35,7 +35,12 @@ def build_model(batch, local_rank, config):
     from cape_amd.load_data import load_graph_mtx
     from cape_amd.models import CAPE
     L, D, U, p, L_d, D_d, _ = load_graph_mtx(None, load_for_demo=True)
-    params = cape_params(config, p=p, batch_size=batch, name='bench')
+    # lr schedule as main.py:67 builds it for the male dataset (README.md:53: 31 036 training meshes, the last
+    # 100 held out as validation, lib/load_data.py:64-65): decay_steps = decay_every * n_train / batch_size, and
+    # the warm-up (lr_warmup: 1) spans 8 * decay_steps steps -- i.e. the timed steps run at the small learning
+    # rates a real run starts with (a 0.008 step on N(0,1) data diverges from the reference initialisers).
+    decay_steps = 2 * (31036 - 100) / 16
+    params = cape_params(config, p=p, batch_size=batch, name='bench', decay_steps=decay_steps)
     model = CAPE(L=L, D=D, U=U, L_d=L_d, D_d=D_d, device='cuda:%d' % local_rank, **params)
     model.build_graph(model.input_num_verts, model.nn_input_channel, phase='train')
     return model
@@ -76,8 +81,18 @@ def kernel_roofline(runner):
     achieved = fl / t / 1e12
     table = {k: dict(launches=v[0] // 3, avg_us=1e6 * v[1] / v[0], tflops=v[2] / v[1] / 1e12, alg_gbs=v[3] / v[1] / 1e9)
              for k, v in agg.items()}
+    # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected separately and
+    # committed as profiles/r01_pmc_summary.json -- counters cannot be read from inside this process)
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        key = dom.replace(",", ", ")
+        key = next((k for k in pmc if k.replace(" ", "") == dom.replace(" ", "")), key)
+        traffic = pmc[key]["hbm_bytes_per_dispatch"]
+    except Exception:
+        traffic = None
     roof = dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
                 launches_per_step=n // 3, avg_launch_us=round(1e6 * t / n, 2),
                 alg_flop_per_launch=fl / n, alg_bytes_per_launch=by / n,
                 hbm_alg_gbs=round(by / t / 1e9, 1), hbm_frac=round(by / t / 1e9 / HBM_PEAK_GBS, 4))

@@ -24,7 +24,7 @@
 
 namespace {
 
-constexpr int KC = 32;   // contraction chunk staged per iteration
+constexpr int KC_DEFAULT = 32;   // contraction chunk staged per iteration (64 for wide, deep layers)
 
 struct SrcDev {
     const float *x;
@@ -59,21 +59,23 @@ struct GconvParams {
 };
 
 // ---- A-tile staging: gathered rows -> LDS [ROWS][KC+4] -----------------------------------
-template <int ROWS, int LDA>
+template <int ROWS, int LDA, int KC>
 __device__ __forceinline__ void stage_gather(float *sA, const SrcDev &S, int n, int r0, int Mo,
                                               int c0, int tid) {
-    const int q = tid & 7;        // float4 column of the 32-wide chunk
-    const int rl0 = tid >> 3;     // 0..31
+    constexpr int QPR = KC / 4;            // float4 columns per row of the chunk
+    constexpr int RP = 256 / QPR;          // rows staged per pass
+    const int q = tid % QPR;
+    const int rl0 = tid / QPR;
     const int c = c0 + 4 * q;
     const float *xb = S.x + (long long)n * S.xs + c;
     const int nvalid = S.C - c;   // channels available from c
-    constexpr int P = ROWS / 32;
+    constexpr int P = ROWS / RP;
     if (!S.rp && S.vec && nvalid >= 4) {
         // plain source, aligned: issue every load of the chunk before the first LDS store
         float4 v[P];
 #pragma unroll
         for (int pass = 0; pass < P; ++pass) {
-            const int r = r0 + rl0 + 32 * pass;
+            const int r = r0 + rl0 + RP * pass;
             // unconditional load from a clamped (always valid) row, zeroed by a select afterwards:
             // a branch around each load would make hipcc wait vmcnt(0) per load (serialised round trips)
             const int rc = r < Mo ? r : Mo - 1;
@@ -81,16 +83,16 @@ __device__ __forceinline__ void stage_gather(float *sA, const SrcDev &S, int n, 
         }
 #pragma unroll
         for (int pass = 0; pass < P; ++pass) {
-            const bool ok = (r0 + rl0 + 32 * pass) < Mo;
+            const bool ok = (r0 + rl0 + RP * pass) < Mo;
             float4 o = v[pass];
             o.x = ok ? o.x : 0.f; o.y = ok ? o.y : 0.f; o.z = ok ? o.z : 0.f; o.w = ok ? o.w : 0.f;
-            *reinterpret_cast<float4 *>(&sA[(rl0 + 32 * pass) * LDA + 4 * q]) = o;
+            *reinterpret_cast<float4 *>(&sA[(rl0 + RP * pass) * LDA + 4 * q]) = o;
         }
         return;
     }
 #pragma unroll
     for (int pass = 0; pass < P; ++pass) {
-        const int rl = rl0 + 32 * pass;
+        const int rl = rl0 + RP * pass;
         const int r = r0 + rl;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < Mo && nvalid > 0) {
@@ -139,7 +141,7 @@ __device__ __forceinline__ void stage_gather(float *sA, const SrcDev &S, int n, 
 
 // ---- B-tile staging: weights [KC x BN] with arbitrary (row, col) strides -> LDS [KC][BN+4]
 // NT = number of staging threads (the loader half of the workgroup)
-template <int BN, int LDB, int NT>
+template <int BN, int LDB, int NT, int KC>
 __device__ __forceinline__ void stage_weights(float *sB, const float *w, long long rs, long long cs,
                                                int C, int F, int c0, int f0, int tid) {
     if (cs == 1 && ((rs & 3) == 0) && ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0)) {
@@ -212,8 +214,8 @@ __device__ __forceinline__ void stage_weights(float *sB, const float *w, long lo
 // waves 4-7 only gather/stage the NEXT [BM x 32] A chunk and [32 x BN] weight chunk into the other
 // LDS buffer.  One barrier per chunk hands the buffers over; the MFMA waves never wait on global
 // memory, the loader waves are free to sit on L2 latency.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool DUAL>
-__global__ __launch_bounds__(CAPE_SPEC ? 512 : 256, (DUAL && BN == 128 && BM == 128) ? 1 : 4) void gconv_fwd_kernel(GconvParams p) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool DUAL, int KC = KC_DEFAULT>
+__global__ __launch_bounds__(CAPE_SPEC ? 512 : 256, (DUAL && BN == 128 && BM == 128) ? 1 : (KC == 64 ? 3 : 4)) void gconv_fwd_kernel(GconvParams p) {
     constexpr int LDA = KC + 4;
     constexpr int LDB = BN + 4;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -265,9 +267,9 @@ __global__ __launch_bounds__(CAPE_SPEC ? 512 : 256, (DUAL && BN == 128 && BM == 
         const SrcDev &S = p.s[l_si];
         float *sA = smem + buf * BUF_SZ;
         float *sB = sA + A_SZ;
-        stage_gather<BM, LDA>(sA, S, n, r0, p.Mo, l_c0, ltid);
-        stage_weights<BN, LDB, 256>(sB, S.w, S.wrs, S.wcs, S.C, p.F, l_c0, f0, ltid);
-        if (DUAL && S.w2) stage_weights<BN, LDB, 256>(sB + B_SZ, S.w2, S.w2rs, S.w2cs, S.C, p.F, l_c0, f0, ltid);
+        stage_gather<BM, LDA, KC>(sA, S, n, r0, p.Mo, l_c0, ltid);
+        stage_weights<BN, LDB, 256, KC>(sB, S.w, S.wrs, S.wcs, S.C, p.F, l_c0, f0, ltid);
+        if (DUAL && S.w2) stage_weights<BN, LDB, 256, KC>(sB + B_SZ, S.w2, S.w2rs, S.w2cs, S.C, p.F, l_c0, f0, ltid);
         l_c0 += KC;
         if (l_c0 >= S.C) { l_c0 = 0; ++l_si; }
     };
@@ -817,12 +819,18 @@ extern "C" int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, in
     // 64-row tiles double the resident workgroups at the price of re-reading the weight tile
     static const int bm64_below = getenv("CAPE_BM64_BELOW") ? atoi(getenv("CAPE_BM64_BELOW")) : 640;
     if (!dual && BN == 128 && (long long)N * ((Mo + 127) / 128) * p.col_tiles < bm64_below) BM = 64;
+    // 64-wide contraction chunks (half the barriers per MFMA) when every source is a multiple of 64 wide
+    static const int kc64_on = getenv("CAPE_KC64") ? atoi(getenv("CAPE_KC64")) : 0;
+    bool kc64 = kc64_on && !dual && BN == 128;
+    for (int i = 0; i < nsrc; ++i) kc64 = kc64 && (srcs[i].C % 64 == 0);
+    if (kc64) BM = 64;
     p.row_tiles = (Mo + BM - 1) / BM;
     dim3 grid((unsigned)(N * p.row_tiles * p.col_tiles)), block(CAPE_SPEC ? 512 : 256);
     hipStream_t st = (hipStream_t)stream;
     if (!dual) {
         if (BN == 32) CAPE_LAUNCH((gconv_fwd_kernel<128, 32, 4, 1, false>), grid, block, 0, st, p);
         else if (BN == 64) CAPE_LAUNCH((gconv_fwd_kernel<128, 64, 4, 1, false>), grid, block, 0, st, p);
+        else if (BM == 64 && kc64) CAPE_LAUNCH((gconv_fwd_kernel<64, 128, 2, 2, false, 64>), grid, block, 0, st, p);
         else if (BM == 64) CAPE_LAUNCH((gconv_fwd_kernel<64, 128, 2, 2, false>), grid, block, 0, st, p);
         else CAPE_LAUNCH((gconv_fwd_kernel<128, 128, 2, 2, false>), grid, block, 0, st, p);
     } else {

@@ -189,9 +189,13 @@ def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=
     if LAUNCH_LOG is None:
         launch()
     else:
+        # mirror of the tile selection in cape_gconv_fwd (csrc/gconv.hip) -- names as rocprofv3 prints them
         dual = any(e.get("w2") is not None for e in entries)
-        bn = 32 if F <= 32 else (64 if F <= 64 else 128)
-        name = "gconv_fwd_kernel<128,%d,%s,%s>" % (bn, "2,2" if bn == 128 else "4,1", "true" if dual else "false")
+        bn = 32 if F <= 32 else (64 if (F <= 64 or dual) else 128)
+        bm = 128
+        if (not dual) and bn == 128 and N * ((Mo + 127) // 128) * ((F + bn - 1) // bn) < 640:
+            bm = 64
+        name = "gconv_fwd_kernel<%d, %d, %s, %s, 32>" % (bm, bn, "2, 2" if bn == 128 else "4, 1", "true" if dual else "false")
         flops, byts = _gconv_work(entries, N, Mo, F)
         _log_launch(name, flops, byts, launch)
     return y
@@ -491,9 +495,8 @@ class ChebConvFn(torch.autograd.Function):
                 gconv_dw([dict(x=xs[k], csr=csr_of(k), w=(dW, k * Fout, K * Fout, 1)) for k in range(K)], dz)
             if W_aff is not None and need_wa:
                 gconv_dw([dict(x=xs[0], csr=csr_of(0), w=(dWa, 0, Fout, 1))], g)
-        if SIDE_STREAM is not None and Cc and (need_w or need_wa):
-            # the rank-1 rows of dW / dWa are written on the main stream below: order them after the kernels
-            torch.cuda.current_stream().wait_stream(SIDE_STREAM)
+        # (the rank-1 rows dW[Ch*K:] / dWa[Ch:] written on the main stream below are disjoint from the rows
+        # the side-stream kernels write, so no ordering between the two is needed)
         if Cc:
             # rank-1 condition terms: dcoef[n,k,f] = sum_r (S_k 1)[r] dz[n,r,f]  (from bwd_prep)
             dcoef = dcoef.view(N, K * Fout)

@@ -20,6 +20,20 @@ def wrapped(entries, y, **kw):
         ops._last_desc = desc + " (3rd rep)"
     return orig(entries, y, **kw)
 ops.gconv_fwd = wrapped
+orig_dw = ops.gconv_dw
+def wrapped_dw(entries, dz, accumulate=False):
+    N, Mo, F = dz.shape
+    if ops.LAUNCH_LOG is None:
+        return orig_dw(entries, dz, accumulate)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    orig_dw(entries, dz, accumulate)
+    e1.record()
+    Cs = [int(e.get("C", e["x"].shape[2])) for e in entries]
+    fl = sum(2.0 * N * Mo * c * F for c in Cs)
+    by = 4.0 * N * Mo * (sum(Cs) + F)
+    ops.LAUNCH_LOG.append(("dW(+reduce)", fl, by, e0, e1, "Mo%5d F%4d src[%s]" % (Mo, F, ",".join(map(str, Cs)))))
+ops.gconv_dw = wrapped_dw
 log = []
 ops.LAUNCH_LOG = []
 torch.cuda.synchronize()

@@ -8,7 +8,7 @@ r.load_batch(**bench.synthetic_batch(model, 1234))
 torch.cuda.synchronize()
 r.capture()
 st = model._opt_state['g']
-for i in range(12):
+for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
     r.step()
     torch.cuda.synchronize()
     print(i, {k: float(v) for k, v in r.losses.items()}, 'gnorm', float(torch.linalg.vector_norm(st['flat_grad'])),
