@@ -54,7 +54,7 @@ SIGNATURES = {
     "cape_bwd_prep_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "cape_bwd_prep": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p, _i32, _p,
                                 _i32, _i32, _i32, _p, _i64, _p]),
-    "cape_spmm": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _f32, _p, _i64, _i32, _f32, _p, _i64, _i32,
+    "cape_spmm": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _i32, _f32, _p, _i64, _i32, _f32, _p, _i64, _i32,
                             _i32, _i32, _i32, _p]),
     "cape_bias_act_fwd": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "cape_act_bwd": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p]),

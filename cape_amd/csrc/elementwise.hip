@@ -62,6 +62,49 @@ __global__ __launch_bounds__(256) void spmm_kernel(CView x, const int *rp, const
     }
 }
 
+// Rows of the mesh operators have 1..16 entries (3-11 for L~, up to ~16 for composed T_k(L~)U).  With a
+// compile-time bound the entry loop unrolls completely: every (index, value) pair is loaded first, then all
+// gathers are in flight together -- two dependent memory round trips per thread instead of one per entry.
+template <int W>
+__global__ __launch_bounds__(256) void spmm_bounded_kernel(CView x, const int *rp, const int *ci, const float *va,
+                                                           float alpha, CView z, float beta, View y, int N, int Mo, int C) {
+    const int cq = C >> 2;
+    const long long total = (long long)N * Mo * cq;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int q = (int)(i % cq);
+        const long long nr = i / cq;
+        const int r = (int)(nr % Mo);
+        const int n = (int)(nr / Mo);
+        const int c = q * 4;
+        const float *xb = x.p + (long long)n * x.ss + c;
+        const int e0 = rp[r], len = rp[r + 1] - e0;
+        int cols[W];
+        float vals[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const int e = e0 + (j < len ? j : 0);      // clamped: always a valid entry of this row
+            cols[j] = ci[e];
+            vals[j] = j < len ? va[e] : 0.f;
+        }
+        float4 xv[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) xv[j] = *reinterpret_cast<const float4 *>(xb + (long long)cols[j] * x.ld);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            acc.x = fmaf(vals[j], xv[j].x, acc.x); acc.y = fmaf(vals[j], xv[j].y, acc.y);
+            acc.z = fmaf(vals[j], xv[j].z, acc.z); acc.w = fmaf(vals[j], xv[j].w, acc.w);
+        }
+        acc.x *= alpha; acc.y *= alpha; acc.z *= alpha; acc.w *= alpha;
+        if (z.p) {
+            const float4 zv = *reinterpret_cast<const float4 *>(z.p + (long long)n * z.ss + (long long)r * z.ld + c);
+            acc.x = fmaf(beta, zv.x, acc.x); acc.y = fmaf(beta, zv.y, acc.y);
+            acc.z = fmaf(beta, zv.z, acc.z); acc.w = fmaf(beta, zv.w, acc.w);
+        }
+        *reinterpret_cast<float4 *>(y.p + (long long)n * y.ss + (long long)r * y.ld + c) = acc;
+    }
+}
+
 // ---- bias + activation ----------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bias_act_kernel(CView x, const float *bias, int bias_mode, int act,
                                                        View y, int N, int M, int C) {
@@ -291,15 +334,20 @@ __global__ __launch_bounds__(256) void rowscale_final_kernel(const float *part, 
 }
 
 // ---- fused backward preparation: dz, bias gradient and rank-1 term gradients in one pass over g ----
-constexpr int BP_RB = 128;                  // rows per block
+constexpr int BP_RB_MAX = 128;              // rows per block (upper bound; shrunk until >= ~1024 blocks)
+inline int bp_rows(int N, int Mo) {
+    int rb = BP_RB_MAX;
+    while (rb > 16 && (long long)N * ((Mo + rb - 1) / rb) < 64) rb >>= 1;   // (smaller chunks measured slower)
+    return rb;
+}
 constexpr int BP_MAXT = RSR_MAXR + 2;       // reduction terms: [0]=sum dz, [1..R]=rowscale_j*dz, [R+1]=rowscale_rg*g
 
 __global__ __launch_bounds__(256) void bwd_prep_kernel(CView g, CView y, int act, const unsigned *mask, View dz,
                                                        const float *rowscale, int R, int rg, int want_bias, int want_g,
-                                                       int N, int Mo, int F, float *part, int chunks) {
+                                                       int N, int Mo, int F, float *part, int chunks, int RB) {
     __shared__ float red[BP_MAXT][256];
     const int n = blockIdx.x / chunks, ch = blockIdx.x % chunks;
-    const int ra = ch * BP_RB, rb = min(Mo, ra + BP_RB);
+    const int ra = ch * RB, rb = min(Mo, ra + RB);
     const int words = (F + 31) / 32;
     const int T = R + 2;
     const int fl = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -341,10 +389,10 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(CView g, CView y, int act
 // float4 variant (F % 4 == 0, 16-byte aligned views, F <= 1024): thread = (float4 column, row lane)
 __global__ __launch_bounds__(256) void bwd_prep_vec_kernel(CView g, CView y, int act, const unsigned *mask, View dz,
                                                            const float *rowscale, int R, int rg, int want_bias, int want_g,
-                                                           int N, int Mo, int F, float *part, int chunks) {
+                                                           int N, int Mo, int F, float *part, int chunks, int RB) {
     __shared__ float4 red[256];
     const int n = blockIdx.x / chunks, ch = blockIdx.x % chunks;
-    const int ra = ch * BP_RB, rb = min(Mo, ra + BP_RB);
+    const int ra = ch * RB, rb = min(Mo, ra + RB);
     const int words = (F + 31) / 32;
     const int T = R + 2;
     float *pp = part + ((long long)n * chunks + ch) * T * F;
@@ -449,7 +497,7 @@ inline int grid_for(long long total) {
 }  // namespace
 
 extern "C" int cape_spmm(const float *x, int64_t x_sample_stride, int32_t ldx, const int32_t *rowptr,
-                         const int32_t *colidx, const float *vals, float alpha, const float *z,
+                         const int32_t *colidx, const float *vals, int32_t max_row_nnz, float alpha, const float *z,
                          int64_t z_sample_stride, int32_t ldz, float beta, float *y, int64_t y_sample_stride,
                          int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
     if (!x || !rowptr || !colidx || !vals || !y || N < 1 || Mo < 1 || C < 1 || ldx < C || ldy < C) return CAPE_EINVAL;
@@ -459,7 +507,13 @@ extern "C" int cape_spmm(const float *x, int64_t x_sample_stride, int32_t ldx, c
     const bool vec = aligned4(x, x_sample_stride, ldx, C) && aligned4(y, y_sample_stride, ldy, C) &&
                      (!z || aligned4(z, z_sample_stride, ldz, C));
     hipStream_t st = (hipStream_t)stream;
-    if (vec) {
+    if (vec && max_row_nnz >= 1 && max_row_nnz <= 16) {
+        const long long total = (long long)N * Mo * (C / 4);
+        const dim3 g(grid_for(total)), b(256);
+        if (max_row_nnz <= 4) CAPE_LAUNCH(spmm_bounded_kernel<4>, g, b, 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
+        else if (max_row_nnz <= 8) CAPE_LAUNCH(spmm_bounded_kernel<8>, g, b, 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
+        else CAPE_LAUNCH(spmm_bounded_kernel<16>, g, b, 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
+    } else if (vec) {
         const long long total = (long long)N * Mo * (C / 4);
         CAPE_LAUNCH(spmm_kernel<true>, dim3(grid_for(total)), dim3(256), 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
     } else {
@@ -584,7 +638,8 @@ extern "C" int cape_rowscale_reduce(const float *dz, int64_t dz_sample_stride, i
 
 extern "C" int64_t cape_bwd_prep_workspace_bytes(int32_t N, int32_t Mo, int32_t F, int32_t R) {
     if (N < 1 || Mo < 1 || F < 1 || R < 0 || R > RSR_MAXR) return CAPE_EINVAL;
-    const long long chunks = (Mo + BP_RB - 1) / BP_RB;
+    const int RB = bp_rows(N, Mo);
+    const long long chunks = (Mo + RB - 1) / RB;
     return (int64_t)N * chunks * (R + 2) * F * (int64_t)sizeof(float);
 }
 
@@ -598,7 +653,8 @@ extern "C" int cape_bwd_prep(const float *g, int64_t g_sample_stride, int32_t ld
     if ((R > 0 || dcoef_g) && !rowscale) return CAPE_EINVAL;
     if (R > 0 && !dcoef) return CAPE_EINVAL;
     if (workspace_bytes < cape_bwd_prep_workspace_bytes(N, Mo, F, R)) return CAPE_EWORKSPACE;
-    const int chunks = (Mo + BP_RB - 1) / BP_RB;
+    const int RB = bp_rows(N, Mo);
+    const int chunks = (Mo + RB - 1) / RB;
     CView gv{g, g_sample_stride, ldg}, yv{y, y_sample_stride, ldy};
     View zv{dz, dz_sample_stride, lddz};
     hipStream_t st = (hipStream_t)stream;
@@ -607,10 +663,10 @@ extern "C" int cape_bwd_prep(const float *g, int64_t g_sample_stride, int32_t ld
                      (F >= 256 ? (F % 256) == 0 : (256 % (F / 4)) == 0) && ((F & 31) == 0 || !mask);
     if (vec)
         CAPE_LAUNCH(bwd_prep_vec_kernel, dim3(N * chunks), dim3(256), 0, st, gv, yv, act, mask, zv, rowscale, R, rg, dbias ? 1 : 0,
-                    dcoef_g ? 1 : 0, N, Mo, F, (float *)workspace, chunks);
+                    dcoef_g ? 1 : 0, N, Mo, F, (float *)workspace, chunks, RB);
     else
         CAPE_LAUNCH(bwd_prep_kernel, dim3(N * chunks), dim3(256), 0, st, gv, yv, act, mask, zv, rowscale, R, rg, dbias ? 1 : 0,
-                    dcoef_g ? 1 : 0, N, Mo, F, (float *)workspace, chunks);
+                    dcoef_g ? 1 : 0, N, Mo, F, (float *)workspace, chunks, RB);
     CAPE_LAUNCH_CHECK();
     if (dbias || R > 0 || dcoef_g) {
         const int fblocks = (F + 63) / 64;

@@ -84,6 +84,7 @@ class HostCSR(object):
         self.vals = m.data.astype(np.float32)
         self.nnz = int(m.nnz)
         self.max_row = int(np.diff(m.indptr).max()) if m.shape[0] else 0
+        self.min_row = int(np.diff(m.indptr).min()) if m.shape[0] else 0
 
     def to_scipy(self):
         return sp.csr_matrix((self.vals, self.colidx, self.rowptr), shape=self.shape)

@@ -19,6 +19,8 @@ from .graph import ConvOperators, HostCSR
 # "twopass": sparse operators applied by the streaming spmm kernel, dense contraction as a plain GEMM
 # "fused":   sparse operators gathered inside the GEMM kernel's A-tile staging (one launch per layer)
 MODE = "twopass"
+import os as _os
+SPMM_BOUNDED = int(_os.environ.get("CAPE_SPMM_BOUNDED", "0"))   # unrolled bounded-row kernel: no measured gain
 
 _ACT_OF = {"b1leakyrelu": ("leaky", _lib.BIAS_CHANNEL), "b1relu": ("relu", _lib.BIAS_CHANNEL),
            "b1tanh": ("tanh", _lib.BIAS_CHANNEL), "b2relu": ("relu", _lib.BIAS_VERTEX)}
@@ -68,6 +70,7 @@ class DeviceCSR(object):
         self.shape = host.shape
         self.identity = host.identity
         self.nnz = host.nnz
+        self.max_row, self.min_row = host.max_row, host.min_row
         if host.identity:
             self.rowptr = self.colidx = self.vals = None
         else:
@@ -229,7 +232,8 @@ def spmm(x, csr, y=None, alpha=1.0, z=None, beta=0.0):
     else:
         zp, zs, zl = None, 0, 0
     rc = lib.cape_spmm(xp, xs, xl, C.c_void_p(csr.rowptr_t.data_ptr()), C.c_void_p(csr.colidx_t.data_ptr()),
-                       C.c_void_p(csr.vals_t.data_ptr()), float(alpha), zp, zs, zl, float(beta),
+                       C.c_void_p(csr.vals_t.data_ptr()), int(csr.max_row if (csr.min_row >= 1 and SPMM_BOUNDED) else 0), float(alpha),
+                       zp, zs, zl, float(beta),
                        yp, ys, yl, N, Mo, Cn, _stream())
     check(rc, "cape_spmm")
     return y

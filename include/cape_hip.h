@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CAPE_ABI_VERSION 3
+#define CAPE_ABI_VERSION 4
 #define CAPE_MAX_SRC 8
 
 /* error codes (negative = argument error; positive values are hipError_t) */
@@ -165,9 +165,11 @@ int cape_bwd_prep(const float *g, int64_t g_sample_stride, int32_t ldg, const fl
                   int32_t R, float *dcoef, int32_t rg, float *dcoef_g, int32_t N, int32_t Mo,
                   int32_t F, void *workspace, int64_t workspace_bytes, void *stream);
 
-/* y[n,r,:] = alpha * sum_e vals[e]*x[n,colidx[e],:] + beta * z[n,r,:]   (z may be NULL, may alias y) */
+/* y[n,r,:] = alpha * sum_e vals[e]*x[n,colidx[e],:] + beta * z[n,r,:]   (z may be NULL, may alias y).
+ * max_row_nnz: upper bound on the entries of any row if the caller knows it (selects a fully unrolled
+ * kernel for <= 4 / 8 / 16; every row must then be non-empty), 0 = unknown. */
 int cape_spmm(const float *x, int64_t x_sample_stride, int32_t ldx, const int32_t *rowptr,
-              const int32_t *colidx, const float *vals, float alpha, const float *z,
+              const int32_t *colidx, const float *vals, int32_t max_row_nnz, float alpha, const float *z,
               int64_t z_sample_stride, int32_t ldz, float beta, float *y,
               int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t C,
               void *stream);
