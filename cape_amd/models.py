@@ -501,7 +501,11 @@ class CAPE(base_model):
     def generator(self, x, y, y2, eps=None):
         with self.variable_scope('generator'):
             z_mean, z_logvar = self.encoder(x, y, y2, use_res_block=self.use_res_block, use_cond=self.cond_encoder)
-            z = self.vae_sampling(z_mean, z_logvar, eps)
+            if eps is None:
+                eps = torch.randn((z_mean.shape[0], int(self.nz)), device=z_mean.device, dtype=torch.float32)
+            # sampling (:193-196) and the KL term (:371-372) share one hand-differentiated op
+            z, self._kl_of_last_sample = ops.VaeSampleKLFn.apply(z_mean, z_logvar, eps)
+            self._kl_inputs = (z_mean, z_logvar)
             z_total = torch.cat([z, y, y2], dim=1)
             x_hat = self.decoder_cond_vert(z_total, y, y2, use_res_block=self.use_res_block_dec)
         return x_hat, z_mean, z_logvar
@@ -551,15 +555,28 @@ class CAPE(base_model):
                                                        float(self.lambda_edge))
             out['edge'] = parts[1]
             total_re = out['recon'] * self.lambda_l1 + e_total
-        lat = -0.5 * torch.sum(1 + z_logvar - z_mean * z_mean - torch.exp(z_logvar), dim=1)
-        out['latent'] = lat.mean()
+        if getattr(self, '_kl_inputs', None) is not None and self._kl_inputs[0] is z_mean and self._kl_inputs[1] is z_logvar:
+            out['latent'] = self._kl_of_last_sample            # computed together with the sampling
+        else:
+            lat = -0.5 * torch.sum(1 + z_logvar - z_mean * z_mean - torch.exp(z_logvar), dim=1)
+            out['latent'] = lat.mean()
         # l2_regularizer(scale)(w) = scale*sum(w^2)/2 on dense kernels under 'generator', multiplied by
-        # `regularization` once more (reference :40, :378-379; quirk C6)
+        # `regularization` once more (reference :40, :378-379; quirk C6).  Its VALUE is reported here from
+        # detached kernels; its GRADIENT (regularization^2 * w) is added to the flat gradient bucket by
+        # backward_to_flat -- identical numbers, without recording 7M-element tape nodes for three kernels.
         reg = 0.0
+        self._reg_names = []
         if self.regularization:
-            ks = [v for n, v in self._vars.items() if self._kinds[n] == 'fc_kernel' and n.startswith('generator')]
-            if ks:
-                reg = sum(0.5 * (k * k).sum() for k in ks) * (self.regularization * self.regularization)
+            self._reg_names = [n for n in self._vars if self._kinds[n] == 'fc_kernel' and n.startswith('generator')]
+            if self._reg_names:
+                coef = self.regularization * self.regularization
+                if self._opt_state is not None and torch.is_grad_enabled() and getattr(self, '_reg_via_bucket', False):
+                    with torch.no_grad():
+                        reg = sum(torch.linalg.vector_norm(self._vars[n]) ** 2 for n in self._reg_names) * (0.5 * coef)
+                    self._reg_in_bucket = True
+                else:
+                    reg = sum(0.5 * (self._vars[n] * self._vars[n]).sum() for n in self._reg_names) * coef
+                    self._reg_in_bucket = False
         out['fc_reg_g'] = reg
         out['total_no_gan'] = total_re + out['latent'] * self.lambda_latent + reg
         return out
@@ -647,6 +664,17 @@ class CAPE(base_model):
         self._opt_state['d']['neg_lr'].fill_(-lr_d)
         return lr_g, lr_d
 
+    def _add_reg_grads(self):
+        """d/dw [regularization^2 * sum(w^2)/2] = regularization^2 * w for the generator's dense kernels."""
+        if not getattr(self, '_reg_in_bucket', False):
+            return
+        coef = self.regularization * self.regularization
+        st = self._opt_state['g']
+        with torch.no_grad():
+            for n in self._reg_names:
+                i = self._g_names.index(n)
+                st['grad_views'][i].add_(self._vars[n], alpha=coef)
+
     def store_grads(self, grp, grads):
         st = self._opt_state[grp]
         with torch.no_grad():
@@ -679,8 +707,12 @@ class CAPE(base_model):
 
     # ======================= training step ========================================================
     def forward_losses(self, data_g, cond_g, cond2_g, gt, data_d=None, cond_d=None, cond2_d=None, eps=None,
-                       with_gan=True):
-        """One evaluation of the training graph: returns dict with loss_g, loss_d and parts."""
+                       with_gan=True, reg_via_bucket=False):
+        """One evaluation of the training graph: returns dict with loss_g, loss_d and parts.
+        ``reg_via_bucket``: the caller will use backward_to_flat(), which adds the dense-kernel
+        regularisation gradient to the flat bucket itself (the loss then carries only its value)."""
+        self._reg_via_bucket = reg_via_bucket
+        self._reg_in_bucket = False
         y_g, y2_g = self._conditions(cond_g, cond2_g)
         x_hat, z_mean, z_logvar = self.generator(data_g, y_g, y2_g, eps=eps)
         out = self.loss_terms(x_hat, gt, z_mean, z_logvar)
@@ -722,6 +754,7 @@ class CAPE(base_model):
             grads_g = torch.autograd.grad(out['loss_g'], g_params, allow_unused=True)
             ops.join_side_stream()
             self.store_grads('g', grads_g)
+            self._add_reg_grads()
             return
         if self.bug_compat:
             grads_g = torch.autograd.grad(out['loss_g'], g_params, allow_unused=True)
@@ -733,12 +766,13 @@ class CAPE(base_model):
             grads_g, grads_d = grads[:len(g_params)], grads[len(g_params):]
         ops.join_side_stream()
         self.store_grads('g', grads_g)
+        self._add_reg_grads()
         self.store_grads('d', grads_d)
 
     def train_step(self, data_g, cond_g, cond2_g, gt, data_d, cond_d, cond2_d, eps=None, grad_hook=None):
         """forward + backward + both optimiser updates on one (G batch, D batch) pair.
         ``grad_hook(flat_grad)`` runs between backward and the update (data-parallel all-reduce)."""
-        out = self.forward_losses(data_g, cond_g, cond2_g, gt, data_d, cond_d, cond2_d, eps=eps)
+        out = self.forward_losses(data_g, cond_g, cond2_g, gt, data_d, cond_d, cond2_d, eps=eps, reg_via_bucket=True)
         self.backward_to_flat(out)
         out['lr_g'], out['lr_d'] = self.set_learning_rates()
         for grp in ('g', 'd'):

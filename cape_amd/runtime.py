@@ -41,9 +41,9 @@ class GraphedTrainStep(object):
         m, b = self.model, self.buf
         if self.with_gan:
             out = m.forward_losses(b['data_g'], b['cond_g'], b['cond2_g'], b['gt'], b['data_d'], b['cond_d'],
-                                   b['cond2_d'], eps=b['eps'])
+                                   b['cond2_d'], eps=b['eps'], reg_via_bucket=True)
         else:
-            out = m.forward_losses(b['data_g'], b['cond_g'], b['cond2_g'], b['gt'], eps=b['eps'], with_gan=False)
+            out = m.forward_losses(b['data_g'], b['cond_g'], b['cond2_g'], b['gt'], eps=b['eps'], with_gan=False, reg_via_bucket=True)
         m.backward_to_flat(out)
         for k in ('loss_g', 'loss_d', 'recon', 'latent', 'edge'):
             if k in out and torch.is_tensor(out[k]):
