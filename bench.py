@@ -67,11 +67,21 @@ def kernel_roofline(runner):
         runner._fwd_bwd()
     torch.cuda.synchronize()
     log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+    # an event pair around NOTHING still measures the record-to-record gap of the stream (a few us): calibrate
+    # it on empty brackets and subtract it, so that the per-launch figure is the kernel's own duration
+    empty = []
+    for _ in range(50):
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        a1.record()
+        empty.append((a0, a1))
+    torch.cuda.synchronize()
+    bracket_ms = float(np.median([a0.elapsed_time(a1) for a0, a1 in empty]))
     agg = {}
     for name, flops, byts, e0, e1 in log:
         a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
         a[0] += 1
-        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[1] += max(e0.elapsed_time(e1) - bracket_ms, 1e-4) * 1e-3
         a[2] += flops
         a[3] += byts
     if not agg:

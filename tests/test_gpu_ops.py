@@ -203,3 +203,27 @@ def test_recon_edge_loss(mesh_ops, dev):
     assert abs(parts[0].item() - recon.item()) < 1e-5 * abs(recon.item())
     assert abs(parts[1].item() - edge.item()) < 1e-5 * abs(edge.item())
     assert vertex_err(hp.grad.cpu().numpy(), tp.grad.numpy()) < TOL
+
+
+def test_baseline_config2_full_size(mesh_ops, dev):
+    """BASELINE.json configs[1]: single Chebyshev K=6 layer fwd+bwd at its FULL size
+    (batch 64 x 6890 x 16 -> 32, L~ from for_demo/A[0], seeds 0/1/2 as in SURVEY section 8d)."""
+    from cape_amd import ops
+    from cape_amd.graph import ConvOperators
+    from oracle import torch_twin as tt
+    N, Cin, Fout, K = 64, 16, 32, 6
+    L = mesh_ops["L"][0]
+    x = np.random.default_rng(0).standard_normal((N, 6890, Cin))
+    W = np.clip(0.1 * np.random.default_rng(1).standard_normal((Cin * K, Fout)), -0.2, 0.2)
+    dy = np.random.default_rng(2).standard_normal((N, 6890, Fout))
+    tx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    tW = torch.tensor(W, dtype=torch.float64, requires_grad=True)
+    ty = tt.chebyshev5(tx, L, tW, K)
+    ty.backward(torch.tensor(dy))
+    hx = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
+    hW = torch.tensor(W, dtype=torch.float32, device=dev, requires_grad=True)
+    hy = ops.chebyshev5(hx, hW, ops.DeviceConvOps(ConvOperators(L, K), dev))
+    hy.backward(torch.tensor(dy, dtype=torch.float32, device=dev))
+    assert vertex_err(hy.detach().cpu().numpy(), ty.detach().numpy()) < TOL
+    assert vertex_err(hx.grad.cpu().numpy(), tx.grad.numpy()) < TOL
+    assert mat_err(hW.grad.cpu().numpy(), tW.grad.numpy()) < TOL
