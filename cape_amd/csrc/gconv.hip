@@ -559,8 +559,9 @@ __global__ __launch_bounds__(256, 4) void gconv_dw_kernel(DwParams p) {
     for (int rbase = ra; rbase < rb; rbase += RK) {
         __syncthreads();
         // A chunk: RK (gathered) rows x CT channels
-        if (!S.rp && S.vec && (c0 + CT <= S.C)) {
-            // plain aligned source, full channel tile: all loads first, clamped rows + select
+        if (!S.rp && S.vec && ((S.C & 3) == 0)) {
+            // plain aligned source: all loads first, clamped rows/columns + select (partial channel tiles
+            // included: a float4 column is either entirely inside [0, C) or entirely outside)
             constexpr int NA = RK * (CT / 4) / 256;
             float4 va4[NA];
 #pragma unroll
@@ -569,13 +570,14 @@ __global__ __launch_bounds__(256, 4) void gconv_dw_kernel(DwParams p) {
                 const int rl = idx / (CT / 4), q = idx % (CT / 4);
                 const int r = rbase + rl;
                 const int rc = r < rb ? r : rb - 1;
-                va4[i] = *reinterpret_cast<const float4 *>(xb + (long long)rc * S.ldx + c0 + 4 * q);
+                const int cc = (c0 + 4 * q) < S.C ? (c0 + 4 * q) : 0;
+                va4[i] = *reinterpret_cast<const float4 *>(xb + (long long)rc * S.ldx + cc);
             }
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int idx = tid + i * 256;
                 const int rl = idx / (CT / 4), q = idx % (CT / 4);
-                const bool ok = (rbase + rl) < rb;
+                const bool ok = ((rbase + rl) < rb) && ((c0 + 4 * q) < S.C);
                 float4 o = va4[i];
                 o.x = ok ? o.x : 0.f; o.y = ok ? o.y : 0.f; o.z = ok ? o.z : 0.f; o.w = ok ? o.w : 0.f;
                 *reinterpret_cast<float4 *>(&sA[rl * LDA + 4 * q]) = o;
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(256, 4) void gconv_dw_kernel(DwParams p) {
             *reinterpret_cast<float4 *>(&sA[rl * LDA + 4 * q]) = v4;
         }
         // B chunk: RK rows of dz x FT channels
-        if (p.dzvec && (f0 + FT <= p.F)) {
+        if (p.dzvec && ((p.F & 3) == 0)) {
             constexpr int NB = RK * (FT / 4) / 256;
             float4 vb4[NB];
 #pragma unroll
@@ -634,13 +636,14 @@ __global__ __launch_bounds__(256, 4) void gconv_dw_kernel(DwParams p) {
                 const int rl = idx / (FT / 4), q = idx % (FT / 4);
                 const int r = rbase + rl;
                 const int rc = r < rb ? r : rb - 1;
-                vb4[i] = *reinterpret_cast<const float4 *>(dzb + (long long)rc * p.lddz + f0 + 4 * q);
+                const int fc = (f0 + 4 * q) < p.F ? (f0 + 4 * q) : 0;
+                vb4[i] = *reinterpret_cast<const float4 *>(dzb + (long long)rc * p.lddz + fc);
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int idx = tid + i * 256;
                 const int rl = idx / (FT / 4), q = idx % (FT / 4);
-                const bool ok = (rbase + rl) < rb;
+                const bool ok = ((rbase + rl) < rb) && ((f0 + 4 * q) < p.F);
                 float4 o = vb4[i];
                 o.x = ok ? o.x : 0.f; o.y = ok ? o.y : 0.f; o.z = ok ? o.z : 0.f; o.w = ok ? o.w : 0.f;
                 *reinterpret_cast<float4 *>(&sB[rl * LDB + 4 * q]) = o;
@@ -713,15 +716,15 @@ struct DwReduceParams {
     long long slab;
 };
 
-// block = 64 consecutive output elements x 4 split lanes; fixed summation order (deterministic)
+// block = 16 consecutive output elements x 16 split lanes; fixed summation order (deterministic)
 __global__ __launch_bounds__(256) void dw_reduce_kernel(DwReduceParams p) {
-    __shared__ float red[4][64];
+    __shared__ float red[16][17];
     const long long total = p.part_off[p.nsrc];
-    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const long long i = (long long)blockIdx.x * 64 + el;
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long long i = (long long)blockIdx.x * 16 + el;
     float sum = 0.f;
     if (i < total)
-        for (int sp = sl; sp < p.nsplit; sp += 4) sum += p.ws[(long long)sp * p.slab + i];
+        for (int sp = sl; sp < p.nsplit; sp += 16) sum += p.ws[(long long)sp * p.slab + i];
     red[sl][el] = sum;
     __syncthreads();
     if (sl == 0 && i < total) {
@@ -729,7 +732,9 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(DwReduceParams p) {
         while (si + 1 < p.nsrc && i >= p.part_off[si + 1]) ++si;
         const long long loc = i - p.part_off[si];
         const long long c = loc / p.F, f = loc % p.F;
-        const float t = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+        float t = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) t += red[l][el];
         float *dst = p.w[si] + c * p.wrs[si] + f * p.wcs[si];
         *dst = p.accumulate ? (*dst + t) : t;
     }
@@ -889,7 +894,7 @@ extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *
     CAPE_LAUNCH_CHECK();
     rp.F = F; rp.nsplit = pl.ngroups * pl.rsplit; rp.accumulate = accumulate; rp.ws = (const float *)workspace; rp.slab = pl.slab;
     long long total = poff;
-    int rblocks = (int)((total + 63) / 64);
+    int rblocks = (int)((total + 15) / 16);
     CAPE_LAUNCH(dw_reduce_kernel, dim3(rblocks), dim3(256), 0, st, rp);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
