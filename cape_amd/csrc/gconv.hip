@@ -501,6 +501,8 @@ struct DwParams {
     SrcDev s[CAPE_MAX_SRC];
     int nsrc;
     const float *dz;
+    const float *dz2;
+    unsigned dz2_mask;
     long long dzs;
     int lddz, dzvec;
     int N, Mo, F;
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(256, 4) void gconv_dw_kernel(DwParams p) {
             for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
 
     for (int n = n_begin; n < n_end; ++n) {
-    const float *dzb = p.dz + (long long)n * p.dzs;
+    const float *dzb = (((p.dz2_mask >> si) & 1u) ? p.dz2 : p.dz) + (long long)n * p.dzs;
     const float *xb = S.x + (long long)n * S.xs;
 
     for (int rbase = ra; rbase < rb; rbase += RK) {
@@ -856,10 +858,12 @@ extern "C" int64_t cape_gconv_dw_workspace_bytes(const cape_src_t *srcs, int32_t
 }
 
 extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *dz,
-                             int64_t dz_sample_stride, int32_t lddz, int32_t N, int32_t Mo, int32_t F,
-                             int32_t accumulate, void *workspace, int64_t workspace_bytes, void *stream) {
+                             int64_t dz_sample_stride, int32_t lddz, const float *dz2, uint32_t dz2_mask,
+                             int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
+                             int64_t workspace_bytes, void *stream) {
     if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || !dz || N < 1 || Mo < 1 || F < 1 || lddz < F || !workspace)
         return CAPE_EINVAL;
+    if (dz2_mask && !dz2) return CAPE_EINVAL;
     DwPlan pl;
     plan_dw(srcs, nsrc, N, Mo, F, pl);
     const long long need = pl.slab * pl.ngroups * pl.rsplit * (long long)sizeof(float);
@@ -879,8 +883,9 @@ extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *
         rp.w[i] = const_cast<float *>(srcs[i].w); rp.wrs[i] = srcs[i].w_rs; rp.wcs[i] = srcs[i].w_cs;
     }
     p.tile_off[nsrc] = toff; p.part_off[nsrc] = poff; rp.part_off[nsrc] = poff;
-    p.dz = dz; p.dzs = dz_sample_stride; p.lddz = lddz;
-    p.dzvec = ((lddz & 3) == 0) && ((dz_sample_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dz) & 15) == 0);
+    p.dz = dz; p.dz2 = dz2; p.dz2_mask = dz2 ? dz2_mask : 0u; p.dzs = dz_sample_stride; p.lddz = lddz;
+    p.dzvec = ((lddz & 3) == 0) && ((dz_sample_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dz) & 15) == 0) &&
+              (!dz2 || (reinterpret_cast<uintptr_t>(dz2) & 15) == 0);
     p.N = N; p.Mo = Mo; p.F = F; p.ftiles = pl.ftiles;
     p.rsplit = pl.rsplit; p.rows_per_split = pl.rows_per_split;
     p.ngroups = pl.ngroups; p.samples_per_group = pl.samples_per_group;

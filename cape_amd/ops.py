@@ -204,8 +204,9 @@ def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=
     return y
 
 
-def gconv_dw(entries, dz, accumulate=False):
-    """entries' ``w`` fields name the gradient blocks to write."""
+def gconv_dw(entries, dz, accumulate=False, dz2=None):
+    """entries' ``w`` fields name the gradient blocks to write; entries with ``use_dz2`` contract against
+    ``dz2`` (same shape and strides as ``dz``) instead of ``dz``."""
     _lib.require_gpu()
     arr = _mk_srcs(entries)
     N, Mo, F = dz.shape
@@ -214,7 +215,14 @@ def gconv_dw(entries, dz, accumulate=False):
         check(int(need), "cape_gconv_dw_workspace_bytes")
     ws = torch.empty((need + 3) // 4, device=dz.device, dtype=torch.float32)
     p, ss, ld = _v(dz)
-    rc = lib.cape_gconv_dw(arr, len(entries), p, ss, ld, N, Mo, F, 1 if accumulate else 0,
+    mask, p2 = 0, None
+    if dz2 is not None:
+        p2, ss2, ld2 = _v(dz2)
+        assert (ss2, ld2) == (ss, ld) and dz2.shape == dz.shape
+        for i, e in enumerate(entries):
+            if e.get("use_dz2"):
+                mask |= 1 << i
+    rc = lib.cape_gconv_dw(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, 1 if accumulate else 0,
                            C.c_void_p(ws.data_ptr()), need, _stream())
     check(rc, "cape_gconv_dw")
 
@@ -495,10 +503,18 @@ class ChebConvFn(torch.autograd.Function):
         if W_aff is not None and need_wa:
             dWa = _grad_buffer(W_aff, ctx.gWa)
         with _on_side_stream(dz, g, dW, dWa, *xs):
+            ent = []
             if need_w:
-                gconv_dw([dict(x=xs[k], csr=csr_of(k), w=(dW, k * Fout, K * Fout, 1)) for k in range(K)], dz)
+                ent += [dict(x=xs[k], csr=csr_of(k), w=(dW, k * Fout, K * Fout, 1)) for k in range(K)]
             if W_aff is not None and need_wa:
-                gconv_dw([dict(x=xs[0], csr=csr_of(0), w=(dWa, 0, Fout, 1))], g)
+                ent.append(dict(x=xs[0], csr=csr_of(0), w=(dWa, 0, Fout, 1), use_dz2=True))
+            if ent:
+                same = (W_aff is None) or (_v(g)[1:] == _v(dz)[1:])
+                if same:
+                    gconv_dw(ent, dz, dz2=g if W_aff is not None else None)      # one launch, one reduction
+                else:
+                    gconv_dw([e for e in ent if not e.get("use_dz2")], dz)
+                    gconv_dw([dict(e, use_dz2=False) for e in ent if e.get("use_dz2")], g)
         # (the rank-1 rows dW[Ch*K:] / dWa[Ch:] written on the main stream below are disjoint from the rows
         # the side-stream kernels write, so no ordering between the two is needed)
         if Cc:

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CAPE_ABI_VERSION 4
+#define CAPE_ABI_VERSION 5
 #define CAPE_MAX_SRC 8
 
 /* error codes (negative = argument error; positive values are hipError_t) */
@@ -136,16 +136,19 @@ int cape_rowscale_reduce(const float *dz, int64_t dz_sample_stride, int32_t lddz
 
 /*
  * Weight gradient of the fused gather-GEMM:
- *   dW_s[c*w_rs + f*w_cs] (+)= sum_{n,r} A_s[n,r,c] * dz[n,r,f]
+ *   dW_s[c*w_rs + f*w_cs] (+)= sum_{n,r} A_s[n,r,c] * dz_s[n,r,f]
  * for every source s (w is the *output* gradient block here and is written, w2 is ignored).
- * accumulate != 0 adds to the existing contents.  Uses a caller-provided workspace of at
- * least cape_gconv_dw_workspace_bytes(...) bytes.
+ * dz_s = dz2 for the sources whose bit is set in dz2_mask (dz2 has the layout of dz), dz otherwise:
+ * res_block_affine's two weight blocks contract the same inputs against different gradients (the
+ * ReLU-masked one and the raw one) and are produced by ONE launch.  accumulate != 0 adds to the existing
+ * contents.  Uses a caller-provided workspace of at least cape_gconv_dw_workspace_bytes(...) bytes.
  */
 int64_t cape_gconv_dw_workspace_bytes(const cape_src_t *srcs, int32_t nsrc, int32_t N,
                                       int32_t Mo, int32_t F);
 int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *dz,
-                  int64_t dz_sample_stride, int32_t lddz, int32_t N, int32_t Mo, int32_t F,
-                  int32_t accumulate, void *workspace, int64_t workspace_bytes, void *stream);
+                  int64_t dz_sample_stride, int32_t lddz, const float *dz2, uint32_t dz2_mask,
+                  int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
+                  int64_t workspace_bytes, void *stream);
 
 /*
  * One pass over the incoming gradient g [N, Mo, F] that produces everything the backward of a conv
