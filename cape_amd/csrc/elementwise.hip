@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void rowscale_final_kernel(const float *part, 
 constexpr int BP_RB_MAX = 128;              // rows per block (upper bound; shrunk until >= ~1024 blocks)
 inline int bp_rows(int N, int Mo) {
     int rb = BP_RB_MAX;
-    while (rb > 16 && (long long)N * ((Mo + rb - 1) / rb) < 64) rb >>= 1;   // (smaller chunks measured slower)
+    while (rb > 16 && (long long)N * ((Mo + rb - 1) / rb) < 448) rb >>= 1;
     return rb;
 }
 constexpr int BP_MAXT = RSR_MAXR + 2;       // reduction terms: [0]=sum dz, [1..R]=rowscale_j*dz, [R+1]=rowscale_rg*g
@@ -453,23 +453,23 @@ __global__ __launch_bounds__(256) void bwd_prep_vec_kernel(CView g, CView y, int
     }
 }
 
-// stage 2: block = (term t, 64 columns) x 4 lanes.  t = 0: dbias[f] = sum over (n, chunk);
+// stage 2: block = (term t, 16 columns) x 16 lanes.  t = 0: dbias[f] = sum over (n, chunk);
 // t = 1..R: dcoef[n, t-1, f] = sum over chunks; t = R+1: dcoef_g[n, f] = sum over chunks.
 __global__ __launch_bounds__(256) void bwd_prep_final_kernel(const float *part, int chunks, int N, int F, int R, float *dbias,
                                                              float *dcoef, float *dcoef_g) {
-    __shared__ float red[4][64];
+    __shared__ float red[16][17];
     const int T = R + 2;
-    const int fblocks = (F + 63) / 64;
-    const int fl = threadIdx.x & 63, ln = threadIdx.x >> 6;
+    const int fblocks = (F + 15) / 16;
+    const int fl = threadIdx.x & 15, ln = threadIdx.x >> 4;
     int b = blockIdx.x;
     const int fb = b % fblocks; b /= fblocks;
-    const int f = fb * 64 + fl;
+    const int f = fb * 16 + fl;
     // block order: [bias blocks: fblocks] then for each n: (R+1) * fblocks
     float s = 0.f;
     float *dst = nullptr;
     if (b == 0) {            // bias
         if (dbias && f < F) {
-            for (long long i = ln; i < (long long)N * chunks; i += 4) s += part[i * T * F + f];
+            for (long long i = ln; i < (long long)N * chunks; i += 16) s += part[i * T * F + f];
             dst = dbias + f;
         }
     } else {
@@ -478,13 +478,18 @@ __global__ __launch_bounds__(256) void bwd_prep_final_kernel(const float *part, 
         float *out = (t <= R) ? (dcoef ? dcoef + ((long long)n * R + (t - 1)) * F : nullptr)
                               : (dcoef_g ? dcoef_g + (long long)n * F : nullptr);
         if (out && f < F) {
-            for (int c = ln; c < chunks; c += 4) s += part[(((long long)n * chunks + c) * T + t) * F + f];
+            for (int c = ln; c < chunks; c += 16) s += part[(((long long)n * chunks + c) * T + t) * F + f];
             dst = out + f;
         }
     }
     red[ln][fl] = s;
     __syncthreads();
-    if (ln == 0 && dst) *dst = (red[0][fl] + red[1][fl]) + (red[2][fl] + red[3][fl]);
+    if (ln == 0 && dst) {
+        float t = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) t += red[l][fl];
+        *dst = t;
+    }
 }
 
 inline int grid_for(long long total) {
@@ -669,7 +674,7 @@ extern "C" int cape_bwd_prep(const float *g, int64_t g_sample_stride, int32_t ld
                     dcoef_g ? 1 : 0, N, Mo, F, (float *)workspace, chunks, RB);
     CAPE_LAUNCH_CHECK();
     if (dbias || R > 0 || dcoef_g) {
-        const int fblocks = (F + 63) / 64;
+        const int fblocks = (F + 15) / 16;
         const int nblk = fblocks * (1 + N * (R + 1));
         CAPE_LAUNCH(bwd_prep_final_kernel, dim3(nblk), dim3(256), 0, st, (const float *)workspace, chunks, N, F, R, dbias, dcoef, dcoef_g);
         CAPE_LAUNCH_CHECK();
