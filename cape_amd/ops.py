@@ -323,13 +323,19 @@ def reduce_cond(dy, scale=None, out=None, accumulate=False):
     return out
 
 
-def bwd_prep(g, y=None, act="none", mask=None, want_bias=False, rowscale=None, R=0, rg=None):
-    """One pass over g: returns (dz, dbias [F] or None, dcoef [N,R,F] or None, dcoef_g [N,F] or None)."""
+def bwd_prep(g, y=None, act="none", mask=None, want_bias=False, rowscale=None, R=0, rg=None, dbias_out=None):
+    """One pass over g: returns (dz, dbias [F] or None, dcoef [N,R,F] or None, dcoef_g [N,F] or None).
+    ``dbias_out``: optional contiguous destination of the bias gradient (a view of the gradient bucket)."""
     _lib.require_gpu()
     N, Mo, F = g.shape
     dev = g.device
     dz = alloc_act(N, Mo, F, dev)
-    dbias = torch.empty(F, device=dev, dtype=torch.float32) if want_bias else None
+    dbias = None
+    if want_bias:
+        if dbias_out is not None and dbias_out.numel() == F and dbias_out.is_contiguous():
+            dbias = dbias_out.view(F)
+        else:
+            dbias = torch.empty(F, device=dev, dtype=torch.float32)
     dcoef = torch.empty((N, R, F), device=dev, dtype=torch.float32) if R else None
     dcoef_g = torch.empty((N, F), device=dev, dtype=torch.float32) if rg is not None else None
     need = lib.cape_bwd_prep_workspace_bytes(N, Mo, F, R)
@@ -425,7 +431,8 @@ class ChebConvFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, W, bias, W_aff, cond_in, cond_out, ops, act, bias_mode, mode, gW=None, gWa=None):
+    def forward(ctx, x, W, bias, W_aff, cond_in, cond_out, ops, act, bias_mode, mode, gW=None, gWa=None, gB=None,
+                wt=None, wat=None):
         x = as_act(x)
         N, Mi, Ch = x.shape
         K, Fout = ops.K, W.shape[1]
@@ -465,7 +472,7 @@ class ChebConvFn(torch.autograd.Function):
             fill_cond(cond_out.contiguous(), yfull[:, :, Fout:])
         ctx.ops, ctx.act, ctx.bias_mode, ctx.Fout, ctx.Co, ctx.Cc = ops, act, bias_mode, Fout, Co, Cc
         ctx.has_bias, ctx.twopass, ctx.xshape = bias is not None, twopass, (N, Mi, Ch)
-        ctx.gW, ctx.gWa = gW, gWa
+        ctx.gW, ctx.gWa, ctx.gB, ctx.wt, ctx.wat = gW, gWa, gB, wt, wat
         ctx.save_for_backward(W, W_aff, mask, yfull if (act != "none" and W_aff is None) else None, cond_in, *xs)
         return yfull
 
@@ -490,7 +497,8 @@ class ChebConvFn(torch.autograd.Function):
         else:
             dz, dbv, dcoef, dca = bwd_prep(g, y=None if ysaved is None else ysaved[:, :, :Fout], act=act, mask=mask,
                                            want_bias=chan_bias, rowscale=ops.rowscale if Cc else None,
-                                           R=K if Cc else 0, rg=(K if (Cc and W_aff is not None) else None))
+                                           R=K if Cc else 0, rg=(K if (Cc and W_aff is not None) else None),
+                                           dbias_out=ctx.gB)
         if need_b and ctx.has_bias:
             if ctx.bias_mode == _lib.BIAS_VERTEX:
                 dB = torch.empty((1, Mo, Fout), device=dev, dtype=torch.float32)
@@ -542,9 +550,11 @@ class ChebConvFn(torch.autograd.Function):
                 # transposed weight blocks with the output index contiguous, Wt[k][f][c] = W[c*K+k][f]: one
                 # small copy per layer; staging the W^T blocks in place through strides (row stride 1,
                 # column stride K*Fout) measured 1.5x slower in the GEMM (scattered LDS writes)
-                Wt = W[:Ch * K].view(Ch, K, Fout).permute(1, 2, 0).contiguous()
+                Wt = ctx.wt if ctx.wt is not None else W[:Ch * K].view(Ch, K, Fout).permute(1, 2, 0).contiguous()
                 wT = lambda k: (Wt, k * Fout * Ch, Ch, 1)
-                waT = (W_aff[:Ch].t().contiguous(), 0, Ch, 1) if W_aff is not None else None
+                waT = None
+                if W_aff is not None:
+                    waT = (ctx.wat if ctx.wat is not None else W_aff[:Ch].t().contiguous(), 0, Ch, 1)
                 contract_first = (Mo < Mi) or (Mo == Mi and Ch < Fout)
                 if contract_first:
                     # G_k = dz W_k^T at the Mo output rows, then dx = sum_k S_k^T G_k
@@ -577,7 +587,7 @@ class ChebConvFn(torch.autograd.Function):
                     gconv_fwd(ent, dx)
         if Co and need_co:
             dco = reduce_cond(gfull[:, :, Fout:])
-        return dx, dW, dB, dWa, dci, dco, None, None, None, None, None, None
+        return dx, dW, dB, dWa, dci, dco, None, None, None, None, None, None, None, None, None
 
 
 class ChebConvRecurrenceFn(torch.autograd.Function):
@@ -746,7 +756,8 @@ class ReconEdgeLossFn(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------
 # functional front-ends with the reference's operator names
 # --------------------------------------------------------------------------------------------
-def chebyshev5(x, W, ops, bias=None, activation=None, cond=None, W_affine=None, cond_in=None, grad_bufs=(None, None)):
+def chebyshev5(x, W, ops, bias=None, activation=None, cond=None, W_affine=None, cond_in=None, grad_bufs=(None, None),
+               bias_grad_buf=None, wt_bufs=(None, None)):
     """Graph convolution (lib/models.py:69-103) with optional fused bias+activation
     (``activation`` in b1leakyrelu/b1relu/b1tanh/b2relu), affine branch, rank-1 input condition
     (``cond_in``) and materialised output condition concat (``cond``)."""
@@ -756,7 +767,8 @@ def chebyshev5(x, W, ops, bias=None, activation=None, cond=None, W_affine=None, 
     else:
         act, bmode = _ACT_OF[activation]
     if ops.fused:
-        return ChebConvFn.apply(x, W, bias, W_affine, cond_in, cond, ops, act, bmode, MODE, grad_bufs[0], grad_bufs[1])
+        return ChebConvFn.apply(x, W, bias, W_affine, cond_in, cond, ops, act, bmode, MODE, grad_bufs[0], grad_bufs[1],
+                                bias_grad_buf, wt_bufs[0], wt_bufs[1])
     assert W_affine is None
     if cond_in is not None:
         x = ConcatCondFn.apply(x, cond_in)
