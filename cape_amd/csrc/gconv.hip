@@ -12,9 +12,6 @@
 // The weight-gradient kernel (contraction over vertices) lives below.
 #include "common.h"
 #include <stdlib.h>
-#ifndef CAPE_EXP
-#define CAPE_EXP 0
-#endif
 #ifndef CAPE_SPEC
 #define CAPE_SPEC 0
 #endif
@@ -70,8 +67,10 @@ __device__ __forceinline__ void stage_gather(float *sA, const SrcDev &S, int n, 
     const float *xb = S.x + (long long)n * S.xs + c;
     const int nvalid = S.C - c;   // channels available from c
     constexpr int P = ROWS / RP;
-    if (!S.rp && S.vec && nvalid >= 4) {
-        // plain source, aligned: issue every load of the chunk before the first LDS store
+    if (!S.rp && S.vec && (nvalid >= 4 || (nvalid > 0 && c + 4 <= S.ldx) || nvalid <= 0)) {
+        // plain source, aligned: issue every load of the chunk before the first LDS store.  A row
+        // padded to a multiple of 4 floats lets the last (partial) float4 be loaded whole; the lanes
+        // beyond C are zeroed below (e.g. the 3-channel network input in a 4-float row).
         float4 v[P];
 #pragma unroll
         for (int pass = 0; pass < P; ++pass) {
@@ -79,13 +78,14 @@ __device__ __forceinline__ void stage_gather(float *sA, const SrcDev &S, int n, 
             // unconditional load from a clamped (always valid) row, zeroed by a select afterwards:
             // a branch around each load would make hipcc wait vmcnt(0) per load (serialised round trips)
             const int rc = r < Mo ? r : Mo - 1;
-            v[pass] = *reinterpret_cast<const float4 *>(xb + (long long)rc * S.ldx);
+            v[pass] = *reinterpret_cast<const float4 *>((nvalid > 0 ? xb : S.x + (long long)n * S.xs) + (long long)rc * S.ldx);
         }
 #pragma unroll
         for (int pass = 0; pass < P; ++pass) {
             const bool ok = (r0 + rl0 + RP * pass) < Mo;
             float4 o = v[pass];
-            o.x = ok ? o.x : 0.f; o.y = ok ? o.y : 0.f; o.z = ok ? o.z : 0.f; o.w = ok ? o.w : 0.f;
+            o.x = (ok && nvalid > 0) ? o.x : 0.f; o.y = (ok && nvalid > 1) ? o.y : 0.f;
+            o.z = (ok && nvalid > 2) ? o.z : 0.f; o.w = (ok && nvalid > 3) ? o.w : 0.f;
             *reinterpret_cast<float4 *>(&sA[(rl0 + RP * pass) * LDA + 4 * q]) = o;
         }
         return;
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256, 4) void gconv_dw_kernel(DwParams p) {
     for (int rbase = ra; rbase < rb; rbase += RK) {
         __syncthreads();
         // A chunk: RK (gathered) rows x CT channels
-        if (!S.rp && S.vec && ((S.C & 3) == 0)) {
+        if (!S.rp && S.vec && (((S.C & 3) == 0) || (((S.C + 3) & ~3) <= S.ldx))) {
             // plain aligned source: all loads first, clamped rows/columns + select (partial channel tiles
             // included: a float4 column is either entirely inside [0, C) or entirely outside)
             constexpr int NA = RK * (CT / 4) / 256;
@@ -579,9 +579,11 @@ __global__ __launch_bounds__(256, 4) void gconv_dw_kernel(DwParams p) {
             for (int i = 0; i < NA; ++i) {
                 const int idx = tid + i * 256;
                 const int rl = idx / (CT / 4), q = idx % (CT / 4);
-                const bool ok = ((rbase + rl) < rb) && ((c0 + 4 * q) < S.C);
+                const bool okr = (rbase + rl) < rb;
+                const int nv = S.C - (c0 + 4 * q);       // valid lanes of this float4 column
                 float4 o = va4[i];
-                o.x = ok ? o.x : 0.f; o.y = ok ? o.y : 0.f; o.z = ok ? o.z : 0.f; o.w = ok ? o.w : 0.f;
+                o.x = (okr && nv > 0) ? o.x : 0.f; o.y = (okr && nv > 1) ? o.y : 0.f;
+                o.z = (okr && nv > 2) ? o.z : 0.f; o.w = (okr && nv > 3) ? o.w : 0.f;
                 *reinterpret_cast<float4 *>(&sA[rl * LDA + 4 * q]) = o;
             }
         } else
