@@ -1,0 +1,128 @@
+"""Ragged / edge-case GPU parity for the C-ABI kernels on small random meshes: channel counts that are
+not multiples of 4, single-sample batches, outputs narrower than one MFMA tile, operators with EMPTY rows
+and with long rows, vertex counts that are not multiples of any tile size, strided (channel-sliced) views.
+Checked against dense float64 numpy."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def rel(a, ref):
+    a, r = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    return np.abs(a - r).max() / max(np.abs(r).max(), 1e-30)
+
+
+def rand_csr(rng, rows, cols, density, empty_rows=0, long_row=None):
+    m = sp.random(rows, cols, density=density, random_state=np.random.RandomState(rng.integers(1 << 30)), format="lil")
+    for r in rng.choice(rows, size=empty_rows, replace=False) if empty_rows else []:
+        m.rows[r], m.data[r] = [], []
+    if long_row is not None:
+        m[0, :long_row] = rng.standard_normal(long_row)
+    return sp.csr_matrix(m, dtype=np.float64)
+
+
+CASES = [  # N, Mi, Mo, [C per source], F, dual, empty_rows
+    (1, 37, 37, [5], 1, False, 0),
+    (3, 131, 97, [7, 7], 3, False, 4),
+    (2, 200, 260, [12, 9, 4], 33, False, 0),
+    (2, 129, 129, [36, 36], 70, True, 3),
+    (1, 300, 150, [64], 130, False, 0),
+    (4, 65, 65, [3, 3, 3], 40, True, 0),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "N%d_Mi%d_Mo%d_F%d%s" % (c[0], c[1], c[2], c[4], "_dual" if c[5] else ""))
+def test_gather_gemm_ragged(case):
+    from cape_amd import ops
+    from cape_amd.graph import HostCSR
+    N, Mi, Mo, Cs, F, dual, empty = case
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(Mi * 1000 + F)
+    ref = np.zeros((N, Mo, F))
+    ref2 = np.zeros((N, Mo, F))
+    entries, keep = [], []
+    for i, C in enumerate(Cs):
+        # source 0 is the identity when shapes allow, the others are random operators (some rows empty, one long)
+        S = None if (i == 0 and Mi == Mo) else rand_csr(rng, Mo, Mi, 0.05, empty_rows=empty, long_row=min(Mi, 40))
+        # activations live inside a wider buffer: a channel-offset, row-padded view
+        buf = torch.zeros(N, Mi, C + 9, device=dev)
+        x = rng.standard_normal((N, Mi, C))
+        buf[:, :, 5:5 + C] = torch.tensor(x, dtype=torch.float32)
+        W = rng.standard_normal((C, F)) * 0.3
+        hW = torch.tensor(W, dtype=torch.float32, device=dev)
+        A = x if S is None else np.stack([S @ x[n] for n in range(N)])
+        ref += A @ W
+        e = dict(x=buf[:, :, 5:5 + C], csr=None if S is None else ops.DeviceCSR(HostCSR(S), dev), w=(hW, 0, F, 1))
+        if dual and i == 0:
+            W2 = rng.standard_normal((C, F)) * 0.3
+            hW2 = torch.tensor(W2, dtype=torch.float32, device=dev)
+            ref2 += A @ W2
+            e["w2"] = (hW2, 0, F, 1)
+            keep.append(hW2)
+        entries.append(e)
+        keep += [buf, hW]
+    y = ops.alloc_act(N, Mo, F, dev)
+    if dual:
+        mask = torch.zeros((N, Mo, (F + 31) // 32), device=dev, dtype=torch.int32)
+        ops.gconv_fwd(entries, y, mask=mask)
+        want = np.maximum(ref, 0) + ref2
+        bits = ((mask.cpu().numpy().astype(np.int64)[..., None] >> np.arange(32)) & 1).reshape(N, Mo, -1)[:, :, :F]
+        safe = np.abs(ref) > 1e-4 * np.abs(ref).max()          # sign is only meaningful away from 0
+        assert np.array_equal(bits[safe] == 1, (ref > 0)[safe])
+    else:
+        b = rng.standard_normal(F) * 0.1
+        hb = torch.tensor(b, dtype=torch.float32, device=dev)
+        ops.gconv_fwd(entries, y, bias=hb, bias_mode=1, act="leaky")
+        z = ref + b
+        want = np.where(z > 0, z, 0.2 * z)
+    torch.cuda.synchronize()
+    assert rel(y.cpu().numpy(), want) < TOL
+    # weight gradients of the same launch geometry
+    dz = rng.standard_normal((N, Mo, F))
+    hdz = torch.tensor(dz, dtype=torch.float32, device=dev)
+    grads = [torch.empty(C, F, device=dev) for C in Cs]
+    ops.gconv_dw([dict(x=e["x"], csr=e["csr"], w=(gw, 0, F, 1)) for e, gw in zip(entries, grads)], hdz)
+    torch.cuda.synchronize()
+    for i, (e, gw) in enumerate(zip(entries, grads)):
+        x = e["x"].cpu().numpy().astype(np.float64)
+        S = None if e["csr"] is None else e["csr"]
+        A = x if S is None else np.stack([sp.csr_matrix((S.vals_t.cpu().numpy().astype(np.float64), S.colidx_t.cpu().numpy(),
+                                                         S.rowptr_t.cpu().numpy()), shape=S.shape) @ x[n] for n in range(N)])
+        want_w = np.einsum('nrc,nrf->cf', A, dz)
+        assert rel(gw.cpu().numpy(), want_w) < TOL, i
+
+
+def test_spmm_empty_rows_and_axpby():
+    from cape_amd import ops
+    from cape_amd.graph import HostCSR
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(3)
+    for C in (1, 6, 8, 33):
+        S = rand_csr(rng, 77, 50, 0.1, empty_rows=10, long_row=30)
+        x, z = rng.standard_normal((2, 50, C)), rng.standard_normal((2, 77, C))
+        csr = ops.DeviceCSR(HostCSR(S), dev)
+        t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+        y = ops.spmm(t(x), csr, alpha=2.0, z=t(z), beta=-1.0)
+        want = np.stack([2.0 * (S @ x[n]) - z[n] for n in range(2)])
+        assert rel(y.cpu().numpy(), want) < TOL
+
+
+def test_bwd_prep_ragged():
+    from cape_amd import ops
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(9)
+    for (N, M, F, R) in ((1, 19, 5, 0), (3, 333, 36, 2), (2, 140, 130, 3)):
+        g, y = rng.standard_normal((N, M, F)), rng.standard_normal((N, M, F))
+        rs = rng.standard_normal((max(R, 1) + 1, M))
+        t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+        dz, db, dc, dcg = ops.bwd_prep(t(g), y=t(y), act="leaky", want_bias=True, rowscale=t(rs).contiguous(), R=R,
+                                       rg=R if R else None)
+        want = g * np.where(y > 0, 1.0, 0.2)
+        assert rel(dz.cpu().numpy(), want) < TOL and rel(db.cpu().numpy(), want.sum((0, 1))) < TOL
+        if R:
+            assert rel(dc.cpu().numpy(), np.einsum('jr,nrf->njf', rs[:R], want)) < TOL
+            assert rel(dcg.cpu().numpy(), np.einsum('r,nrf->nf', rs[R], g)) < TOL
