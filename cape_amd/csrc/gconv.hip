@@ -11,49 +11,13 @@
 // mode (:776-793) and -- with transposed operators and weights -- their data gradients.
 // The weight-gradient kernel (contraction over vertices) lives below.
 #include "common.h"
+#include "gconv_shared.h"
+#include "gemm_plain.h"
 #include <stdlib.h>
-#ifndef CAPE_SPEC
-#define CAPE_SPEC 0
-#endif
-#ifndef CAPE_PIPE
-#define CAPE_PIPE 0
-#endif
 
 namespace {
 
-constexpr int KC_DEFAULT = 32;   // contraction chunk staged per iteration (64 for wide, deep layers)
-
-struct SrcDev {
-    const float *x;
-    long long xs;
-    int ldx, C;
-    const int *rp;
-    const int *ci;
-    const float *va;
-    const float *w;
-    long long wrs, wcs;
-    const float *w2;
-    long long w2rs, w2cs;
-    int vec;   // 1: float4 gathers legal (ldx % 4 == 0, base 16B aligned)
-};
-
-struct GconvParams {
-    SrcDev s[CAPE_MAX_SRC];
-    int nsrc;
-    float *y;
-    long long ys;
-    int ldy;
-    int N, Mo, F;
-    const float *bias;
-    int bias_mode, act;
-    unsigned *mask;
-    int mask_words;
-    int row_tiles, col_tiles;
-    int rankR;
-    const float *rowscale;
-    const float *coef;
-    unsigned rank_to2;
-};
+constexpr int KC_DEFAULT = 32;   // contraction chunk staged per iteration
 
 // ---- A-tile staging: gathered rows -> LDS [ROWS][KC+4] -----------------------------------
 template <int ROWS, int LDA, int KC>
@@ -209,13 +173,12 @@ __device__ __forceinline__ void stage_weights(float *sB, const float *w, long lo
     }
 }
 
-// Workgroup = 8 waves with SPLIT ROLES (CDNA4: MFMA and VALU/VMEM are separate pipes that co-issue
-// from different waves of a SIMD): waves 0-3 only read LDS tiles and issue v_mfma_f32_32x32x2_f32,
-// waves 4-7 only gather/stage the NEXT [BM x 32] A chunk and [32 x BN] weight chunk into the other
-// LDS buffer.  One barrier per chunk hands the buffers over; the MFMA waves never wait on global
-// memory, the loader waves are free to sit on L2 latency.
+// Workgroup = 4 waves; every wave stages its share of the [BM x KC] gathered A chunk and the [KC x BN]
+// weight chunk, then multiplies.  3-4 resident workgroups per CU overlap each other's staging and MFMA
+// phases (measured faster here than a loader/MFMA wave split and than a register-prefetch pipeline, which
+// cost occupancy on the gather path; plain sources take the pipelined kernel of gemm_plain.h instead).
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool DUAL, int KC = KC_DEFAULT>
-__global__ __launch_bounds__(CAPE_SPEC ? 512 : 256, (DUAL && BN == 128 && BM == 128) ? 1 : (KC == 64 ? 3 : 4)) void gconv_fwd_kernel(GconvParams p) {
+__global__ __launch_bounds__(256, 4) void gconv_fwd_kernel(GconvParams p) {
     constexpr int LDA = KC + 4;
     constexpr int LDB = BN + 4;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -225,15 +188,10 @@ __global__ __launch_bounds__(CAPE_SPEC ? 512 : 256, (DUAL && BN == 128 && BM == 
     static_assert(WAVES_M * WAVES_N == 4, "4 MFMA waves per workgroup");
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
 
-    __shared__ __attribute__((aligned(16))) float smem[((CAPE_SPEC || CAPE_PIPE) ? 2 : 1) * BUF_SZ];
+    __shared__ __attribute__((aligned(16))) float smem[BUF_SZ];
 
     const int tid = threadIdx.x;
-#if CAPE_SPEC
-    const bool loader = tid >= 256;
-#else
-    const bool loader = false;
-#endif
-    const int ltid = tid & 255;
+    const int ltid = tid;
     const int lane = tid & 63, wave = (tid >> 6) & 3;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int li = lane & 31, lh = lane >> 5;
@@ -327,168 +285,14 @@ __global__ __launch_bounds__(CAPE_SPEC ? 512 : 256, (DUAL && BN == 128 && BM == 
             if (c_c0 >= p.s[c_si].C) { c_c0 = 0; ++c_si; }
     };
 
-#if CAPE_SPEC
-    if (loader) stage(0);
-    __syncthreads();
-    for (int it = 0; it < total; ++it) {
-        if (loader) {
-            if (it + 1 < total) stage((it + 1) & 1);
-        } else {
-            compute(it & 1);
-        }
-        __syncthreads();
-    }
-#elif !CAPE_PIPE
-    // All 4 waves stage, then multiply; 3-4 resident workgroups per CU overlap each other's staging
-    // and MFMA phases (measured faster on MI355X than both the loader/MFMA wave split above and the
-    // register-prefetch pipeline below, which cost occupancy).
     for (int it = 0; it < total; ++it) {
         __syncthreads();
         stage(0);
         __syncthreads();
         compute(0);
     }
-#else
-    // Software pipeline (all 4 waves stage AND multiply): the global loads of chunk it+1 are issued
-    // into registers before the MFMAs of chunk it and written to the other LDS buffer after them --
-    // one barrier per chunk, HBM/L2 latency hidden behind 64 MFMAs per wave.  Plain aligned sources
-    // with output-contiguous weights take this path; anything else (gathered / unaligned / strided
-    // weights) is staged synchronously after the multiply.
-    constexpr int P = BM / 32;
-    constexpr int NLB = (KC * (BN / 4)) / 256;
-    float4 ra[P], rb[NLB], rb2[DUAL ? NLB : 1];
-    const int q = ltid & 7, rl0 = ltid >> 3;
-    auto is_fast = [&](int si) -> bool {
-        const SrcDev &S = p.s[si];
-        const bool wfast = (S.wcs == 1) && ((S.wrs & 3) == 0) && ((p.F & 3) == 0) && ((reinterpret_cast<uintptr_t>(S.w) & 15) == 0);
-        const bool w2fast = !(DUAL && S.w2) || ((S.w2cs == 1) && ((S.w2rs & 3) == 0) && ((reinterpret_cast<uintptr_t>(S.w2) & 15) == 0));
-        return (S.rp == nullptr) && S.vec && ((S.C & 3) == 0) && wfast && w2fast;
-    };
-    auto load_regs = [&](int si, int c0) {
-        const SrcDev &S = p.s[si];
-        const int c = c0 + 4 * q;
-        const int cc = c < S.C ? c : 0;
-        const float *xb = S.x + (long long)n * S.xs + cc;
-#pragma unroll
-        for (int pass = 0; pass < P; ++pass) {
-            const int r = r0 + rl0 + 32 * pass;
-            const int rc = r < p.Mo ? r : p.Mo - 1;
-            ra[pass] = *reinterpret_cast<const float4 *>(xb + (long long)rc * S.ldx);
-        }
-#pragma unroll
-        for (int i = 0; i < NLB; ++i) {
-            const int idx = ltid + i * 256;
-            const int j4 = idx % (BN / 4), kk = idx / (BN / 4);
-            const int cw = c0 + kk, f = f0 + 4 * j4;
-            const int cwc = cw < S.C ? cw : S.C - 1, fc = f < p.F ? f : 0;
-            rb[i] = *reinterpret_cast<const float4 *>(S.w + cwc * S.wrs + fc);
-            if (DUAL && S.w2) rb2[i] = *reinterpret_cast<const float4 *>(S.w2 + cwc * S.w2rs + fc);
-        }
-    };
-    auto store_regs = [&](int buf, int si, int c0) {
-        const SrcDev &S = p.s[si];
-        float *sA = smem + buf * BUF_SZ;
-        float *sB = sA + A_SZ;
-        const bool cok = (c0 + 4 * q) < S.C;
-#pragma unroll
-        for (int pass = 0; pass < P; ++pass) {
-            const bool ok = cok && ((r0 + rl0 + 32 * pass) < p.Mo);
-            float4 o = ra[pass];
-            o.x = ok ? o.x : 0.f; o.y = ok ? o.y : 0.f; o.z = ok ? o.z : 0.f; o.w = ok ? o.w : 0.f;
-            *reinterpret_cast<float4 *>(&sA[(rl0 + 32 * pass) * LDA + 4 * q]) = o;
-        }
-#pragma unroll
-        for (int i = 0; i < NLB; ++i) {
-            const int idx = ltid + i * 256;
-            const int j4 = idx % (BN / 4), kk = idx / (BN / 4);
-            const bool ok = (c0 + kk < S.C) && (f0 + 4 * j4 < p.F);
-            float4 o = rb[i];
-            o.x = ok ? o.x : 0.f; o.y = ok ? o.y : 0.f; o.z = ok ? o.z : 0.f; o.w = ok ? o.w : 0.f;
-            *reinterpret_cast<float4 *>(&sB[kk * LDB + 4 * j4]) = o;
-            if (DUAL && S.w2) {
-                float4 o2 = rb2[i];
-                o2.x = ok ? o2.x : 0.f; o2.y = ok ? o2.y : 0.f; o2.z = ok ? o2.z : 0.f; o2.w = ok ? o2.w : 0.f;
-                *reinterpret_cast<float4 *>(&sB[B_SZ + kk * LDB + 4 * j4]) = o2;
-            }
-        }
-    };
-    // prologue: chunk 0 -> buffer 0
-    if (is_fast(0)) {
-        load_regs(0, 0);
-        store_regs(0, 0, 0);
-        l_c0 += KC;
-        if (l_c0 >= p.s[l_si].C) { l_c0 = 0; ++l_si; }
-    } else {
-        stage(0);
-    }
-    __syncthreads();
-    for (int it = 0; it < total; ++it) {
-        const bool more = (it + 1 < total);
-        const bool fast = more && is_fast(l_si);
-        const int n_si = l_si, n_c0 = l_c0;
-        if (fast) load_regs(n_si, n_c0);
-        compute(it & 1);
-        if (more) {
-            if (fast) {
-                store_regs((it + 1) & 1, n_si, n_c0);
-                l_c0 += KC;
-                if (l_c0 >= p.s[l_si].C) { l_c0 = 0; ++l_si; }
-            } else {
-                stage((it + 1) & 1);
-            }
-        }
-        __syncthreads();
-    }
-#endif
-    if (loader) return;
 
-    // ---- epilogue: C layout of 32x32 MFMA: col = lane&31, row = (g&3) + 8*(g>>2) + 4*(lane>>5)
-    float *yb = p.y + (long long)n * p.ys;
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int f = f0 + wn * WTN + b * 32 + li;
-            float coef[CAPE_MAX_SRC];
-#pragma unroll
-            for (int j = 0; j < CAPE_MAX_SRC; ++j)
-                coef[j] = (j < p.rankR && f < p.F) ? p.coef[((long long)n * p.rankR + j) * p.F + f] : 0.f;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int r = r0 + wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
-                const bool ok = (r < p.Mo) && (f < p.F);
-                float v = acc[a][b][g];
-                float v2add = 0.f;
-                if (p.rankR > 0 && r < p.Mo) {
-#pragma unroll
-                    for (int j = 0; j < CAPE_MAX_SRC; ++j)
-                        if (j < p.rankR) {
-                            const float t = p.rowscale[(long long)j * p.Mo + r] * coef[j];
-                            if (DUAL && ((p.rank_to2 >> j) & 1u)) v2add += t;
-                            else v += t;
-                        }
-                }
-                if (DUAL) {
-                    const bool pos = ok && (v > 0.f);
-                    if (p.mask) {
-                        const unsigned long long bal = __ballot(pos);
-                        if (li == 0 && r < p.Mo && (f0 + wn * WTN + b * 32) < p.F) {
-                            const unsigned word = lh ? (unsigned)(bal >> 32) : (unsigned)bal;
-                            p.mask[((long long)n * p.Mo + r) * p.mask_words + ((f0 + wn * WTN + b * 32) >> 5)] = word;
-                        }
-                    }
-                    v = (v > 0.f ? v : 0.f) + acc2[a][b][g] + v2add;
-                } else {
-                    if (ok) {
-                        if (p.bias_mode == CAPE_BIAS_CHANNEL) v += p.bias[f];
-                        else if (p.bias_mode == CAPE_BIAS_VERTEX) v += p.bias[(long long)r * p.F + f];
-                    }
-                    v = cape_act(v, p.act);
-                }
-                if (ok) yb[(long long)r * p.ldy + f] = v;
-            }
-        }
-    }
+    gconv_epilogue<BM, BN, WAVES_M, WAVES_N, DUAL>(p, acc, acc2, n, r0, f0, wm, wn, li, lh);
 }
 
 // =============================================================================================
@@ -789,7 +593,63 @@ inline void plan_dw(const cape_src_t *srcs, int nsrc, int N, int Mo, int F, DwPl
     pl.ngroups = (N + pl.samples_per_group - 1) / pl.samples_per_group;
 }
 
+
+// Kernel choice of one forward launch (pure function of the arguments).
+struct FwdPlan {
+    int family;   // 0: gather-GEMM (gconv_fwd_kernel), 1: pipelined plain GEMM (gemm_plain_kernel)
+    int BM, BN;
+    int layout;   // family 1: 1 = weights contraction-contiguous, 0 = output-contiguous
+};
+
+inline FwdPlan plan_fwd(const GconvParams &p, const cape_src_t *srcs, bool dual) {
+    FwdPlan pl;
+    static const int gp_on = getenv("CAPE_GEMM_PLAIN") ? atoi(getenv("CAPE_GEMM_PLAIN")) : 1;   // 0: A/B against the gather kernel
+    pl.layout = gp_on ? gp_weight_layout(p, dual) : -1;
+    for (int i = 0; i < p.nsrc && pl.layout >= 0; ++i) {
+        const long long ws = srcs[i].w_cs > srcs[i].w_rs ? srcs[i].w_cs : srcs[i].w_rs;
+        if ((long long)p.Mo * srcs[i].ldx >= (1LL << 31) || (long long)p.F * ws >= (1LL << 31)) pl.layout = -1;   // 32-bit offsets
+    }
+    if (pl.layout >= 0) {
+        pl.family = 1;
+        gp_tile(dual, p.F, pl.BM, pl.BN);
+        return pl;
+    }
+    pl.family = 0;
+    pl.BN = (p.F <= 32) ? 32 : (p.F <= 64 || dual) ? 64 : 128;
+    pl.BM = 128;
+    // small meshes: 128-row tiles leave <= 2 workgroups per CU (no overlap partner while staging);
+    // 64-row tiles double the resident workgroups at the price of re-reading the weight tile
+    static const int bm64_below = getenv("CAPE_BM64_BELOW") ? atoi(getenv("CAPE_BM64_BELOW")) : 640;
+    if (pl.BN == 128 && (long long)p.N * ((p.Mo + 127) / 128) * ((p.F + 127) / 128) < bm64_below) pl.BM = 64;
+    return pl;
+}
+
+inline int fill_fwd_srcs(GconvParams &p, const cape_src_t *srcs, int nsrc, bool &dual) {
+    dual = false;
+    for (int i = 0; i < nsrc; ++i) {
+        if (!srcs[i].w) return CAPE_EINVAL;
+        int rc = fill_src(p.s[i], srcs[i]);
+        if (rc) return rc;
+        dual = dual || (srcs[i].w2 != nullptr);
+    }
+    p.nsrc = nsrc;
+    return CAPE_OK;
+}
+
 }  // namespace
+
+extern "C" int cape_gconv_fwd_plan(const cape_src_t *srcs, int32_t nsrc, int32_t N, int32_t Mo, int32_t F,
+                                   int32_t plan[4]) {
+    if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || N < 1 || Mo < 1 || F < 1 || !plan) return CAPE_EINVAL;
+    GconvParams p;
+    bool dual;
+    int rc = fill_fwd_srcs(p, srcs, nsrc, dual);
+    if (rc) return rc;
+    p.N = N; p.Mo = Mo; p.F = F;
+    const FwdPlan pl = plan_fwd(p, srcs, dual);
+    plan[0] = pl.family; plan[1] = pl.BM; plan[2] = pl.BN; plan[3] = pl.family ? pl.layout : 0;
+    return CAPE_OK;
+}
 
 extern "C" int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, int64_t y_sample_stride,
                               int32_t ldy, int32_t N, int32_t Mo, int32_t F, const float *bias,
@@ -799,16 +659,12 @@ extern "C" int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, in
     if (bias_mode != CAPE_BIAS_NONE && !bias) return CAPE_EINVAL;
     if (act < CAPE_ACT_NONE || act > CAPE_ACT_TANH) return CAPE_EINVAL;
     GconvParams p;
-    bool dual = false;
-    for (int i = 0; i < nsrc; ++i) {
-        if (!srcs[i].w) return CAPE_EINVAL;
-        int rc = fill_src(p.s[i], srcs[i]);
-        if (rc) return rc;
-        dual = dual || (srcs[i].w2 != nullptr);
-    }
+    bool dual;
+    int rc = fill_fwd_srcs(p, srcs, nsrc, dual);
+    if (rc) return rc;
     if (mask_out && !dual) return CAPE_EINVAL;
     if (dual && (bias_mode != CAPE_BIAS_NONE || act != CAPE_ACT_NONE)) return CAPE_EINVAL;
-    p.nsrc = nsrc; p.y = y; p.ys = y_sample_stride; p.ldy = ldy;
+    p.y = y; p.ys = y_sample_stride; p.ldy = ldy;
     p.N = N; p.Mo = Mo; p.F = F;
     p.bias = bias; p.bias_mode = bias ? bias_mode : CAPE_BIAS_NONE; p.act = act;
     p.mask = mask_out; p.mask_words = (F + 31) / 32;
@@ -818,34 +674,21 @@ extern "C" int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, in
         if (rank->to_acc2 && !dual) return CAPE_EINVAL;
         p.rankR = rank->R; p.rowscale = rank->rowscale; p.coef = rank->coef; p.rank_to2 = rank->to_acc2;
     }
-    int BM = 128;
-    static const int dual_wide = getenv("CAPE_DUAL_WIDE") ? atoi(getenv("CAPE_DUAL_WIDE")) : 0;
-    const bool dualw = dual && dual_wide && F > 64;      // DUAL: 64x128 tiles (two accumulator sets = 64 AGPRs)
-    const int BN = (F <= 32) ? 32 : (F <= 64 || (dual && !dualw)) ? 64 : 128;
-    if (dualw) BM = 64;
-    p.col_tiles = (F + BN - 1) / BN;
-    // small meshes: 128-row tiles leave <= 2 workgroups per CU (no overlap partner while staging);
-    // 64-row tiles double the resident workgroups at the price of re-reading the weight tile
-    static const int bm64_below = getenv("CAPE_BM64_BELOW") ? atoi(getenv("CAPE_BM64_BELOW")) : 640;
-    if (!dual && BN == 128 && (long long)N * ((Mo + 127) / 128) * p.col_tiles < bm64_below) BM = 64;
-    // 64-wide contraction chunks (half the barriers per MFMA) when every source is a multiple of 64 wide
-    static const int kc64_on = getenv("CAPE_KC64") ? atoi(getenv("CAPE_KC64")) : 0;
-    bool kc64 = kc64_on && !dual && BN == 128;
-    for (int i = 0; i < nsrc; ++i) kc64 = kc64 && (srcs[i].C % 64 == 0);
-    if (kc64) BM = 64;
-    p.row_tiles = (Mo + BM - 1) / BM;
-    dim3 grid((unsigned)(N * p.row_tiles * p.col_tiles)), block(CAPE_SPEC ? 512 : 256);
+    const FwdPlan pl = plan_fwd(p, srcs, dual);
+    p.row_tiles = (Mo + pl.BM - 1) / pl.BM;
+    p.col_tiles = (F + pl.BN - 1) / pl.BN;
+    dim3 grid((unsigned)(N * p.row_tiles * p.col_tiles)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (!dual) {
-        if (BN == 32) CAPE_LAUNCH((gconv_fwd_kernel<128, 32, 4, 1, false>), grid, block, 0, st, p);
-        else if (BN == 64) CAPE_LAUNCH((gconv_fwd_kernel<128, 64, 4, 1, false>), grid, block, 0, st, p);
-        else if (BM == 64 && kc64) CAPE_LAUNCH((gconv_fwd_kernel<64, 128, 2, 2, false, 64>), grid, block, 0, st, p);
-        else if (BM == 64) CAPE_LAUNCH((gconv_fwd_kernel<64, 128, 2, 2, false>), grid, block, 0, st, p);
+    if (pl.family == 1) {
+        gp_launch(p, dual, pl.BM, pl.BN, pl.layout, grid, st);
+    } else if (!dual) {
+        if (pl.BN == 32) CAPE_LAUNCH((gconv_fwd_kernel<128, 32, 4, 1, false>), grid, block, 0, st, p);
+        else if (pl.BN == 64) CAPE_LAUNCH((gconv_fwd_kernel<128, 64, 4, 1, false>), grid, block, 0, st, p);
+        else if (pl.BM == 64) CAPE_LAUNCH((gconv_fwd_kernel<64, 128, 2, 2, false>), grid, block, 0, st, p);
         else CAPE_LAUNCH((gconv_fwd_kernel<128, 128, 2, 2, false>), grid, block, 0, st, p);
     } else {
-        if (BN == 32) CAPE_LAUNCH((gconv_fwd_kernel<128, 32, 4, 1, true>), grid, block, 0, st, p);
-        else if (BN == 64) CAPE_LAUNCH((gconv_fwd_kernel<128, 64, 4, 1, true>), grid, block, 0, st, p);
-        else CAPE_LAUNCH((gconv_fwd_kernel<64, 128, 2, 2, true>), grid, block, 0, st, p);
+        if (pl.BN == 32) CAPE_LAUNCH((gconv_fwd_kernel<128, 32, 4, 1, true>), grid, block, 0, st, p);
+        else CAPE_LAUNCH((gconv_fwd_kernel<128, 64, 4, 1, true>), grid, block, 0, st, p);
     }
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;

@@ -192,13 +192,16 @@ def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=
     if LAUNCH_LOG is None:
         launch()
     else:
-        # mirror of the tile selection in cape_gconv_fwd (csrc/gconv.hip) -- names as rocprofv3 prints them
+        # the library reports the kernel it selects; names as rocprofv3 prints them
         dual = any(e.get("w2") is not None for e in entries)
-        bn = 32 if F <= 32 else (64 if (F <= 64 or dual) else 128)
-        bm = 128
-        if (not dual) and bn == 128 and N * ((Mo + 127) // 128) * ((F + bn - 1) // bn) < 640:
-            bm = 64
-        name = "gconv_fwd_kernel<%d, %d, %s, %s, 32>" % (bm, bn, "2, 2" if bn == 128 else "4, 1", "true" if dual else "false")
+        plan = (C.c_int32 * 4)()
+        check(lib.cape_gconv_fwd_plan(arr, len(entries), N, Mo, F, plan), "cape_gconv_fwd_plan")
+        fam, bm, bn, layout = list(plan)
+        waves = "2, 2" if (bm, bn) in ((64, 128), (128, 128), (64, 64)) else "4, 1"
+        if fam == 1:
+            name = "gemm_plain_kernel<%d, %d, %s, %s, %s>" % (bm, bn, waves, "true" if dual else "false", "true" if layout else "false")
+        else:
+            name = "gconv_fwd_kernel<%d, %d, %s, %s, 32>" % (bm, bn, waves, "true" if dual else "false")
         flops, byts = _gconv_work(entries, N, Mo, F)
         _log_launch(name, flops, byts, launch)
     return y

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CAPE_ABI_VERSION 5
+#define CAPE_ABI_VERSION 6
 #define CAPE_MAX_SRC 8
 
 /* error codes (negative = argument error; positive values are hipError_t) */
@@ -124,6 +124,13 @@ int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, int64_t y_sam
                    int32_t ldy, int32_t N, int32_t Mo, int32_t F, const float *bias,
                    int32_t bias_mode, int32_t act, uint32_t *mask_out, const cape_rank_t *rank,
                    void *stream);
+
+/* Which kernel cape_gconv_fwd would run for these arguments (pure query, no launch):
+ * plan[0] = family (0: gather-GEMM gconv_fwd_kernel, 1: pipelined plain-source gemm_plain_kernel),
+ * plan[1], plan[2] = workgroup tile rows x columns, plan[3] = weight layout of family 1
+ * (1: contraction-contiguous, 0: output-contiguous).  Used by bench.py to attribute per-launch work to
+ * the kernel names rocprofv3 reports. */
+int cape_gconv_fwd_plan(const cape_src_t *srcs, int32_t nsrc, int32_t N, int32_t Mo, int32_t F, int32_t plan[4]);
 
 /*
  * Gradient of the rank-1 terms w.r.t. coef:  out[n, j, f] = sum_r rowscale[j, r] * dz[n, r, f]
