@@ -28,6 +28,11 @@ class CapeSrc(C.Structure):
     ]
 
 
+class CapeCondLayer(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("w_aff", C.c_void_p), ("coef", C.c_void_p), ("dcoef", C.c_void_p),
+                ("gw", C.c_void_p), ("gw_aff", C.c_void_p), ("K", C.c_int32), ("F", C.c_int32)]
+
+
 class CapeRank(C.Structure):
     _fields_ = [("R", C.c_int32), ("rowscale", C.c_void_p), ("coef", C.c_void_p), ("to_acc2", C.c_uint32)]
 
@@ -54,7 +59,7 @@ SIGNATURES = {
     "cape_gconv_dw": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _p, C.c_uint32, _i32, _i32, _i32, _i32, _p, _i64, _p]),
     "cape_bwd_prep_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "cape_bwd_prep": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p, _i32, _p,
-                                _i32, _i32, _i32, _p, _i64, _p]),
+                                _i64, _i32, _i32, _i32, _p, _i64, _p]),
     "cape_spmm": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _i32, _f32, _p, _i64, _i32, _f32, _p, _i64, _i32,
                             _i32, _i32, _i32, _p]),
     "cape_bias_act_fwd": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p]),
@@ -68,6 +73,8 @@ SIGNATURES = {
                                      _i32, _i32, _i32, _p]),
     "cape_groupnorm_bwd": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _p, _i64, _i32, _p, _p, _i32, _i32,
                                      _p, _i64, _i32, _p, _p, _p, _i32, _i32, _i32, _p]),
+    "cape_cond_coef_fwd": (C.c_int, [_p, _i32, _i32, _i32, C.POINTER(CapeCondLayer), _i32, _p]),
+    "cape_cond_coef_bwd": (C.c_int, [_p, _i32, _i32, _i32, C.POINTER(CapeCondLayer), _i32, _p, _i32, _i32, _p]),
     "cape_recon_edge_workspace_bytes": (_i64, [_i32, _i32, _i32]),
     "cape_recon_edge_loss_fwd_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _f32,
                                                _p, _p, _p, _i64, _p]),

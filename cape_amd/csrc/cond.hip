@@ -1,0 +1,158 @@
+// Rank-1 condition coefficients of ALL consumers of one condition vector in one launch.
+//
+// The decoder concatenates the same tiled condition vector [N, Cc] to the input of every block
+// (reference lib/models.py:591-594, 606-609 fit_cond_dim + tf.concat).  Those channels are vertex-constant,
+// so their contribution to layer l is  sum_j rowscale_j[r] * coef_l[n, j, f]  with
+//     coef_l[n, k, f] = sum_c cond[n, c] * W_l[(Ch_l + c) * K_l + k, f]      k < K_l
+//     coef_l[n, K_l, f] = sum_c cond[n, c] * Waff_l[Ch_l + c, f]             (affine blocks only)
+// (cape_rank_t).  Per layer these are 16 x 64 x F products: far too small for a launch each (a dispatch
+// costs ~5 us on MI355X, 9 layers x (2 forward + 5 backward) of them were ~0.4 ms of a 5 ms step), so the
+// forward of all layers is one kernel here, and so are the weight-row gradients and the condition gradient.
+#include "common.h"
+
+namespace {
+
+struct CondLayers {
+    cape_cond_layer_t l[CAPE_MAX_COND_LAYERS];
+    int nlayers;
+    int blk_off[CAPE_MAX_COND_LAYERS + 1];   // first block of each layer: (K + has_aff) * ceil(F / 256) blocks per layer
+};
+
+__device__ __forceinline__ void locate(const CondLayers &L, int b, int &li, int &r, int &f0) {
+    li = 0;
+    while (li + 1 < L.nlayers && b >= L.blk_off[li + 1]) ++li;
+    const int lb = b - L.blk_off[li];
+    const int fblocks = (L.l[li].F + 255) / 256;
+    r = lb / fblocks;
+    f0 = (lb % fblocks) * 256;
+}
+
+// coef[n, r, f]: one thread per f, 16 samples at a time in registers, cond in LDS
+__global__ __launch_bounds__(256) void cond_coef_fwd_kernel(CondLayers L, const float *cond, int ldc, int N, int Cc) {
+    extern __shared__ float scond[];    // [N][Cc]
+    for (int i = threadIdx.x; i < N * Cc; i += 256) scond[i] = cond[(long long)(i / Cc) * ldc + (i % Cc)];
+    __syncthreads();
+    int li, r, f0;
+    locate(L, blockIdx.x, li, r, f0);
+    const cape_cond_layer_t &Y = L.l[li];
+    const int f = f0 + threadIdx.x;
+    if (f >= Y.F) return;
+    const int R = Y.K + (Y.w_aff ? 1 : 0);
+    const float *w = (r < Y.K) ? Y.w + (long long)r * Y.F + f : Y.w_aff + f;
+    const long long wstep = (r < Y.K) ? (long long)Y.K * Y.F : Y.F;
+    for (int n0 = 0; n0 < N; n0 += 16) {
+        float acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int c = 0; c < Cc; ++c) {
+            const float wv = w[c * wstep];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (n0 + i < N) acc[i] = fmaf(scond[(n0 + i) * Cc + c], wv, acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (n0 + i < N) Y.coef[((long long)(n0 + i) * R + r) * Y.F + f] = acc[i];
+    }
+}
+
+// gw[(c*K + k), f] = sum_n cond[n, c] * dcoef[n, k, f]   (and the affine rows): thread per f, loops c
+__global__ __launch_bounds__(256) void cond_coef_dw_kernel(CondLayers L, const float *cond, int ldc, int N, int Cc) {
+    extern __shared__ float scond[];
+    for (int i = threadIdx.x; i < N * Cc; i += 256) scond[i] = cond[(long long)(i / Cc) * ldc + (i % Cc)];
+    __syncthreads();
+    int li, r, f0;
+    locate(L, blockIdx.x, li, r, f0);
+    const cape_cond_layer_t &Y = L.l[li];
+    const int f = f0 + threadIdx.x;
+    if (f >= Y.F) return;
+    const int R = Y.K + (Y.w_aff ? 1 : 0);
+    float *gw = (r < Y.K) ? Y.gw : Y.gw_aff;
+    if (!gw) return;
+    gw += (r < Y.K) ? (long long)r * Y.F + f : f;
+    const long long wstep = (r < Y.K) ? (long long)Y.K * Y.F : Y.F;
+    for (int c = 0; c < Cc; ++c) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s = fmaf(scond[n * Cc + c], Y.dcoef[((long long)n * R + r) * Y.F + f], s);
+        gw[c * wstep] = s;
+    }
+}
+
+// dcond[n, c] = sum_l sum_r sum_f dcoef_l[n, r, f] * Wrow_l(c, r)[f]: block = (n, group of 16 c), 16 lanes per c
+__global__ __launch_bounds__(256) void cond_coef_dcond_kernel(CondLayers L, float *dcond, int ldd, int N, int Cc, int accumulate) {
+    const int cgroups = (Cc + 15) / 16;
+    const int n = blockIdx.x / cgroups;
+    const int c = (blockIdx.x % cgroups) * 16 + (threadIdx.x >> 4);
+    const int lane = threadIdx.x & 15;
+    float s = 0.f;
+    if (c < Cc) {
+        for (int li = 0; li < L.nlayers; ++li) {
+            const cape_cond_layer_t &Y = L.l[li];
+            const int R = Y.K + (Y.w_aff ? 1 : 0);
+            for (int r = 0; r < R; ++r) {
+                const float *w = (r < Y.K) ? Y.w + ((long long)c * Y.K + r) * Y.F : Y.w_aff + (long long)c * Y.F;
+                const float *d = Y.dcoef + ((long long)n * R + r) * Y.F;
+                for (int f = lane; f < Y.F; f += 16) s = fmaf(d[f], w[f], s);
+            }
+        }
+    }
+    // fixed-order reduction over the 16 lanes of this c (lanes of one c are contiguous within a wave)
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) s += __shfl_down(s, off, 16);
+    if (lane == 0 && c < Cc) {
+        float *dst = dcond + (long long)n * ldd + c;
+        *dst = accumulate ? (*dst + s) : s;
+    }
+}
+
+inline int fill_layers(CondLayers &L, const cape_cond_layer_t *layers, int nlayers, bool bwd) {
+    if (!layers || nlayers < 1 || nlayers > CAPE_MAX_COND_LAYERS) return CAPE_EINVAL;
+    int off = 0;
+    for (int i = 0; i < nlayers; ++i) {
+        const cape_cond_layer_t &y = layers[i];
+        if (!y.w || y.K < 1 || y.F < 1) return CAPE_EINVAL;
+        if (!bwd && !y.coef) return CAPE_EINVAL;
+        if (bwd && !y.dcoef) return CAPE_EINVAL;
+        L.l[i] = y;
+        L.blk_off[i] = off;
+        off += (y.K + (y.w_aff ? 1 : 0)) * ((y.F + 255) / 256);
+    }
+    L.blk_off[nlayers] = off;
+    L.nlayers = nlayers;
+    return CAPE_OK;
+}
+
+}  // namespace
+
+extern "C" int cape_cond_coef_fwd(const float *cond, int32_t ldc, int32_t N, int32_t Cc,
+                                  const cape_cond_layer_t *layers, int32_t nlayers, void *stream) {
+    if (!cond || N < 1 || Cc < 1 || ldc < Cc || (long long)N * Cc * 4 > 48 * 1024) return CAPE_EINVAL;
+    CondLayers L;
+    int rc = fill_layers(L, layers, nlayers, false);
+    if (rc) return rc;
+    CAPE_LAUNCH(cond_coef_fwd_kernel, dim3(L.blk_off[nlayers]), dim3(256), (size_t)N * Cc * 4, (hipStream_t)stream, L, cond, ldc, N, Cc);
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}
+
+extern "C" int cape_cond_coef_bwd(const float *cond, int32_t ldc, int32_t N, int32_t Cc,
+                                  const cape_cond_layer_t *layers, int32_t nlayers, float *dcond, int32_t ldd,
+                                  int32_t accumulate, void *stream) {
+    if (!cond || N < 1 || Cc < 1 || ldc < Cc || (long long)N * Cc * 4 > 48 * 1024) return CAPE_EINVAL;
+    if (dcond && ldd < Cc) return CAPE_EINVAL;
+    CondLayers L;
+    int rc = fill_layers(L, layers, nlayers, true);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    bool any_gw = false;
+    for (int i = 0; i < nlayers; ++i) any_gw = any_gw || layers[i].gw || layers[i].gw_aff;
+    if (any_gw) {
+        CAPE_LAUNCH(cond_coef_dw_kernel, dim3(L.blk_off[nlayers]), dim3(256), (size_t)N * Cc * 4, st, L, cond, ldc, N, Cc);
+        CAPE_LAUNCH_CHECK();
+    }
+    if (dcond) {
+        CAPE_LAUNCH(cond_coef_dcond_kernel, dim3(N * ((Cc + 15) / 16)), dim3(256), 0, st, L, dcond, ldd, N, Cc, accumulate);
+        CAPE_LAUNCH_CHECK();
+    }
+    return CAPE_OK;
+}

@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void bwd_prep_vec_kernel(CView g, CView y, int
 // stage 2: block = (term t, 16 columns) x 16 lanes.  t = 0: dbias[f] = sum over (n, chunk);
 // t = 1..R: dcoef[n, t-1, f] = sum over chunks; t = R+1: dcoef_g[n, f] = sum over chunks.
 __global__ __launch_bounds__(256) void bwd_prep_final_kernel(const float *part, int chunks, int N, int F, int R, float *dbias,
-                                                             float *dcoef, float *dcoef_g) {
+                                                             float *dcoef, float *dcoef_g, long long cs, long long cgs) {
     __shared__ float red[16][17];
     const int T = R + 2;
     const int fblocks = (F + 15) / 16;
@@ -475,8 +475,8 @@ __global__ __launch_bounds__(256) void bwd_prep_final_kernel(const float *part, 
     } else {
         const int idx = b - 1;
         const int n = idx / (R + 1), t = 1 + idx % (R + 1);
-        float *out = (t <= R) ? (dcoef ? dcoef + ((long long)n * R + (t - 1)) * F : nullptr)
-                              : (dcoef_g ? dcoef_g + (long long)n * F : nullptr);
+        float *out = (t <= R) ? (dcoef ? dcoef + (long long)n * cs + (long long)(t - 1) * F : nullptr)
+                              : (dcoef_g ? dcoef_g + (long long)n * cgs : nullptr);
         if (out && f < F) {
             for (int c = ln; c < chunks; c += 16) s += part[(((long long)n * chunks + c) * T + t) * F + f];
             dst = out + f;
@@ -650,8 +650,9 @@ extern "C" int64_t cape_bwd_prep_workspace_bytes(int32_t N, int32_t Mo, int32_t 
 
 extern "C" int cape_bwd_prep(const float *g, int64_t g_sample_stride, int32_t ldg, const float *y, int64_t y_sample_stride,
                              int32_t ldy, int32_t act, const uint32_t *mask, float *dz, int64_t dz_sample_stride, int32_t lddz,
-                             float *dbias, const float *rowscale, int32_t R, float *dcoef, int32_t rg, float *dcoef_g, int32_t N,
-                             int32_t Mo, int32_t F, void *workspace, int64_t workspace_bytes, void *stream) {
+                             float *dbias, const float *rowscale, int32_t R, float *dcoef, int32_t rg, float *dcoef_g,
+                             int64_t dcoef_sample_stride, int32_t N, int32_t Mo, int32_t F, void *workspace, int64_t workspace_bytes,
+                             void *stream) {
     if (!g || !dz || !workspace || N < 1 || Mo < 1 || F < 1 || ldg < F || lddz < F || R < 0 || R > RSR_MAXR) return CAPE_EINVAL;
     if (act < CAPE_ACT_NONE || act > CAPE_ACT_TANH) return CAPE_EINVAL;
     if (!mask && act != CAPE_ACT_NONE && (!y || ldy < F)) return CAPE_EINVAL;
@@ -676,7 +677,9 @@ extern "C" int cape_bwd_prep(const float *g, int64_t g_sample_stride, int32_t ld
     if (dbias || R > 0 || dcoef_g) {
         const int fblocks = (F + 15) / 16;
         const int nblk = fblocks * (1 + N * (R + 1));
-        CAPE_LAUNCH(bwd_prep_final_kernel, dim3(nblk), dim3(256), 0, st, (const float *)workspace, chunks, N, F, R, dbias, dcoef, dcoef_g);
+        CAPE_LAUNCH(bwd_prep_final_kernel, dim3(nblk), dim3(256), 0, st, (const float *)workspace, chunks, N, F, R, dbias, dcoef, dcoef_g,
+                    dcoef_sample_stride ? (long long)dcoef_sample_stride : (long long)R * F,
+                    dcoef_sample_stride ? (long long)dcoef_sample_stride : (long long)F);
         CAPE_LAUNCH_CHECK();
     }
     return CAPE_OK;

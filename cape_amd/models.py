@@ -100,9 +100,10 @@ class base_model(object):
         self._init_rng = np.random.default_rng(seed)
         self._grad_views = {}      # TF variable name -> view of the flat gradient bucket (train phase)
         self._conv_meta = {}       # conv weight name -> (feature channels, K, Fout), recorded while tracing
-        self._wt_views = {}        # conv weight name -> view [K, Fout, Ch] of the transposed-weight buffer
-        self._wt_state = {}
-        self._wt_fresh = False     # transposed blocks match the current variables (see refresh_transposed_weights)
+        self._cond_plan = None     # consumers of the decoder's condition vector, recorded on the first pass
+        self._cond_rec = None      # ... while recording
+        self._cond_bank = None     # iterator over the precomputed coefficient tensors of the current pass
+        self._cond_vec = None      # the condition tensor those consumers share
 
     # ---- data assets ---------------------------------------------------------------------------
     def _load_template(self):
@@ -203,15 +204,48 @@ class base_model(object):
         self._conv_meta[wname] = (Ch, int(K), int(Fout))
         gW = self._grad_views.get(wname)
         gB = self._grad_views.get(bname) if (bias is not None and bias.shape[1] == 1) else None
-        gWa = wat = None
+        gWa = None
         if W_affine is not None:
             self._conv_meta[waname] = (Ch, 1, int(Fout))
             gWa = self._grad_views.get(waname)
-            wat = self._wt_views.get(waname)
+        coef = None
+        if cond_in is not None and cond_in is self._cond_vec:
+            # one of the consumers of the decoder's condition vector: its rank-1 coefficients come from the
+            # all-layers launch (CondCoefFn) once the list of consumers is known, i.e. from the second pass on
+            if self._cond_bank is not None:
+                coef, cond_in = next(self._cond_bank), None
+            elif self._cond_rec is not None:
+                self._cond_rec.append(dict(wname=wname, waname=waname if W_affine is not None else None, Ch=Ch, K=int(K)))
         return ops.chebyshev5(x, W, self._conv_ops(L, K, unpool=unpool, pool=pool), bias=bias,
                               activation=activation, cond=cond, W_affine=W_affine, cond_in=cond_in,
-                              grad_bufs=(gW, gWa), bias_grad_buf=gB,
-                              wt_bufs=((self._wt_views.get(wname), wat) if self._wt_fresh else (None, None)))
+                              grad_bufs=(gW, gWa), bias_grad_buf=gB, coef=coef)
+
+    # ---- condition-coefficient bank (decoder) -------------------------------------------------------
+    def _cond_bank_begin(self, cond):
+        """Called with the decoder's condition vector before its first consumer runs."""
+        self._cond_vec, self._cond_bank, self._cond_rec = cond, None, None
+        plan = self._cond_plan
+        if plan is None:
+            self._cond_rec = []
+            return
+        need_grad = torch.is_grad_enabled()
+        layers = []
+        for e in plan:
+            gW = self._grad_views.get(e['wname'])
+            gWa = self._grad_views.get(e['waname']) if e['waname'] else None
+            if need_grad and (gW is None or (e['waname'] and gWa is None)):
+                return            # no gradient bucket to write into (e.g. a bare autograd.grad call): per-layer path
+            layers.append(dict(W=self._vars[e['wname']], Wa=self._vars[e['waname']] if e['waname'] else None,
+                               Ch=e['Ch'], K=e['K'], gW=gW, gWa=gWa))
+        if layers:
+            self._cond_bank = iter(ops.CondCoefFn.apply(cond, layers))
+
+    def _cond_bank_end(self):
+        if self._cond_rec is not None:
+            self._cond_plan, self._cond_rec = self._cond_rec, None
+        elif self._cond_bank is not None:
+            assert next(self._cond_bank, None) is None, "condition-consumer list changed between passes"
+        self._cond_vec = self._cond_bank = None
 
     def _brelu_named(self, x, kind):
         shape = [1, x.shape[1], x.shape[2]] if kind == 'b2relu' else [1, 1, x.shape[2]]
@@ -306,7 +340,6 @@ class base_model(object):
                         raise ValueError("shape mismatch for %s: %s vs %s" % (k, a.shape, tuple(v.shape)))
                     v.copy_(torch.from_numpy(a).to(v.device))
         self._weights_loaded = True
-        self._wt_fresh = False
 
 
 class CAPE(base_model):
@@ -473,6 +506,8 @@ class CAPE(base_model):
         # the GraphCMR block group-normalises over the concatenated [features | condition] channels, so it
         # needs the condition materialised; every other consumer takes it as rank-1 ``cond_in`` terms.
         materialise = bool(use_res_block and not self.affine) or not self._fusable()
+        if not materialise:
+            self._cond_bank_begin(cond)
         with self.variable_scope('decoder'):
             with self.variable_scope('fc1'):
                 out_nodes = int(self.p[-1] * self.out_channels[-1]) // self.reduce_rate
@@ -510,6 +545,8 @@ class CAPE(base_model):
                                         cond_in=None if materialise else cond)
                 else:
                     x = self.filter(x, self.Laplacian[0], Fo, self.poly_order[0]) + b
+        if not materialise:
+            self._cond_bank_end()
         return x
 
     def generator(self, x, y, y2, eps=None):
@@ -651,29 +688,6 @@ class CAPE(base_model):
                 # fake pass (two contributions that autograd must add) and keep private gradient tensors.
                 for nm, view in zip(names, views):
                     self._grad_views[nm] = view
-            # transposed weight blocks Wt[k][f][c] = W[(c*K + k)*Fout + f] (c < feature channels) for the data-
-            # gradient GEMMs of every conv layer of this group: ONE gather from the flat bucket per step
-            # (refresh_transposed_weights) instead of one permute-copy per layer
-            idx_parts, cursor, offs = [], 0, 0
-            poff = {}
-            for nm, prm in zip(names, params):
-                poff[nm] = offs
-                offs += al(prm.numel())
-            for nm in names:
-                if nm in self._conv_meta:
-                    Ch, Kk, Fo = self._conv_meta[nm]
-                    k_i, f_i, c_i = np.meshgrid(np.arange(Kk), np.arange(Fo), np.arange(Ch), indexing='ij')
-                    idx_parts.append((poff[nm] + (c_i * Kk + k_i) * Fo + f_i).reshape(-1))
-                    self._wt_views[nm] = (cursor, (Kk, Fo, Ch))
-                    cursor += Kk * Fo * Ch
-            if idx_parts:
-                idx = torch.from_numpy(np.concatenate(idx_parts).astype(np.int64)).to(self.device)
-                wt_flat = torch.empty(cursor, device=self.device, dtype=torch.float32)
-                self._wt_state[grp] = (flat, idx, wt_flat)
-                for nm in names:
-                    if nm in self._conv_meta and isinstance(self._wt_views.get(nm), tuple):
-                        c0, shp = self._wt_views[nm]
-                        self._wt_views[nm] = wt_flat[c0:c0 + shp[0] * shp[1] * shp[2]].view(shp)
             st = {'params': params, 'flat': flat, 'flat_grad': flat_grad, 'grad_views': views,
                   'm': torch.zeros_like(flat),
                   'neg_lr': torch.zeros((), device=self.device, dtype=torch.float32)}
@@ -682,14 +696,6 @@ class CAPE(base_model):
                 st['t'] = 0
             self._opt_state[grp] = st
         self.global_step = 0
-
-    def refresh_transposed_weights(self):
-        """Rebuild the transposed weight blocks from the current variables (call once per step, after the
-        previous update and before the backward pass)."""
-        with torch.no_grad():
-            for grp, (flat, idx, wt_flat) in self._wt_state.items():
-                torch.index_select(flat, 0, idx, out=wt_flat)
-        self._wt_fresh = bool(self._wt_state)
 
     def _lr_at(self, base_lr, step, warmup_duration=8):
         ds = int(self.decay_steps)
@@ -733,7 +739,6 @@ class CAPE(base_model):
         """clip_by_global_norm(5.0) (:461) + Momentum (non-Nesterov, TF semantics: accum = m*accum + g;
         var -= lr*accum) or Adam, on the flat buffers.  Capturable: no host reads."""
         st = self._opt_state[grp]
-        self._wt_fresh = False
         g, flat, m = st['flat_grad'], st['flat'], st['m']
         with torch.no_grad():
             gnorm = torch.linalg.vector_norm(g)
@@ -759,8 +764,6 @@ class CAPE(base_model):
         regularisation gradient to the flat bucket itself (the loss then carries only its value)."""
         self._reg_via_bucket = reg_via_bucket
         self._reg_in_bucket = False
-        if torch.is_grad_enabled() and self._wt_state and not self._wt_fresh:
-            self.refresh_transposed_weights()
         y_g, y2_g = self._conditions(cond_g, cond2_g)
         x_hat, z_mean, z_logvar = self.generator(data_g, y_g, y2_g, eps=eps)
         out = self.loss_terms(x_hat, gt, z_mean, z_logvar)
@@ -820,7 +823,6 @@ class CAPE(base_model):
     def train_step(self, data_g, cond_g, cond2_g, gt, data_d, cond_d, cond2_d, eps=None, grad_hook=None):
         """forward + backward + both optimiser updates on one (G batch, D batch) pair.
         ``grad_hook(flat_grad)`` runs between backward and the update (data-parallel all-reduce)."""
-        self.refresh_transposed_weights()
         out = self.forward_losses(data_g, cond_g, cond2_g, gt, data_d, cond_d, cond2_d, eps=eps, reg_via_bucket=True)
         self.backward_to_flat(out)
         out['lr_g'], out['lr_d'] = self.set_learning_rates()

@@ -326,9 +326,11 @@ def reduce_cond(dy, scale=None, out=None, accumulate=False):
     return out
 
 
-def bwd_prep(g, y=None, act="none", mask=None, want_bias=False, rowscale=None, R=0, rg=None, dbias_out=None):
+def bwd_prep(g, y=None, act="none", mask=None, want_bias=False, rowscale=None, R=0, rg=None, dbias_out=None, joint=False):
     """One pass over g: returns (dz, dbias [F] or None, dcoef [N,R,F] or None, dcoef_g [N,F] or None).
-    ``dbias_out``: optional contiguous destination of the bias gradient (a view of the gradient bucket)."""
+    ``dbias_out``: optional contiguous destination of the bias gradient (a view of the gradient bucket).
+    ``joint``: dcoef and dcoef_g are slices of ONE [N, R+1, F] buffer (returned as dcoef; the layout
+    cape_cond_coef_bwd consumes)."""
     _lib.require_gpu()
     N, Mo, F = g.shape
     dev = g.device
@@ -339,8 +341,14 @@ def bwd_prep(g, y=None, act="none", mask=None, want_bias=False, rowscale=None, R
             dbias = dbias_out.view(F)
         else:
             dbias = torch.empty(F, device=dev, dtype=torch.float32)
-    dcoef = torch.empty((N, R, F), device=dev, dtype=torch.float32) if R else None
-    dcoef_g = torch.empty((N, F), device=dev, dtype=torch.float32) if rg is not None else None
+    cstride = 0
+    if joint and R and rg is not None:
+        dcoef = torch.empty((N, R + 1, F), device=dev, dtype=torch.float32)
+        dcoef_g = dcoef[:, R]
+        cstride = (R + 1) * F
+    else:
+        dcoef = torch.empty((N, R, F), device=dev, dtype=torch.float32) if R else None
+        dcoef_g = torch.empty((N, F), device=dev, dtype=torch.float32) if rg is not None else None
     need = lib.cape_bwd_prep_workspace_bytes(N, Mo, F, R)
     ws = torch.empty((need + 3) // 4, device=dev, dtype=torch.float32)
     gp, gs, gl = _v(g)
@@ -351,7 +359,7 @@ def bwd_prep(g, y=None, act="none", mask=None, want_bias=False, rowscale=None, R
         yp, ys, yl = None, 0, 0
     rc = lib.cape_bwd_prep(gp, gs, gl, yp, ys, yl, _lib.ACT[act] if mask is None else 0, _ptr(mask), zp, zs, zl,
                            _ptr(dbias), _ptr(rowscale), R, _ptr(dcoef), 0 if rg is None else int(rg), _ptr(dcoef_g),
-                           N, Mo, F, _ptr(ws), need, _stream())
+                           cstride, N, Mo, F, _ptr(ws), need, _stream())
     check(rc, "cape_bwd_prep")
     return dz, dbias, dcoef, dcoef_g
 
@@ -435,7 +443,7 @@ class ChebConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, bias, W_aff, cond_in, cond_out, ops, act, bias_mode, mode, gW=None, gWa=None, gB=None,
-                wt=None, wat=None):
+                coef=None):
         x = as_act(x)
         if (x.shape[2] & 3) and (x.stride(1) & 3):
             # e.g. the [N, 6890, 3] network input: re-home it in a row-padded buffer so that the kernels can use
@@ -445,7 +453,11 @@ class ChebConvFn(torch.autograd.Function):
             x = xp
         N, Mi, Ch = x.shape
         K, Fout = ops.K, W.shape[1]
-        Cc = 0 if cond_in is None else cond_in.shape[1]
+        # ``coef`` [N, K (+1), Fout]: the rank-1 coefficients of the tiled condition channels, precomputed for
+        # all layers at once by CondCoefFn (then cond_in is None and the weight rows beyond Ch*K belong to it)
+        assert coef is None or cond_in is None
+        banked = coef is not None
+        Cc = (W.shape[0] // K - Ch) if coef is not None else (0 if cond_in is None else cond_in.shape[1])
         assert ops.fused and W.shape[0] == (Ch + Cc) * K and Mi == ops.Mi
         assert W.is_contiguous() and (W_aff is None or (W_aff.is_contiguous() and W_aff.shape == (Ch + Cc, Fout)))
         Co = 0 if cond_out is None else cond_out.shape[1]
@@ -460,7 +472,11 @@ class ChebConvFn(torch.autograd.Function):
                 e["w2"] = (W_aff, 0, Fout, 1)
             entries.append(e)
         rank = None
-        if Cc:
+        if coef is not None:
+            assert coef.is_contiguous() and coef.shape == (N, K + (1 if W_aff is not None else 0), Fout)
+            rank = ((ops.rowscale if W_aff is not None else ops.rowscale[:K]).contiguous(), coef,
+                    (1 << K) if W_aff is not None else 0)
+        elif Cc:
             cond_in = cond_in.contiguous()
             coef = torch.mm(cond_in, W[Ch * K:].view(Cc, K * Fout)).view(N, K, Fout)
             to2 = 0
@@ -481,7 +497,7 @@ class ChebConvFn(torch.autograd.Function):
             fill_cond(cond_out.contiguous(), yfull[:, :, Fout:])
         ctx.ops, ctx.act, ctx.bias_mode, ctx.Fout, ctx.Co, ctx.Cc = ops, act, bias_mode, Fout, Co, Cc
         ctx.has_bias, ctx.twopass, ctx.xshape = bias is not None, twopass, (N, Mi, Ch)
-        ctx.gW, ctx.gWa, ctx.gB, ctx.wt, ctx.wat = gW, gWa, gB, wt, wat
+        ctx.gW, ctx.gWa, ctx.gB, ctx.banked = gW, gWa, gB, banked
         ctx.save_for_backward(W, W_aff, mask, yfull if (act != "none" and W_aff is None) else None, cond_in, *xs)
         return yfull
 
@@ -496,7 +512,7 @@ class ChebConvFn(torch.autograd.Function):
         gfull = as_act(gfull)
         g = gfull[:, :, :Fout]
         need_x, need_w, need_b, need_wa, need_ci, need_co = (ctx.needs_input_grad[i] for i in range(6))
-        dW = dB = dWa = dci = dco = dx = None
+        dW = dB = dWa = dci = dco = dx = dcoef_out = None
         # one pass over g: dz (activation / ReLU-mask gradient), channel-bias gradient and the rank-1
         # condition-term gradients
         chan_bias = need_b and ctx.has_bias and ctx.bias_mode != _lib.BIAS_VERTEX
@@ -507,7 +523,7 @@ class ChebConvFn(torch.autograd.Function):
             dz, dbv, dcoef, dca = bwd_prep(g, y=None if ysaved is None else ysaved[:, :, :Fout], act=act, mask=mask,
                                            want_bias=chan_bias, rowscale=ops.rowscale if Cc else None,
                                            R=K if Cc else 0, rg=(K if (Cc and W_aff is not None) else None),
-                                           dbias_out=ctx.gB)
+                                           dbias_out=ctx.gB, joint=ctx.banked)
         if need_b and ctx.has_bias:
             if ctx.bias_mode == _lib.BIAS_VERTEX:
                 dB = torch.empty((1, Mo, Fout), device=dev, dtype=torch.float32)
@@ -534,7 +550,9 @@ class ChebConvFn(torch.autograd.Function):
                     gconv_dw([dict(e, use_dz2=False) for e in ent if e.get("use_dz2")], g)
         # (the rank-1 rows dW[Ch*K:] / dWa[Ch:] written on the main stream below are disjoint from the rows
         # the side-stream kernels write, so no ordering between the two is needed)
-        if Cc:
+        if Cc and ctx.banked:
+            dcoef_out = dcoef        # CondCoefFn turns it into the weight-row and condition gradients of all layers
+        elif Cc:
             # rank-1 condition terms: dcoef[n,k,f] = sum_r (S_k 1)[r] dz[n,r,f]  (from bwd_prep)
             dcoef = dcoef.view(N, K * Fout)
             Wc = W[Ch * K:].view(Cc, K * Fout)
@@ -556,14 +574,10 @@ class ChebConvFn(torch.autograd.Function):
                     entries.append(dict(x=g, csr=ops.bwd[0], w=(W_aff, 0, 1, Fout)))
                 gconv_fwd(entries, dx)
             else:
-                # transposed weight blocks with the output index contiguous, Wt[k][f][c] = W[c*K+k][f]: one
-                # small copy per layer; staging the W^T blocks in place through strides (row stride 1,
-                # column stride K*Fout) measured 1.5x slower in the GEMM (scattered LDS writes)
-                Wt = ctx.wt if ctx.wt is not None else W[:Ch * K].view(Ch, K, Fout).permute(1, 2, 0).contiguous()
-                wT = lambda k: (Wt, k * Fout * Ch, Ch, 1)
-                waT = None
-                if W_aff is not None:
-                    waT = (ctx.wat if ctx.wat is not None else W_aff[:Ch].t().contiguous(), 0, Ch, 1)
+                # W^T blocks read in place, contraction index (f) contiguous: B_k[f, c] = W[c*K + k, f]  (the
+                # pipelined plain GEMM stages either weight layout at the same speed, so no transposed copy)
+                wT = lambda k: (W, k * Fout, 1, K * Fout)
+                waT = (W_aff, 0, 1, Fout) if W_aff is not None else None
                 contract_first = (Mo < Mi) or (Mo == Mi and Ch < Fout)
                 if contract_first:
                     # G_k = dz W_k^T at the Mo output rows, then dx = sum_k S_k^T G_k
@@ -596,7 +610,7 @@ class ChebConvFn(torch.autograd.Function):
                     gconv_fwd(ent, dx)
         if Co and need_co:
             dco = reduce_cond(gfull[:, :, Fout:])
-        return dx, dW, dB, dWa, dci, dco, None, None, None, None, None, None, None, None, None
+        return dx, dW, dB, dWa, dci, dco, None, None, None, None, None, None, None, dcoef_out
 
 
 class ChebConvRecurrenceFn(torch.autograd.Function):
@@ -766,10 +780,11 @@ class ReconEdgeLossFn(torch.autograd.Function):
 # functional front-ends with the reference's operator names
 # --------------------------------------------------------------------------------------------
 def chebyshev5(x, W, ops, bias=None, activation=None, cond=None, W_affine=None, cond_in=None, grad_bufs=(None, None),
-               bias_grad_buf=None, wt_bufs=(None, None)):
+               bias_grad_buf=None, coef=None):
     """Graph convolution (lib/models.py:69-103) with optional fused bias+activation
     (``activation`` in b1leakyrelu/b1relu/b1tanh/b2relu), affine branch, rank-1 input condition
-    (``cond_in``) and materialised output condition concat (``cond``)."""
+    (``cond_in``, or its coefficients ``coef`` precomputed by CondCoefFn) and materialised output condition
+    concat (``cond``)."""
     if activation is None:
         act, bmode = "none", (_lib.BIAS_NONE if bias is None else
                               (_lib.BIAS_VERTEX if bias.shape[1] > 1 else _lib.BIAS_CHANNEL))
@@ -777,14 +792,73 @@ def chebyshev5(x, W, ops, bias=None, activation=None, cond=None, W_affine=None, 
         act, bmode = _ACT_OF[activation]
     if ops.fused:
         return ChebConvFn.apply(x, W, bias, W_affine, cond_in, cond, ops, act, bmode, MODE, grad_bufs[0], grad_bufs[1],
-                                bias_grad_buf, wt_bufs[0], wt_bufs[1])
-    assert W_affine is None
+                                bias_grad_buf, coef)
+    assert W_affine is None and coef is None
     if cond_in is not None:
         x = ConcatCondFn.apply(x, cond_in)
     y = ChebConvRecurrenceFn.apply(x, W, bias, ops, act, bmode)
     if cond is not None:
         y = ConcatCondFn.apply(y, cond)
     return y
+
+
+class CondCoefFn(torch.autograd.Function):
+    """Rank-1 condition coefficients of every consumer of one condition vector, one launch (csrc/cond.hip).
+
+    ``layers``: list of dicts  W [(Ch+Cc)*K, F], Wa (None or [Ch+Cc, F]), Ch, K, gW, gWa  -- gW / gWa are the
+    gradient-bucket views of W / Wa.  Returns one contiguous coef [N, K (+1), F] per layer (ChebConvFn's
+    ``coef`` input).  The weights are deliberately NOT autograd inputs: backward writes the gradient rows of the
+    condition channels (rows >= Ch*K of gW, >= Ch of gWa) straight into the bucket views -- disjoint from the rows
+    ChebConvFn's weight-gradient kernel writes -- and returns only d(cond)."""
+
+    @staticmethod
+    def _descr(layers, N, coefs=None, dcoefs=None, grads=False):
+        arr = (_lib.CapeCondLayer * len(layers))()
+        for i, ly in enumerate(layers):
+            W, Wa, Ch, K = ly["W"], ly["Wa"], int(ly["Ch"]), int(ly["K"])
+            F = int(W.shape[1])
+            d = arr[i]
+            d.K, d.F = K, F
+            d.w = W.data_ptr() + 4 * Ch * K * F
+            d.w_aff = None if Wa is None else Wa.data_ptr() + 4 * Ch * F
+            d.coef = None if coefs is None else coefs[i].data_ptr()
+            d.dcoef = None if dcoefs is None else dcoefs[i].data_ptr()
+            d.gw = d.gw_aff = None
+            if grads:
+                gW, gWa = ly["gW"], ly["gWa"]
+                assert gW.shape == W.shape and gW.is_contiguous() and (Wa is None or (gWa.shape == Wa.shape and gWa.is_contiguous()))
+                d.gw = gW.data_ptr() + 4 * Ch * K * F
+                d.gw_aff = None if Wa is None else gWa.data_ptr() + 4 * Ch * F
+        return arr
+
+    @staticmethod
+    def forward(ctx, cond, layers):
+        _lib.require_gpu()
+        cond = cond.contiguous()
+        N, Cc = cond.shape
+        coefs = []
+        for ly in layers:
+            W, Wa, K = ly["W"], ly["Wa"], int(ly["K"])
+            assert W.is_contiguous() and W.shape[0] == (int(ly["Ch"]) + Cc) * K and (Wa is None or Wa.is_contiguous())
+            coefs.append(torch.empty((N, K + (0 if Wa is None else 1), W.shape[1]), device=cond.device, dtype=torch.float32))
+        arr = CondCoefFn._descr(layers, N, coefs=coefs)
+        check(lib.cape_cond_coef_fwd(C.c_void_p(cond.data_ptr()), Cc, N, Cc, arr, len(layers), _stream()), "cape_cond_coef_fwd")
+        ctx.layers = layers
+        ctx.save_for_backward(cond)
+        return tuple(coefs)
+
+    @staticmethod
+    def backward(ctx, *dcoefs):
+        (cond,) = ctx.saved_tensors
+        layers = ctx.layers
+        N, Cc = cond.shape
+        dcoefs = [torch.zeros((N, int(ly["K"]) + (0 if ly["Wa"] is None else 1), ly["W"].shape[1]), device=cond.device)
+                  if d is None else d.contiguous() for d, ly in zip(dcoefs, layers)]
+        arr = CondCoefFn._descr(layers, N, dcoefs=dcoefs, grads=True)
+        dcond = torch.empty_like(cond) if ctx.needs_input_grad[0] else None
+        check(lib.cape_cond_coef_bwd(C.c_void_p(cond.data_ptr()), Cc, N, Cc, arr, len(layers), _ptr(dcond), Cc, 0, _stream()),
+              "cape_cond_coef_bwd")
+        return dcond, None
 
 
 def poolwT(x, fwd_csr, bwd_csr):

@@ -39,7 +39,6 @@ class GraphedTrainStep(object):
 
     def _fwd_bwd_inner(self):
         m, b = self.model, self.buf
-        m.refresh_transposed_weights()
         if self.with_gan:
             out = m.forward_losses(b['data_g'], b['cond_g'], b['cond2_g'], b['gt'], b['data_d'], b['cond_d'],
                                    b['cond2_d'], eps=b['eps'], reg_via_bucket=True)

@@ -104,6 +104,26 @@ typedef struct cape_rank {
     uint32_t to_acc2;      /* bit j set: term j goes to the second accumulator (DUAL mode)      */
 } cape_rank_t;
 
+/*
+ * Condition coefficients of all consumers of one condition vector (cape_rank_t.coef of every layer) in one
+ * launch, and their gradients.  Per layer (pointers are to the CONDITION rows of the layer's weights):
+ *   w      [Cc*K, F]  = W + Ch*K*F   (row c*K + k; lib/models.py:97-101 layout restricted to the tiled channels)
+ *   w_aff  NULL or [Cc, F] = W_affine + Ch*F      (res_block_affine, :776-793)
+ *   coef   out [N, K (+1), F]   coef[n,k,f] = sum_c cond[n,c] w[c*K+k, f];  coef[n,K,f] = sum_c cond[n,c] w_aff[c,f]
+ *   dcoef  in  [N, K (+1), F]   gradient of the loss w.r.t. coef (cape_bwd_prep writes it)
+ *   gw, gw_aff  out (may be NULL): gradient rows, same layout as w / w_aff
+ */
+#define CAPE_MAX_COND_LAYERS 16
+typedef struct cape_cond_layer {
+    const float *w;
+    const float *w_aff;
+    float *coef;
+    const float *dcoef;
+    float *gw;
+    float *gw_aff;
+    int32_t K, F;
+} cape_cond_layer_t;
+
 int cape_abi_version(void);
 
 /* Host-side structural check of a CSR operator (host pointers). */
@@ -166,14 +186,16 @@ int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *dz,
  *   dbias[f]       = sum_{n,r} dz           (dbias != NULL; channel bias of lib/models.py:105-121)
  *   dcoef[n,j,f]   = sum_r rowscale[j,r] * dz[n,r,f]   j < R      (rank-1 condition terms)
  *   dcoef_g[n,f]   = sum_r rowscale[rg,r] * g[n,r,f]              (dcoef_g != NULL: affine branch)
+ * dcoef_sample_stride: elements between samples of BOTH dcoef and dcoef_g (so that the two can be slices of one
+ * [N, R+1, F] buffer, the layout cape_cond_coef_bwd reads); 0 = contiguous (R*F and F).
  * dz may alias g.  Deterministic two-stage reductions; workspace >= cape_bwd_prep_workspace_bytes.
  */
 int64_t cape_bwd_prep_workspace_bytes(int32_t N, int32_t Mo, int32_t F, int32_t R);
 int cape_bwd_prep(const float *g, int64_t g_sample_stride, int32_t ldg, const float *y,
                   int64_t y_sample_stride, int32_t ldy, int32_t act, const uint32_t *mask, float *dz,
                   int64_t dz_sample_stride, int32_t lddz, float *dbias, const float *rowscale,
-                  int32_t R, float *dcoef, int32_t rg, float *dcoef_g, int32_t N, int32_t Mo,
-                  int32_t F, void *workspace, int64_t workspace_bytes, void *stream);
+                  int32_t R, float *dcoef, int32_t rg, float *dcoef_g, int64_t dcoef_sample_stride,
+                  int32_t N, int32_t Mo, int32_t F, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* y[n,r,:] = alpha * sum_e vals[e]*x[n,colidx[e],:] + beta * z[n,r,:]   (z may be NULL, may alias y).
  * max_row_nnz: upper bound on the entries of any row if the caller knows it (selects a fully unrolled
@@ -245,6 +267,16 @@ int cape_recon_edge_loss_fwd_bwd(const float *pred, const float *gt, const float
                                  const int32_t *vert_edge_idx, int32_t N, int32_t M, int32_t E,
                                  float w_recon, float w_edge, float *loss_out, float *dpred,
                                  void *workspace, int64_t workspace_bytes, void *stream);
+
+/* coef of every layer <- cond [N, Cc] (row stride ldc).  N * Cc <= 12288. */
+int cape_cond_coef_fwd(const float *cond, int32_t ldc, int32_t N, int32_t Cc,
+                       const cape_cond_layer_t *layers, int32_t nlayers, void *stream);
+
+/* gw / gw_aff of every layer <- cond^T dcoef;  dcond[n,c] (+)= sum over layers, k, f of dcoef * w
+ * (dcond may be NULL).  Deterministic (fixed summation order). */
+int cape_cond_coef_bwd(const float *cond, int32_t ldc, int32_t N, int32_t Cc,
+                       const cape_cond_layer_t *layers, int32_t nlayers, float *dcond, int32_t ldd,
+                       int32_t accumulate, void *stream);
 
 #ifdef __cplusplus
 }

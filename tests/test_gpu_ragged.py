@@ -126,3 +126,43 @@ def test_bwd_prep_ragged():
         if R:
             assert rel(dc.cpu().numpy(), np.einsum('jr,nrf->njf', rs[:R], want)) < TOL
             assert rel(dcg.cpu().numpy(), np.einsum('r,nrf->nf', rs[R], g)) < TOL
+
+
+def test_cond_coef_all_layers():
+    """cape_cond_coef_fwd / _bwd (all consumers of one condition vector in one launch) against numpy."""
+    from cape_amd import ops
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(21)
+    N, Cc = 5, 24
+    cond = rng.standard_normal((N, Cc))
+    spec = [(40, 2, 64, True), (8, 3, 300, False), (16, 1, 36, True), (12, 2, 3, False)]     # Ch, K, F, affine
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    layers, ref = [], []
+    for Ch, K, F, aff in spec:
+        W = rng.standard_normal(((Ch + Cc) * K, F))
+        Wa = rng.standard_normal((Ch + Cc, F)) if aff else None
+        hW, hWa = t(W), (t(Wa) if aff else None)
+        layers.append(dict(W=hW, Wa=hWa, Ch=Ch, K=K, gW=torch.full_like(hW, 7.0), gWa=torch.full_like(hWa, 7.0) if aff else None))
+        Wc = W[Ch * K:].reshape(Cc, K, F)
+        c = np.einsum('nc,ckf->nkf', cond, Wc)
+        if aff:
+            c = np.concatenate([c, (cond @ Wa[Ch:])[:, None]], 1)
+        ref.append((Wc, Wa[Ch:] if aff else None, c))
+    hc = t(cond).requires_grad_(True)
+    coefs = ops.CondCoefFn.apply(hc, layers)
+    for got, (_, _, c) in zip(coefs, ref):
+        assert rel(got.detach().cpu().numpy(), c) < TOL
+    dco = [rng.standard_normal(c.shape) for _, _, c in ref]
+    torch.autograd.backward(list(coefs), [t(d) for d in dco])
+    want_dc = np.zeros((N, Cc))
+    for ly, (Wc, Wac, c), d, (Ch, K, F, aff) in zip(layers, ref, dco, spec):
+        want_dc += np.einsum('nkf,ckf->nc', d[:, :K], Wc)
+        gw = ly["gW"].cpu().numpy()
+        assert np.all(gw[:Ch * K] == 7.0)                      # feature rows untouched
+        assert rel(gw[Ch * K:].reshape(Cc, K, F), np.einsum('nc,nkf->ckf', cond, d[:, :K])) < TOL
+        if aff:
+            want_dc += d[:, K] @ Wac.T
+            ga = ly["gWa"].cpu().numpy()
+            assert np.all(ga[:Ch] == 7.0)
+            assert rel(ga[Ch:], cond.T @ d[:, K]) < TOL
+    assert rel(hc.grad.cpu().numpy(), want_dc) < TOL
