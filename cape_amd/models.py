@@ -622,8 +622,9 @@ class CAPE(base_model):
             if self._reg_names:
                 coef = self.regularization * self.regularization
                 if self._opt_state is not None and torch.is_grad_enabled() and getattr(self, '_reg_via_bucket', False):
+                    st = self._opt_state['g']
                     with torch.no_grad():
-                        reg = sum(torch.linalg.vector_norm(self._vars[n]) ** 2 for n in self._reg_names) * (0.5 * coef)
+                        reg = ops.sumsq_ranges(st['flat'], self._reg_ranges(), 0.5 * coef, st['ws'])
                     self._reg_in_bucket = True
                 else:
                     reg = sum(0.5 * (self._vars[n] * self._vars[n]).sum() for n in self._reg_names) * coef
@@ -674,10 +675,11 @@ class CAPE(base_model):
             total = sum(al(p.numel()) for p in params)
             flat = torch.zeros(total, device=self.device, dtype=torch.float32)
             flat_grad = torch.zeros(total, device=self.device, dtype=torch.float32)
-            views, off = [], 0
+            views, off, offsets = [], 0, {}
             with torch.no_grad():
-                for p in params:
+                for nm_, p in zip(names, params):
                     n = p.numel()
+                    offsets[nm_] = (off, al(n))
                     flat[off:off + n].copy_(p.detach().reshape(-1))
                     p.data = flat[off:off + n].view(p.shape)
                     views.append(flat_grad[off:off + n].view(p.shape))
@@ -688,8 +690,9 @@ class CAPE(base_model):
                 # fake pass (two contributions that autograd must add) and keep private gradient tensors.
                 for nm, view in zip(names, views):
                     self._grad_views[nm] = view
-            st = {'params': params, 'flat': flat, 'flat_grad': flat_grad, 'grad_views': views,
-                  'm': torch.zeros_like(flat),
+            st = {'params': params, 'flat': flat, 'flat_grad': flat_grad, 'grad_views': views, 'offsets': offsets,
+                  'm': torch.zeros_like(flat), 'sumsq': torch.zeros((), device=self.device, dtype=torch.float32),
+                  'ws': ops.flat_workspace(self.device),
                   'neg_lr': torch.zeros((), device=self.device, dtype=torch.float32)}
             if self.optimizer == 'adam':
                 st['v'] = torch.zeros_like(flat)
@@ -715,9 +718,16 @@ class CAPE(base_model):
         self._opt_state['d']['neg_lr'].fill_(-lr_d)
         return lr_g, lr_d
 
+    def _reg_ranges(self):
+        """Element ranges (padded to the 256-byte variable alignment; the padding holds zeros) of the generator's
+        regularised dense kernels inside the G bucket."""
+        off = self._opt_state['g']['offsets']
+        return [(off[n][0], off[n][0] + off[n][1]) for n in getattr(self, '_reg_names', [])]
+
     def _add_reg_grads(self):
-        """d/dw [regularization^2 * sum(w^2)/2] = regularization^2 * w for the generator's dense kernels."""
-        if not getattr(self, '_reg_in_bucket', False):
+        """d/dw [regularization^2 * sum(w^2)/2] = regularization^2 * w for the generator's dense kernels.  The
+        momentum path folds this into the fused update kernels (apply_updates); Adam adds it to the bucket here."""
+        if not getattr(self, '_reg_in_bucket', False) or self.optimizer != 'adam':
             return
         coef = self.regularization * self.regularization
         st = self._opt_state['g']
@@ -729,11 +739,15 @@ class CAPE(base_model):
     def store_grads(self, grp, grads):
         st = self._opt_state[grp]
         with torch.no_grad():
+            dst, src = [], []
             for view, g in zip(st['grad_views'], grads):
                 if g is None:
                     view.zero_()
                 elif g.data_ptr() != view.data_ptr():      # kernels may already have written the bucket
-                    view.copy_(g)
+                    dst.append(view)
+                    src.append(g.reshape(view.shape))
+            if dst:
+                torch._foreach_copy_(dst, src)             # one multi-tensor launch for the small variables
 
     def apply_updates(self, grp, clip=5.0):
         """clip_by_global_norm(5.0) (:461) + Momentum (non-Nesterov, TF semantics: accum = m*accum + g;
@@ -741,9 +755,9 @@ class CAPE(base_model):
         st = self._opt_state[grp]
         g, flat, m = st['flat_grad'], st['flat'], st['m']
         with torch.no_grad():
-            gnorm = torch.linalg.vector_norm(g)
-            scale = clip / torch.clamp(gnorm, min=clip)
             if self.optimizer == 'adam':
+                gnorm = torch.linalg.vector_norm(g)
+                scale = clip / torch.clamp(gnorm, min=clip)
                 st['t'] += 1
                 b1, b2, eps = 0.9, 0.999, 1e-8
                 corr = float(np.sqrt(1 - b2 ** st['t']) / (1 - b1 ** st['t']))
@@ -751,10 +765,15 @@ class CAPE(base_model):
                 m.mul_(b1).add_(gs, alpha=1 - b1)
                 st['v'].mul_(b2).addcmul_(gs, gs, value=1 - b2)
                 flat.add_(st['neg_lr'] * corr * m / (st['v'].sqrt() + eps))
-            else:
-                m.mul_(self.momentum).addcmul_(g, scale)
-                flat.addcmul_(m, st['neg_lr'])
-        return gnorm
+                return gnorm
+            # momentum: 3 launches on the flat buckets (csrc/optim.hip); the dense kernels' regulariser gradient
+            # regularization^2 * w is part of the effective gradient (norm AND update) on its ranges
+            ranges, coef = [], 0.0
+            if grp == 'g' and getattr(self, '_reg_in_bucket', False):
+                ranges, coef = self._reg_ranges(), self.regularization * self.regularization
+            ops.flat_gradnorm(g, flat, ranges, coef, st['sumsq'], st['ws'])
+            ops.flat_momentum_update(flat, g, m, self.momentum, clip, st['sumsq'], st['neg_lr'], ranges, coef)
+        return st['sumsq']
 
     # ======================= training step ========================================================
     def forward_losses(self, data_g, cond_g, cond2_g, gt, data_d=None, cond_d=None, cond2_d=None, eps=None,

@@ -967,24 +967,70 @@ def dense_splitk(x, kernel, bias, min_long=8192, grad_buf=None):
     return torch.addmm(bias, x, kernel)
 
 
+def _ranges_arg(ranges):
+    flat = [int(v) for r in ranges for v in r]
+    return (C.c_int64 * max(len(flat), 1))(*flat), len(ranges)
+
+
+def flat_workspace(device):
+    return torch.empty(int(lib.cape_flat_workspace_bytes()) // 4, device=device, dtype=torch.float32)
+
+
+def flat_gradnorm(g, w, ranges, coef, sumsq_out, ws):
+    """sumsq_out <- sum (g + coef*w on ``ranges``)^2 over a flat bucket (two deterministic launches)."""
+    _lib.require_gpu()
+    arr, nr = _ranges_arg(ranges)
+    check(lib.cape_flat_gradnorm(C.c_void_p(g.data_ptr()), _ptr(w), g.numel(), arr, nr, float(coef),
+                                 C.c_void_p(sumsq_out.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel() * 4, _stream()),
+          "cape_flat_gradnorm")
+    return sumsq_out
+
+
+def flat_momentum_update(w, g, m, momentum, clip, sumsq, neg_lr, ranges, coef):
+    """clip-by-global-norm + momentum update of a flat bucket in one launch (csrc/optim.hip)."""
+    _lib.require_gpu()
+    arr, nr = _ranges_arg(ranges)
+    check(lib.cape_flat_momentum_update(C.c_void_p(w.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
+                                        w.numel(), float(momentum), float(clip), C.c_void_p(sumsq.data_ptr()),
+                                        C.c_void_p(neg_lr.data_ptr()), arr, nr, float(coef), _stream()),
+          "cape_flat_momentum_update")
+
+
+def sumsq_ranges(x, ranges, scale, ws):
+    """scale * sum of x^2 over element ranges of a flat buffer -> 0-dim tensor."""
+    _lib.require_gpu()
+    arr, nr = _ranges_arg(ranges)
+    out = torch.empty((), device=x.device, dtype=torch.float32)
+    check(lib.cape_sumsq_ranges(C.c_void_p(x.data_ptr()), arr, nr, float(scale), C.c_void_p(out.data_ptr()),
+                                C.c_void_p(ws.data_ptr()), ws.numel() * 4, _stream()), "cape_sumsq_ranges")
+    return out
+
+
 class VaeSampleKLFn(torch.autograd.Function):
     """z = mean + exp(0.5*logvar)*eps  and  kl = mean_n( -0.5 * sum_j(1 + logvar - mean^2 - exp(logvar)) )
-    (reference lib/models.py:193-196, :371-372) with hand-written gradients: 8 small launches instead of the
+    (reference lib/models.py:193-196, :371-372): one launch forward, one backward (csrc/optim.hip) instead of the
     ~25 an op-by-op autograd tape replays on these [N, nz] tensors."""
 
     @staticmethod
     def forward(ctx, mean, logvar, eps):
-        std = torch.exp(0.5 * logvar)
-        var = std * std
-        z = torch.addcmul(mean, std, eps)
-        kl = (-0.5 / mean.shape[0]) * torch.sum(1 + logvar - mean * mean - var)
-        ctx.save_for_backward(mean, std, var, eps)
+        _lib.require_gpu()
+        mean, logvar, eps = mean.contiguous(), logvar.contiguous(), eps.contiguous()
+        N, nz = mean.shape
+        z = torch.empty_like(mean)
+        kl = torch.empty((), device=mean.device, dtype=torch.float32)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        check(lib.cape_vae_sample_kl_fwd(p(mean), p(logvar), p(eps), p(z), p(kl), N, nz, _stream()), "cape_vae_sample_kl_fwd")
+        ctx.save_for_backward(mean, logvar, eps)
         return z, kl
 
     @staticmethod
     def backward(ctx, gz, gkl):
-        mean, std, var, eps = ctx.saved_tensors
-        c = gkl / mean.shape[0]
-        dmean = torch.addcmul(gz, mean, c)                     # gz + c * mean
-        dlv = 0.5 * (gz * std * eps + c * (var - 1))
+        mean, logvar, eps = ctx.saved_tensors
+        N, nz = mean.shape
+        dmean, dlv = torch.empty_like(mean), torch.empty_like(mean)
+        gz = None if gz is None else gz.contiguous()
+        gkl = None if gkl is None else gkl.contiguous()
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        check(lib.cape_vae_sample_kl_bwd(p(mean), p(logvar), p(eps), p(gz), p(gkl), p(dmean), p(dlv), N, nz, _stream()),
+              "cape_vae_sample_kl_bwd")
         return dmean, dlv, None

@@ -278,6 +278,35 @@ int cape_cond_coef_bwd(const float *cond, int32_t ldc, int32_t N, int32_t Cc,
                        const cape_cond_layer_t *layers, int32_t nlayers, float *dcond, int32_t ldd,
                        int32_t accumulate, void *stream);
 
+/*
+ * Optimiser step on flat fp32 buckets (parameters w, gradients g, momentum m; n % 4 == 0, 16-byte aligned):
+ * tf.clip_by_global_norm(5.0) + tf.train.MomentumOptimizer (lib/models.py:448-461) with the dense kernels' L2
+ * regulariser gradient (:40, :378-379) folded in.  reg_ranges: HOST array of nranges [begin, end) element
+ * ranges (multiples of 4) on which the effective gradient is g + reg_coef * w.
+ *   cape_flat_gradnorm:        *sumsq_out = sum (g + reg)^2            (two deterministic launches)
+ *   cape_flat_momentum_update: s = clip / max(sqrt(*sumsq), clip);  m = momentum*m + s*(g + reg);  w += (*neg_lr)*m
+ *   cape_sumsq_ranges:         *out = scale * sum over the ranges of x^2  (the regulariser's VALUE)
+ * sumsq / neg_lr / out are DEVICE scalars (nothing is read back: the sequence is graph-capturable).
+ */
+int64_t cape_flat_workspace_bytes(void);
+int cape_flat_gradnorm(const float *g, const float *w, int64_t n, const int64_t *reg_ranges, int32_t nranges,
+                       float reg_coef, float *sumsq_out, void *workspace, int64_t workspace_bytes, void *stream);
+int cape_flat_momentum_update(float *w, const float *g, float *m, int64_t n, float momentum, float clip,
+                              const float *sumsq, const float *neg_lr, const int64_t *reg_ranges,
+                              int32_t nranges, float reg_coef, void *stream);
+int cape_sumsq_ranges(const float *x, const int64_t *ranges, int32_t nranges, float scale, float *out,
+                      void *workspace, int64_t workspace_bytes, void *stream);
+
+/*
+ * VAE sampling + KL term (lib/models.py:193-196, :371-372) on contiguous [N, nz] tensors:
+ *   z = mean + exp(0.5*logvar) * eps ;  *kl = (-0.5/N) * sum(1 + logvar - mean^2 - exp(logvar))
+ * backward: dmean = gz + (gkl/N)*mean ; dlogvar = 0.5*(gz*std*eps + (gkl/N)*(exp(logvar) - 1)).  gz / gkl may be NULL.
+ */
+int cape_vae_sample_kl_fwd(const float *mean, const float *logvar, const float *eps, float *z, float *kl,
+                           int32_t N, int32_t nz, void *stream);
+int cape_vae_sample_kl_bwd(const float *mean, const float *logvar, const float *eps, const float *gz,
+                           const float *gkl, float *dmean, float *dlogvar, int32_t N, int32_t nz, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
