@@ -469,7 +469,19 @@ __global__ __launch_bounds__(256) void bwd_prep_final_kernel(const float *part, 
     float *dst = nullptr;
     if (b == 0) {            // bias
         if (dbias && f < F) {
-            for (long long i = ln; i < (long long)N * chunks; i += 16) s += part[i * T * F + f];
+            // four independent partial sums: the chain of dependent L2 loads, not bandwidth, bounds this loop
+            const long long total = (long long)N * chunks;
+            const long long TF = (long long)T * F;
+            float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            long long i = ln;
+            for (; i + 48 < total; i += 64) {
+                s += part[i * TF + f];
+                s1 += part[(i + 16) * TF + f];
+                s2 += part[(i + 32) * TF + f];
+                s3 += part[(i + 48) * TF + f];
+            }
+            for (; i < total; i += 16) s += part[i * TF + f];
+            s = (s + s1) + (s2 + s3);
             dst = dbias + f;
         }
     } else {

@@ -268,7 +268,7 @@ int cape_recon_edge_loss_fwd_bwd(const float *pred, const float *gt, const float
                                  float w_recon, float w_edge, float *loss_out, float *dpred,
                                  void *workspace, int64_t workspace_bytes, void *stream);
 
-/* coef of every layer <- cond [N, Cc] (row stride ldc).  N * Cc <= 12288. */
+/* coef of every layer <- cond [N, Cc] (row stride ldc).  N * Cc <= 10240. */
 int cape_cond_coef_fwd(const float *cond, int32_t ldc, int32_t N, int32_t Cc,
                        const cape_cond_layer_t *layers, int32_t nlayers, void *stream);
 
