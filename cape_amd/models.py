@@ -164,15 +164,19 @@ class base_model(object):
     def _bias_variable(self, shape):
         return self._get_variable('bias', shape, 'bias')
 
-    def _dense(self, x, units, activation=None):
-        """tf.layers.dense (x @ kernel + bias) -- rocBLAS via torch; not a custom kernel."""
+    def _dense_vars(self, in_dim, units):
+        """kernel, bias of a tf.layers.dense in the current scope and the gradient-bucket views of both."""
         with self.variable_scope('dense'):
-            k = self._get_variable('kernel', (x.shape[-1], units), 'fc_kernel')
+            k = self._get_variable('kernel', (in_dim, units), 'fc_kernel')
             b = self._get_variable('bias', (units,), 'fc_bias')
-        y = ops.dense_splitk(x, k, b, grad_buf=self._grad_views.get('/'.join(self._scope + ['dense', 'kernel'])))
-        if activation == 'leaky_relu':
-            y = torch.nn.functional.leaky_relu(y, 0.2)
-        return y
+            base = '/'.join(self._scope)
+        return k, b, (self._grad_views.get(base + '/kernel'), self._grad_views.get(base + '/bias'))
+
+    def _dense(self, x, units, activation=None):
+        """tf.layers.dense (act(x @ kernel + bias)): the two 7M-parameter layers run on the weight-streaming
+        kernels of csrc/fc.hip, the small condition-MLP layers on rocBLAS via torch."""
+        k, b, gv = self._dense_vars(int(x.shape[-1]), units)
+        return ops.dense(x, k, b, activation=activation, grad_bufs=gv)
 
     # ---- operator caches -----------------------------------------------------------------------
     def _conv_ops(self, L, K, unpool=None, pool=None):
@@ -495,9 +499,10 @@ class CAPE(base_model):
                     x = self.filter(x, self.Laplacian[-1], self.out_channels[-1] // self.reduce_rate, K=1)
             x = x.reshape(x.shape[0], -1)
             with self.variable_scope('fc_mean'):
-                z_mean = self._dense(x, int(self.nz))
+                km, bm, gm = self._dense_vars(int(x.shape[-1]), int(self.nz))
             with self.variable_scope('fc_var'):
-                z_var = self._dense(x, int(self.nz))
+                kv, bv, gv = self._dense_vars(int(x.shape[-1]), int(self.nz))
+            z_mean, z_var = ops.dense_pair(x, km, bm, kv, bv, (gm, gv))      # both layers in one pass over x
         return z_mean, z_var
 
     def decoder_cond_vert(self, x, y, y2, use_res_block=False):

@@ -895,76 +895,128 @@ def brelu(x, bias, activation):
     return BiasActFn.apply(x, bias, act, bmode)
 
 
-class _SplitKMatmulFn(torch.autograd.Function):
-    """y = x @ W for a skinny x ([16, in]) and a very long contraction (in = 55168 = 862 vertices x 64
-    channels, the encoder's fc_mean/fc_var and -- transposed -- the decoder fc1 data gradient): rocBLAS
-    picks a single-wave-of-tiles kernel without split-K (160 us); batching the contraction into S chunks
-    fills the chip.  Plumbing around rocBLAS, not a custom kernel (the FCs are a 'next' row)."""
+def _parr(tensors):
+    """HOST array of device pointers (None -> NULL)."""
+    return (C.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+class FcLongFn(torch.autograd.Function):
+    """y_m = x @ W_m + b_m for 1 or 2 matrices sharing a [N <= 64, in] input with a very long ``in`` (encoder
+    fc_mean / fc_var, reference lib/models.py:555-560): weight-streaming kernels of csrc/fc.hip -- two launches
+    forward, one backward (dW_m, db_m written into the gradient bucket views, one dx for both matrices)."""
 
     @staticmethod
-    def forward(ctx, x, W, S, gW=None):
-        ctx.S, ctx.gW = S, gW
-        ctx.save_for_backward(x, W)
-        return _splitk_mm(x, W, S)
+    def forward(ctx, x, gbufs, *wb):
+        _lib.require_gpu()
+        x = x.contiguous()
+        N, kin = x.shape
+        Ws, bs = list(wb[0::2]), list(wb[1::2])
+        nmat, out = len(Ws), int(Ws[0].shape[1])
+        assert all(W.is_contiguous() and tuple(W.shape) == (kin, out) for W in Ws)
+        ys = [torch.empty((N, out), device=x.device, dtype=torch.float32) for _ in Ws]
+        need = int(lib.cape_fc_long_workspace_bytes(N, kin, out, nmat))
+        if need < 0:
+            check(need, "cape_fc_long_workspace_bytes")
+        ws = torch.empty((need + 3) // 4, device=x.device, dtype=torch.float32)
+        check(lib.cape_fc_long_fwd(C.c_void_p(x.data_ptr()), kin, N, kin, out, nmat, _parr(Ws), _parr(bs), _parr(ys),
+                                   C.c_void_p(ws.data_ptr()), need, _stream()), "cape_fc_long_fwd")
+        ctx.gbufs, ctx.nmat, ctx.has_b = gbufs, nmat, [b is not None for b in bs]
+        ctx.save_for_backward(x, *Ws)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        x, *Ws = ctx.saved_tensors
+        N, kin = x.shape
+        out, nmat = int(Ws[0].shape[1]), ctx.nmat
+        gs = [torch.zeros((N, out), device=x.device) if g is None else g.contiguous() for g in gs]
+        gbufs = ctx.gbufs or [(None, None)] * nmat
+        dWs, dbs = [], []
+        for m in range(nmat):
+            dWs.append(_grad_buffer(Ws[m], gbufs[m][0]) if ctx.needs_input_grad[2 + 2 * m] else None)
+            if ctx.has_b[m] and ctx.needs_input_grad[3 + 2 * m]:
+                gb = gbufs[m][1]
+                dbs.append(gb if (gb is not None and gb.numel() == out and gb.is_contiguous()) else
+                           torch.empty(out, device=x.device, dtype=torch.float32))
+            else:
+                dbs.append(None)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        check(lib.cape_fc_long_bwd(C.c_void_p(x.data_ptr()), kin, N, kin, out, nmat, _parr(Ws), _parr(gs), _parr(dWs), _parr(dbs),
+                                   _ptr(dx), kin, _stream()), "cape_fc_long_bwd")
+        grads = [dx, None]
+        for m in range(nmat):
+            grads += [dWs[m], dbs[m]]
+        return tuple(grads)
+
+
+class FcWideFn(torch.autograd.Function):
+    """y = act(x @ W + b) for a [N <= 64, in <= 200] input and a very wide output (decoder fc1, reference
+    lib/models.py:579-583, bias and leaky-ReLU fused): one launch forward, three backward (csrc/fc.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act, gW, gb):
+        _lib.require_gpu()
+        x = x.contiguous()
+        N, kin = x.shape
+        out = int(W.shape[1])
+        assert W.is_contiguous() and W.shape[0] == kin
+        y = torch.empty((N, out), device=x.device, dtype=torch.float32)
+        check(lib.cape_fc_wide_fwd(C.c_void_p(x.data_ptr()), kin, N, kin, out, C.c_void_p(W.data_ptr()), _ptr(b), _lib.ACT[act],
+                                   C.c_void_p(y.data_ptr()), out, _stream()), "cape_fc_wide_fwd")
+        ctx.act, ctx.gW, ctx.gb, ctx.has_b = act, gW, gb, b is not None
+        ctx.save_for_backward(x, W, y)
+        return y
 
     @staticmethod
     def backward(ctx, g):
-        x, W = ctx.saved_tensors
-        dx = dW = None
+        x, W, y = ctx.saved_tensors
+        N, kin = x.shape
+        out = int(W.shape[1])
+        g = g.contiguous()
+        dW = _grad_buffer(W, ctx.gW) if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            gb = ctx.gb
+            db = gb if (gb is not None and gb.numel() == out and gb.is_contiguous()) else torch.empty(out, device=x.device, dtype=torch.float32)
+        dx = ws = None
+        need = 0
         if ctx.needs_input_grad[0]:
-            dx = torch.mm(g, W.t())
-        if ctx.needs_input_grad[1]:
-            dW = _grad_buffer(W, ctx.gW)
-            torch.mm(x.t(), g, out=dW)
-        return dx, dW, None, None
+            dx = torch.empty_like(x)
+            need = int(lib.cape_fc_wide_bwd_workspace_bytes(N, kin, out))
+            ws = torch.empty((need + 3) // 4, device=x.device, dtype=torch.float32)
+        check(lib.cape_fc_wide_bwd(C.c_void_p(x.data_ptr()), kin, C.c_void_p(g.data_ptr()), out, C.c_void_p(y.data_ptr()), out,
+                                   _lib.ACT[ctx.act], N, kin, out, C.c_void_p(W.data_ptr()), _ptr(dW), _ptr(db), _ptr(dx), kin,
+                                   _ptr(ws), need, _stream()), "cape_fc_wide_bwd")
+        return dx, dW, db, None, None, None
 
 
-def _splitk_mm(x, W, S):
-    n, kin = x.shape
-    kc = kin // S
-    parts = torch.bmm(x.view(n, S, kc).transpose(0, 1), W.view(S, kc, W.shape[1]))     # [S, n, out]
-    return parts.sum(0)
+_FC_LONG = 8192       # a side at least this long takes the weight-streaming kernels
 
 
-class _WideMatmulFn(torch.autograd.Function):
-    """y = x @ W with a very wide output (decoder fc1: 128 -> 55168): the data gradient g @ W^T has the
-    long contraction and takes the split path."""
-
-    @staticmethod
-    def forward(ctx, x, W, S, gW=None):
-        ctx.S, ctx.gW = S, gW
-        ctx.save_for_backward(x, W)
-        return torch.mm(x, W)
-
-    @staticmethod
-    def backward(ctx, g):
-        x, W = ctx.saved_tensors
-        dx = dW = None
-        if ctx.needs_input_grad[0]:
-            n, kout = g.shape
-            S, kc = ctx.S, kout // ctx.S
-            parts = torch.bmm(g.view(n, S, kc).transpose(0, 1), W.view(W.shape[0], S, kc).permute(1, 2, 0))
-            dx = parts.sum(0)
-        if ctx.needs_input_grad[1]:
-            dW = _grad_buffer(W, ctx.gW)
-            torch.mm(x.t(), g, out=dW)
-        return dx, dW, None, None
+def _fc_long_ok(x, kernels):
+    return x.is_cuda and x.dim() == 2 and x.shape[0] <= 64 and x.shape[1] >= _FC_LONG and x.shape[0] * kernels[0].shape[1] * len(kernels) <= 8192
 
 
-def dense_splitk(x, kernel, bias, min_long=8192, grad_buf=None):
-    """tf.layers.dense: x @ kernel + bias, with split contraction for the 55168-long sides."""
+def dense(x, kernel, bias, activation=None, grad_bufs=(None, None)):
+    """tf.layers.dense: act(x @ kernel + bias), activation in (None, 'leaky_relu')."""
     kin, kout = kernel.shape
+    act = "none" if activation is None else "leaky"
+    if _fc_long_ok(x, [kernel]):
+        y = FcLongFn.apply(x, [grad_bufs], kernel, bias)[0]
+    elif x.is_cuda and x.dim() == 2 and x.shape[0] <= 64 and kout >= _FC_LONG and kin <= 200 and x.shape[0] * kin <= 12288:
+        return FcWideFn.apply(x, kernel, bias, act, grad_bufs[0], grad_bufs[1])
+    else:
+        y = torch.addmm(bias, x, kernel)
+    if activation == 'leaky_relu':
+        y = torch.nn.functional.leaky_relu(y, 0.2)
+    return y
 
-    def splits(n):
-        for S in (64, 32, 16, 8):
-            if n % S == 0:
-                return S
-        return 0
-    if kin >= min_long and splits(kin) and x.shape[0] <= 64:
-        return _SplitKMatmulFn.apply(x, kernel, splits(kin), grad_buf) + bias
-    if kout >= min_long and splits(kout) and x.shape[0] <= 64:
-        return _WideMatmulFn.apply(x, kernel, splits(kout), grad_buf) + bias
-    return torch.addmm(bias, x, kernel)
+
+def dense_pair(x, k0, b0, k1, b1, grad_bufs=((None, None), (None, None))):
+    """Two dense layers on the same input (encoder fc_mean / fc_var): one pass over x when it is long."""
+    if _fc_long_ok(x, [k0, k1]) and k0.shape == k1.shape:
+        return FcLongFn.apply(x, list(grad_bufs), k0, b0, k1, b1)
+    return dense(x, k0, b0, grad_bufs=grad_bufs[0]), dense(x, k1, b1, grad_bufs=grad_bufs[1])
 
 
 def _ranges_arg(ranges):

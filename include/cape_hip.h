@@ -307,6 +307,33 @@ int cape_vae_sample_kl_fwd(const float *mean, const float *logvar, const float *
 int cape_vae_sample_kl_bwd(const float *mean, const float *logvar, const float *eps, const float *gz,
                            const float *gkl, float *dmean, float *dlogvar, int32_t N, int32_t nz, void *stream);
 
+/*
+ * Dense layers with one very long side (tf.layers.dense, lib/models.py:557, :560, :582): weight-streaming
+ * kernels, N <= 64 batch rows, W row-major [in, out].  Pointer arrays are HOST arrays of device pointers.
+ *
+ * long input (in >> out; nmat = 1 or 2 matrices sharing x, e.g. fc_mean / fc_var):
+ *   fwd:  y_m[n,j] = b_m[j] + sum_i x[n,i] W_m[i,j]                 (two deterministic launches)
+ *   bwd:  dW_m[i,j] = sum_n x[n,i] g_m[n,j];  db_m[j] = sum_n g_m[n,j];  dx[n,i] = sum_m sum_j g_m[n,j] W_m[i,j]
+ *         (g_m contiguous [N,out]; dW / db arrays or entries may be NULL; dx may be NULL)
+ * wide output (out >> in, N*in <= 12288, in <= 200):
+ *   fwd:  y[n,j] = act(b[j] + sum_i x[n,i] W[i,j])
+ *   bwd:  dz = g * act'(y) (y = activation output);  dW[i,j] = sum_n x[n,i] dz[n,j];  db[j] = sum_n dz[n,j];
+ *         dx[n,i] = sum_j dz[n,j] W[i,j]   (two-stage, workspace >= cape_fc_wide_bwd_workspace_bytes)
+ */
+int64_t cape_fc_long_workspace_bytes(int32_t N, int32_t in, int32_t out, int32_t nmat);
+int cape_fc_long_fwd(const float *x, int32_t ldx, int32_t N, int32_t in, int32_t out, int32_t nmat,
+                     const float *const *W, const float *const *b, float *const *y, void *workspace,
+                     int64_t workspace_bytes, void *stream);
+int cape_fc_long_bwd(const float *x, int32_t ldx, int32_t N, int32_t in, int32_t out, int32_t nmat,
+                     const float *const *W, const float *const *g, float *const *dW, float *const *db,
+                     float *dx, int32_t lddx, void *stream);
+int cape_fc_wide_fwd(const float *x, int32_t ldx, int32_t N, int32_t in, int32_t out, const float *W,
+                     const float *b, int32_t act, float *y, int32_t ldy, void *stream);
+int64_t cape_fc_wide_bwd_workspace_bytes(int32_t N, int32_t in, int32_t out);
+int cape_fc_wide_bwd(const float *x, int32_t ldx, const float *g, int32_t ldg, const float *y, int32_t ldy,
+                     int32_t act, int32_t N, int32_t in, int32_t out, const float *W, float *dW, float *db,
+                     float *dx, int32_t lddx, void *workspace, int64_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

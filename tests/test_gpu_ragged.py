@@ -166,3 +166,49 @@ def test_cond_coef_all_layers():
             assert np.all(ga[:Ch] == 7.0)
             assert rel(ga[Ch:], cond.T @ d[:, K]) < TOL
     assert rel(hc.grad.cpu().numpy(), want_dc) < TOL
+
+
+@pytest.mark.parametrize("N,kin,out", [(5, 9001, 18), (16, 8256, 64), (11, 8200, 20)])
+def test_fc_long_pair(N, kin, out):
+    """Encoder fc_mean / fc_var kernels (csrc/fc.hip) against float64 numpy, ragged sizes."""
+    from cape_amd import ops
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(N + out)
+    x = rng.standard_normal((N, kin))
+    W = [rng.standard_normal((kin, out)) * 0.05 for _ in range(2)]
+    b = [rng.standard_normal(out) for _ in range(2)]
+    gy = [rng.standard_normal((N, out)) for _ in range(2)]
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev, requires_grad=True)
+    hx, hW, hb = t(x), [t(w) for w in W], [t(v) for v in b]
+    y0, y1 = ops.dense_pair(hx, hW[0], hb[0], hW[1], hb[1])
+    assert rel(y0.detach().cpu().numpy(), x @ W[0] + b[0]) < TOL and rel(y1.detach().cpu().numpy(), x @ W[1] + b[1]) < TOL
+    torch.autograd.backward([y0, y1], [torch.tensor(g, dtype=torch.float32, device=dev) for g in gy])
+    assert rel(hx.grad.cpu().numpy(), gy[0] @ W[0].T + gy[1] @ W[1].T) < TOL
+    for m in range(2):
+        assert rel(hW[m].grad.cpu().numpy(), x.T @ gy[m]) < TOL
+        assert rel(hb[m].grad.cpu().numpy(), gy[m].sum(0)) < TOL
+    # single-matrix entry point
+    hx2 = t(x)
+    y = ops.dense(hx2, hW[0].detach(), hb[0].detach())
+    assert rel(y.detach().cpu().numpy(), x @ W[0] + b[0]) < TOL
+
+
+@pytest.mark.parametrize("N,kin,out,act", [(3, 50, 9001, "leaky_relu"), (16, 128, 8256, None), (13, 132, 8448, "leaky_relu")])
+def test_fc_wide(N, kin, out, act):
+    """Decoder fc1 kernels (bias + leaky-ReLU fused) against float64 numpy."""
+    from cape_amd import ops
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(N + kin)
+    x, W, b = rng.standard_normal((N, kin)), rng.standard_normal((kin, out)) * 0.2, rng.standard_normal(out)
+    gy = rng.standard_normal((N, out))
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev, requires_grad=True)
+    hx, hW, hb = t(x), t(W), t(b)
+    y = ops.dense(hx, hW, hb, activation=act)
+    z = x @ W + b
+    want = np.where(z > 0, z, 0.2 * z) if act else z
+    assert rel(y.detach().cpu().numpy(), want) < TOL
+    y.backward(torch.tensor(gy, dtype=torch.float32, device=dev))
+    dz = gy * (np.where(z > 0, 1.0, 0.2) if act else 1.0)
+    assert rel(hW.grad.cpu().numpy(), x.T @ dz) < TOL
+    assert rel(hb.grad.cpu().numpy(), dz.sum(0)) < TOL
+    assert rel(hx.grad.cpu().numpy(), dz @ W.T) < 5 * TOL
