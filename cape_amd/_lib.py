@@ -90,7 +90,7 @@ SIGNATURES = {
     "cape_fc_wide_bwd": (C.c_int, [_p, _i32, _p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _p, _i64, _p]),
     "cape_recon_edge_workspace_bytes": (_i64, [_i32, _i32, _i32]),
     "cape_recon_edge_loss_fwd_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _f32,
-                                               _p, _p, _p, _i64, _p]),
+                                               _p, _p, _p, _p, _i64, _p]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

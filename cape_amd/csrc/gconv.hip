@@ -548,6 +548,45 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(DwReduceParams p) {
     }
 }
 
+// Vector form: thread = 4 consecutive output elements (one float4 of a weight-gradient row), all splits summed
+// in order with four independent partial sums -- fully coalesced slab reads.  Needs F % 4 == 0, unit column
+// stride and 16-byte aligned destinations (the layer weights in the gradient bucket).
+__global__ __launch_bounds__(256) void dw_reduce_vec_kernel(DwReduceParams p) {
+    const long long total4 = p.part_off[p.nsrc] >> 2;
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= total4) return;
+    const long long i = q << 2;
+    const float4 *src = reinterpret_cast<const float4 *>(p.ws + i);
+    const long long step = p.slab >> 2;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    int sp = 0;
+    for (; sp + 3 < p.nsplit; sp += 4) {
+        const float4 v0 = src[(long long)sp * step], v1 = src[(long long)(sp + 1) * step];
+        const float4 v2 = src[(long long)(sp + 2) * step], v3 = src[(long long)(sp + 3) * step];
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+        a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+        a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+    }
+    for (; sp < p.nsplit; ++sp) {
+        const float4 v0 = src[(long long)sp * step];
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    }
+    float4 t;
+    t.x = (a0.x + a1.x) + (a2.x + a3.x); t.y = (a0.y + a1.y) + (a2.y + a3.y);
+    t.z = (a0.z + a1.z) + (a2.z + a3.z); t.w = (a0.w + a1.w) + (a2.w + a3.w);
+    int si = 0;
+    while (si + 1 < p.nsrc && i >= p.part_off[si + 1]) ++si;
+    const long long loc = i - p.part_off[si];
+    const long long c = loc / p.F, f = loc % p.F;
+    float4 *dst = reinterpret_cast<float4 *>(p.w[si] + c * p.wrs[si] + f);
+    if (p.accumulate) {
+        const float4 o = *dst;
+        t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+    }
+    *dst = t;
+}
+
 inline int fill_src(SrcDev &d, const cape_src_t &s) {
     if (!s.x || s.C <= 0 || s.ldx < s.C) return CAPE_EINVAL;
     if (s.rowptr && (!s.colidx || !s.vals)) return CAPE_EINVAL;
@@ -745,7 +784,11 @@ extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *
     rp.F = F; rp.nsplit = pl.ngroups * pl.rsplit; rp.accumulate = accumulate; rp.ws = (const float *)workspace; rp.slab = pl.slab;
     long long total = poff;
     int rblocks = (int)((total + 15) / 16);
-    CAPE_LAUNCH(dw_reduce_kernel, dim3(rblocks), dim3(256), 0, st, rp);
+    bool rvec = (F & 3) == 0 && (pl.slab & 3) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
+    for (int i = 0; i < nsrc; ++i)
+        rvec = rvec && srcs[i].w_cs == 1 && (srcs[i].w_rs & 3) == 0 && (reinterpret_cast<uintptr_t>(srcs[i].w) & 15) == 0;
+    if (rvec) CAPE_LAUNCH(dw_reduce_vec_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, rp);
+    else CAPE_LAUNCH(dw_reduce_kernel, dim3(rblocks), dim3(256), 0, st, rp);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(LB) void vert_kernel(const float *pred, const float
 }
 
 __global__ __launch_bounds__(LB) void loss_final_kernel(const float *part_e, int ne, float inv_e, const float *part_v, int nv,
-                                                        float inv_v, float *loss_out) {
+                                                        float inv_v, float *loss_out, float w_recon, float w_edge, float *total_out) {
     __shared__ float red[4];
     float s = 0.f;
     for (int i = threadIdx.x; i < nv; i += LB) s += part_v[i];
@@ -100,6 +100,7 @@ __global__ __launch_bounds__(LB) void loss_final_kernel(const float *part_e, int
     if (threadIdx.x == 0) {
         loss_out[0] = s * inv_v;
         loss_out[1] = t * inv_e;
+        if (total_out) *total_out = w_recon * (s * inv_v) + w_edge * (t * inv_e);
     }
 }
 
@@ -118,8 +119,8 @@ extern "C" int64_t cape_recon_edge_workspace_bytes(int32_t N, int32_t M, int32_t
 
 extern "C" int cape_recon_edge_loss_fwd_bwd(const float *pred, const float *gt, const float *verts_ref, const int32_t *edges,
                                             const int32_t *vert_edge_ptr, const int32_t *vert_edge_idx, int32_t N, int32_t M,
-                                            int32_t E, float w_recon, float w_edge, float *loss_out, float *dpred,
-                                            void *workspace, int64_t workspace_bytes, void *stream) {
+                                            int32_t E, float w_recon, float w_edge, float *loss_out, float *total_out,
+                                            float *dpred, void *workspace, int64_t workspace_bytes, void *stream) {
     if (!pred || !gt || !verts_ref || !edges || !loss_out || !workspace || N < 1 || M < 1 || E < 1) return CAPE_EINVAL;
     if (dpred && (!vert_edge_ptr || !vert_edge_idx)) return CAPE_EINVAL;
     if (workspace_bytes < cape_recon_edge_workspace_bytes(N, M, E)) return CAPE_EWORKSPACE;
@@ -134,7 +135,7 @@ extern "C" int cape_recon_edge_loss_fwd_bwd(const float *pred, const float *gt, 
     CAPE_LAUNCH(vert_kernel, dim3(nv), dim3(LB), 0, st, pred, gt, unit, vert_edge_ptr, vert_edge_idx, N, M, E, cr, ce, dpred, part_v);
     CAPE_LAUNCH_CHECK();
     CAPE_LAUNCH(loss_final_kernel, dim3(1), dim3(LB), 0, st, part_e, ne, 1.0f / ((float)N * (float)E), part_v, nv,
-                       1.0f / ((float)N * (float)M * 3.0f), loss_out);
+                       1.0f / ((float)N * (float)M * 3.0f), loss_out, w_recon, w_edge, total_out);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }

@@ -825,8 +825,11 @@ class CAPE(base_model):
         """Gradients of loss_g w.r.t. the G group and loss_d w.r.t. the D group -> flat gradient buffers."""
         g_params = self._opt_state['g']['params']
         d_params = self._opt_state['d']['params']
+        if getattr(self, '_one', None) is None:
+            self._one = torch.ones((), device=self.device, dtype=torch.float32)      # d(loss)/d(loss), allocated once
+        one = self._one
         if 'loss_d' not in out:
-            grads_g = torch.autograd.grad(out['loss_g'], g_params, allow_unused=True)
+            grads_g = torch.autograd.grad(out['loss_g'], g_params, grad_outputs=one, allow_unused=True)
             ops.join_side_stream()
             self.store_grads('g', grads_g)
             self._add_reg_grads()
@@ -836,7 +839,7 @@ class CAPE(base_model):
             grads_d = [p.detach() for p in d_params]          # quirk C2: the WEIGHTS are clipped and applied
         else:
             grads = torch.autograd.grad([out['loss_g'], out['loss_d']], g_params + d_params,
-                                        grad_outputs=[torch.ones_like(out['loss_g']), torch.ones_like(out['loss_d'])],
+                                        grad_outputs=[one, one],
                                         allow_unused=True)
             grads_g, grads_d = grads[:len(g_params)], grads[len(g_params):]
         ops.join_side_stream()

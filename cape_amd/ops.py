@@ -760,13 +760,13 @@ class ReconEdgeLossFn(torch.autograd.Function):
         need = lib.cape_recon_edge_workspace_bytes(N, M, E)
         ws = torch.empty((need + 3) // 4, device=pred.device, dtype=torch.float32)
         out = torch.empty(2, device=pred.device, dtype=torch.float32)
+        total = torch.empty((), device=pred.device, dtype=torch.float32)
         dpred = torch.empty_like(pred)
         rc = lib.cape_recon_edge_loss_fwd_bwd(_ptr(pred), _ptr(gt), _ptr(verts_ref), _ptr(edges), _ptr(vptr), _ptr(vidx),
-                                              N, M, E, float(w_recon), float(w_edge), _ptr(out), _ptr(dpred), _ptr(ws),
-                                              need, _stream())
+                                              N, M, E, float(w_recon), float(w_edge), _ptr(out), _ptr(total), _ptr(dpred),
+                                              _ptr(ws), need, _stream())
         check(rc, "cape_recon_edge_loss_fwd_bwd")
         ctx.save_for_backward(dpred)
-        total = w_recon * out[0] + w_edge * out[1]
         ctx.mark_non_differentiable(out)
         return total, out
 

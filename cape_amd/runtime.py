@@ -18,8 +18,11 @@ class GraphedTrainStep(object):
         B, d = model.batch_size, model.device
         M, Cn = model.input_num_verts, model.nn_input_channel
         z = lambda *s: torch.zeros(s, device=d, dtype=torch.float32)
-        self.buf = dict(data_g=z(B, M, Cn), cond_g=z(B, model.cond_dim), cond2_g=z(B, model.cond2_dim), gt=z(B, M, Cn),
-                        data_d=z(B, M, Cn), cond_d=z(B, model.cond_dim), cond2_d=z(B, model.cond2_dim),
+        # network inputs live in row-padded buffers ([.., 3] views of [.., 4] rows): the first conv reads them with
+        # aligned float4 loads directly instead of re-homing them every step
+        zp = lambda: z(B, M, (Cn + 3) // 4 * 4)[:, :, :Cn]
+        self.buf = dict(data_g=zp(), cond_g=z(B, model.cond_dim), cond2_g=z(B, model.cond2_dim), gt=z(B, M, Cn),
+                        data_d=zp(), cond_d=z(B, model.cond_dim), cond2_d=z(B, model.cond2_dim),
                         eps=z(B, int(model.nz)))
         self.losses = {}
         self._gA = self._gB = None
@@ -45,11 +48,15 @@ class GraphedTrainStep(object):
         else:
             out = m.forward_losses(b['data_g'], b['cond_g'], b['cond2_g'], b['gt'], eps=b['eps'], with_gan=False, reg_via_bucket=True)
         m.backward_to_flat(out)
+        dst, src = [], []
         for k in ('loss_g', 'loss_d', 'recon', 'latent', 'edge'):
             if k in out and torch.is_tensor(out[k]):
                 if k not in self.losses:
                     self.losses[k] = torch.zeros((), device=m.device)
-                self.losses[k].copy_(out[k].detach())
+                dst.append(self.losses[k])
+                src.append(out[k].detach().reshape(()))
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def _groups(self):
         return ('g', 'd') if self.with_gan else ('g',)

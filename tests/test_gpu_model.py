@@ -218,5 +218,7 @@ def test_train_step_matches_manual_update(mesh_ops):
         d = (model._vars[n].detach() - expect[n]).abs().max().item()
         ref = (before[n] - expect[n]).abs().max().item()
         worst = max(worst, d / max(ref, 1e-12))
-        assert d <= 2e-3 * max(ref, 1e-12) + 1e-9, (n, d, ref)
+        # one fp32 ulp of the weight itself is the floor for any evaluation order of w - lr*(scale*g)
+        ulp = 1.2e-7 * before[n].abs().max().item()
+        assert d <= 2e-3 * max(ref, 1e-12) + 1e-9 + ulp, (n, d, ref)
     assert model.global_step == 2
