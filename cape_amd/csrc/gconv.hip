@@ -301,24 +301,6 @@ __global__ __launch_bounds__(256, 4) void gconv_fwd_kernel(GconvParams p) {
 // slice of the vertex dimension; partials go to the workspace and are summed in a fixed order
 // by dw_reduce_kernel (deterministic; no float atomics).
 // =============================================================================================
-struct DwParams {
-    SrcDev s[CAPE_MAX_SRC];
-    int nsrc;
-    const float *dz;
-    const float *dz2;
-    unsigned dz2_mask;
-    long long dzs;
-    int lddz, dzvec;
-    int N, Mo, F;
-    int ftiles;
-    int tile_off[CAPE_MAX_SRC + 1];   // first output tile of each source (c-tiles * ftiles)
-    long long part_off[CAPE_MAX_SRC + 1];   // element offset of each source inside one partial slab
-    int rsplit, rows_per_split;
-    int ngroups, samples_per_group;
-    float *ws;
-    long long slab;   // elements per split slab
-};
-
 template <int CT, int FT>
 __global__ __launch_bounds__(256, 4) void gconv_dw_kernel(DwParams p) {
     constexpr int RK = 32;
@@ -531,8 +513,18 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(DwReduceParams p) {
     const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const long long i = (long long)blockIdx.x * 16 + el;
     float sum = 0.f;
-    if (i < total)
-        for (int sp = sl; sp < p.nsplit; sp += 16) sum += p.ws[(long long)sp * p.slab + i];
+    if (i < total) {
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int sp = sl;
+        for (; sp + 48 < p.nsplit; sp += 64) {
+            sum += p.ws[(long long)sp * p.slab + i];
+            s1 += p.ws[(long long)(sp + 16) * p.slab + i];
+            s2 += p.ws[(long long)(sp + 32) * p.slab + i];
+            s3 += p.ws[(long long)(sp + 48) * p.slab + i];
+        }
+        for (; sp < p.nsplit; sp += 16) sum += p.ws[(long long)sp * p.slab + i];
+        sum = (sum + s1) + (s2 + s3);
+    }
     red[sl][el] = sum;
     __syncthreads();
     if (sl == 0 && i < total) {
@@ -600,9 +592,29 @@ inline int fill_src(SrcDev &d, const cape_src_t &s) {
 
 struct DwPlan {
     int ct, ft, ctiles[CAPE_MAX_SRC], ftiles, ntiles, rsplit, rows_per_split, ngroups, samples_per_group;
+    int vstart[CAPE_MAX_SRC + 1];      // plain kernel: virtual channel axis (see DwParams)
     long long slab;
 };
 
+inline void plan_dw_splits(int N, int Mo, DwPlan &pl) {
+    // aim for ~512 workgroups: split the vertex dimension down to 128 rows, then the batch into groups
+    static const int dw_wgs = getenv("CAPE_DW_WGS") ? atoi(getenv("CAPE_DW_WGS")) : 512;
+    int S = (dw_wgs + pl.ntiles - 1) / pl.ntiles;
+    if (S < 1) S = 1;
+    int maxr = (Mo + 127) / 128;
+    int rsplit = S < maxr ? S : maxr;
+    int rows = (Mo + rsplit - 1) / rsplit;
+    rows = ((rows + 31) / 32) * 32;
+    pl.rows_per_split = rows;
+    pl.rsplit = (Mo + rows - 1) / rows;
+    int ngroups = (S + pl.rsplit - 1) / pl.rsplit;
+    if (ngroups > N) ngroups = N;
+    if (ngroups < 1) ngroups = 1;
+    pl.samples_per_group = (N + ngroups - 1) / ngroups;
+    pl.ngroups = (N + pl.samples_per_group - 1) / pl.samples_per_group;
+}
+
+// gather kernel: one [ct x ft] tile grid per source
 inline void plan_dw(const cape_src_t *srcs, int nsrc, int N, int Mo, int F, DwPlan &pl) {
     int maxC = 0;
     for (int i = 0; i < nsrc; ++i) maxC = srcs[i].C > maxC ? srcs[i].C : maxC;
@@ -616,20 +628,46 @@ inline void plan_dw(const cape_src_t *srcs, int nsrc, int N, int Mo, int F, DwPl
         pl.ntiles += pl.ctiles[i] * pl.ftiles;
         pl.slab += (long long)srcs[i].C * F;
     }
-    // aim for ~512 workgroups: split the vertex dimension down to 128 rows, then the batch into groups
-    int S = (512 + pl.ntiles - 1) / pl.ntiles;
-    if (S < 1) S = 1;
-    int maxr = (Mo + 127) / 128;
-    int rsplit = S < maxr ? S : maxr;
-    int rows = (Mo + rsplit - 1) / rsplit;
-    rows = ((rows + 31) / 32) * 32;
-    pl.rows_per_split = rows;
-    pl.rsplit = (Mo + rows - 1) / rows;
-    int ngroups = (S + pl.rsplit - 1) / pl.rsplit;
-    if (ngroups > N) ngroups = N;
-    if (ngroups < 1) ngroups = 1;
-    pl.samples_per_group = (N + ngroups - 1) / ngroups;
-    pl.ngroups = (N + pl.samples_per_group - 1) / pl.samples_per_group;
+    plan_dw_splits(N, Mo, pl);
+}
+
+// pipelined plain kernel: tiles over the virtual channel axis.  Sources that share dz are packed back to back, so
+// the narrow layers (3 x 32 channels at 6890 vertices) run as ONE tile that reads dz once instead of three
+// half-empty tiles; with dz2 in play every source starts on a tile boundary (a tile has one gradient operand).
+inline void plan_dw_plain(const cape_src_t *srcs, int nsrc, int N, int Mo, int F, bool pack, DwPlan &pl) {
+    static const int dw_ct = getenv("CAPE_DW_CT") ? atoi(getenv("CAPE_DW_CT")) : 0;
+    static const int dw_ft = getenv("CAPE_DW_FT") ? atoi(getenv("CAPE_DW_FT")) : 0;
+    int sumC = 0, maxC = 0;
+    pl.slab = 0;
+    for (int i = 0; i < nsrc; ++i) {
+        sumC += srcs[i].C;
+        maxC = srcs[i].C > maxC ? srcs[i].C : maxC;
+        pl.slab += (long long)srcs[i].C * F;
+    }
+    const int span = pack ? sumC : maxC;
+    const int n128 = (span + 127) / 128, n64 = (span + 63) / 64;
+    pl.ft = (F <= 32) ? 32 : (F <= 64) ? 64 : 128;
+    pl.ct = (pl.ft == 32 || n64 == 2 * n128) ? 128 : 64;      // 64-wide tiles only where they save MFMA work
+    if (dw_ct && dw_ft && !(dw_ft == 32 && dw_ct != 128)) { pl.ct = dw_ct; pl.ft = dw_ft; }
+    pl.ftiles = (F + pl.ft - 1) / pl.ft;
+    int v = 0;
+    for (int i = 0; i < nsrc; ++i) {
+        if (!pack) v = (v + pl.ct - 1) / pl.ct * pl.ct;
+        pl.vstart[i] = v;
+        v += srcs[i].C;
+    }
+    pl.vstart[nsrc] = v;
+    pl.ntiles = ((v + pl.ct - 1) / pl.ct) * pl.ftiles;
+    plan_dw_splits(N, Mo, pl);
+}
+
+inline bool dw_srcs_plain(const cape_src_t *srcs, int nsrc, int F) {
+    if (F & 3) return false;
+    for (int i = 0; i < nsrc; ++i)
+        if (srcs[i].rowptr || (srcs[i].C & 3) || (srcs[i].ldx & 3) || (srcs[i].x_sample_stride & 3) ||
+            (reinterpret_cast<uintptr_t>(srcs[i].x) & 15))
+            return false;
+    return true;
 }
 
 
@@ -738,7 +776,13 @@ extern "C" int64_t cape_gconv_dw_workspace_bytes(const cape_src_t *srcs, int32_t
     if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || N < 1 || Mo < 1 || F < 1) return CAPE_EINVAL;
     DwPlan pl;
     plan_dw(srcs, nsrc, N, Mo, F, pl);
-    return (int64_t)pl.slab * pl.ngroups * pl.rsplit * (int64_t)sizeof(float);
+    long long need = pl.slab * pl.ngroups * pl.rsplit;
+    if (dw_srcs_plain(srcs, nsrc, F)) {      // whichever kernel the launch ends up taking (depends on dz too)
+        plan_dw_plain(srcs, nsrc, N, Mo, F, true, pl);
+        const long long n2 = pl.slab * pl.ngroups * pl.rsplit;
+        need = n2 > need ? n2 : need;
+    }
+    return (int64_t)need * (int64_t)sizeof(float);
 }
 
 extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *dz,
@@ -748,8 +792,19 @@ extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *
     if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || !dz || N < 1 || Mo < 1 || F < 1 || lddz < F || !workspace)
         return CAPE_EINVAL;
     if (dz2_mask && !dz2) return CAPE_EINVAL;
+    static const int dwp_on = getenv("CAPE_DW_PLAIN") ? atoi(getenv("CAPE_DW_PLAIN")) : 1;      // 0: A/B against the gather kernel
+    const bool dzvec = ((lddz & 3) == 0) && ((dz_sample_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dz) & 15) == 0) &&
+                       (!dz2 || (reinterpret_cast<uintptr_t>(dz2) & 15) == 0);
+    const bool plain = dwp_on && dzvec && dw_srcs_plain(srcs, nsrc, F);
     DwPlan pl;
-    plan_dw(srcs, nsrc, N, Mo, F, pl);
+    static const int dw_pack = getenv("CAPE_DW_PACK") ? atoi(getenv("CAPE_DW_PACK")) : 1;
+    int sumC = 0;
+    for (int i = 0; i < nsrc; ++i) sumC += srcs[i].C;
+    // packing pays where several sources fit ONE tile (narrow layers of the fine mesh levels)
+    // (and the output is narrow: with F > 64 the single packed tile over-splits the rows -- measured 1.8x slower)
+    const bool packed = plain && dw_pack && !(dz2 && dz2_mask) && nsrc > 1 && sumC <= 128 && F <= 64;
+    if (packed) plan_dw_plain(srcs, nsrc, N, Mo, F, true, pl);
+    else plan_dw(srcs, nsrc, N, Mo, F, pl);
     const long long need = pl.slab * pl.ngroups * pl.rsplit * (long long)sizeof(float);
     if (workspace_bytes < need) return CAPE_EWORKSPACE;
     DwParams p;
@@ -762,20 +817,33 @@ extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *
         int rc = fill_src(p.s[i], srcs[i]);
         if (rc) return rc;
         p.tile_off[i] = toff; p.part_off[i] = poff; rp.part_off[i] = poff;
-        toff += pl.ctiles[i] * pl.ftiles;
+        toff += packed ? 0 : pl.ctiles[i] * pl.ftiles;
         poff += (long long)srcs[i].C * F;
+        p.vstart[i] = packed ? pl.vstart[i] : 0;
         rp.w[i] = const_cast<float *>(srcs[i].w); rp.wrs[i] = srcs[i].w_rs; rp.wcs[i] = srcs[i].w_cs;
     }
     p.tile_off[nsrc] = toff; p.part_off[nsrc] = poff; rp.part_off[nsrc] = poff;
+    p.vstart[nsrc] = packed ? pl.vstart[nsrc] : 0;
     p.dz = dz; p.dz2 = dz2; p.dz2_mask = dz2 ? dz2_mask : 0u; p.dzs = dz_sample_stride; p.lddz = lddz;
-    p.dzvec = ((lddz & 3) == 0) && ((dz_sample_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dz) & 15) == 0) &&
-              (!dz2 || (reinterpret_cast<uintptr_t>(dz2) & 15) == 0);
+    p.dzvec = dzvec;
     p.N = N; p.Mo = Mo; p.F = F; p.ftiles = pl.ftiles;
     p.rsplit = pl.rsplit; p.rows_per_split = pl.rows_per_split;
     p.ngroups = pl.ngroups; p.samples_per_group = pl.samples_per_group;
     p.ws = (float *)workspace; p.slab = pl.slab;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(pl.ntiles * pl.ngroups * pl.rsplit)), block(256);
+    if (packed) {
+        if (pl.ft == 32) CAPE_LAUNCH((dw_packed_kernel<128, 32, 4, 1>), grid, block, 0, st, p);
+        else if (pl.ct == 64 && pl.ft == 64) CAPE_LAUNCH((dw_packed_kernel<64, 64, 2, 2>), grid, block, 0, st, p);
+        else if (pl.ct == 64) CAPE_LAUNCH((dw_packed_kernel<64, 128, 2, 2>), grid, block, 0, st, p);
+        else if (pl.ft == 64) CAPE_LAUNCH((dw_packed_kernel<128, 64, 2, 2>), grid, block, 0, st, p);
+        else CAPE_LAUNCH((dw_packed_kernel<128, 128, 2, 2>), grid, block, 0, st, p);
+    } else if (plain) {
+        if (pl.ct == 64 && pl.ft == 64) CAPE_LAUNCH((dw_plain_kernel<64, 64, 2, 2>), grid, block, 0, st, p);
+        else if (pl.ct == 64) CAPE_LAUNCH((dw_plain_kernel<64, 128, 2, 2>), grid, block, 0, st, p);
+        else if (pl.ft == 64) CAPE_LAUNCH((dw_plain_kernel<128, 64, 2, 2>), grid, block, 0, st, p);
+        else CAPE_LAUNCH((dw_plain_kernel<128, 128, 2, 2>), grid, block, 0, st, p);
+    } else
     if (pl.ct == 64 && pl.ft == 64) CAPE_LAUNCH((gconv_dw_kernel<64, 64>), grid, block, 0, st, p);
     else if (pl.ct == 64) CAPE_LAUNCH((gconv_dw_kernel<64, 128>), grid, block, 0, st, p);
     else if (pl.ft == 64) CAPE_LAUNCH((gconv_dw_kernel<128, 64>), grid, block, 0, st, p);
@@ -784,7 +852,9 @@ extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *
     rp.F = F; rp.nsplit = pl.ngroups * pl.rsplit; rp.accumulate = accumulate; rp.ws = (const float *)workspace; rp.slab = pl.slab;
     long long total = poff;
     int rblocks = (int)((total + 15) / 16);
-    bool rvec = (F & 3) == 0 && (pl.slab & 3) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
+    // the float4 form sums a quad's splits serially: only when the slab alone fills the chip (>= 256 blocks of quads);
+    // small slabs with many splits (fine mesh levels) take the kernel that also spreads the splits over 16 lanes
+    bool rvec = (F & 3) == 0 && (pl.slab & 3) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && total >= 262144;
     for (int i = 0; i < nsrc; ++i)
         rvec = rvec && srcs[i].w_cs == 1 && (srcs[i].w_rs & 3) == 0 && (reinterpret_cast<uintptr_t>(srcs[i].w) & 15) == 0;
     if (rvec) CAPE_LAUNCH(dw_reduce_vec_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, rp);

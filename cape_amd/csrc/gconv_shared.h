@@ -37,6 +37,30 @@ struct GconvParams {
     unsigned rank_to2;
 };
 
+// Weight-gradient launch: each workgroup owns one [CT x FT] tile of one source's dW and one (sample group,
+// row range) slice of the contraction; partials go to a workspace slab per split.
+struct DwParams {
+    SrcDev s[CAPE_MAX_SRC];
+    int nsrc;
+    const float *dz;
+    const float *dz2;
+    unsigned dz2_mask;
+    long long dzs;
+    int lddz, dzvec;
+    int N, Mo, F;
+    int ftiles;
+    int tile_off[CAPE_MAX_SRC + 1];   // first output tile of each source (c-tiles * ftiles)
+    long long part_off[CAPE_MAX_SRC + 1];   // element offset of each source inside one partial slab
+    int rsplit, rows_per_split;
+    int ngroups, samples_per_group;
+    float *ws;
+    long long slab;   // elements per split slab
+    // dw_plain_kernel: tiles run over a VIRTUAL channel axis on which source s occupies [vstart[s], vstart[s] + C_s);
+    // sources are packed back to back when they share dz (small layers: one tile holds several sources), otherwise
+    // each source starts on a tile boundary.  vstart[nsrc] = length of the axis.
+    int vstart[CAPE_MAX_SRC + 1];
+};
+
 // Epilogue of one workgroup tile: rank-1 condition terms, bias + activation (or, in DUAL mode,
 // relu(acc) + acc2 with the ReLU sign bitmask), store.  Accumulator layout of the 32x32 MFMA:
 // col = lane & 31, row = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5).

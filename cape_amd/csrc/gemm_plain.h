@@ -251,6 +251,329 @@ __global__ __launch_bounds__(256, 2) void gemm_plain_kernel(GconvParams p) {
     gconv_epilogue<BM, BN, WAVES_M, WAVES_N, DUAL>(p, acc, acc2, n, r0, f0, wm, wn, li, lh);
 }
 
+// =============================================================================================================
+// Weight gradient of plain sources, software-pipelined:  dW_s[c, f] = sum_{n, r} X_s[n, r, c] * dz[n, r, f].
+// Same decomposition as gconv_dw_kernel (one [CT x FT] tile x one (sample group, row range) split per
+// workgroup, partial slabs reduced by dw_reduce_*), but the [32 x CT] activation chunk and the [32 x FT]
+// gradient chunk of iteration i+1 are in flight in registers while iteration i is on the MFMA pipe.
+// Requires: source plain, 16-byte aligned, C % 4 == 0; dz 16-byte aligned, F % 4 == 0.
+// =============================================================================================================
+template <int CT, int FT, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, 2) void dw_plain_kernel(DwParams p) {
+    constexpr int RK = 32;
+    constexpr int LDA = CT + 4, LDB = FT + 4;
+    constexpr int WTM = CT / WAVES_M, WTN = FT / WAVES_N;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int NA = RK * (CT / 4) / 256, NB = (RK * (FT / 4) + 255) / 256;
+    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "4 waves, each at least one 32x32 MFMA tile");
+    __shared__ __attribute__((aligned(16))) float smem[RK * LDA + RK * LDB];
+    float *sA = smem;
+    float *sB = smem + RK * LDA;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int ntiles = p.tile_off[p.nsrc];
+    const int tile = blockIdx.x % ntiles;
+    const int split = blockIdx.x / ntiles;   // split = group * rsplit + rs
+    const int grp = split / p.rsplit;
+    const int rs = split % p.rsplit;
+    const int n_begin = grp * p.samples_per_group;
+    const int n_end = min(p.N, n_begin + p.samples_per_group);
+    int si = 0;
+    while (si + 1 < p.nsrc && tile >= p.tile_off[si + 1]) ++si;
+    const SrcDev &S = p.s[si];
+    const int lt = tile - p.tile_off[si];
+    const int c0 = (lt / p.ftiles) * CT;
+    const int f0 = (lt % p.ftiles) * FT;
+    const int ra = rs * p.rows_per_split;
+    const int rb = min(p.Mo, ra + p.rows_per_split);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+
+    // per-thread staging coordinates (fixed for the whole kernel)
+    int a_rl[NA], a_col[NA], b_rl[NB], b_col[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int idx = tid + i * 256;
+        a_rl[i] = idx / (CT / 4);
+        const int c = c0 + 4 * (idx % (CT / 4));
+        a_col[i] = c < S.C ? c : 0;              // columns beyond C feed output rows that are never stored
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int idx = tid + i * 256;
+        b_rl[i] = (idx / (FT / 4)) % RK;
+        const int f = f0 + 4 * (idx % (FT / 4));
+        b_col[i] = f < p.F ? f : 0;
+    }
+    const float *dz0 = ((p.dz2_mask >> si) & 1u) ? p.dz2 : p.dz;
+
+    const int chunks = (rb - ra + RK - 1) / RK;
+    const int total = (n_end - n_begin) * chunks;
+    int l_n = n_begin, l_r = ra;              // loader cursor
+    float4 ra4[NA], rb4[NB];
+    unsigned okA = 0, okB = 0;
+
+    auto load_regs = [&]() {
+        const float *xb = S.x + (long long)l_n * S.xs;
+        const float *zb = dz0 + (long long)l_n * p.dzs;
+        okA = okB = 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int r = l_r + a_rl[i];
+            okA |= (r < rb ? 1u : 0u) << i;
+            ra4[i] = *reinterpret_cast<const float4 *>(xb + (long long)min(r, rb - 1) * S.ldx + a_col[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int r = l_r + b_rl[i];
+            okB |= (r < rb ? 1u : 0u) << i;
+            rb4[i] = *reinterpret_cast<const float4 *>(zb + (long long)min(r, rb - 1) * p.lddz + b_col[i]);
+        }
+        l_r += RK;
+        if (l_r >= rb) { l_r = ra; ++l_n; }
+    };
+    auto store_regs = [&]() {
+        // rows beyond the split's range must contribute zero (they are clamped, finite data in both tiles)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const bool ok = (okA >> i) & 1u;
+            float4 o = ra4[i];
+            o.x = ok ? o.x : 0.f; o.y = ok ? o.y : 0.f; o.z = ok ? o.z : 0.f; o.w = ok ? o.w : 0.f;
+            *reinterpret_cast<float4 *>(&sA[a_rl[i] * LDA + 4 * ((tid + i * 256) % (CT / 4))]) = o;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const bool ok = (okB >> i) & 1u;
+            float4 o = rb4[i];
+            o.x = ok ? o.x : 0.f; o.y = ok ? o.y : 0.f; o.z = ok ? o.z : 0.f; o.w = ok ? o.w : 0.f;
+            if (tid + i * 256 < RK * (FT / 4)) *reinterpret_cast<float4 *>(&sB[b_rl[i] * LDB + 4 * ((tid + i * 256) % (FT / 4))]) = o;
+        }
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int kb = 0; kb < RK / 8; ++kb) {
+            float av[TM][4], bv[TN][4];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) av[a][u] = sA[(kb * 8 + 4 * lh + u) * LDA + wm * WTM + a * 32 + li];
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bv[b][u] = sB[(kb * 8 + 4 * lh + u) * LDB + wn * WTN + b * 32 + li];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][u], bv[b][u], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    if (total > 0) {
+        load_regs();
+        store_regs();
+        __syncthreads();
+        for (int it = 0; it < total; ++it) {
+            const bool more = it + 1 < total;
+            if (more) load_regs();
+            compute();
+            __syncthreads();
+            if (more) store_regs();
+            __syncthreads();
+        }
+    }
+
+    // partial slab layout: [split][part_off[si] + c*F + f]
+    float *out = p.ws + (long long)split * p.slab + p.part_off[si];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int f = f0 + wn * WTN + b * 32 + li;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int c = c0 + wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                if (c < S.C && f < p.F) out[(long long)c * p.F + f] = acc[a][b][g];
+            }
+        }
+}
+
+// The packed variant (dw_packed_kernel) lays several narrow sources side by side on one tile's channel axis
+// (virtual axis, DwParams::vstart): at 6890 vertices the layers are 3 x 32 channels wide, and three half-empty
+// tiles that each re-read dz become one.  It carries per-slot source pointers; layers wide enough to fill
+// their own tiles use dw_plain_kernel (one source per tile, scalar base addresses -- measured 14 % faster there).
+template <int CT, int FT, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, 2) void dw_packed_kernel(DwParams p) {
+    constexpr int RK = 32;
+    constexpr int LDA = CT + 4, LDB = FT + 4;
+    constexpr int WTM = CT / WAVES_M, WTN = FT / WAVES_N;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int NA = RK * (CT / 4) / 256, NB = (RK * (FT / 4) + 255) / 256;
+    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "4 waves, each at least one 32x32 MFMA tile");
+    __shared__ __attribute__((aligned(16))) float smem[RK * LDA + RK * LDB];
+    float *sA = smem;
+    float *sB = smem + RK * LDA;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int V = p.vstart[p.nsrc];
+    const int ntiles = ((V + CT - 1) / CT) * p.ftiles;
+    const int tile = blockIdx.x % ntiles;
+    const int split = blockIdx.x / ntiles;   // split = group * rsplit + rs
+    const int grp = split / p.rsplit;
+    const int rs = split % p.rsplit;
+    const int n_begin = grp * p.samples_per_group;
+    const int n_end = min(p.N, n_begin + p.samples_per_group);
+    const int v0 = (tile / p.ftiles) * CT;
+    const int f0 = (tile % p.ftiles) * FT;
+    const int ra = rs * p.rows_per_split;
+    const int rb = min(p.Mo, ra + p.rows_per_split);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+
+    // per-thread staging coordinates (fixed for the whole kernel): slot i of the A chunk reads 4 channels of ONE source
+    const float *a_ptr[NA];
+    long long a_xs[NA];
+    int a_ld[NA], a_rl[NA], b_rl[NB], b_col[NB];
+    int first_src = 0;
+    while (first_src + 1 < p.nsrc && v0 >= p.vstart[first_src + 1]) ++first_src;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int idx = tid + i * 256;
+        a_rl[i] = idx / (CT / 4);
+        const int vc = v0 + 4 * (idx % (CT / 4));
+        int si = 0;
+        while (si + 1 < p.nsrc && vc >= p.vstart[si + 1]) ++si;
+        const bool ok = vc - p.vstart[si] < p.s[si].C;      // padding columns read column 0: their outputs are never stored
+        a_ptr[i] = p.s[si].x + (ok ? vc - p.vstart[si] : 0);
+        a_xs[i] = p.s[si].xs;
+        a_ld[i] = p.s[si].ldx;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int idx = tid + i * 256;
+        b_rl[i] = (idx / (FT / 4)) % RK;
+        const int f = f0 + 4 * (idx % (FT / 4));
+        b_col[i] = f < p.F ? f : 0;
+    }
+    const float *dz0 = ((p.dz2_mask >> first_src) & 1u) ? p.dz2 : p.dz;
+
+    const int chunks = (rb - ra + RK - 1) / RK;
+    const int total = (n_end - n_begin) * chunks;
+    int l_n = n_begin, l_r = ra;              // loader cursor
+    float4 ra4[NA], rb4[NB];
+    unsigned okA = 0, okB = 0;
+
+    auto load_regs = [&]() {
+        const float *zb = dz0 + (long long)l_n * p.dzs;
+        okA = okB = 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int r = l_r + a_rl[i];
+            okA |= (r < rb ? 1u : 0u) << i;
+            ra4[i] = *reinterpret_cast<const float4 *>(a_ptr[i] + (long long)l_n * a_xs[i] + (long long)min(r, rb - 1) * a_ld[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int r = l_r + b_rl[i];
+            okB |= (r < rb ? 1u : 0u) << i;
+            rb4[i] = *reinterpret_cast<const float4 *>(zb + (long long)min(r, rb - 1) * p.lddz + b_col[i]);
+        }
+        l_r += RK;
+        if (l_r >= rb) { l_r = ra; ++l_n; }
+    };
+    auto store_regs = [&]() {
+        // rows beyond the split's range must contribute zero (they are clamped, finite data in both tiles)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const bool ok = (okA >> i) & 1u;
+            float4 o = ra4[i];
+            o.x = ok ? o.x : 0.f; o.y = ok ? o.y : 0.f; o.z = ok ? o.z : 0.f; o.w = ok ? o.w : 0.f;
+            *reinterpret_cast<float4 *>(&sA[a_rl[i] * LDA + 4 * ((tid + i * 256) % (CT / 4))]) = o;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const bool ok = (okB >> i) & 1u;
+            float4 o = rb4[i];
+            o.x = ok ? o.x : 0.f; o.y = ok ? o.y : 0.f; o.z = ok ? o.z : 0.f; o.w = ok ? o.w : 0.f;
+            if (tid + i * 256 < RK * (FT / 4)) *reinterpret_cast<float4 *>(&sB[b_rl[i] * LDB + 4 * ((tid + i * 256) % (FT / 4))]) = o;
+        }
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int kb = 0; kb < RK / 8; ++kb) {
+            float av[TM][4], bv[TN][4];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) av[a][u] = sA[(kb * 8 + 4 * lh + u) * LDA + wm * WTM + a * 32 + li];
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bv[b][u] = sB[(kb * 8 + 4 * lh + u) * LDB + wn * WTN + b * 32 + li];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][u], bv[b][u], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    if (total > 0) {
+        load_regs();
+        store_regs();
+        __syncthreads();
+        for (int it = 0; it < total; ++it) {
+            const bool more = it + 1 < total;
+            if (more) load_regs();
+            compute();
+            __syncthreads();
+            if (more) store_regs();
+            __syncthreads();
+        }
+    }
+
+    // partial slab layout: [split][part_off[source] + c*F + f]
+    float *out = p.ws + (long long)split * p.slab;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int f = f0 + wn * WTN + b * 32 + li;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int vc = v0 + wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                int si = 0;
+                while (si + 1 < p.nsrc && vc >= p.vstart[si + 1]) ++si;
+                const int c = vc - p.vstart[si];
+                if (vc < V && c < p.s[si].C && f < p.F) out[p.part_off[si] + (long long)c * p.F + f] = acc[a][b][g];
+            }
+        }
+}
+
 // Layout class of one launch's weight operands: 1 = contraction-contiguous, 0 = output-contiguous,
 // -1 = not eligible for the plain kernel.
 inline int gp_weight_layout(const GconvParams &p, bool dual) {

@@ -32,6 +32,9 @@ CASES = [  # N, Mi, Mo, [C per source], F, dual, empty_rows
     (2, 129, 129, [36, 36], 70, True, 3),
     (1, 300, 150, [64], 130, False, 0),
     (4, 65, 65, [3, 3, 3], 40, True, 0),
+    (2, 150, 150, [12, 8, 4], 32, False, 2),      # aligned: pipelined kernels, three sources packed into one dW tile
+    (3, 170, 90, [36, 36], 72, False, 0),
+    (2, 140, 140, [68, 132], 136, False, 0),
 ]
 
 
