@@ -51,7 +51,7 @@ SIGNATURES = {
     "cape_abi_version": (C.c_int, []),
     "cape_csr_validate": (C.c_int, [_i32, _i32, _i64, _p, _p]),
     "cape_gconv_fwd": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p, _i32, _i32, _p,
-                                 C.POINTER(CapeRank), _p]),
+                                 C.POINTER(CapeRank), _i32, _p]),
     "cape_gconv_fwd_plan": (C.c_int, [_SRCP, _i32, _i32, _i32, _i32, C.POINTER(_i32)]),
     "cape_rowscale_reduce_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "cape_rowscale_reduce": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _i32, _i32, _p, _p, _i64, _p]),

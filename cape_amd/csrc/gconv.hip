@@ -661,10 +661,12 @@ inline void plan_dw_plain(const cape_src_t *srcs, int nsrc, int N, int Mo, int F
     plan_dw_splits(N, Mo, pl);
 }
 
-inline bool dw_srcs_plain(const cape_src_t *srcs, int nsrc, int F) {
-    if (F & 3) return false;
+// Plain = no gather and float4-addressable rows.  A channel count that is not a multiple of 4 qualifies when the
+// row is padded to one (ld >= round_up(C, 4)): the pad lane only feeds an output row that is never stored
+// (the 3-channel network input / output layers).
+inline bool dw_srcs_plain(const cape_src_t *srcs, int nsrc) {
     for (int i = 0; i < nsrc; ++i)
-        if (srcs[i].rowptr || (srcs[i].C & 3) || (srcs[i].ldx & 3) || (srcs[i].x_sample_stride & 3) ||
+        if (srcs[i].rowptr || (((srcs[i].C + 3) & ~3) > srcs[i].ldx) || (srcs[i].ldx & 3) || (srcs[i].x_sample_stride & 3) ||
             (reinterpret_cast<uintptr_t>(srcs[i].x) & 15))
             return false;
     return true;
@@ -731,8 +733,12 @@ extern "C" int cape_gconv_fwd_plan(const cape_src_t *srcs, int32_t nsrc, int32_t
 extern "C" int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, int64_t y_sample_stride,
                               int32_t ldy, int32_t N, int32_t Mo, int32_t F, const float *bias,
                               int32_t bias_mode, int32_t act, uint32_t *mask_out, const cape_rank_t *rank,
-                              void *stream) {
-    if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || !y || N < 1 || Mo < 1 || F < 1 || ldy < F) return CAPE_EINVAL;
+                              int32_t out_deinterleave, void *stream) {
+    if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || !y || N < 1 || Mo < 1 || F < 1) return CAPE_EINVAL;
+    const int dK = out_deinterleave > 1 ? out_deinterleave : 1;
+    const int dstride = dK > 1 ? ((F / dK + 3) & ~3) : 0;
+    if (dK > 1 && (F % dK != 0 || mask_out || rank || ldy < dK * dstride)) return CAPE_EINVAL;
+    if (dK == 1 && ldy < F) return CAPE_EINVAL;
     if (bias_mode != CAPE_BIAS_NONE && !bias) return CAPE_EINVAL;
     if (act < CAPE_ACT_NONE || act > CAPE_ACT_TANH) return CAPE_EINVAL;
     GconvParams p;
@@ -746,6 +752,7 @@ extern "C" int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, in
     p.bias = bias; p.bias_mode = bias ? bias_mode : CAPE_BIAS_NONE; p.act = act;
     p.mask = mask_out; p.mask_words = (F + 31) / 32;
     p.rankR = 0; p.rowscale = nullptr; p.coef = nullptr; p.rank_to2 = 0;
+    p.deintK = dK; p.deint_stride = dstride;
     if (rank && rank->R > 0) {
         if (rank->R > CAPE_MAX_SRC || !rank->rowscale || !rank->coef) return CAPE_EINVAL;
         if (rank->to_acc2 && !dual) return CAPE_EINVAL;
@@ -777,7 +784,7 @@ extern "C" int64_t cape_gconv_dw_workspace_bytes(const cape_src_t *srcs, int32_t
     DwPlan pl;
     plan_dw(srcs, nsrc, N, Mo, F, pl);
     long long need = pl.slab * pl.ngroups * pl.rsplit;
-    if (dw_srcs_plain(srcs, nsrc, F)) {      // whichever kernel the launch ends up taking (depends on dz too)
+    if (dw_srcs_plain(srcs, nsrc)) {      // whichever kernel the launch ends up taking (depends on dz too)
         plan_dw_plain(srcs, nsrc, N, Mo, F, true, pl);
         const long long n2 = pl.slab * pl.ngroups * pl.rsplit;
         need = n2 > need ? n2 : need;
@@ -795,14 +802,16 @@ extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *
     static const int dwp_on = getenv("CAPE_DW_PLAIN") ? atoi(getenv("CAPE_DW_PLAIN")) : 1;      // 0: A/B against the gather kernel
     const bool dzvec = ((lddz & 3) == 0) && ((dz_sample_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dz) & 15) == 0) &&
                        (!dz2 || (reinterpret_cast<uintptr_t>(dz2) & 15) == 0);
-    const bool plain = dwp_on && dzvec && dw_srcs_plain(srcs, nsrc, F);
+    const bool plain = dwp_on && dzvec && (((F + 3) & ~3) <= lddz) && dw_srcs_plain(srcs, nsrc);
     DwPlan pl;
     static const int dw_pack = getenv("CAPE_DW_PACK") ? atoi(getenv("CAPE_DW_PACK")) : 1;
     int sumC = 0;
     for (int i = 0; i < nsrc; ++i) sumC += srcs[i].C;
     // packing pays where several sources fit ONE tile (narrow layers of the fine mesh levels)
     // (and the output is narrow: with F > 64 the single packed tile over-splits the rows -- measured 1.8x slower)
-    const bool packed = plain && dw_pack && !(dz2 && dz2_mask) && nsrc > 1 && sumC <= 128 && F <= 64;
+    bool c4 = true;
+    for (int i = 0; i < nsrc; ++i) c4 = c4 && (srcs[i].C & 3) == 0;
+    const bool packed = plain && c4 && dw_pack && !(dz2 && dz2_mask) && nsrc > 1 && sumC <= 128 && F <= 64;
     if (packed) plan_dw_plain(srcs, nsrc, N, Mo, F, true, pl);
     else plan_dw(srcs, nsrc, N, Mo, F, pl);
     const long long need = pl.slab * pl.ngroups * pl.rsplit * (long long)sizeof(float);

@@ -35,6 +35,7 @@ struct GconvParams {
     const float *rowscale;
     const float *coef;
     unsigned rank_to2;
+    int deintK, deint_stride;
 };
 
 // Weight-gradient launch: each workgroup owns one [CT x FT] tile of one source's dW and one (sample group,
@@ -77,6 +78,8 @@ __device__ __forceinline__ void gconv_epilogue(const GconvParams &p,
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int f = f0 + wn * WTN + b * 32 + li;
+            // optional de-interleave of the output columns: column j = c*K + k is stored at channel k*stride + c
+            const int fm = p.deintK > 1 ? (f % p.deintK) * p.deint_stride + f / p.deintK : f;
             float coef[CAPE_MAX_SRC];
 #pragma unroll
             for (int j = 0; j < CAPE_MAX_SRC; ++j)
@@ -113,7 +116,7 @@ __device__ __forceinline__ void gconv_epilogue(const GconvParams &p,
                     }
                     v = cape_act(v, p.act);
                 }
-                if (ok) yb[(long long)r * p.ldy + f] = v;
+                if (ok) yb[(long long)r * p.ldy + fm] = v;
             }
         }
     }

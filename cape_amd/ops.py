@@ -170,11 +170,13 @@ def _log_launch(name, flops, byts, fn):
 # --------------------------------------------------------------------------------------------
 # raw kernel wrappers (no autograd)
 # --------------------------------------------------------------------------------------------
-def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=None, rank=None):
-    """rank = (rowscale [R,Mo], coef [N,R,F], to_acc2 bitmask) or None."""
+def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=None, rank=None, deinterleave=0, F=None):
+    """rank = (rowscale [R,Mo], coef [N,R,F], to_acc2 bitmask) or None.  ``deinterleave`` = K: the launch computes
+    ``F`` = K*C output columns (column c*K + k) and stores them as K channel blocks of ``y`` [N, Mo, K*round_up(C,4)]."""
     _lib.require_gpu()
     arr = _mk_srcs(entries)
-    N, Mo, F = y.shape
+    N, Mo = y.shape[0], y.shape[1]
+    F = int(y.shape[2]) if F is None else int(F)
     p, ss, ld = _v(y)
     rk = None
     if rank is not None:
@@ -186,7 +188,7 @@ def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=
     def launch():
         rc = lib.cape_gconv_fwd(arr, len(entries), p, ss, ld, N, Mo, F, _ptr(bias),
                                 bias_mode if bias is not None else _lib.BIAS_NONE, _lib.ACT[act],
-                                _ptr(mask), C.byref(rk) if rk is not None else None, _stream())
+                                _ptr(mask), C.byref(rk) if rk is not None else None, int(deinterleave), _stream())
         check(rc, "cape_gconv_fwd")
 
     if LAUNCH_LOG is None:
@@ -579,7 +581,29 @@ class ChebConvFn(torch.autograd.Function):
                 wT = lambda k: (W, k * Fout, 1, K * Fout)
                 waT = (W_aff, 0, 1, Fout) if W_aff is not None else None
                 contract_first = (Mo < Mi) or (Mo == Mi and Ch < Fout)
-                if contract_first:
+                if contract_first and W_aff is None and K > 1:
+                    # all K orders in ONE launch: G = dz W[:Ch*K]^T has column c*K + k; the epilogue stores it as K
+                    # channel blocks G_k (de-interleave), then dx = sum_k S_k^T G_k
+                    ChP = _pad4(Ch)
+                    Gall = alloc_act(N, Mo, K * ChP, dev)
+                    gconv_fwd([dict(x=dz, csr=None, w=(W, 0, 1, Fout))], Gall, deinterleave=K, F=K * Ch)
+                    dx, first = None, True
+                    for k in range(K):
+                        Gk = Gall[:, :, k * ChP:k * ChP + Ch]
+                        if ops.bwd[k].identity:
+                            if first:
+                                dx = Gk
+                            else:
+                                dx.add_(Gk)
+                        elif first:
+                            dx = alloc_act(N, Mi, Ch, dev)
+                            spmm(Gk, ops.bwd[k], y=dx)
+                        else:
+                            if dx.shape[1] != Mi:      # identity block came first on a pooled layer: cannot happen (Mo < Mi)
+                                raise AssertionError("operator shapes")
+                            spmm(Gk, ops.bwd[k], z=dx, beta=1.0, y=dx)
+                        first = False
+                elif contract_first:
                     # G_k = dz W_k^T at the Mo output rows, then dx = sum_k S_k^T G_k
                     first = True
                     for k in range(K):

@@ -139,11 +139,15 @@ int cape_csr_validate(int32_t rows, int32_t cols, int64_t nnz, const int32_t *ro
  *        mask_out[(n*Mo + r)*ceil(F/32) + f/32] = (acc1 > 0)
  * bias: NULL or [F] (CAPE_BIAS_CHANNEL) or [Mo,F] (CAPE_BIAS_VERTEX).
  * rank: NULL or rank-1 terms added to the accumulators before the epilogue.
+ * out_deinterleave = K > 1 (single mode, no rank/mask, F % K == 0): output column j = c*K + k is stored at channel
+ *   k * round_up(F/K, 4) + c, i.e. the reference's fin*K + k weight-row order (lib/models.py:97-101) comes out as
+ *   K contiguous channel blocks -- ONE launch  G = dz W^T  for all K orders of a data gradient, each block then
+ *   being the operand of its S_k^T (ldy >= K * round_up(F/K, 4)).  0 / 1 = off.
  */
 int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, int64_t y_sample_stride,
                    int32_t ldy, int32_t N, int32_t Mo, int32_t F, const float *bias,
                    int32_t bias_mode, int32_t act, uint32_t *mask_out, const cape_rank_t *rank,
-                   void *stream);
+                   int32_t out_deinterleave, void *stream);
 
 /* Which kernel cape_gconv_fwd would run for these arguments (pure query, no launch):
  * plan[0] = family (0: gather-GEMM gconv_fwd_kernel, 1: pipelined plain-source gemm_plain_kernel),

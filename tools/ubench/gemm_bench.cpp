@@ -58,7 +58,7 @@ int main(int argc, char **argv) {
         if (s.dual) hipMalloc(&mask, (size_t)s.N * s.Mo * ((s.F + 31) / 32) * 4);
         auto run = [&]() {
             return cape_gconv_fwd(srcs, s.nsrc, y, (int64_t)s.Mo * s.F, s.F, s.N, s.Mo, s.F, s.dual ? nullptr : bias,
-                                  s.dual ? CAPE_BIAS_NONE : CAPE_BIAS_CHANNEL, s.dual ? CAPE_ACT_NONE : CAPE_ACT_LEAKY, mask, nullptr, nullptr);
+                                  s.dual ? CAPE_BIAS_NONE : CAPE_BIAS_CHANNEL, s.dual ? CAPE_ACT_NONE : CAPE_ACT_LEAKY, mask, nullptr, 0, nullptr);
         };
         int rc = run();
         if (rc) { printf("rc %d\n", rc); return 1; }
