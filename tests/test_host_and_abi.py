@@ -112,3 +112,10 @@ def test_vertex_edge_table(mesh_ops):
     inc = idx[ptr[v]:ptr[v + 1]]
     for code in inc:
         assert edges[code >> 1][code & 1] == v
+
+
+def test_build_entry_point_runs():
+    """__graft_entry__.build() (what the driver calls): make is a no-op when the library is current; the ABI
+    version the library reports must be the header's."""
+    import __graft_entry__ as g
+    g.build()
