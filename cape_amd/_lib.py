@@ -33,6 +33,12 @@ class CapeCondLayer(C.Structure):
                 ("gw", C.c_void_p), ("gw_aff", C.c_void_p), ("K", C.c_int32), ("F", C.c_int32)]
 
 
+class CapeSpmmTerm(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("x_sample_stride", C.c_int64), ("ldx", C.c_int32),
+                ("rowptr", C.c_void_p), ("colidx", C.c_void_p), ("vals", C.c_void_p),
+                ("y", C.c_void_p), ("y_sample_stride", C.c_int64), ("ldy", C.c_int32)]
+
+
 class CapeRank(C.Structure):
     _fields_ = [("R", C.c_int32), ("rowscale", C.c_void_p), ("coef", C.c_void_p), ("to_acc2", C.c_uint32)]
 
@@ -62,6 +68,7 @@ SIGNATURES = {
                                 _i64, _i32, _i32, _i32, _p, _i64, _p]),
     "cape_spmm": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _i32, _f32, _p, _i64, _i32, _f32, _p, _i64, _i32,
                             _i32, _i32, _i32, _p]),
+    "cape_spmm_multi": (C.c_int, [C.POINTER(CapeSpmmTerm), _i32, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "cape_bias_act_fwd": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "cape_act_bwd": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "cape_colsum_workspace_bytes": (_i64, [_i32, _i32, _i32]),

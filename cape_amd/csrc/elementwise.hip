@@ -62,6 +62,67 @@ __global__ __launch_bounds__(256) void spmm_kernel(CView x, const int *rp, const
     }
 }
 
+// ---- several operator applications in one launch -----------------------------------------------------------
+// separate mode: y_k = S_k x_k for every term (the X_k = S_k x of one Chebyshev layer, or T_k = S_k^T dz of its
+// data gradient);  sum mode: y = sum_k S_k x_k (dx = sum_k S_k^T G_k).  A term without CSR is the identity.
+// One thread = (sample, output row, 4 channels) of ALL terms: a layer pays one dispatch instead of K, and the
+// terms' gathers of one neighbourhood hit the same L1/L2 lines.
+struct SpmmTerms {
+    struct T {
+        const float *x; long long xs; int ldx;
+        const int *rp; const int *ci; const float *va;
+        float *y; long long ys; int ldy;
+    } t[CAPE_MAX_SPMM_TERMS];
+    int n;
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void spmm_multi_kernel(SpmmTerms P, int sum, View y, int N, int Mo, int C) {
+    const int W = VEC ? 4 : 1;
+    const int cq = (C + W - 1) / W;
+    const long long total = (long long)N * Mo * cq;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int q = (int)(i % cq);
+        const long long nr = i / cq;
+        const int r = (int)(nr % Mo);
+        const int n = (int)(nr / Mo);
+        const int c = q * W;
+        float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < P.n; ++k) {
+            const SpmmTerms::T &T = P.t[k];
+            const float *xb = T.x + (long long)n * T.xs + c;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!T.rp) {
+                if (VEC) acc = *reinterpret_cast<const float4 *>(xb + (long long)r * T.ldx);
+                else acc.x = xb[(long long)r * T.ldx];
+            } else {
+                const int e1 = T.rp[r + 1];
+                for (int e = T.rp[r]; e < e1; ++e) {
+                    const float v = T.va[e];
+                    if (VEC) {
+                        const float4 xv = *reinterpret_cast<const float4 *>(xb + (long long)T.ci[e] * T.ldx);
+                        acc.x = fmaf(v, xv.x, acc.x); acc.y = fmaf(v, xv.y, acc.y);
+                        acc.z = fmaf(v, xv.z, acc.z); acc.w = fmaf(v, xv.w, acc.w);
+                    } else {
+                        acc.x = fmaf(v, xb[(long long)T.ci[e] * T.ldx], acc.x);
+                    }
+                }
+            }
+            if (sum) {
+                tot.x += acc.x; tot.y += acc.y; tot.z += acc.z; tot.w += acc.w;
+            } else if (VEC) {
+                *reinterpret_cast<float4 *>(T.y + (long long)n * T.ys + (long long)r * T.ldy + c) = acc;
+            } else {
+                T.y[(long long)n * T.ys + (long long)r * T.ldy + c] = acc.x;
+            }
+        }
+        if (sum) {
+            if (VEC) *reinterpret_cast<float4 *>(y.p + (long long)n * y.ss + (long long)r * y.ld + c) = tot;
+            else y.p[(long long)n * y.ss + (long long)r * y.ld + c] = tot.x;
+        }
+    }
+}
+
 // Rows of the mesh operators have 1..16 entries (3-11 for L~, up to ~16 for composed T_k(L~)U).  With a
 // compile-time bound the entry loop unrolls completely: every (index, value) pair is loaded first, then all
 // gathers are in flight together -- two dependent memory round trips per thread instead of one per entry.
@@ -537,6 +598,31 @@ extern "C" int cape_spmm(const float *x, int64_t x_sample_stride, int32_t ldx, c
         const long long total = (long long)N * Mo * C;
         CAPE_LAUNCH(spmm_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
     }
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}
+
+extern "C" int cape_spmm_multi(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, float *y, int64_t y_sample_stride,
+                               int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
+    if (!terms || nterms < 1 || nterms > CAPE_MAX_SPMM_TERMS || N < 1 || Mo < 1 || C < 1) return CAPE_EINVAL;
+    if (sum && (!y || ldy < C)) return CAPE_EINVAL;
+    SpmmTerms P;
+    P.n = nterms;
+    bool vec = !sum || aligned4(y, y_sample_stride, ldy, C);
+    for (int k = 0; k < nterms; ++k) {
+        const cape_spmm_term_t &t = terms[k];
+        if (!t.x || t.ldx < C) return CAPE_EINVAL;
+        if (t.rowptr && (!t.colidx || !t.vals)) return CAPE_EINVAL;
+        if (!sum && (!t.y || t.ldy < C)) return CAPE_EINVAL;
+        P.t[k].x = t.x; P.t[k].xs = t.x_sample_stride; P.t[k].ldx = t.ldx;
+        P.t[k].rp = t.rowptr; P.t[k].ci = t.colidx; P.t[k].va = t.vals;
+        P.t[k].y = t.y; P.t[k].ys = t.y_sample_stride; P.t[k].ldy = t.ldy;
+        vec = vec && aligned4(t.x, t.x_sample_stride, t.ldx, C) && (sum || aligned4(t.y, t.y_sample_stride, t.ldy, C));
+    }
+    View yv{y, y_sample_stride, ldy};
+    hipStream_t st = (hipStream_t)stream;
+    if (vec) CAPE_LAUNCH(spmm_multi_kernel<true>, dim3(grid_for((long long)N * Mo * (C / 4))), dim3(256), 0, st, P, sum, yv, N, Mo, C);
+    else CAPE_LAUNCH(spmm_multi_kernel<false>, dim3(grid_for((long long)N * Mo * C)), dim3(256), 0, st, P, sum, yv, N, Mo, C);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }

@@ -252,6 +252,41 @@ def spmm(x, csr, y=None, alpha=1.0, z=None, beta=0.0):
     return y
 
 
+def spmm_multi(xs, csrs, sum=False):
+    """Several operator applications in one launch: ``sum=False`` -> [S_k x_k for k]; ``sum=True`` -> sum_k S_k x_k.
+    ``csrs[k]`` None or an identity DeviceCSR = identity term.  All operators have the same number of rows."""
+    _lib.require_gpu()
+    n = len(xs)
+    assert 1 <= n <= 4 and len(csrs) == n
+    N, _, Cn = xs[0].shape
+    ident = [c is None or c.identity for c in csrs]
+    Mo = next((c.shape[0] for c, i in zip(csrs, ident) if not i), xs[0].shape[1])
+    arr = (_lib.CapeSpmmTerm * n)()
+    outs = []
+    for k in range(n):
+        assert xs[k].shape[0] == N and xs[k].shape[2] == Cn and (not ident[k] or xs[k].shape[1] == Mo)
+        t = arr[k]
+        xp, t.x_sample_stride, t.ldx = _v(xs[k])
+        t.x = xp.value
+        if ident[k]:
+            t.rowptr = t.colidx = t.vals = None
+        else:
+            assert csrs[k].shape[0] == Mo and csrs[k].shape[1] == xs[k].shape[1]
+            t.rowptr, t.colidx, t.vals = csrs[k].rowptr_t.data_ptr(), csrs[k].colidx_t.data_ptr(), csrs[k].vals_t.data_ptr()
+        if not sum:
+            yk = alloc_act(N, Mo, Cn, xs[0].device)
+            yp, t.y_sample_stride, t.ldy = _v(yk)
+            t.y = yp.value
+            outs.append(yk)
+    if sum:
+        y = alloc_act(N, Mo, Cn, xs[0].device)
+        yp, ys, yl = _v(y)
+    else:
+        y, yp, ys, yl = None, None, 0, 0
+    check(lib.cape_spmm_multi(arr, n, 1 if sum else 0, yp, ys, yl, N, Mo, Cn, _stream()), "cape_spmm_multi")
+    return y if sum else outs
+
+
 def bias_act_fwd(x, bias, bias_mode, act, y=None):
     _lib.require_gpu()
     N, M, Cn = x.shape
@@ -466,7 +501,14 @@ class ChebConvFn(torch.autograd.Function):
         yfull = alloc_act(N, ops.Mo, Fout + Co, x.device)
         y = yfull[:, :, :Fout]
         twopass = (mode == "twopass")
-        xs = [x if (ops.fwd[k].identity or not twopass) else spmm(x, ops.fwd[k]) for k in range(K)]
+        xs = [x] * K
+        if twopass:
+            ks = [k for k in range(K) if not ops.fwd[k].identity]
+            if len(ks) == 1:
+                xs[ks[0]] = spmm(x, ops.fwd[ks[0]])
+            elif ks:                                   # X_k = S_k x of all orders in one launch
+                for k, xk in zip(ks, spmm_multi([x] * len(ks), [ops.fwd[k] for k in ks])):
+                    xs[k] = xk
         entries = []
         for k in range(K):
             e = dict(x=xs[k], csr=None if twopass else ops.fwd[k], w=(W, k * Fout, K * Fout, 1))
@@ -587,22 +629,7 @@ class ChebConvFn(torch.autograd.Function):
                     ChP = _pad4(Ch)
                     Gall = alloc_act(N, Mo, K * ChP, dev)
                     gconv_fwd([dict(x=dz, csr=None, w=(W, 0, 1, Fout))], Gall, deinterleave=K, F=K * Ch)
-                    dx, first = None, True
-                    for k in range(K):
-                        Gk = Gall[:, :, k * ChP:k * ChP + Ch]
-                        if ops.bwd[k].identity:
-                            if first:
-                                dx = Gk
-                            else:
-                                dx.add_(Gk)
-                        elif first:
-                            dx = alloc_act(N, Mi, Ch, dev)
-                            spmm(Gk, ops.bwd[k], y=dx)
-                        else:
-                            if dx.shape[1] != Mi:      # identity block came first on a pooled layer: cannot happen (Mo < Mi)
-                                raise AssertionError("operator shapes")
-                            spmm(Gk, ops.bwd[k], z=dx, beta=1.0, y=dx)
-                        first = False
+                    dx = spmm_multi([Gall[:, :, k * ChP:k * ChP + Ch] for k in range(K)], [ops.bwd[k] for k in range(K)], sum=True)
                 elif contract_first:
                     # G_k = dz W_k^T at the Mo output rows, then dx = sum_k S_k^T G_k
                     first = True
@@ -624,13 +651,17 @@ class ChebConvFn(torch.autograd.Function):
                         first = False
                 else:
                     # T_k = S_k^T dz at the Mi input rows, then one GEMM over all sources
-                    ent = []
-                    for k in range(K):
-                        Tk = dz if ops.bwd[k].identity else spmm(dz, ops.bwd[k])
-                        ent.append(dict(x=Tk, csr=None, w=wT(k)))
+                    srcs = [(dz, ops.bwd[k]) for k in range(K)] + ([(g, ops.bwd[0])] if W_aff is not None else [])
+                    todo = [i for i, (_, c) in enumerate(srcs) if not c.identity]
+                    Ts = [t for t, _ in srcs]
+                    if len(todo) == 1:
+                        Ts[todo[0]] = spmm(srcs[todo[0]][0], srcs[todo[0]][1])
+                    elif todo:                         # every S^T application of this layer in one launch
+                        for i, ti in zip(todo, spmm_multi([srcs[i][0] for i in todo], [srcs[i][1] for i in todo])):
+                            Ts[i] = ti
+                    ent = [dict(x=Ts[k], csr=None, w=wT(k)) for k in range(K)]
                     if W_aff is not None:
-                        Ta = g if ops.bwd[0].identity else spmm(g, ops.bwd[0])
-                        ent.append(dict(x=Ta, csr=None, w=waT))
+                        ent.append(dict(x=Ts[K], csr=None, w=waT))
                     gconv_fwd(ent, dx)
         if Co and need_co:
             dco = reduce_cond(gfull[:, :, Fout:])

@@ -210,6 +210,27 @@ int cape_spmm(const float *x, int64_t x_sample_stride, int32_t ldx, const int32_
               int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t C,
               void *stream);
 
+/*
+ * Several operator applications in one launch (all operators have Mo rows, all operands C channels):
+ *   sum = 0:  terms[k].y = S_k x_k for every k   (X_k = S_k x of one layer; T_k = S_k^T dz of its data gradient)
+ *   sum = 1:  y = sum_k S_k x_k                  (dx = sum_k S_k^T G_k)
+ * A term with rowptr == NULL is the identity (its input then has Mo rows).  y / terms[k].y must not alias an input.
+ */
+#define CAPE_MAX_SPMM_TERMS 4
+typedef struct cape_spmm_term {
+    const float *x;
+    int64_t x_sample_stride;
+    int32_t ldx;
+    const int32_t *rowptr;
+    const int32_t *colidx;
+    const float *vals;
+    float *y;
+    int64_t y_sample_stride;
+    int32_t ldy;
+} cape_spmm_term_t;
+int cape_spmm_multi(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, float *y, int64_t y_sample_stride,
+                    int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream);
+
 /* y = act(x + bias) over [N, M, C] views (y may alias x). */
 int cape_bias_act_fwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *bias,
                       int32_t bias_mode, int32_t act, float *y, int64_t y_sample_stride,

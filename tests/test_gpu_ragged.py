@@ -215,3 +215,26 @@ def test_fc_wide(N, kin, out, act):
     assert rel(hW.grad.cpu().numpy(), x.T @ dz) < TOL
     assert rel(hb.grad.cpu().numpy(), dz.sum(0)) < TOL
     assert rel(hx.grad.cpu().numpy(), dz @ W.T) < 5 * TOL
+
+
+def test_spmm_multi_separate_and_sum():
+    """cape_spmm_multi: several operators in one launch (separate outputs / summed), identity terms, empty rows."""
+    from cape_amd import ops
+    from cape_amd.graph import HostCSR
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    for C in (3, 8, 36):
+        N, Mi, Mo = 3, 61, 47
+        S = [rand_csr(rng, Mo, Mi, 0.1, empty_rows=5, long_row=20) for _ in range(3)]
+        x = rng.standard_normal((N, Mi, C))
+        cs = [ops.DeviceCSR(HostCSR(m), dev) for m in S]
+        outs = ops.spmm_multi([t(x)] * 3, cs)
+        for m, o in zip(S, outs):
+            assert rel(o.cpu().numpy(), np.stack([m @ x[n] for n in range(N)])) < TOL
+        # sum mode with distinct inputs and an identity term (square operators)
+        Sq = [rand_csr(rng, Mi, Mi, 0.1, empty_rows=3) for _ in range(2)]
+        xs = [rng.standard_normal((N, Mi, C)) for _ in range(3)]
+        y = ops.spmm_multi([t(v) for v in xs], [None] + [ops.DeviceCSR(HostCSR(m), dev) for m in Sq], sum=True)
+        want = xs[0] + np.stack([Sq[0] @ xs[1][n] + Sq[1] @ xs[2][n] for n in range(N)])
+        assert rel(y.cpu().numpy(), want) < TOL
