@@ -796,26 +796,19 @@ class CAPE(base_model):
         loss_g = out['total_no_gan']
         if with_gan:
             smooth = 0.1
-            # G path: gradient flows through D into G only (D variables frozen on this path)
-            frozen = {n: self._vars[n] for n in self._d_names}
-            try:
-                for n in self._d_names:
-                    self._vars[n] = frozen[n].detach()
-                d_fake_for_g = self.discriminator(x_hat, y_g, y2_g)
-            finally:
-                for n in self._d_names:
-                    self._vars[n] = frozen[n]
-            out['gan_g'] = self._bce(d_fake_for_g, 1 - smooth)
+            # ONE discriminator pass over the generated batch serves both losses (the reference builds D(fake) once,
+            # lib/models.py:299-302): loss_g is differentiated w.r.t. the generator/condition variables only and
+            # loss_d w.r.t. the discriminator variables only (backward_to_flat), so neither gradient leaks.
+            d_fake = self.discriminator(x_hat, y_g, y2_g)
+            out['gan_g'] = self._bce(d_fake, 1 - smooth)
             loss_g = loss_g + out['gan_g'] * self.lambda_gan
-            # D path: real batch + detached fake batch
             y_d, y2_d = self._conditions(cond_d, cond2_d)
             if self.bug_compat:
                 with torch.no_grad():
                     d_real = self.discriminator(data_d, y_d, y2_d)
-                    d_fake = d_fake_for_g.detach()
+                d_fake = d_fake.detach()
             else:
                 d_real = self.discriminator(data_d, y_d.detach(), y2_d.detach())
-                d_fake = self.discriminator(x_hat.detach(), y_g.detach(), y2_g.detach())
             out['gan_d'] = self._bce(d_real, 1 - smooth) + self._bce(d_fake, smooth)
             out['loss_d'] = out['gan_d'] * self.lambda_gan
         out['loss_g'] = loss_g
@@ -838,10 +831,10 @@ class CAPE(base_model):
             grads_g = torch.autograd.grad(out['loss_g'], g_params, allow_unused=True)
             grads_d = [p.detach() for p in d_params]          # quirk C2: the WEIGHTS are clipped and applied
         else:
-            grads = torch.autograd.grad([out['loss_g'], out['loss_d']], g_params + d_params,
-                                        grad_outputs=[one, one],
-                                        allow_unused=True)
-            grads_g, grads_d = grads[:len(g_params)], grads[len(g_params):]
+            # two sweeps over the shared D(fake) graph: the first needs only data gradients inside D, the second only
+            # reaches the discriminator variables
+            grads_g = torch.autograd.grad(out['loss_g'], g_params, grad_outputs=one, retain_graph=True, allow_unused=True)
+            grads_d = torch.autograd.grad(out['loss_d'], d_params, grad_outputs=one, allow_unused=True)
         ops.join_side_stream()
         self.store_grads('g', grads_g)
         self._add_reg_grads()

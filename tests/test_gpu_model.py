@@ -203,7 +203,11 @@ def test_train_step_matches_manual_update(mesh_ops):
     out = model.forward_losses(*args, eps=t(eps))                       # reg inside the loss (autograd path)
     names = model._g_names + model._d_names
     params = [model._vars[n] for n in names]
-    grads = torch.autograd.grad([out['loss_g'], out['loss_d']], params, allow_unused=True)
+    # the reference differentiates loss_g w.r.t. the generator/condition variables and loss_d w.r.t. the discriminator
+    # variables (lib/models.py:447-467); D(fake) is one shared sub-graph, so the two must be taken separately
+    ng = len(model._g_names)
+    grads = (torch.autograd.grad(out['loss_g'], params[:ng], retain_graph=True, allow_unused=True)
+             + torch.autograd.grad(out['loss_d'], params[ng:], allow_unused=True))
     before = {n: p.detach().clone() for n, p in zip(names, params)}
     expect = {}
     for grp, gn, lr in (('g', model._g_names, model.lr_g), ('d', model._d_names, model.lr_d)):
