@@ -93,10 +93,12 @@ __global__ __launch_bounds__(256, 2) void gemm_plain_kernel(GconvParams p) {
     float4 ra[PA], rb[PB], rb2[DUAL ? PB : 1];
     bool s_cok = false, s_has2 = false;       // of the chunk held in ra/rb
     unsigned s_kok = 0;
+    int s_nv = 0;
 
     auto load_regs = [&]() {
         const int c = l_c0 + 4 * q;
         s_cok = c < l_C;
+        s_nv = l_C - c;                    // valid lanes of this thread's activation float4 (row-padded sources: C % 4 != 0)
         const int cc = s_cok ? c : 0;
         s_has2 = DUAL && (l_w2 != nullptr);
 #pragma unroll
@@ -138,8 +140,11 @@ __global__ __launch_bounds__(256, 2) void gemm_plain_kernel(GconvParams p) {
         float *sA = smem;
         float *sB = sA + A_SZ;
 #pragma unroll
-        for (int i = 0; i < PA; ++i)
-            *reinterpret_cast<float4 *>(&sA[(t8 + 32 * i) * GP_LD + 4 * q]) = zsel(ra[i], s_cok);
+        for (int i = 0; i < PA; ++i) {
+            float4 o = ra[i];
+            o.x = s_nv > 0 ? o.x : 0.f; o.y = s_nv > 1 ? o.y : 0.f; o.z = s_nv > 2 ? o.z : 0.f; o.w = s_nv > 3 ? o.w : 0.f;
+            *reinterpret_cast<float4 *>(&sA[(t8 + 32 * i) * GP_LD + 4 * q]) = o;
+        }
         if (BKC) {
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
@@ -583,8 +588,9 @@ inline int gp_weight_layout(const GconvParams &p, bool dual) {
     auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     for (int i = 0; i < p.nsrc; ++i) {
         const SrcDev &S = p.s[i];
-        if (S.rp || !S.vec || (S.C & 3) || !al16(S.w)) return -1;
-        kc = kc && S.wrs == 1 && (S.wcs & 3) == 0 && S.wcs < (1LL << 20);
+        if (S.rp || !S.vec || (((S.C + 3) & ~3) > S.ldx) || !al16(S.w)) return -1;
+        // contraction-contiguous weight rows are read as float4 along the contraction: whole float4s only
+        kc = kc && (S.C & 3) == 0 && S.wrs == 1 && (S.wcs & 3) == 0 && S.wcs < (1LL << 20);
         nc = nc && S.wcs == 1 && (S.wrs & 3) == 0 && (p.F & 3) == 0;
         if (dual && S.w2) {
             if (!al16(S.w2)) return -1;
