@@ -204,9 +204,10 @@ def main():
         "value": round(args.batch * world * args.steps / elapsed, 2), "unit": "meshes/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "CAPE-affineconv_nz64 Mesh-CVAE%s: fwd+bwd+clip+momentum update, batch %d per GPU, "
-                               "6890-vertex SMPL hierarchy (BASELINE configs[2])"
-                               % (" + mesh-patch discriminator (adversarial step)" if args.gan else "", args.batch),
+        "config": {"workload": "%s Mesh-CVAE%s: fwd+bwd+clip+momentum update, batch %d per GPU, "
+                               "6890-vertex SMPL hierarchy%s"
+                               % (args.config.replace("_pose32_clotype32_male", ""), " + mesh-patch discriminator (adversarial step)" if args.gan else "",
+                                  args.batch, " (BASELINE configs[2])" if args.config.startswith("CAPE-affineconv_nz64") else ""),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "graph_replay": runner._gA is not None,
                    "final_loss_g": loss},
         "roofline": roof,
