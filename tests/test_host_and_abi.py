@@ -119,3 +119,42 @@ def test_build_entry_point_runs():
     version the library reports must be the header's."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_forward_plan_query_is_pure_host_logic():
+    """cape_gconv_fwd_plan / cape_gconv_dw_workspace_bytes run without a GPU: kernel family and tile selection."""
+    import ctypes as C
+    from cape_amd import _lib
+    lib = _lib.lib
+
+    def srcs(specs):
+        arr = (_lib.CapeSrc * len(specs))()
+        for s, (Cn, ldx, gather, w_rs, w_cs, base) in zip(arr, specs):
+            s.x, s.x_sample_stride, s.ldx, s.C = base, 6890 * ldx, ldx, Cn
+            s.rowptr = s.colidx = s.vals = (0x2000 if gather else None)
+            s.w, s.w_rs, s.w_cs = 0x10000, w_rs, w_cs
+            s.w2, s.w2_rs, s.w2_cs = None, 0, 0
+        return arr
+
+    def plan(specs, N, Mo, F):
+        out = (C.c_int32 * 4)()
+        assert lib.cape_gconv_fwd_plan(srcs(specs), len(specs), N, Mo, F, out) == 0
+        return list(out)
+
+    # plain aligned sources, forward weight layout (rows c*K+k of [C*K, F], F contiguous) -> pipelined kernel, 64x64
+    assert plan([(64, 64, False, 2 * 128, 1, 0x4000), (64, 64, False, 2 * 128, 1, 0x8000)], 16, 862, 128) == [1, 64, 64, 0]
+    # data-gradient layout (contraction contiguous)
+    assert plan([(128, 128, False, 1, 2 * 128, 0x4000)], 16, 862, 64)[:2] == [1, 64] and \
+        plan([(128, 128, False, 1, 2 * 128, 0x4000)], 16, 862, 64)[3] == 1
+    # narrow output -> 128 x 32 tiles
+    assert plan([(64, 64, False, 32, 1, 0x4000)], 16, 6890, 32) == [1, 128, 32, 0]
+    # gathered source, unaligned base, or unpadded odd channel count -> gather kernel
+    assert plan([(64, 64, True, 128, 1, 0x4000)], 16, 862, 128)[0] == 0
+    assert plan([(64, 64, False, 128, 1, 0x4004)], 16, 862, 128)[0] == 0
+    assert plan([(3, 3, False, 64, 1, 0x4000)], 16, 6890, 64)[0] == 0
+    assert plan([(3, 4, False, 64, 1, 0x4000)], 16, 6890, 64)[0] == 1          # row-padded 3-channel input
+    assert lib.cape_gconv_fwd_plan(None, 1, 16, 862, 128, (C.c_int32 * 4)()) == -1
+    # weight-gradient workspace: positive, grows with the output size, argument errors reported
+    w1 = lib.cape_gconv_dw_workspace_bytes(srcs([(64, 64, False, 64, 1, 0x4000)]), 1, 16, 862, 64)
+    w2 = lib.cape_gconv_dw_workspace_bytes(srcs([(512, 512, False, 512, 1, 0x4000)] * 2), 2, 16, 862, 512)
+    assert 0 < w1 < w2 and lib.cape_gconv_dw_workspace_bytes(None, 1, 16, 862, 64) == -1
