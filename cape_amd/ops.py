@@ -542,7 +542,12 @@ class ChebConvFn(torch.autograd.Function):
         ctx.ops, ctx.act, ctx.bias_mode, ctx.Fout, ctx.Co, ctx.Cc = ops, act, bias_mode, Fout, Co, Cc
         ctx.has_bias, ctx.twopass, ctx.xshape = bias is not None, twopass, (N, Mi, Ch)
         ctx.gW, ctx.gWa, ctx.gB, ctx.banked = gW, gWa, gB, banked
-        ctx.save_for_backward(W, W_aff, mask, yfull if (act != "none" and W_aff is None) else None, cond_in, *xs)
+        # up-sampling layers (Mo > Mi): the data gradient needs T_k = S_k^T dz at the Mi input rows anyway, and
+        # dW_k = X_k^T dz = x^T T_k -- the weight gradient contracts over the COARSE rows (half the flops) and the
+        # fine-level X_k need not be kept for the backward pass at all
+        ctx.coarse_dw = bool(twopass and ops.Mo > Mi and ctx.needs_input_grad[0] and not any(ops.fwd[k].identity for k in range(K)))
+        ctx.save_for_backward(W, W_aff, mask, yfull if (act != "none" and W_aff is None) else None, cond_in,
+                              *([x] if ctx.coarse_dw else xs))
         return yfull
 
     @staticmethod
@@ -581,9 +586,11 @@ class ChebConvFn(torch.autograd.Function):
             dWa = _grad_buffer(W_aff, ctx.gWa)
         with _on_side_stream(dz, g, dW, dWa, *xs):
             ent = []
-            if need_w:
+            if ctx.coarse_dw:
+                pass                                   # computed from the T_k below
+            elif need_w:
                 ent += [dict(x=xs[k], csr=csr_of(k), w=(dW, k * Fout, K * Fout, 1)) for k in range(K)]
-            if W_aff is not None and need_wa:
+            if W_aff is not None and need_wa and not ctx.coarse_dw:
                 ent.append(dict(x=xs[0], csr=csr_of(0), w=(dWa, 0, Fout, 1), use_dz2=True))
             if ent:
                 same = (W_aff is None) or (_v(g)[1:] == _v(dz)[1:])
@@ -663,6 +670,15 @@ class ChebConvFn(torch.autograd.Function):
                     if W_aff is not None:
                         ent.append(dict(x=Ts[K], csr=None, w=waT))
                     gconv_fwd(ent, dx)
+                    if ctx.coarse_dw:
+                        # dW_k^T[f, c] = sum_{n, r} T_k[n, r, f] x[n, r, c]: the T_k are the sources, x the gradient operand
+                        wen = []
+                        if need_w:
+                            wen += [dict(x=Ts[k], csr=None, w=(dW, k * Fout, 1, K * Fout)) for k in range(K)]
+                        if W_aff is not None and need_wa:
+                            wen.append(dict(x=Ts[K], csr=None, w=(dWa, 0, 1, Fout)))
+                        if wen:
+                            gconv_dw(wen, xs[0])
         if Co and need_co:
             dco = reduce_cond(gfull[:, :, Fout:])
         return dx, dW, dB, dWa, dci, dco, None, None, None, None, None, None, None, dcoef_out
