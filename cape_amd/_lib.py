@@ -69,6 +69,8 @@ SIGNATURES = {
     "cape_spmm": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _i32, _f32, _p, _i64, _i32, _f32, _p, _i64, _i32,
                             _i32, _i32, _i32, _p]),
     "cape_spmm_multi": (C.c_int, [C.POINTER(CapeSpmmTerm), _i32, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p]),
+    "cape_spmm_combine": (C.c_int, [C.POINTER(CapeSpmmTerm), _i32, C.c_uint32, C.POINTER(CapeRank), _p, _i32, _i32, _i32, _p, _p,
+                                    _i64, _i32, _i32, _i32, _i32, _p]),
     "cape_bias_act_fwd": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "cape_act_bwd": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "cape_colsum_workspace_bytes": (_i64, [_i32, _i32, _i32]),

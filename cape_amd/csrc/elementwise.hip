@@ -123,6 +123,99 @@ __global__ __launch_bounds__(256) void spmm_multi_kernel(SpmmTerms P, int sum, V
     }
 }
 
+// ---- operator applications AFTER the dense contraction (up-sampling layers) ----------------------------------
+// (S_k x) W_k = S_k (x W_k): on an up-sampling layer the contraction runs on the coarse input rows (half the
+// GEMM work) and this kernel applies the operators to the F-channel products Z_k, adds the rank-1 condition terms
+// and performs the layer epilogue:   single:  y = act(acc1 + bias)      dual:  y = relu(acc1) + acc2, sign bits out
+//   acc1 = sum_{k not in to2} S_k Z_k + sum_{j not in rank_to2} rowscale_j[r] coef[n,j,f];   acc2 likewise.
+struct CombineParams {
+    SpmmTerms P;
+    unsigned to2;
+    int rankR;
+    const float *rowscale;
+    const float *coef;
+    unsigned rank_to2;
+    const float *bias;
+    int bias_mode, act, dual;
+    unsigned *mask;
+    int mask_words;
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void spmm_combine_kernel(CombineParams Q, View y, int N, int Mo, int F) {
+    const int W = VEC ? 4 : 1;
+    const int cq = (F + W - 1) / W;
+    const long long total = (long long)N * Mo * cq;
+    const long long span = ((total + 255) / 256) * 256;      // whole blocks: the mask shuffles need every lane
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < span; i += (long long)gridDim.x * 256) {
+        const bool live = i < total;
+        const long long ii = live ? i : total - 1;
+        const int q = (int)(ii % cq);
+        const long long nr = ii / cq;
+        const int r = (int)(nr % Mo);
+        const int n = (int)(nr / Mo);
+        const int c = q * W;
+        float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < Q.P.n; ++k) {
+            const SpmmTerms::T &T = Q.P.t[k];
+            const float *xb = T.x + (long long)n * T.xs + c;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!T.rp) {
+                if (VEC) acc = *reinterpret_cast<const float4 *>(xb + (long long)r * T.ldx);
+                else acc.x = xb[(long long)r * T.ldx];
+            } else {
+                const int e1 = T.rp[r + 1];
+                for (int e = T.rp[r]; e < e1; ++e) {
+                    const float v = T.va[e];
+                    if (VEC) {
+                        const float4 xv = *reinterpret_cast<const float4 *>(xb + (long long)T.ci[e] * T.ldx);
+                        acc.x = fmaf(v, xv.x, acc.x); acc.y = fmaf(v, xv.y, acc.y);
+                        acc.z = fmaf(v, xv.z, acc.z); acc.w = fmaf(v, xv.w, acc.w);
+                    } else {
+                        acc.x = fmaf(v, xb[(long long)T.ci[e] * T.ldx], acc.x);
+                    }
+                }
+            }
+            float *dst = ((Q.to2 >> k) & 1u) ? a2 : a1;
+            dst[0] += acc.x; dst[1] += acc.y; dst[2] += acc.z; dst[3] += acc.w;
+        }
+        for (int j = 0; j < Q.rankR; ++j) {
+            const float rs = Q.rowscale[(long long)j * Mo + r];
+            float *dst = ((Q.rank_to2 >> j) & 1u) ? a2 : a1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < W && c + u < F) dst[u] = fmaf(rs, Q.coef[((long long)n * Q.rankR + j) * F + c + u], dst[u]);
+        }
+        float o[4];
+        unsigned bits = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v = a1[u];
+            if (Q.dual) {
+                if (v > 0.f) bits |= 1u << u;
+                v = (v > 0.f ? v : 0.f) + a2[u];
+            } else {
+                if (u < W && c + u < F) {
+                    if (Q.bias_mode == CAPE_BIAS_CHANNEL) v += Q.bias[c + u];
+                    else if (Q.bias_mode == CAPE_BIAS_VERTEX) v += Q.bias[(long long)r * F + c + u];
+                }
+                v = cape_act(v, Q.act);
+            }
+            o[u] = v;
+        }
+        if (Q.mask) {
+            // VEC only, F % 32 == 0: the 8 lanes of one 32-channel word are consecutive and aligned
+            unsigned w = live ? (bits << (4 * (q & 7))) : 0u;
+            w |= __shfl_xor(w, 1); w |= __shfl_xor(w, 2); w |= __shfl_xor(w, 4);
+            if (live && (q & 7) == 0) Q.mask[((long long)n * Mo + r) * Q.mask_words + (q >> 3)] = w;
+        }
+        if (live) {
+            if (VEC) *reinterpret_cast<float4 *>(y.p + (long long)n * y.ss + (long long)r * y.ld + c) = make_float4(o[0], o[1], o[2], o[3]);
+            else y.p[(long long)n * y.ss + (long long)r * y.ld + c] = o[0];
+        }
+    }
+}
+
 // Rows of the mesh operators have 1..16 entries (3-11 for L~, up to ~16 for composed T_k(L~)U).  With a
 // compile-time bound the entry loop unrolls completely: every (index, value) pair is loaded first, then all
 // gathers are in flight together -- two dependent memory round trips per thread instead of one per entry.
@@ -623,6 +716,43 @@ extern "C" int cape_spmm_multi(const cape_spmm_term_t *terms, int32_t nterms, in
     hipStream_t st = (hipStream_t)stream;
     if (vec) CAPE_LAUNCH(spmm_multi_kernel<true>, dim3(grid_for((long long)N * Mo * (C / 4))), dim3(256), 0, st, P, sum, yv, N, Mo, C);
     else CAPE_LAUNCH(spmm_multi_kernel<false>, dim3(grid_for((long long)N * Mo * C)), dim3(256), 0, st, P, sum, yv, N, Mo, C);
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}
+
+extern "C" int cape_spmm_combine(const cape_spmm_term_t *terms, int32_t nterms, uint32_t to_acc2, const cape_rank_t *rank,
+                                 const float *bias, int32_t bias_mode, int32_t act, int32_t dual, uint32_t *mask_out, float *y,
+                                 int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t F, void *stream) {
+    if (!terms || nterms < 1 || nterms > CAPE_MAX_SPMM_TERMS || !y || N < 1 || Mo < 1 || F < 1 || ldy < F) return CAPE_EINVAL;
+    if (bias_mode != CAPE_BIAS_NONE && !bias) return CAPE_EINVAL;
+    if (act < CAPE_ACT_NONE || act > CAPE_ACT_TANH) return CAPE_EINVAL;
+    if (dual && (bias_mode != CAPE_BIAS_NONE || act != CAPE_ACT_NONE)) return CAPE_EINVAL;
+    if (!dual && (to_acc2 || mask_out)) return CAPE_EINVAL;
+    CombineParams Q;
+    Q.P.n = nterms;
+    bool vec = aligned4(y, y_sample_stride, ldy, F);
+    for (int k = 0; k < nterms; ++k) {
+        const cape_spmm_term_t &t = terms[k];
+        if (!t.x || t.ldx < F) return CAPE_EINVAL;
+        if (t.rowptr && (!t.colidx || !t.vals)) return CAPE_EINVAL;
+        Q.P.t[k].x = t.x; Q.P.t[k].xs = t.x_sample_stride; Q.P.t[k].ldx = t.ldx;
+        Q.P.t[k].rp = t.rowptr; Q.P.t[k].ci = t.colidx; Q.P.t[k].va = t.vals;
+        Q.P.t[k].y = nullptr; Q.P.t[k].ys = 0; Q.P.t[k].ldy = 0;
+        vec = vec && aligned4(t.x, t.x_sample_stride, t.ldx, F);
+    }
+    Q.to2 = to_acc2;
+    Q.rankR = 0; Q.rowscale = nullptr; Q.coef = nullptr; Q.rank_to2 = 0;
+    if (rank && rank->R > 0) {
+        if (rank->R > CAPE_MAX_SRC || !rank->rowscale || !rank->coef || (rank->to_acc2 && !dual)) return CAPE_EINVAL;
+        Q.rankR = rank->R; Q.rowscale = rank->rowscale; Q.coef = rank->coef; Q.rank_to2 = rank->to_acc2;
+    }
+    Q.bias = bias; Q.bias_mode = bias ? bias_mode : CAPE_BIAS_NONE; Q.act = act; Q.dual = dual ? 1 : 0;
+    Q.mask = mask_out; Q.mask_words = (F + 31) / 32;
+    if (mask_out && (!vec || (F & 31))) return CAPE_EINVAL;      // sign words are assembled from 8 float4 lanes
+    View yv{y, y_sample_stride, ldy};
+    hipStream_t st = (hipStream_t)stream;
+    if (vec) CAPE_LAUNCH(spmm_combine_kernel<true>, dim3(grid_for((long long)N * Mo * (F / 4))), dim3(256), 0, st, Q, yv, N, Mo, F);
+    else CAPE_LAUNCH(spmm_combine_kernel<false>, dim3(grid_for((long long)N * Mo * F)), dim3(256), 0, st, Q, yv, N, Mo, F);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }

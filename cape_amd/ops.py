@@ -287,6 +287,35 @@ def spmm_multi(xs, csrs, sum=False):
     return y if sum else outs
 
 
+def spmm_combine(xs, csrs, y, to_acc2=0, rank=None, bias=None, bias_mode=_lib.BIAS_NONE, act="none", dual=False, mask=None):
+    """y = epilogue(sum_k S_k x_k [+ rank-1 terms]): the operators applied after the dense contraction (cape_spmm_combine)."""
+    _lib.require_gpu()
+    n = len(xs)
+    N, Mo, F = y.shape
+    arr = (_lib.CapeSpmmTerm * n)()
+    for k in range(n):
+        t = arr[k]
+        xp, t.x_sample_stride, t.ldx = _v(xs[k])
+        t.x = xp.value
+        assert xs[k].shape[2] == F
+        if csrs[k] is None or csrs[k].identity:
+            t.rowptr = t.colidx = t.vals = None
+        else:
+            assert csrs[k].shape[0] == Mo and csrs[k].shape[1] == xs[k].shape[1]
+            t.rowptr, t.colidx, t.vals = csrs[k].rowptr_t.data_ptr(), csrs[k].colidx_t.data_ptr(), csrs[k].vals_t.data_ptr()
+        t.y, t.y_sample_stride, t.ldy = None, 0, 0
+    rk = None
+    if rank is not None:
+        rowscale, coef, to2 = rank
+        assert coef.is_contiguous() and rowscale.is_contiguous() and coef.shape[0] == N and coef.shape[2] == F
+        rk = _lib.CapeRank(int(coef.shape[1]), rowscale.data_ptr(), coef.data_ptr(), int(to2))
+    yp, ys, yl = _v(y)
+    check(lib.cape_spmm_combine(arr, n, int(to_acc2), C.byref(rk) if rk is not None else None, _ptr(bias),
+                                bias_mode if bias is not None else _lib.BIAS_NONE, _lib.ACT[act], 1 if dual else 0, _ptr(mask),
+                                yp, ys, yl, N, Mo, F, _stream()), "cape_spmm_combine")
+    return y
+
+
 def bias_act_fwd(x, bias, bias_mode, act, y=None):
     _lib.require_gpu()
     N, M, Cn = x.shape
@@ -501,6 +530,14 @@ class ChebConvFn(torch.autograd.Function):
         yfull = alloc_act(N, ops.Mo, Fout + Co, x.device)
         y = yfull[:, :, :Fout]
         twopass = (mode == "twopass")
+        # up-sampling layer in two-pass mode: contract on the coarse rows, apply the operators to the products
+        # (only when backward will not ask for the fine-level X_k: inference, or the coarse weight-gradient form)
+        any_grad = any(ctx.needs_input_grad[i] for i in (0, 1, 2, 3, 4))
+        coarse = bool(twopass and ops.Mo > Mi and not any(ops.fwd[k].identity for k in range(K))
+                      and (W_aff is None or Fout % 32 == 0) and Fout % 4 == 0 and (ctx.needs_input_grad[0] or not any_grad))
+        if coarse:
+            return ChebConvFn._forward_coarse(ctx, x, W, bias, W_aff, cond_in, cond_out, ops, act, bias_mode, gW, gWa, gB, coef,
+                                              banked, Cc, yfull, y)
         xs = [x] * K
         if twopass:
             ks = [k for k in range(K) if not ops.fwd[k].identity]
@@ -548,6 +585,52 @@ class ChebConvFn(torch.autograd.Function):
         ctx.coarse_dw = bool(twopass and ops.Mo > Mi and ctx.needs_input_grad[0] and not any(ops.fwd[k].identity for k in range(K)))
         ctx.save_for_backward(W, W_aff, mask, yfull if (act != "none" and W_aff is None) else None, cond_in,
                               *([x] if ctx.coarse_dw else xs))
+        return yfull
+
+    @staticmethod
+    def _forward_coarse(ctx, x, W, bias, W_aff, cond_in, cond_out, ops, act, bias_mode, gW, gWa, gB, coef, banked, Cc, yfull, y):
+        """(S_k x) W_k = S_k (x W_k): one GEMM on the Mi input rows for all K orders (the feature rows of W viewed
+        as [Ch, K*Fout]), one for the affine weights, then cape_spmm_combine applies the operators, the rank-1 terms
+        and the epilogue.  Backward is the ordinary one in its coarse weight-gradient form (needs only x)."""
+        N, Mi, Ch = x.shape
+        K, Fout = ops.K, W.shape[1]
+        Z = alloc_act(N, Mi, K * Fout, x.device)
+        gconv_fwd([dict(x=x, csr=None, w=(W, 0, K * Fout, 1))], Z)
+        zs = [Z[:, :, k * Fout:(k + 1) * Fout] for k in range(K)]
+        csrs = [ops.fwd[k] for k in range(K)]
+        to2 = 0
+        if W_aff is not None:
+            Za = alloc_act(N, Mi, Fout, x.device)
+            gconv_fwd([dict(x=x, csr=None, w=(W_aff, 0, Fout, 1))], Za)
+            zs.append(Za)
+            csrs.append(ops.fwd[0])
+            to2 = 1 << K
+        rank = None
+        if coef is not None:
+            assert coef.is_contiguous() and coef.shape == (N, K + (1 if W_aff is not None else 0), Fout)
+            rank = ((ops.rowscale if W_aff is not None else ops.rowscale[:K]).contiguous(), coef,
+                    (1 << K) if W_aff is not None else 0)
+        elif Cc:
+            cond_in = cond_in.contiguous()
+            cf = torch.mm(cond_in, W[Ch * K:].view(Cc, K * Fout)).view(N, K, Fout)
+            if W_aff is not None:
+                cf = torch.cat([cf, torch.mm(cond_in, W_aff[Ch:]).view(N, 1, Fout)], dim=1)
+            rank = ((ops.rowscale if W_aff is not None else ops.rowscale[:K]).contiguous(), cf.contiguous(),
+                    (1 << K) if W_aff is not None else 0)
+        mask = None
+        if W_aff is not None:
+            mask = torch.empty((N, ops.Mo, (Fout + 31) // 32), device=x.device, dtype=torch.int32)
+            spmm_combine(zs, csrs, y, to_acc2=to2, rank=rank, dual=True, mask=mask)
+        else:
+            spmm_combine(zs, csrs, y, rank=rank, bias=bias, bias_mode=bias_mode, act=act)
+        Co = 0 if cond_out is None else cond_out.shape[1]
+        if Co:
+            fill_cond(cond_out.contiguous(), yfull[:, :, Fout:])
+        ctx.ops, ctx.act, ctx.bias_mode, ctx.Fout, ctx.Co, ctx.Cc = ops, act, bias_mode, Fout, Co, Cc
+        ctx.has_bias, ctx.twopass, ctx.xshape = bias is not None, True, (N, Mi, Ch)
+        ctx.gW, ctx.gWa, ctx.gB, ctx.banked = gW, gWa, gB, banked
+        ctx.coarse_dw = True
+        ctx.save_for_backward(W, W_aff, mask, yfull if (act != "none" and W_aff is None) else None, cond_in, x)
         return yfull
 
     @staticmethod

@@ -231,6 +231,17 @@ typedef struct cape_spmm_term {
 int cape_spmm_multi(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, float *y, int64_t y_sample_stride,
                     int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream);
 
+/*
+ * Operators applied AFTER the dense contraction, with the layer epilogue -- for up-sampling layers, where
+ * (S_k x) W_k = S_k (x W_k) lets the contraction run on the coarse input rows:
+ *   acc1 = sum_{k: bit k of to_acc2 clear} S_k x_k + rank-1 terms (bits of rank->to_acc2 clear);  acc2 = the others
+ *   dual = 0:  y = act(acc1 + bias)          dual = 1:  y = relu(acc1) + acc2, sign bits of acc1 to mask_out
+ * (same epilogue semantics as cape_gconv_fwd; mask_out needs F % 32 == 0 and 16-byte aligned operands).
+ */
+int cape_spmm_combine(const cape_spmm_term_t *terms, int32_t nterms, uint32_t to_acc2, const cape_rank_t *rank,
+                      const float *bias, int32_t bias_mode, int32_t act, int32_t dual, uint32_t *mask_out, float *y,
+                      int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t F, void *stream);
+
 /* y = act(x + bias) over [N, M, C] views (y may alias x). */
 int cape_bias_act_fwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *bias,
                       int32_t bias_mode, int32_t act, float *y, int64_t y_sample_stride,
