@@ -238,3 +238,40 @@ def test_spmm_multi_separate_and_sum():
         y = ops.spmm_multi([t(v) for v in xs], [None] + [ops.DeviceCSR(HostCSR(m), dev) for m in Sq], sum=True)
         want = xs[0] + np.stack([Sq[0] @ xs[1][n] + Sq[1] @ xs[2][n] for n in range(N)])
         assert rel(y.cpu().numpy(), want) < TOL
+
+
+@pytest.mark.parametrize("dual", [False, True])
+def test_spmm_combine_epilogues(dual):
+    """cape_spmm_combine: operators applied after the contraction, rank-1 terms, single and DUAL epilogues."""
+    from cape_amd import ops
+    from cape_amd.graph import HostCSR
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(11 + dual)
+    N, Mi, Mo, F = 3, 53, 101, 64 if dual else 36
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    S = [rand_csr(rng, Mo, Mi, 0.08, empty_rows=4, long_row=16) for _ in range(3)]
+    Z = [rng.standard_normal((N, Mi, F)) for _ in range(3)]
+    R = 3
+    rowscale, coef = rng.standard_normal((R, Mo)), rng.standard_normal((N, R, F))
+    cs = [ops.DeviceCSR(HostCSR(m), dev) for m in S]
+    app = lambda m, z: np.stack([m @ z[n] for n in range(N)])
+    r1 = lambda j: rowscale[j][None, :, None] * coef[:, j][:, None, :]
+    y = ops.alloc_act(N, Mo, F, dev)
+    if dual:
+        mask = torch.zeros((N, Mo, F // 32), device=dev, dtype=torch.int32)
+        ops.spmm_combine([t(z) for z in Z], cs, y, to_acc2=0b100, rank=(t(rowscale).contiguous(), t(coef).contiguous(), 0b100),
+                         dual=True, mask=mask)
+        a1 = app(S[0], Z[0]) + app(S[1], Z[1]) + r1(0) + r1(1)
+        a2 = app(S[2], Z[2]) + r1(2)
+        want = np.maximum(a1, 0) + a2
+        bits = ((mask.cpu().numpy().astype(np.int64)[..., None] >> np.arange(32)) & 1).reshape(N, Mo, -1)[:, :, :F]
+        safe = np.abs(a1) > 1e-4 * np.abs(a1).max()
+        assert np.array_equal(bits[safe] == 1, (a1 > 0)[safe])
+    else:
+        b = rng.standard_normal((Mo, F))
+        ops.spmm_combine([t(z) for z in Z], cs, y, rank=(t(rowscale).contiguous(), t(coef).contiguous(), 0), bias=t(b),
+                         bias_mode=2, act="leaky")
+        z = sum(app(S[k], Z[k]) + r1(k) for k in range(3)) + b
+        want = np.where(z > 0, z, 0.2 * z)
+    torch.cuda.synchronize()
+    assert rel(y.cpu().numpy(), want) < TOL
