@@ -150,7 +150,6 @@ def main():
     ap.add_argument('--config', default='CAPE-affineconv_nz64_pose32_clotype32_male')
     ap.add_argument('--gan', action='store_true', help='include the discriminator passes/update (adversarial step)')
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--side-stream', action='store_true', help='issue weight-gradient kernels on a parallel graph branch (measured slower)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -171,8 +170,7 @@ def main():
         for grp in ('g', 'd'):
             cdist.broadcast_flat(model._opt_state[grp]['flat'])
         hook = cdist.GradAverager()
-    runner = GraphedTrainStep(model, with_gan=args.gan, grad_hook=hook, use_graph=not args.no_graph,
-                              side_stream=args.side_stream)
+    runner = GraphedTrainStep(model, with_gan=args.gan, grad_hook=hook, use_graph=not args.no_graph)
     runner.load_batch(**synthetic_batch(model, seed=1234 + rank))
     torch.cuda.synchronize()
     runner.capture()

@@ -598,8 +598,7 @@ struct DwPlan {
 
 inline void plan_dw_splits(int N, int Mo, DwPlan &pl) {
     // aim for ~512 workgroups: split the vertex dimension down to 128 rows, then the batch into groups
-    static const int dw_wgs = getenv("CAPE_DW_WGS") ? atoi(getenv("CAPE_DW_WGS")) : 512;
-    int S = (dw_wgs + pl.ntiles - 1) / pl.ntiles;
+    int S = (512 + pl.ntiles - 1) / pl.ntiles;
     if (S < 1) S = 1;
     int maxr = (Mo + 127) / 128;
     int rsplit = S < maxr ? S : maxr;
@@ -635,8 +634,6 @@ inline void plan_dw(const cape_src_t *srcs, int nsrc, int N, int Mo, int F, DwPl
 // the narrow layers (3 x 32 channels at 6890 vertices) run as ONE tile that reads dz once instead of three
 // half-empty tiles; with dz2 in play every source starts on a tile boundary (a tile has one gradient operand).
 inline void plan_dw_plain(const cape_src_t *srcs, int nsrc, int N, int Mo, int F, bool pack, DwPlan &pl) {
-    static const int dw_ct = getenv("CAPE_DW_CT") ? atoi(getenv("CAPE_DW_CT")) : 0;
-    static const int dw_ft = getenv("CAPE_DW_FT") ? atoi(getenv("CAPE_DW_FT")) : 0;
     int sumC = 0, maxC = 0;
     pl.slab = 0;
     for (int i = 0; i < nsrc; ++i) {
@@ -648,7 +645,6 @@ inline void plan_dw_plain(const cape_src_t *srcs, int nsrc, int N, int Mo, int F
     const int n128 = (span + 127) / 128, n64 = (span + 63) / 64;
     pl.ft = (F <= 32) ? 32 : (F <= 64) ? 64 : 128;
     pl.ct = (pl.ft == 32 || n64 == 2 * n128) ? 128 : 64;      // 64-wide tiles only where they save MFMA work
-    if (dw_ct && dw_ft && !(dw_ft == 32 && dw_ct != 128)) { pl.ct = dw_ct; pl.ft = dw_ft; }
     pl.ftiles = (F + pl.ft - 1) / pl.ft;
     int v = 0;
     for (int i = 0; i < nsrc; ++i) {
@@ -804,14 +800,13 @@ extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *
                        (!dz2 || (reinterpret_cast<uintptr_t>(dz2) & 15) == 0);
     const bool plain = dwp_on && dzvec && (((F + 3) & ~3) <= lddz) && dw_srcs_plain(srcs, nsrc);
     DwPlan pl;
-    static const int dw_pack = getenv("CAPE_DW_PACK") ? atoi(getenv("CAPE_DW_PACK")) : 1;
     int sumC = 0;
     for (int i = 0; i < nsrc; ++i) sumC += srcs[i].C;
     // packing pays where several sources fit ONE tile (narrow layers of the fine mesh levels)
     // (and the output is narrow: with F > 64 the single packed tile over-splits the rows -- measured 1.8x slower)
     bool c4 = true;
     for (int i = 0; i < nsrc; ++i) c4 = c4 && (srcs[i].C & 3) == 0;
-    const bool packed = plain && c4 && dw_pack && !(dz2 && dz2_mask) && nsrc > 1 && sumC <= 128 && F <= 64;
+    const bool packed = plain && c4 && !(dz2 && dz2_mask) && nsrc > 1 && sumC <= 128 && F <= 64;
     if (packed) plan_dw_plain(srcs, nsrc, N, Mo, F, true, pl);
     else plan_dw(srcs, nsrc, N, Mo, F, pl);
     const long long need = pl.slab * pl.ngroups * pl.rsplit * (long long)sizeof(float);

@@ -823,7 +823,6 @@ class CAPE(base_model):
         one = self._one
         if 'loss_d' not in out:
             grads_g = torch.autograd.grad(out['loss_g'], g_params, grad_outputs=one, allow_unused=True)
-            ops.join_side_stream()
             self.store_grads('g', grads_g)
             self._add_reg_grads()
             return
@@ -835,7 +834,6 @@ class CAPE(base_model):
             # reaches the discriminator variables
             grads_g = torch.autograd.grad(out['loss_g'], g_params, grad_outputs=one, retain_graph=True, allow_unused=True)
             grads_d = torch.autograd.grad(out['loss_d'], d_params, grad_outputs=one, allow_unused=True)
-        ops.join_side_stream()
         self.store_grads('g', grads_g)
         self._add_reg_grads()
         self.store_grads('d', grads_d)

@@ -446,43 +446,6 @@ def rowscale_reduce(dz, rowscale, R):
 
 # --------------------------------------------------------------------------------------------
 # autograd operators
-# --------------------------------------------------------------------------------------------
-# Weight-gradient side stream.  The weight gradients (dW GEMM + split reduction) of a layer depend only on
-# dz and the saved inputs and are consumed by the optimiser; the data-gradient chain is the critical path
-# of the backward pass.  When SIDE_STREAM is set (by the training-step runner) the weight-gradient kernels
-# are issued on it -- inside a captured HIP graph this becomes a parallel branch that fills the CUs the
-# small fine-level kernels and the tile-quantised deep-level GEMMs leave idle.  join_side_stream() must be
-# called before the gradients are read.
-SIDE_STREAM = None
-
-
-class _on_side_stream(object):
-    def __init__(self, *tensors):
-        self.tensors = tensors
-
-    def __enter__(self):
-        self.side = SIDE_STREAM
-        if self.side is None:
-            return self
-        self.main = torch.cuda.current_stream()
-        self.side.wait_stream(self.main)
-        for t in self.tensors:
-            if t is not None:
-                t.record_stream(self.side)
-        self.ctx = torch.cuda.stream(self.side)
-        self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *a):
-        if self.side is not None:
-            self.ctx.__exit__(*a)
-
-
-def join_side_stream():
-    if SIDE_STREAM is not None:
-        torch.cuda.current_stream().wait_stream(SIDE_STREAM)
-
-
 def _grad_buffer(W, view=None):
     """Destination of a weight gradient: the caller-provided view of the flat gradient bucket (the
     kernels then write straight into the bucket and the per-variable copy disappears) or a fresh tensor."""
@@ -667,23 +630,20 @@ class ChebConvFn(torch.autograd.Function):
             dW = _grad_buffer(W, ctx.gW)
         if W_aff is not None and need_wa:
             dWa = _grad_buffer(W_aff, ctx.gWa)
-        with _on_side_stream(dz, g, dW, dWa, *xs):
-            ent = []
-            if ctx.coarse_dw:
-                pass                                   # computed from the T_k below
-            elif need_w:
-                ent += [dict(x=xs[k], csr=csr_of(k), w=(dW, k * Fout, K * Fout, 1)) for k in range(K)]
-            if W_aff is not None and need_wa and not ctx.coarse_dw:
-                ent.append(dict(x=xs[0], csr=csr_of(0), w=(dWa, 0, Fout, 1), use_dz2=True))
-            if ent:
-                same = (W_aff is None) or (_v(g)[1:] == _v(dz)[1:])
-                if same:
-                    gconv_dw(ent, dz, dz2=g if W_aff is not None else None)      # one launch, one reduction
-                else:
-                    gconv_dw([e for e in ent if not e.get("use_dz2")], dz)
-                    gconv_dw([dict(e, use_dz2=False) for e in ent if e.get("use_dz2")], g)
-        # (the rank-1 rows dW[Ch*K:] / dWa[Ch:] written on the main stream below are disjoint from the rows
-        # the side-stream kernels write, so no ordering between the two is needed)
+        ent = []
+        if ctx.coarse_dw:
+            pass                                   # computed from the T_k below
+        elif need_w:
+            ent += [dict(x=xs[k], csr=csr_of(k), w=(dW, k * Fout, K * Fout, 1)) for k in range(K)]
+        if W_aff is not None and need_wa and not ctx.coarse_dw:
+            ent.append(dict(x=xs[0], csr=csr_of(0), w=(dWa, 0, Fout, 1), use_dz2=True))
+        if ent:
+            same = (W_aff is None) or (_v(g)[1:] == _v(dz)[1:])
+            if same:
+                gconv_dw(ent, dz, dz2=g if W_aff is not None else None)      # one launch, one reduction
+            else:
+                gconv_dw([e for e in ent if not e.get("use_dz2")], dz)
+                gconv_dw([dict(e, use_dz2=False) for e in ent if e.get("use_dz2")], g)
         if Cc and ctx.banked:
             dcoef_out = dcoef        # CondCoefFn turns it into the weight-row and condition gradients of all layers
         elif Cc:

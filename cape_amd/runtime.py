@@ -3,7 +3,7 @@ graph and replayed -- the MI355X counterpart of the reference's static ``tf.Grap
 ``sess.run`` (reference lib/models.py:267-351, :905-906).  Shapes are static there too
 (``batch_size`` is baked into the placeholders, :272-282), which is what makes capture legal.
 
-A step is ~150 short kernels; eager launches would be host-bound (>=3 us each), graph replay is
+A step is ~190 short kernels; eager launches would be host-bound (>=3 us each), graph replay is
 one submission.  With more than one rank the step is split at the gradient exchange:
 graph A (fwd + bwd -> flat gradients), eager RCCL all-reduce, graph B (clip + update).
 """
@@ -11,9 +11,8 @@ import torch
 
 
 class GraphedTrainStep(object):
-    def __init__(self, model, with_gan=False, grad_hook=None, use_graph=True, side_stream=False):
+    def __init__(self, model, with_gan=False, grad_hook=None, use_graph=True):
         self.model, self.with_gan, self.grad_hook = model, with_gan, grad_hook
-        self.side = torch.cuda.Stream(device=model.device) if side_stream else None
         self.use_graph = use_graph and model.optimizer != "adam"   # Adam keeps a host-side step counter
         B, d = model.batch_size, model.device
         M, Cn = model.input_num_verts, model.nn_input_channel
@@ -33,14 +32,6 @@ class GraphedTrainStep(object):
 
     # ---- the two halves of a step -------------------------------------------------------------------
     def _fwd_bwd(self):
-        from . import ops
-        ops.SIDE_STREAM = self.side
-        try:
-            self._fwd_bwd_inner()
-        finally:
-            ops.SIDE_STREAM = None
-
-    def _fwd_bwd_inner(self):
         m, b = self.model, self.buf
         if self.with_gan:
             out = m.forward_losses(b['data_g'], b['cond_g'], b['cond2_g'], b['gt'], b['data_d'], b['cond_d'],
