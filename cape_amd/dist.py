@@ -52,6 +52,20 @@ class GradAverager(object):
             flat_grad.div_(self.world)
         return flat_grad
 
+    def start(self, flat_grad):
+        """Asynchronous form: enqueue the sum on the collective stream (it starts once the work queued so far on the
+        current stream is done and then runs beside whatever is queued next); ``finish`` makes the current stream wait
+        for it and completes the mean."""
+        if self.world <= 1:
+            return None
+        return (dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat_grad)
+
+    def finish(self, handle):
+        if handle is not None:
+            work, flat_grad = handle
+            work.wait()
+            flat_grad.div_(self.world)
+
 
 def broadcast_flat(flat, src=0, group=None):
     """Make every rank start from rank ``src``'s variables."""

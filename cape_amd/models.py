@@ -497,6 +497,12 @@ class CAPE(base_model):
             if self.reduce_dim > 0:
                 with self.variable_scope('1x1-conv'):
                     x = self.filter(x, self.Laplacian[-1], self.out_channels[-1] // self.reduce_rate, K=1)
+            if getattr(self, 'split_backward', False) and torch.is_grad_enabled() and x.requires_grad:
+                # two-phase backward (data-parallel overlap, see backward_phase1/2): the graph is cut here, below the
+                # dense layers -- everything downstream of the cut is differentiated first
+                self._enc_feat = x
+                x = x.detach().requires_grad_(True)
+                self._enc_feat_cut = x
             x = x.reshape(x.shape[0], -1)
             with self.variable_scope('fc_mean'):
                 km, bm, gm = self._dense_vars(int(x.shape[-1]), int(self.nz))
@@ -657,8 +663,14 @@ class CAPE(base_model):
             y, y2 = self._conditions(c, c2)
             x_hat, _, _ = self.generator(x, y, y2, eps=torch.zeros((B, int(self.nz)), device=d))
             self.discriminator(x_hat, y, y2)
-        self._g_names = [n for n in self._vars if n.startswith('generator') or
-                         (self.optim_condnet and 'condition' in n)]
+        g_names = [n for n in self._vars if n.startswith('generator') or (self.optim_condnet and 'condition' in n)]
+        # "late" variables: their gradient is only complete once the backward pass has run through the encoder
+        # convolutions (the encoder conv stack and the condition nets, which also feed a conditioned encoder); all other
+        # gradients (decoder, dense layers: 96 % of the bucket) are final earlier and can be exchanged while the
+        # encoder backward still runs.  Late variables sit at the end of the flat bucket.
+        is_late = lambda n: ('condition' in n) or (n.startswith('generator/encoder/') and '/fc_' not in n)
+        self._g_names = [n for n in g_names if not is_late(n)] + [n for n in g_names if is_late(n)]
+        self._g_early = sum(1 for n in g_names if not is_late(n))
         self._d_names = [n for n in self._vars if n.startswith('discriminator')]
         if phase == 'train':
             self._init_optimizer()
@@ -695,7 +707,10 @@ class CAPE(base_model):
                 # fake pass (two contributions that autograd must add) and keep private gradient tensors.
                 for nm, view in zip(names, views):
                     self._grad_views[nm] = view
+            n_early = self._g_early if grp == 'g' else len(names)
+            split_off = offsets[names[n_early]][0] if n_early < len(names) else total
             st = {'params': params, 'flat': flat, 'flat_grad': flat_grad, 'grad_views': views, 'offsets': offsets,
+                  'n_early': n_early, 'split_off': split_off,
                   'm': torch.zeros_like(flat), 'sumsq': torch.zeros((), device=self.device, dtype=torch.float32),
                   'ws': ops.flat_workspace(self.device),
                   'neg_lr': torch.zeros((), device=self.device, dtype=torch.float32)}
@@ -741,11 +756,12 @@ class CAPE(base_model):
                 i = self._g_names.index(n)
                 st['grad_views'][i].add_(self._vars[n], alpha=coef)
 
-    def store_grads(self, grp, grads):
+    def store_grads(self, grp, grads, lo=0, hi=None):
+        """Put the gradients of variables [lo, hi) of a group into its flat gradient bucket."""
         st = self._opt_state[grp]
         with torch.no_grad():
             dst, src = [], []
-            for view, g in zip(st['grad_views'], grads):
+            for view, g in zip(st['grad_views'][lo:hi], grads):
                 if g is None:
                     view.zero_()
                 elif g.data_ptr() != view.data_ptr():      # kernels may already have written the bucket
@@ -789,6 +805,7 @@ class CAPE(base_model):
         self._reg_via_bucket = reg_via_bucket
         self._reg_in_bucket = False
         y_g, y2_g = self._conditions(cond_g, cond2_g)
+        self._y_pair = (y_g, y2_g)
         x_hat, z_mean, z_logvar = self.generator(data_g, y_g, y2_g, eps=eps)
         out = self.loss_terms(x_hat, gt, z_mean, z_logvar)
         out['prediction'] = x_hat
@@ -814,13 +831,54 @@ class CAPE(base_model):
         out['loss_g'] = loss_g
         return out
 
-    def backward_to_flat(self, out):
-        """Gradients of loss_g w.r.t. the G group and loss_d w.r.t. the D group -> flat gradient buffers."""
-        g_params = self._opt_state['g']['params']
-        d_params = self._opt_state['d']['params']
+    def _one_scalar(self):
         if getattr(self, '_one', None) is None:
             self._one = torch.ones((), device=self.device, dtype=torch.float32)      # d(loss)/d(loss), allocated once
-        one = self._one
+        return self._one
+
+    def backward_phase1(self, out):
+        """First half of the two-phase backward (``split_backward``): everything downstream of the encoder's
+        convolution stack -- decoder, dense layers, discriminator.  Afterwards the EARLY part of the G bucket
+        ([0, split_off)) and the whole D bucket are final and may be exchanged while phase 2 runs."""
+        st = self._opt_state['g']
+        ne = st['n_early']
+        one = self._one_scalar()
+        heads = [t for t in (self._enc_feat_cut,) + tuple(self._y_pair) if t.requires_grad]
+        res = torch.autograd.grad(out['loss_g'], st['params'][:ne] + heads, grad_outputs=one, retain_graph=True, allow_unused=True)
+        self.store_grads('g', res[:ne], 0, ne)
+        self._phase_heads = (heads, list(res[ne:]))
+        if 'loss_d' in out:
+            grads_d = torch.autograd.grad(out['loss_d'], self._opt_state['d']['params'], grad_outputs=one, retain_graph=True,
+                                          allow_unused=True)
+            self.store_grads('d', grads_d)
+
+    def backward_phase2(self):
+        """Second half: from the cut (and the condition embeddings) through the encoder convolutions and the
+        condition nets -> the LATE part of the G bucket."""
+        st = self._opt_state['g']
+        ne = st['n_early']
+        heads, gouts = self._phase_heads
+        roots, seeds = [], []
+        for h, g in zip(heads, gouts):
+            if g is not None:
+                roots.append(self._enc_feat if h is self._enc_feat_cut else h)
+                seeds.append(g)
+        late = st['params'][ne:]
+        if late:
+            res = torch.autograd.grad(roots, late, grad_outputs=seeds, allow_unused=True) if roots else [None] * len(late)
+            self.store_grads('g', res, ne, None)
+        self._phase_heads = self._enc_feat = self._enc_feat_cut = None
+        self._add_reg_grads()
+
+    def backward_to_flat(self, out):
+        """Gradients of loss_g w.r.t. the G group and loss_d w.r.t. the D group -> flat gradient buffers."""
+        if getattr(self, 'split_backward', False) and not self.bug_compat and getattr(self, '_enc_feat_cut', None) is not None:
+            self.backward_phase1(out)
+            self.backward_phase2()
+            return
+        g_params = self._opt_state['g']['params']
+        d_params = self._opt_state['d']['params']
+        one = self._one_scalar()
         if 'loss_d' not in out:
             grads_g = torch.autograd.grad(out['loss_g'], g_params, grad_outputs=one, allow_unused=True)
             self.store_grads('g', grads_g)

@@ -4,15 +4,32 @@ graph and replayed -- the MI355X counterpart of the reference's static ``tf.Grap
 (``batch_size`` is baked into the placeholders, :272-282), which is what makes capture legal.
 
 A step is ~190 short kernels; eager launches would be host-bound (>=3 us each), graph replay is
-one submission.  With more than one rank the step is split at the gradient exchange:
-graph A (fwd + bwd -> flat gradients), eager RCCL all-reduce, graph B (clip + update).
+one submission.  With more than one rank the step is split at the gradient exchanges and the backward
+pass runs in two phases so that the exchange of the early 96 % of the gradient bucket (decoder + dense
+layers, final once the backward pass reaches the encoder convolutions) overlaps with the rest of it:
+
+    graph A1 (fwd + backward phase 1)  ->  async all-reduce of flat_grad[:split]  (RCCL stream)
+    graph A2 (backward phase 2: encoder convolutions, condition nets)  ||  ... all-reduce running
+    async all-reduce of flat_grad[split:]  ->  wait both  ->  graph B (clip + update)
+
+xGMI is point-to-point: between two GPUs the 65 MB bucket takes ~1.3 ms on one link against a 4 ms step, which
+is what the overlap hides (phase 2 is ~1.3 ms).
 """
+import os
+
 import torch
 
 
 class GraphedTrainStep(object):
-    def __init__(self, model, with_gan=False, grad_hook=None, use_graph=True):
+    def __init__(self, model, with_gan=False, grad_hook=None, use_graph=True, split=None):
         self.model, self.with_gan, self.grad_hook = model, with_gan, grad_hook
+        # two-phase backward: on whenever gradients are exchanged (CAPE_DP_SPLIT=1 forces it for single-rank tests,
+        # CAPE_DP_SPLIT=0 falls back to one sweep + one synchronous exchange)
+        if split is None:
+            env = os.environ.get("CAPE_DP_SPLIT", "")
+            split = env == "1" or (grad_hook is not None and env != "0")
+        self.split = bool(split) and not model.bug_compat
+        model.split_backward = self.split
         self.use_graph = use_graph and model.optimizer != "adam"   # Adam keeps a host-side step counter
         B, d = model.batch_size, model.device
         M, Cn = model.input_num_verts, model.nn_input_channel
@@ -24,21 +41,22 @@ class GraphedTrainStep(object):
                         data_d=zp(), cond_d=z(B, model.cond_dim), cond2_d=z(B, model.cond2_dim),
                         eps=z(B, int(model.nz)))
         self.losses = {}
-        self._gA = self._gB = None
+        self._gA = self._gA2 = self._gB = None
 
     def load_batch(self, **arrays):
         for k, v in arrays.items():
             self.buf[k].copy_(torch.as_tensor(v, dtype=torch.float32), non_blocking=True)
 
     # ---- the two halves of a step -------------------------------------------------------------------
-    def _fwd_bwd(self):
+    def _forward(self):
         m, b = self.model, self.buf
         if self.with_gan:
-            out = m.forward_losses(b['data_g'], b['cond_g'], b['cond2_g'], b['gt'], b['data_d'], b['cond_d'],
-                                   b['cond2_d'], eps=b['eps'], reg_via_bucket=True)
-        else:
-            out = m.forward_losses(b['data_g'], b['cond_g'], b['cond2_g'], b['gt'], eps=b['eps'], with_gan=False, reg_via_bucket=True)
-        m.backward_to_flat(out)
+            return m.forward_losses(b['data_g'], b['cond_g'], b['cond2_g'], b['gt'], b['data_d'], b['cond_d'],
+                                    b['cond2_d'], eps=b['eps'], reg_via_bucket=True)
+        return m.forward_losses(b['data_g'], b['cond_g'], b['cond2_g'], b['gt'], eps=b['eps'], with_gan=False, reg_via_bucket=True)
+
+    def _keep_losses(self, out):
+        m = self.model
         dst, src = [], []
         for k in ('loss_g', 'loss_d', 'recon', 'latent', 'edge'):
             if k in out and torch.is_tensor(out[k]):
@@ -49,6 +67,20 @@ class GraphedTrainStep(object):
         if dst:
             torch._foreach_copy_(dst, src)
 
+    def _fwd_bwd(self):
+        """forward + the whole backward pass (single-rank path; also what bench.py's per-launch timing replays)."""
+        out = self._forward()
+        self.model.backward_to_flat(out)
+        self._keep_losses(out)
+
+    def _fwd_bwd1(self):
+        out = self._forward()
+        self.model.backward_phase1(out)
+        self._keep_losses(out)
+
+    def _bwd2(self):
+        self.model.backward_phase2()
+
     def _groups(self):
         return ('g', 'd') if self.with_gan else ('g',)
 
@@ -57,10 +89,44 @@ class GraphedTrainStep(object):
             self.model.apply_updates(grp)
 
     def _exchange(self):
+        """Synchronous exchange of every bucket (unsplit path)."""
         if self.grad_hook is not None:
             for grp in self._groups():
                 if not (grp == 'd' and self.model.bug_compat):
                     self.grad_hook(self.model._opt_state[grp]['flat_grad'])
+
+    def _start(self, t):
+        h = self.grad_hook
+        if h is None or t.numel() == 0:
+            return None
+        if hasattr(h, 'start'):
+            return h.start(t)
+        h(t)
+        return None
+
+    def _finish(self, works):
+        for w in works:
+            if w is not None:
+                self.grad_hook.finish(w)
+
+    def _exchange_early(self):
+        st = self.model._opt_state
+        works = [self._start(st['g']['flat_grad'][:st['g']['split_off']])]
+        if self.with_gan:
+            works.append(self._start(st['d']['flat_grad']))
+        return works
+
+    def _exchange_late(self):
+        st = self.model._opt_state['g']
+        return [self._start(st['flat_grad'][st['split_off']:])]
+
+    def _split_step_eager(self):
+        self._fwd_bwd1()
+        works = self._exchange_early()
+        self._bwd2()
+        works += self._exchange_late()
+        self._finish(works)
+        self._update()
 
     # ---- capture / replay --------------------------------------------------------------------------
     def capture(self, warmup=2):
@@ -70,18 +136,31 @@ class GraphedTrainStep(object):
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):        # allocator warm-up outside capture
-                self._fwd_bwd()
-                self._exchange()
-                self._update()
+                if self.split:
+                    self._split_step_eager()
+                else:
+                    self._fwd_bwd()
+                    self._exchange()
+                    self._update()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        split = self.grad_hook is not None
         self._gA = torch.cuda.CUDAGraph()
+        if self.split:
+            with torch.cuda.graph(self._gA):
+                self._fwd_bwd1()
+            self._gA2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._gA2, pool=self._gA.pool()):
+                self._bwd2()
+            self._gB = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._gB, pool=self._gA.pool()):
+                self._update()
+            return self
+        exchange = self.grad_hook is not None
         with torch.cuda.graph(self._gA):
             self._fwd_bwd()
-            if not split:
+            if not exchange:
                 self._update()
-        if split:
+        if exchange:
             self._gB = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._gB, pool=self._gA.pool()):
                 self._update()
@@ -91,9 +170,19 @@ class GraphedTrainStep(object):
         m = self.model
         m.set_learning_rates()
         if self._gA is None:
-            self._fwd_bwd()
-            self._exchange()
-            self._update()
+            if self.split:
+                self._split_step_eager()
+            else:
+                self._fwd_bwd()
+                self._exchange()
+                self._update()
+        elif self.split:
+            self._gA.replay()
+            works = self._exchange_early()
+            self._gA2.replay()
+            works += self._exchange_late()
+            self._finish(works)
+            self._gB.replay()
         else:
             self._gA.replay()
             if self._gB is not None:

@@ -47,7 +47,14 @@ def _worker(rank, world, port, out_dir):
         loss = ((pred - Y[b:e]) ** 2).mean() * 50.0          # big enough that clipping is active
         (g,) = torch.autograd.grad(loss, p)
         flat_grad = g.clone()
-        hook(flat_grad)
+        if _ == 1:
+            # the two-segment asynchronous form the split step runner uses (early part, then the rest)
+            works = [hook.start(flat_grad[:16])]
+            works.append(hook.start(flat_grad[16:]))
+            for wk in works:
+                hook.finish(wk)
+        else:
+            hook(flat_grad)
         _flat_sgd_step(flat, flat_grad, m)
     np.save(os.path.join(out_dir, "flat_%d.npy" % rank), flat.numpy())
     assert cdist.max_over_ranks(rank + 1.0, torch.device("cpu")) == float(world)

@@ -226,3 +226,43 @@ def test_train_step_matches_manual_update(mesh_ops):
         ulp = 1.2e-7 * before[n].abs().max().item()
         assert d <= 2e-3 * max(ref, 1e-12) + 1e-9 + ulp, (n, d, ref)
     assert model.global_step == 2
+
+
+@pytest.mark.parametrize("gan", [False, True])
+def test_two_phase_backward_equals_single_sweep(gan, mesh_ops):
+    """The data-parallel step runner differentiates in two phases (decoder + dense layers first, encoder convolutions
+    and condition nets second, graph cut below the dense layers) so that the early 96 % of the bucket can be exchanged
+    while phase 2 runs.  Same kernels, same order inside each layer: the updated variables must equal the single-sweep
+    step's, with and without HIP-graph capture."""
+    from cape_amd.runtime import GraphedTrainStep
+    N = 2
+    finals = {}
+    for split, graph in ((False, False), (True, False), (True, True)):
+        P, twin, model = _build("affine_nz64", mesh_ops, N, dict(regularization=0.5, lr_warmup=False, decay_steps=1000))
+        if not finals:
+            x, gt, xd, cond, cond_d, clo, clo_d, eps = _inputs(N, P["nz"])
+        assert model._opt_state['g']['split_off'] < model._opt_state['g']['flat'].numel()
+        runner = GraphedTrainStep(model, with_gan=gan, use_graph=graph, split=split)
+        runner.load_batch(data_g=x, cond_g=cond, cond2_g=clo, gt=gt, data_d=xd, cond_d=cond_d, cond2_d=clo_d, eps=eps)
+        # one eager pass first (loads every kernel before capture; the learning-rate scalars are still 0, so it only
+        # fills the momentum buffers -- identically in all three variants), then capture without further warm-up
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                  # (a side stream, as graph capture requires of its warm-up)
+            if split:
+                runner._split_step_eager()
+            else:
+                runner._fwd_bwd()
+                runner._update()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        runner.capture(warmup=0)
+        for _ in range(2):
+            runner.step()
+        torch.cuda.synchronize()
+        finals[(split, graph)] = {g: model._opt_state[g]['flat'].detach().clone() for g in (('g', 'd') if gan else ('g',))}
+    ref = finals[(False, False)]
+    for key in ((True, False), (True, True)):
+        for g, v in finals[key].items():
+            d = (v - ref[g]).abs().max().item()
+            assert d <= 1e-6 * max(ref[g].abs().max().item(), 1.0), (key, g, d)
