@@ -58,6 +58,9 @@ class GradAverager(object):
         for it and completes the mean."""
         if self.world <= 1:
             return None
+        if dist.get_backend(self.group) != "nccl":
+            self(flat_grad)                  # host-staged transports (gloo) cannot overlap with device work anyway
+            return None
         return (dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat_grad)
 
     def finish(self, handle):

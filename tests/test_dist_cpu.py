@@ -52,7 +52,7 @@ def _worker(rank, world, port, out_dir):
             works = [hook.start(flat_grad[:16])]
             works.append(hook.start(flat_grad[16:]))
             for wk in works:
-                hook.finish(wk)
+                hook.finish(wk)              # (gloo completes in start(); the handles are None)
         else:
             hook(flat_grad)
         _flat_sgd_step(flat, flat_grad, m)

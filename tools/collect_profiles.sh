@@ -25,7 +25,7 @@ python $R/tools/pmc_merge.py $O/pmc_fetch.json $O/pmc_write.json $O/pmc_sq.json 
 ls -la $O | tail -15
 # single Chebyshev K=6 layer (BASELINE configs[1]) and the 2-rank code path on one GPU (gloo transport, both ranks on device 0)
 cd $R && python tools/bench_config2.py > $O/${TAG}_config2.json 2>> $O/${TAG}_bench.err
-CAPE_DIST_BACKEND=gloo CAPE_FORCE_DEVICE=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 10 --warmup 3 --no-roofline > $O/${TAG}_bench_2rank_1gpu.json 2>> $O/${TAG}_bench.err
+CAPE_DIST_BACKEND=gloo CAPE_FORCE_DEVICE=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 4 --warmup 1 --no-roofline > $O/${TAG}_bench_2rank_1gpu.json 2>> $O/${TAG}_bench.err
 tail -c 400 $O/${TAG}_bench_2rank_1gpu.json
 make -C $R/tools/ubench > /dev/null 2>&1
 (cd $R/tools/ubench && ./mfma_peak) > $O/${TAG}_ubench_mfma_peak.txt 2>&1
