@@ -42,12 +42,13 @@ def shard_range(total, world, rank):
 class GradAverager(object):
     """``hook(flat_grad)``: in-place mean over ranks of a flat gradient bucket."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, always=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.always = bool(always) and dist.is_initialized()      # issue the collectives even for one rank (self-test)
 
     def __call__(self, flat_grad):
-        if self.world > 1:
+        if self.world > 1 or self.always:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             flat_grad.div_(self.world)
         return flat_grad
@@ -56,7 +57,7 @@ class GradAverager(object):
         """Asynchronous form: enqueue the sum on the collective stream (it starts once the work queued so far on the
         current stream is done and then runs beside whatever is queued next); ``finish`` makes the current stream wait
         for it and completes the mean."""
-        if self.world <= 1:
+        if self.world <= 1 and not self.always:
             return None
         if dist.get_backend(self.group) != "nccl":
             self(flat_grad)                  # host-staged transports (gloo) cannot overlap with device work anyway

@@ -29,3 +29,5 @@ CAPE_DIST_BACKEND=gloo CAPE_FORCE_DEVICE=0 python -m torch.distributed.run --nno
 tail -c 400 $O/${TAG}_bench_2rank_1gpu.json
 make -C $R/tools/ubench > /dev/null 2>&1
 (cd $R/tools/ubench && ./mfma_peak) > $O/${TAG}_ubench_mfma_peak.txt 2>&1
+# split data-parallel step with the real collective backend (one-rank RCCL group, collectives forced on)
+python $R/tools/dp_selftest.py 2>&1 | grep -v "UserWarning\|run_backward\|amdgpu.ids\|socket.cpp\|^$" > $O/${TAG}_dp_selftest.txt
