@@ -437,6 +437,50 @@ __global__ __launch_bounds__(256) void reduce_cond_kernel(CView dy, const float 
     }
 }
 
+// float4 form: thread = (channel quad, row lane), 256 / quads row lanes, two independent partial sums per lane --
+// the scalar form above walks all M rows with four row lanes per block (208 us at M = 6890 for 32 condition channels)
+__global__ __launch_bounds__(256) void reduce_cond_vec_kernel(CView dy, const float *scale, float *dcond, int ldc,
+                                                              int N, int M, int C, int accumulate) {
+    __shared__ float4 red[256];
+    const int cgroups = (C + 63) / 64;
+    const int n = blockIdx.x / cgroups, cg = blockIdx.x % cgroups;
+    const int gw = min(64, C - cg * 64);                // channels of this block's group (C % 4 == 0)
+    int qp = 1;
+    while (qp < gw / 4) qp <<= 1;                       // quad lanes per row (power of two)
+    const int RL = 256 / qp;
+    const int q = threadIdx.x % qp, rl = threadIdx.x / qp;
+    const int c = cg * 64 + 4 * q;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (4 * q < gw && c < C) {
+        const float *p = dy.p + (long long)n * dy.ss + c;
+        int m = rl;
+        for (; m + RL < M; m += 2 * RL) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(p + (long long)m * dy.ld);
+            const float4 v1 = *reinterpret_cast<const float4 *>(p + (long long)(m + RL) * dy.ld);
+            const float s0 = scale ? scale[m] : 1.f, s1 = scale ? scale[m + RL] : 1.f;
+            a.x = fmaf(s0, v0.x, a.x); a.y = fmaf(s0, v0.y, a.y); a.z = fmaf(s0, v0.z, a.z); a.w = fmaf(s0, v0.w, a.w);
+            b.x = fmaf(s1, v1.x, b.x); b.y = fmaf(s1, v1.y, b.y); b.z = fmaf(s1, v1.z, b.z); b.w = fmaf(s1, v1.w, b.w);
+        }
+        if (m < M) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(p + (long long)m * dy.ld);
+            const float s0 = scale ? scale[m] : 1.f;
+            a.x = fmaf(s0, v0.x, a.x); a.y = fmaf(s0, v0.y, a.y); a.z = fmaf(s0, v0.z, a.z); a.w = fmaf(s0, v0.w, a.w);
+        }
+    }
+    red[threadIdx.x] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    __syncthreads();
+    if (threadIdx.x < qp && 4 * threadIdx.x < gw && cg * 64 + 4 * (int)threadIdx.x < C) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int l = 0; l < RL; ++l) {
+            const float4 v = red[l * qp + threadIdx.x];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        float *d = dcond + (long long)n * ldc + cg * 64 + 4 * threadIdx.x;
+        if (accumulate) { t.x += d[0]; t.y += d[1]; t.z += d[2]; t.w += d[3]; }
+        d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+    }
+}
+
 // ---- out[n, j, f] = sum_r rowscale[j, r] * dz[n, r, f]   (gradient of the rank-1 condition terms)
 constexpr int RSR_RB = 32;    // rows per block
 constexpr int RSR_MAXR = 4;
@@ -842,7 +886,10 @@ extern "C" int cape_reduce_cond(const float *dy, int64_t dy_sample_stride, int32
     if (!dy || !dcond || N < 1 || M < 1 || C < 1 || lddy < C || ldc < C) return CAPE_EINVAL;
     CView gv{dy, dy_sample_stride, lddy};
     const int cgroups = (C + 63) / 64;
-    CAPE_LAUNCH(reduce_cond_kernel, dim3(N * cgroups), dim3(256), 0, (hipStream_t)stream, gv, scale, dcond, ldc, N, M, C, accumulate);
+    if (aligned4(dy, dy_sample_stride, lddy, C))
+        CAPE_LAUNCH(reduce_cond_vec_kernel, dim3(N * cgroups), dim3(256), 0, (hipStream_t)stream, gv, scale, dcond, ldc, N, M, C, accumulate);
+    else
+        CAPE_LAUNCH(reduce_cond_kernel, dim3(N * cgroups), dim3(256), 0, (hipStream_t)stream, gv, scale, dcond, ldc, N, M, C, accumulate);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }

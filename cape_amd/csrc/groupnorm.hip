@@ -57,41 +57,63 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *x, long long
     }
 }
 
-// per (n, g): per-channel sums of dy' and dy'*xhat, and the two group sums weighted by gamma
+// per (n, g): per-channel sums of dy' and dy'*xhat, and the two group sums weighted by gamma.
+// Thread = (row lane, channel of the group): a wave reads whole contiguous channel segments of consecutive rows
+// (the per-channel strided loop this replaces touched every cache line Cg times: 290 us per launch at 862 x 544).
 __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float *x, long long xs, int ldx, const float *y,
                                                            long long ys, int ldy, const float *dy, long long dys, int lddy,
                                                            const float *gamma, const float *stats, int G, int relu, int V,
                                                            int C, float *dgamma_p, float *dbeta_p, float *gstats) {
-    __shared__ float red[4];
-    __shared__ float sg[2];
+    __shared__ float r1[256], r2[256];
     const int n = blockIdx.x / G, g = blockIdx.x % G;
     const int Cg = C / G;
     const float mean = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
     float S1 = 0.f, S2 = 0.f;
-    for (int cc = 0; cc < Cg; ++cc) {
-        const int c = g * Cg + cc;
+    // channel tiles of up to 64 (groups are at most a few dozen channels wide in every CAPE configuration)
+    for (int c0 = 0; c0 < Cg; c0 += 64) {
+        const int cw = min(64, Cg - c0);
+        int cp = 1;
+        while (cp < cw) cp <<= 1;                       // lanes per row (power of two >= tile width)
+        const int VL = 256 / cp;
+        const int cc = threadIdx.x % cp, vl = threadIdx.x / cp;
+        const int c = g * Cg + c0 + cc;
         float s1 = 0.f, s2 = 0.f;
-        for (int v = threadIdx.x; v < V; v += 256) {
-            float d = dy[(long long)n * dys + (long long)v * lddy + c];
-            if (relu && !(y[(long long)n * ys + (long long)v * ldy + c] > 0.f)) d = 0.f;
-            const float xh = (x[(long long)n * xs + (long long)v * ldx + c] - mean) * rstd;
-            s1 += d;
-            s2 = fmaf(d, xh, s2);
+        if (cc < cw) {
+            for (int v = vl; v < V; v += VL) {
+                float d = dy[(long long)n * dys + (long long)v * lddy + c];
+                if (relu && !(y[(long long)n * ys + (long long)v * ldy + c] > 0.f)) d = 0.f;
+                const float xh = (x[(long long)n * xs + (long long)v * ldx + c] - mean) * rstd;
+                s1 += d;
+                s2 = fmaf(d, xh, s2);
+            }
         }
-        s1 = block_sum(s1, red);
-        s2 = block_sum(s2, red);
-        if (threadIdx.x == 0) {
-            dbeta_p[(long long)n * C + c] = s1;
-            dgamma_p[(long long)n * C + c] = s2;
+        __syncthreads();
+        r1[threadIdx.x] = s1;
+        r2[threadIdx.x] = s2;
+        __syncthreads();
+        if (threadIdx.x < cw) {                         // fixed-order sum over the row lanes of this channel
+            float t1 = 0.f, t2 = 0.f;
+            for (int l = 0; l < VL; ++l) {
+                t1 += r1[l * cp + threadIdx.x];
+                t2 += r2[l * cp + threadIdx.x];
+            }
+            const int ch = g * Cg + c0 + threadIdx.x;
+            dbeta_p[(long long)n * C + ch] = t1;
+            dgamma_p[(long long)n * C + ch] = t2;
+            r1[threadIdx.x] = gamma[ch] * t1;
+            r2[threadIdx.x] = gamma[ch] * t2;
         }
-        S1 = fmaf(gamma[c], s1, S1);
-        S2 = fmaf(gamma[c], s2, S2);
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int l = 0; l < cw; ++l) {
+                S1 += r1[l];
+                S2 += r2[l];
+            }
     }
     if (threadIdx.x == 0) {
         gstats[2 * blockIdx.x] = S1;
         gstats[2 * blockIdx.x + 1] = S2;
     }
-    (void)sg;
 }
 
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *x, long long xs, int ldx, const float *y, long long ys,
