@@ -36,7 +36,7 @@ class CapeCondLayer(C.Structure):
 class CapeSpmmTerm(C.Structure):
     _fields_ = [("x", C.c_void_p), ("x_sample_stride", C.c_int64), ("ldx", C.c_int32),
                 ("rowptr", C.c_void_p), ("colidx", C.c_void_p), ("vals", C.c_void_p),
-                ("y", C.c_void_p), ("y_sample_stride", C.c_int64), ("ldy", C.c_int32)]
+                ("y", C.c_void_p), ("y_sample_stride", C.c_int64), ("ldy", C.c_int32), ("scale", C.c_float)]
 
 
 class CapeRank(C.Structure):

@@ -72,6 +72,7 @@ struct SpmmTerms {
         const float *x; long long xs; int ldx;
         const int *rp; const int *ci; const float *va;
         float *y; long long ys; int ldy;
+        float scale;
     } t[CAPE_MAX_SPMM_TERMS];
     int n;
 };
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(256) void spmm_multi_kernel(SpmmTerms P, int sum, V
                     }
                 }
             }
+            acc.x *= T.scale; acc.y *= T.scale; acc.z *= T.scale; acc.w *= T.scale;
             if (sum) {
                 tot.x += acc.x; tot.y += acc.y; tot.z += acc.z; tot.w += acc.w;
             } else if (VEC) {
@@ -177,7 +179,8 @@ __global__ __launch_bounds__(256) void spmm_combine_kernel(CombineParams Q, View
                 }
             }
             float *dst = ((Q.to2 >> k) & 1u) ? a2 : a1;
-            dst[0] += acc.x; dst[1] += acc.y; dst[2] += acc.z; dst[3] += acc.w;
+            dst[0] = fmaf(T.scale, acc.x, dst[0]); dst[1] = fmaf(T.scale, acc.y, dst[1]);
+            dst[2] = fmaf(T.scale, acc.z, dst[2]); dst[3] = fmaf(T.scale, acc.w, dst[3]);
         }
         for (int j = 0; j < Q.rankR; ++j) {
             const float rs = Q.rowscale[(long long)j * Mo + r];
@@ -754,6 +757,7 @@ extern "C" int cape_spmm_multi(const cape_spmm_term_t *terms, int32_t nterms, in
         P.t[k].x = t.x; P.t[k].xs = t.x_sample_stride; P.t[k].ldx = t.ldx;
         P.t[k].rp = t.rowptr; P.t[k].ci = t.colidx; P.t[k].va = t.vals;
         P.t[k].y = t.y; P.t[k].ys = t.y_sample_stride; P.t[k].ldy = t.ldy;
+        P.t[k].scale = t.scale;
         vec = vec && aligned4(t.x, t.x_sample_stride, t.ldx, C) && (sum || aligned4(t.y, t.y_sample_stride, t.ldy, C));
     }
     View yv{y, y_sample_stride, ldy};
@@ -782,6 +786,7 @@ extern "C" int cape_spmm_combine(const cape_spmm_term_t *terms, int32_t nterms, 
         Q.P.t[k].x = t.x; Q.P.t[k].xs = t.x_sample_stride; Q.P.t[k].ldx = t.ldx;
         Q.P.t[k].rp = t.rowptr; Q.P.t[k].ci = t.colidx; Q.P.t[k].va = t.vals;
         Q.P.t[k].y = nullptr; Q.P.t[k].ys = 0; Q.P.t[k].ldy = 0;
+        Q.P.t[k].scale = t.scale;
         vec = vec && aligned4(t.x, t.x_sample_stride, t.ldx, F);
     }
     Q.to2 = to_acc2;

@@ -252,9 +252,10 @@ def spmm(x, csr, y=None, alpha=1.0, z=None, beta=0.0):
     return y
 
 
-def spmm_multi(xs, csrs, sum=False):
-    """Several operator applications in one launch: ``sum=False`` -> [S_k x_k for k]; ``sum=True`` -> sum_k S_k x_k.
-    ``csrs[k]`` None or an identity DeviceCSR = identity term.  All operators have the same number of rows."""
+def spmm_multi(xs, csrs, sum=False, scales=None):
+    """Several operator applications in one launch: ``sum=False`` -> [s_k S_k x_k for k]; ``sum=True`` -> sum_k s_k S_k x_k
+    (``scales`` default 1).  ``csrs[k]`` None or an identity DeviceCSR = identity term.  All operators have the same
+    number of rows."""
     _lib.require_gpu()
     n = len(xs)
     assert 1 <= n <= 4 and len(csrs) == n
@@ -268,6 +269,7 @@ def spmm_multi(xs, csrs, sum=False):
         t = arr[k]
         xp, t.x_sample_stride, t.ldx = _v(xs[k])
         t.x = xp.value
+        t.scale = 1.0 if scales is None else float(scales[k])
         if ident[k]:
             t.rowptr = t.colidx = t.vals = None
         else:
@@ -298,6 +300,7 @@ def spmm_combine(xs, csrs, y, to_acc2=0, rank=None, bias=None, bias_mode=_lib.BI
         xp, t.x_sample_stride, t.ldx = _v(xs[k])
         t.x = xp.value
         assert xs[k].shape[2] == F
+        t.scale = 1.0
         if csrs[k] is None or csrs[k].identity:
             t.rowptr = t.colidx = t.vals = None
         else:
@@ -767,24 +770,27 @@ class ChebConvRecurrenceFn(torch.autograd.Function):
             dW = torch.empty_like(W)
             gconv_dw([dict(x=xs[k], csr=None, w=(dW, k * Fout, K * Fout, 1)) for k in range(K)], dz)
         if ctx.needs_input_grad[0]:
-            # G_k = dz W_k^T, then Clenshaw for sum_k T_k(L~)^T G_k
-            G = []
-            for k in range(K):
-                gk = alloc_act(N, M, Cin, g.device)
-                gconv_fwd([dict(x=dz, csr=None, w=(W, k * Fout, 1, K * Fout))], gk)
-                G.append(gk)
+            # all G_k = dz W_k^T in ONE launch (de-interleaving epilogue), then Clenshaw for sum_k T_k(L~)^T G_k with
+            # every step  b_k = 2 L~^T b_{k+1} + G_k - b_{k+2}  as one scaled multi-term launch
+            CP = _pad4(Cin)
+            Gall = alloc_act(N, M, K * CP, g.device)
+            gconv_fwd([dict(x=dz, csr=None, w=(W, 0, 1, Fout))], Gall, deinterleave=K, F=K * Cin)
+            G = [Gall[:, :, k * CP:k * CP + Cin] for k in range(K)]
             b1 = b2 = None   # b_{k+1}, b_{k+2}
             for k in range(K - 1, 0, -1):
                 if b1 is None:
                     bk = G[k]
+                elif b2 is None:
+                    bk = spmm_multi([b1, G[k]], [ops.LtT, None], sum=True, scales=[2.0, 1.0])
                 else:
-                    bk = spmm(b1, ops.LtT, alpha=2.0, z=G[k], beta=1.0)
-                    if b2 is not None:
-                        bk.sub_(b2)
+                    bk = spmm_multi([b1, G[k], b2], [ops.LtT, None, None], sum=True, scales=[2.0, 1.0, -1.0])
                 b1, b2 = bk, b1
-            dx = spmm(b1, ops.LtT, alpha=1.0, z=G[0], beta=1.0) if b1 is not None else G[0]
-            if b2 is not None:
-                dx.sub_(b2)
+            if b1 is None:
+                dx = G[0]
+            elif b2 is None:
+                dx = spmm_multi([b1, G[0]], [ops.LtT, None], sum=True, scales=[1.0, 1.0])
+            else:
+                dx = spmm_multi([b1, G[0], b2], [ops.LtT, None, None], sum=True, scales=[1.0, 1.0, -1.0])
         return dx, dW, dB, None, None, None
 
 

@@ -213,7 +213,7 @@ int cape_spmm(const float *x, int64_t x_sample_stride, int32_t ldx, const int32_
 /*
  * Several operator applications in one launch (all operators have Mo rows, all operands C channels):
  *   sum = 0:  terms[k].y = S_k x_k for every k   (X_k = S_k x of one layer; T_k = S_k^T dz of its data gradient)
- *   sum = 1:  y = sum_k S_k x_k                  (dx = sum_k S_k^T G_k)
+ *   sum = 1:  y = sum_k scale_k S_k x_k          (dx = sum_k S_k^T G_k; a Clenshaw step 2 L~^T b_{k+1} + G_k - b_{k+2})
  * A term with rowptr == NULL is the identity (its input then has Mo rows).  y / terms[k].y must not alias an input.
  */
 #define CAPE_MAX_SPMM_TERMS 4
@@ -227,6 +227,7 @@ typedef struct cape_spmm_term {
     float *y;
     int64_t y_sample_stride;
     int32_t ldy;
+    float scale;             /* the term is scale * S_k x_k (1.0f for a plain application) */
 } cape_spmm_term_t;
 int cape_spmm_multi(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, float *y, int64_t y_sample_stride,
                     int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream);
