@@ -39,6 +39,11 @@ class CapeSpmmTerm(C.Structure):
                 ("y", C.c_void_p), ("y_sample_stride", C.c_int64), ("ldy", C.c_int32), ("scale", C.c_float)]
 
 
+class CapeBwdPrepItem(C.Structure):
+    _fields_ = [("workspace", C.c_void_p), ("N", C.c_int32), ("Mo", C.c_int32), ("F", C.c_int32), ("R", C.c_int32),
+                ("dbias", C.c_void_p), ("dcoef", C.c_void_p), ("dcoef_g", C.c_void_p), ("dcoef_sample_stride", C.c_int64)]
+
+
 class CapeRank(C.Structure):
     _fields_ = [("R", C.c_int32), ("rowscale", C.c_void_p), ("coef", C.c_void_p), ("to_acc2", C.c_uint32)]
 
@@ -65,7 +70,8 @@ SIGNATURES = {
     "cape_gconv_dw": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _p, C.c_uint32, _i32, _i32, _i32, _i32, _p, _i64, _p]),
     "cape_bwd_prep_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "cape_bwd_prep": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p, _i32, _p,
-                                _i64, _i32, _i32, _i32, _p, _i64, _p]),
+                                _i64, _i32, _i32, _i32, _i32, _p, _i64, _p]),
+    "cape_bwd_prep_finalize": (C.c_int, [C.c_void_p, _i32, _p]),
     "cape_spmm": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _i32, _f32, _p, _i64, _i32, _f32, _p, _i64, _i32,
                             _i32, _i32, _i32, _p]),
     "cape_spmm_multi": (C.c_int, [C.POINTER(CapeSpmmTerm), _i32, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p]),

@@ -656,13 +656,13 @@ __global__ __launch_bounds__(256) void bwd_prep_vec_kernel(CView g, CView y, int
 
 // stage 2: block = (term t, 16 columns) x 16 lanes.  t = 0: dbias[f] = sum over (n, chunk);
 // t = 1..R: dcoef[n, t-1, f] = sum over chunks; t = R+1: dcoef_g[n, f] = sum over chunks.
-__global__ __launch_bounds__(256) void bwd_prep_final_kernel(const float *part, int chunks, int N, int F, int R, float *dbias,
-                                                             float *dcoef, float *dcoef_g, long long cs, long long cgs) {
+__device__ __forceinline__ void bwd_prep_final_block(int bid, const float *part, int chunks, int N, int F, int R, float *dbias,
+                                                     float *dcoef, float *dcoef_g, long long cs, long long cgs) {
     __shared__ float red[16][17];
     const int T = R + 2;
     const int fblocks = (F + 15) / 16;
     const int fl = threadIdx.x & 15, ln = threadIdx.x >> 4;
-    int b = blockIdx.x;
+    int b = bid;
     const int fb = b % fblocks; b /= fblocks;
     const int f = fb * 16 + fl;
     // block order: [bias blocks: fblocks] then for each n: (R+1) * fblocks
@@ -703,6 +703,31 @@ __global__ __launch_bounds__(256) void bwd_prep_final_kernel(const float *part, 
         for (int l = 0; l < 16; ++l) t += red[l][fl];
         *dst = t;
     }
+}
+
+__global__ __launch_bounds__(256) void bwd_prep_final_kernel(const float *part, int chunks, int N, int F, int R, float *dbias,
+                                                             float *dcoef, float *dcoef_g, long long cs, long long cgs) {
+    bwd_prep_final_block(blockIdx.x, part, chunks, N, F, R, dbias, dcoef, dcoef_g, cs, cgs);
+}
+
+// the final stage of SEVERAL bwd_prep calls in one launch (their partial slabs stay in their workspaces until then):
+// the per-layer finals are 5 us dispatches whose results are only needed at the end of the backward pass
+struct BpFinalBatch {
+    struct I {
+        const float *part;
+        int chunks, N, F, R;
+        float *dbias, *dcoef, *dcoef_g;
+        long long cs, cgs;
+    } it[CAPE_MAX_BWD_PREP_ITEMS];
+    int blk_off[CAPE_MAX_BWD_PREP_ITEMS + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void bwd_prep_final_batch_kernel(BpFinalBatch B) {
+    int i = 0;
+    while (i + 1 < B.n && (int)blockIdx.x >= B.blk_off[i + 1]) ++i;
+    const BpFinalBatch::I &I = B.it[i];
+    bwd_prep_final_block((int)blockIdx.x - B.blk_off[i], I.part, I.chunks, I.N, I.F, I.R, I.dbias, I.dcoef, I.dcoef_g, I.cs, I.cgs);
 }
 
 inline int grid_for(long long total) {
@@ -931,8 +956,8 @@ extern "C" int64_t cape_bwd_prep_workspace_bytes(int32_t N, int32_t Mo, int32_t 
 extern "C" int cape_bwd_prep(const float *g, int64_t g_sample_stride, int32_t ldg, const float *y, int64_t y_sample_stride,
                              int32_t ldy, int32_t act, const uint32_t *mask, float *dz, int64_t dz_sample_stride, int32_t lddz,
                              float *dbias, const float *rowscale, int32_t R, float *dcoef, int32_t rg, float *dcoef_g,
-                             int64_t dcoef_sample_stride, int32_t N, int32_t Mo, int32_t F, void *workspace, int64_t workspace_bytes,
-                             void *stream) {
+                             int64_t dcoef_sample_stride, int32_t finalize, int32_t N, int32_t Mo, int32_t F, void *workspace,
+                             int64_t workspace_bytes, void *stream) {
     if (!g || !dz || !workspace || N < 1 || Mo < 1 || F < 1 || ldg < F || lddz < F || R < 0 || R > RSR_MAXR) return CAPE_EINVAL;
     if (act < CAPE_ACT_NONE || act > CAPE_ACT_TANH) return CAPE_EINVAL;
     if (!mask && act != CAPE_ACT_NONE && (!y || ldy < F)) return CAPE_EINVAL;
@@ -954,7 +979,7 @@ extern "C" int cape_bwd_prep(const float *g, int64_t g_sample_stride, int32_t ld
         CAPE_LAUNCH(bwd_prep_kernel, dim3(N * chunks), dim3(256), 0, st, gv, yv, act, mask, zv, rowscale, R, rg, dbias ? 1 : 0,
                     dcoef_g ? 1 : 0, N, Mo, F, (float *)workspace, chunks, RB);
     CAPE_LAUNCH_CHECK();
-    if (dbias || R > 0 || dcoef_g) {
+    if (finalize && (dbias || R > 0 || dcoef_g)) {
         const int fblocks = (F + 15) / 16;
         const int nblk = fblocks * (1 + N * (R + 1));
         CAPE_LAUNCH(bwd_prep_final_kernel, dim3(nblk), dim3(256), 0, st, (const float *)workspace, chunks, N, F, R, dbias, dcoef, dcoef_g,
@@ -962,5 +987,29 @@ extern "C" int cape_bwd_prep(const float *g, int64_t g_sample_stride, int32_t ld
                     dcoef_sample_stride ? (long long)dcoef_sample_stride : (long long)F);
         CAPE_LAUNCH_CHECK();
     }
+    return CAPE_OK;
+}
+
+extern "C" int cape_bwd_prep_finalize(const cape_bwd_prep_item_t *items, int32_t nitems, void *stream) {
+    if (!items || nitems < 1 || nitems > CAPE_MAX_BWD_PREP_ITEMS) return CAPE_EINVAL;
+    BpFinalBatch B;
+    B.n = nitems;
+    int off = 0;
+    for (int i = 0; i < nitems; ++i) {
+        const cape_bwd_prep_item_t &t = items[i];
+        if (!t.workspace || t.N < 1 || t.Mo < 1 || t.F < 1 || t.R < 0 || t.R > RSR_MAXR || (t.R > 0 && !t.dcoef)) return CAPE_EINVAL;
+        const int RB = bp_rows(t.N, t.Mo);
+        B.it[i].part = (const float *)t.workspace;
+        B.it[i].chunks = (t.Mo + RB - 1) / RB;
+        B.it[i].N = t.N; B.it[i].F = t.F; B.it[i].R = t.R;
+        B.it[i].dbias = t.dbias; B.it[i].dcoef = t.dcoef; B.it[i].dcoef_g = t.dcoef_g;
+        B.it[i].cs = t.dcoef_sample_stride ? (long long)t.dcoef_sample_stride : (long long)t.R * t.F;
+        B.it[i].cgs = t.dcoef_sample_stride ? (long long)t.dcoef_sample_stride : (long long)t.F;
+        B.blk_off[i] = off;
+        off += ((t.F + 15) / 16) * (1 + t.N * (t.R + 1));
+    }
+    B.blk_off[nitems] = off;
+    CAPE_LAUNCH(bwd_prep_final_batch_kernel, dim3(off), dim3(256), 0, (hipStream_t)stream, B);
+    CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }

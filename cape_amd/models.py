@@ -836,6 +836,15 @@ class CAPE(base_model):
             self._one = torch.ones((), device=self.device, dtype=torch.float32)      # d(loss)/d(loss), allocated once
         return self._one
 
+    def _deferred_begin(self):
+        ops.DEFERRED = []
+
+    def _deferred_end(self):
+        try:
+            ops.flush_deferred()
+        finally:
+            ops.DEFERRED = None
+
     def backward_phase1(self, out):
         """First half of the two-phase backward (``split_backward``): everything downstream of the encoder's
         convolution stack -- decoder, dense layers, discriminator.  Afterwards the EARLY part of the G bucket
@@ -843,6 +852,7 @@ class CAPE(base_model):
         st = self._opt_state['g']
         ne = st['n_early']
         one = self._one_scalar()
+        self._deferred_begin()
         heads = [t for t in (self._enc_feat_cut,) + tuple(self._y_pair) if t.requires_grad]
         res = torch.autograd.grad(out['loss_g'], st['params'][:ne] + heads, grad_outputs=one, retain_graph=True, allow_unused=True)
         self.store_grads('g', res[:ne], 0, ne)
@@ -851,6 +861,7 @@ class CAPE(base_model):
             grads_d = torch.autograd.grad(out['loss_d'], self._opt_state['d']['params'], grad_outputs=one, retain_graph=True,
                                           allow_unused=True)
             self.store_grads('d', grads_d)
+        self._deferred_end()
 
     def backward_phase2(self):
         """Second half: from the cut (and the condition embeddings) through the encoder convolutions and the
@@ -864,9 +875,11 @@ class CAPE(base_model):
                 roots.append(self._enc_feat if h is self._enc_feat_cut else h)
                 seeds.append(g)
         late = st['params'][ne:]
+        self._deferred_begin()
         if late:
             res = torch.autograd.grad(roots, late, grad_outputs=seeds, allow_unused=True) if roots else [None] * len(late)
             self.store_grads('g', res, ne, None)
+        self._deferred_end()
         self._phase_heads = self._enc_feat = self._enc_feat_cut = None
         self._add_reg_grads()
 
@@ -879,6 +892,13 @@ class CAPE(base_model):
         g_params = self._opt_state['g']['params']
         d_params = self._opt_state['d']['params']
         one = self._one_scalar()
+        self._deferred_begin()
+        try:
+            self._backward_to_flat_single(out, g_params, d_params, one)
+        finally:
+            self._deferred_end()
+
+    def _backward_to_flat_single(self, out, g_params, d_params, one):
         if 'loss_d' not in out:
             grads_g = torch.autograd.grad(out['loss_g'], g_params, grad_outputs=one, allow_unused=True)
             self.store_grads('g', grads_g)

@@ -395,7 +395,32 @@ def reduce_cond(dy, scale=None, out=None, accumulate=False):
     return out
 
 
-def bwd_prep(g, y=None, act="none", mask=None, want_bias=False, rowscale=None, R=0, rg=None, dbias_out=None, joint=False):
+# Deferred finalisation of bwd_prep's reductions: while DEFERRED is a list (set by the training step around the backward
+# pass) calls with defer=True leave their bias / coefficient-gradient reductions as partial slabs and queue them;
+# flush_deferred() finishes all queued ones in ONE launch (csrc cape_bwd_prep_finalize).  Consumers flush before reading.
+DEFERRED = None
+
+
+def flush_deferred():
+    global DEFERRED
+    if not DEFERRED:
+        return
+    items, DEFERRED[:] = list(DEFERRED), []
+    for i0 in range(0, len(items), 16):
+        chunk = items[i0:i0 + 16]
+        arr = (_lib.CapeBwdPrepItem * len(chunk))()
+        for a, it in zip(arr, chunk):
+            a.workspace = it["ws"].data_ptr()
+            a.N, a.Mo, a.F, a.R = it["N"], it["Mo"], it["F"], it["R"]
+            a.dbias = None if it["dbias"] is None else it["dbias"].data_ptr()
+            a.dcoef = None if it["dcoef"] is None else it["dcoef"].data_ptr()
+            a.dcoef_g = None if it["dcoef_g"] is None else it["dcoef_g"].data_ptr()
+            a.dcoef_sample_stride = it["cstride"]
+        check(lib.cape_bwd_prep_finalize(arr, len(chunk), _stream()), "cape_bwd_prep_finalize")
+
+
+def bwd_prep(g, y=None, act="none", mask=None, want_bias=False, rowscale=None, R=0, rg=None, dbias_out=None, joint=False,
+             defer=False):
     """One pass over g: returns (dz, dbias [F] or None, dcoef [N,R,F] or None, dcoef_g [N,F] or None).
     ``dbias_out``: optional contiguous destination of the bias gradient (a view of the gradient bucket).
     ``joint``: dcoef and dcoef_g are slices of ONE [N, R+1, F] buffer (returned as dcoef; the layout
@@ -428,8 +453,10 @@ def bwd_prep(g, y=None, act="none", mask=None, want_bias=False, rowscale=None, R
         yp, ys, yl = None, 0, 0
     rc = lib.cape_bwd_prep(gp, gs, gl, yp, ys, yl, _lib.ACT[act] if mask is None else 0, _ptr(mask), zp, zs, zl,
                            _ptr(dbias), _ptr(rowscale), R, _ptr(dcoef), 0 if rg is None else int(rg), _ptr(dcoef_g),
-                           cstride, N, Mo, F, _ptr(ws), need, _stream())
+                           cstride, 0 if (defer and DEFERRED is not None) else 1, N, Mo, F, _ptr(ws), need, _stream())
     check(rc, "cape_bwd_prep")
+    if defer and DEFERRED is not None and (dbias is not None or R or rg is not None):
+        DEFERRED.append(dict(ws=ws, N=N, Mo=Mo, F=F, R=R, dbias=dbias, dcoef=dcoef, dcoef_g=dcoef_g, cstride=cstride))
     return dz, dbias, dcoef, dcoef_g
 
 
@@ -621,7 +648,9 @@ class ChebConvFn(torch.autograd.Function):
             dz, dbv, dcoef, dca = bwd_prep(g, y=None if ysaved is None else ysaved[:, :, :Fout], act=act, mask=mask,
                                            want_bias=chan_bias, rowscale=ops.rowscale if Cc else None,
                                            R=K if Cc else 0, rg=(K if (Cc and W_aff is not None) else None),
-                                           dbias_out=ctx.gB, joint=ctx.banked)
+                                           dbias_out=ctx.gB, joint=ctx.banked,
+                                           # results read only at the end of the backward pass (bucket view / CondCoefFn)
+                                           defer=(not chan_bias or ctx.gB is not None) and (not Cc or ctx.banked))
         if need_b and ctx.has_bias:
             if ctx.bias_mode == _lib.BIAS_VERTEX:
                 dB = torch.empty((1, Mo, Fout), device=dev, dtype=torch.float32)
@@ -969,6 +998,7 @@ class CondCoefFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *dcoefs):
+        flush_deferred()                 # the dcoef reductions of the decoder layers were queued, finish them now
         (cond,) = ctx.saved_tensors
         layers = ctx.layers
         N, Cc = cond.shape

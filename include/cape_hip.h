@@ -198,8 +198,22 @@ int64_t cape_bwd_prep_workspace_bytes(int32_t N, int32_t Mo, int32_t F, int32_t 
 int cape_bwd_prep(const float *g, int64_t g_sample_stride, int32_t ldg, const float *y,
                   int64_t y_sample_stride, int32_t ldy, int32_t act, const uint32_t *mask, float *dz,
                   int64_t dz_sample_stride, int32_t lddz, float *dbias, const float *rowscale,
-                  int32_t R, float *dcoef, int32_t rg, float *dcoef_g, int64_t dcoef_sample_stride,
+                  int32_t R, float *dcoef, int32_t rg, float *dcoef_g, int64_t dcoef_sample_stride, int32_t finalize,
                   int32_t N, int32_t Mo, int32_t F, void *workspace, int64_t workspace_bytes, void *stream);
+
+/* finalize = 0 above leaves the reductions as partial slabs in the workspace; this entry finishes up to
+ * CAPE_MAX_BWD_PREP_ITEMS of them in ONE launch (same N, Mo, F, R and destinations as the deferred calls, whose
+ * workspaces must still be intact).  dz is always complete after cape_bwd_prep itself. */
+#define CAPE_MAX_BWD_PREP_ITEMS 16
+typedef struct cape_bwd_prep_item {
+    const void *workspace;
+    int32_t N, Mo, F, R;
+    float *dbias;
+    float *dcoef;
+    float *dcoef_g;
+    int64_t dcoef_sample_stride;
+} cape_bwd_prep_item_t;
+int cape_bwd_prep_finalize(const cape_bwd_prep_item_t *items, int32_t nitems, void *stream);
 
 /* y[n,r,:] = alpha * sum_e vals[e]*x[n,colidx[e],:] + beta * z[n,r,:]   (z may be NULL, may alias y).
  * max_row_nnz: upper bound on the entries of any row if the caller knows it (selects a fully unrolled
