@@ -23,6 +23,7 @@ import torch
 
 from . import ops
 from . import _lib
+from . import tf_checkpoint
 from .graph import ConvOperators, HostCSR, is_identity, vertex_edge_table
 from .load_data import load_pack
 
@@ -946,20 +947,86 @@ class CAPE(base_model):
         return fn
 
     def latest_checkpoint(self):
-        files = glob.glob(os.path.join(self._get_path('checkpoints'), 'model-*.npz'))
-        return max(files, key=os.path.getmtime) if files else None
+        """Newest checkpoint of this experiment: an ``.npz`` written by ``save_checkpoint`` or a TensorFlow
+        bundle named by the directory's ``checkpoint`` state file (the reference's
+        ``tf.train.latest_checkpoint``, :213) -- e.g. a pretrained model dropped into ``checkpoints/<name>/``."""
+        path = self._get_path('checkpoints')
+        files = glob.glob(os.path.join(path, 'model-*.npz'))
+        newest = max(files, key=os.path.getmtime) if files else None
+        tf_prefix = tf_checkpoint.latest_checkpoint(path)
+        if tf_prefix is not None and (newest is None or
+                                      os.path.getmtime(tf_prefix + '.index') > os.path.getmtime(newest)):
+            return tf_prefix
+        return newest
+
+    # TF slot-variable names (tf.train.MomentumOptimizer / AdamOptimizer, reference :447-452)
+    _SLOTS = {'m': {'momentum': '/Momentum', 'adam': '/Adam'}, 'v': {'adam': '/Adam_1'}}
+
+    def _slot_suffix(self, buf):
+        return self._SLOTS[buf].get('adam' if self.optimizer == 'adam' else 'momentum')
 
     def restore(self, filename):
-        with np.load(filename) as ck:
-            arrays = {k: ck[k] for k in ck.files}
+        """Load variables (and optimiser state when present) from an ``.npz`` of ``save_checkpoint`` or from a
+        TensorFlow checkpoint prefix (``.../model-1234``, files ``.index`` + ``.data-*``) with the variable
+        names of the reference graph."""
+        if os.path.isfile(filename + '.index'):
+            arrays = tf_checkpoint.BundleReader(filename).read_all()
+        elif filename.endswith('.index') and os.path.isfile(filename):
+            arrays = tf_checkpoint.BundleReader(filename[:-len('.index')]).read_all()
+        else:
+            with np.load(filename) as ck:
+                arrays = {k: ck[k] for k in ck.files}
         self.load_variables(arrays, strict=True)
         self.global_step = int(arrays.get('training/global_step', 0))
-        if self._opt_state is not None:
-            with torch.no_grad():
-                for grp in ('g', 'd'):
-                    key = 'training/momentum_' + grp
-                    if key in arrays and arrays[key].shape == tuple(self._opt_state[grp]['m'].shape):
-                        self._opt_state[grp]['m'].copy_(torch.from_numpy(arrays[key]).to(self.device))
+        if self._opt_state is None:
+            return
+        with torch.no_grad():
+            for grp in ('g', 'd'):
+                st = self._opt_state[grp]
+                key = 'training/momentum_' + grp
+                if key in arrays and arrays[key].shape == tuple(st['m'].shape):
+                    st['m'].copy_(torch.from_numpy(arrays[key]).to(self.device))
+                    continue
+                for buf in ('m', 'v'):                     # per-variable TF slots -> flat bucket
+                    suffix = self._slot_suffix(buf)
+                    if suffix is None or buf not in st:
+                        continue
+                    for name, (off, _) in st['offsets'].items():
+                        a = arrays.get(name + suffix)
+                        if a is not None and a.size == self._vars[name].numel():
+                            st[buf][off:off + a.size].copy_(
+                                torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32).reshape(-1)).to(self.device))
+                if 't' in st:
+                    b1p = arrays.get('training/beta1_power' if grp == 'g' else 'training/beta1_power_1')
+                    st['t'] = int(round(np.log(float(b1p)) / np.log(0.9))) if b1p is not None and 0 < float(b1p) < 1 \
+                        else self.global_step // 2
+
+    def export_tf_checkpoint(self, prefix=None, with_slots=True):
+        """Write the variables as a TensorFlow V2 checkpoint the reference's ``tf.train.Saver`` can restore
+        (names and layouts of its graph; optimiser slots as ``<var>/Momentum`` or ``<var>/Adam[_1]``) and
+        record it in the directory's ``checkpoint`` state file."""
+        if prefix is None:
+            prefix = os.path.join(self._get_path('checkpoints'), 'model-%d' % self.global_step)
+        arrays = dict(self.variables())
+        arrays['training/global_step'] = np.asarray(self.global_step, dtype=np.int32)
+        if with_slots and self._opt_state is not None:
+            for grp in ('g', 'd'):
+                st = self._opt_state[grp]
+                for buf in ('m', 'v'):
+                    suffix = self._slot_suffix(buf)
+                    if suffix is None or buf not in st:
+                        continue
+                    flat = st[buf].detach().cpu().numpy()
+                    for name, (off, _) in st['offsets'].items():
+                        v = self._vars[name]
+                        arrays[name + suffix] = flat[off:off + v.numel()].reshape(tuple(v.shape)).copy()
+                if 't' in st:
+                    tag = '' if grp == 'g' else '_1'
+                    arrays['training/beta1_power' + tag] = np.asarray(0.9 ** st['t'], dtype=np.float32)
+                    arrays['training/beta2_power' + tag] = np.asarray(0.999 ** st['t'], dtype=np.float32)
+        tf_checkpoint.write_bundle(prefix, arrays)
+        tf_checkpoint.update_checkpoint_state(os.path.dirname(os.path.abspath(prefix)), os.path.abspath(prefix))
+        return prefix
 
     def _get_session(self, sess=None):
         """The reference restores the latest checkpoint on every inference call (:209-215, quirk C9);
