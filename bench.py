@@ -152,6 +152,9 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--host-inputs', action='store_true',
+                    help='hand every step a fresh batch of HOST numpy arrays (as fit() does): the PCIe-inclusive rate '
+                         'quoted in DESIGN.md; never the headline value')
     args = ap.parse_args()
 
     from cape_amd import dist as cdist
@@ -175,15 +178,25 @@ def main():
     torch.cuda.synchronize()
     runner.capture()
 
-    for _ in range(args.warmup):
+    host = None
+    if args.host_inputs:               # pageable numpy arrays, one distinct batch per step
+        host = [{k: v.numpy() for k, v in synthetic_batch(model, seed=99 + 1000 * rank + i).items()}
+                for i in range(min(args.steps, 8))]
+
+    def one_step(i):
+        if host is not None:
+            runner.load_batch(**host[i % len(host)])
         runner.step()
+
+    for i in range(args.warmup):
+        one_step(i)
     torch.cuda.synchronize()
     if world > 1:
         tdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        runner.step()
+    for i in range(args.steps):
+        one_step(i)
     torch.cuda.synchronize()
     if world > 1:
         tdist.barrier()
@@ -207,6 +220,7 @@ def main():
                                % (args.config.replace("_pose32_clotype32_male", ""), " + mesh-patch discriminator (adversarial step)" if args.gan else "",
                                   args.batch, " (BASELINE configs[2])" if args.config.startswith("CAPE-affineconv_nz64") else ""),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "graph_replay": runner._gA is not None,
+                   "inputs": "host numpy per step (PCIe-inclusive)" if args.host_inputs else "resident in HBM",
                    "final_loss_g": loss},
         "roofline": roof,
     }
