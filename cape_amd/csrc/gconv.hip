@@ -13,6 +13,7 @@
 #include "common.h"
 #include "gconv_shared.h"
 #include "gemm_plain.h"
+#include "gemm_split.h"
 #include <stdlib.h>
 
 namespace {
@@ -671,7 +672,8 @@ inline bool dw_srcs_plain(const cape_src_t *srcs, int nsrc) {
 
 // Kernel choice of one forward launch (pure function of the arguments).
 struct FwdPlan {
-    int family;   // 0: gather-GEMM (gconv_fwd_kernel), 1: pipelined plain GEMM (gemm_plain_kernel)
+    int family;   // 0: gather-GEMM (gconv_fwd_kernel), 1: pipelined plain GEMM (gemm_plain_kernel),
+                  // 2: plain GEMM on the bf16 matrix pipe with exact three-way operand split (gemm_split_kernel)
     int BM, BN;
     int layout;   // family 1: 1 = weights contraction-contiguous, 0 = output-contiguous
 };
@@ -685,6 +687,13 @@ inline FwdPlan plan_fwd(const GconvParams &p, const cape_src_t *srcs, bool dual)
         if ((long long)p.Mo * srcs[i].ldx >= (1LL << 31) || (long long)p.F * ws >= (1LL << 31)) pl.layout = -1;   // 32-bit offsets
     }
     if (pl.layout >= 0) {
+        // CAPE_GEMM_BF16X6=0: keep every contraction on the exact-fp32 MFMA (A/B switch)
+        static const int gs_on = getenv("CAPE_GEMM_BF16X6") ? atoi(getenv("CAPE_GEMM_BF16X6")) : CAPE_GEMM_BF16X6_DEFAULT;
+        if (gs_on && gs_eligible(p, dual)) {
+            pl.family = 2;
+            gs_tile(p.N, p.Mo, p.F, pl.BM, pl.BN);
+            return pl;
+        }
         pl.family = 1;
         gp_tile(dual, p.F, pl.BM, pl.BN);
         return pl;
@@ -759,7 +768,9 @@ extern "C" int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, in
     p.col_tiles = (F + pl.BN - 1) / pl.BN;
     dim3 grid((unsigned)(N * p.row_tiles * p.col_tiles)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (pl.family == 1) {
+    if (pl.family == 2) {
+        gs_launch(p, pl.BM, pl.layout, grid, st);
+    } else if (pl.family == 1) {
         gp_launch(p, dual, pl.BM, pl.BN, pl.layout, grid, st);
     } else if (!dual) {
         if (pl.BN == 32) CAPE_LAUNCH((gconv_fwd_kernel<128, 32, 4, 1, false>), grid, block, 0, st, p);

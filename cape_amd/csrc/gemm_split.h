@@ -1,0 +1,266 @@
+// fp32 GEMM for PLAIN sources on the bf16 matrix pipe ("bf16x6"): the same contraction as gemm_plain.h
+// (y[n] = epilogue(sum_s X_s[n] @ B_s), reference lib/models.py:99-102), with every fp32 operand split EXACTLY
+// into three bf16 pieces while it is staged into LDS,
+//     x = hi + mid + lo      (8 + 8 + 8 significand bits; truncation split, both subtractions exact)
+// and six of the nine cross products accumulated in the fp32 accumulator of v_mfma_f32_32x32x16_bf16
+// (smallest first):  hi*lo + lo*hi + mid*mid + hi*mid + mid*hi + hi*hi.
+// The three dropped products are <= 2^-24 relative to the exact product, i.e. below the rounding of an fp32
+// multiply; measured against float64 the result is as accurate as an fp32 FMA chain (tools/ubench/gemm_bf16x3.hip:
+// rms error 4.96e-07 vs 5.74e-07 of rms(ref) at K = 1024; all nine products: 4.95e-07).  The bf16 pipe sustains
+// ~1.7-1.85 PFLOP/s on this chip (same ubench), /6 = ~290 TFLOP/s fp32-equivalent against the 142 TFLOP/s the
+// exact-fp32 MFMA sustains.
+//
+// Scope: non-DUAL launches whose sources all have C % 32 == 0 (whole 32-wide chunks, no masking); weights in
+// either layout (contraction-contiguous, or output-contiguous with a transposing stage).  Same block mapping,
+// epilogue (rank-1 terms, bias, activation, de-interleave) and software pipeline as gemm_plain_kernel.
+// Not bit-identical to the fp32-MFMA kernels (different summation tree); inf inputs give NaN (inf - inf in the split).
+#pragma once
+#include "gconv_shared.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#ifndef CAPE_GEMM_BF16X6_DEFAULT
+#define CAPE_GEMM_BF16X6_DEFAULT 1
+#endif
+
+constexpr int GS_KC = 32;       // contraction indices per staged chunk = two k16 MFMA steps
+constexpr int GS_PITCH = 80;    // bytes per LDS row of one piece plane: 32 bf16 + 16 B pad (conflict-free ds_read_b128)
+
+__device__ __forceinline__ unsigned gs_bits(float v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ float gs_float(unsigned v) { return __builtin_bit_cast(float, v); }
+
+// two fp32 -> their three bf16 pieces, packed pairwise (first element in the low half)
+__device__ __forceinline__ void gs_split2(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
+    const unsigned h0 = gs_bits(x0) & 0xFFFF0000u, h1 = gs_bits(x1) & 0xFFFF0000u;
+    const float r0 = x0 - gs_float(h0), r1 = x1 - gs_float(h1);                 // exact
+    const unsigned m0 = gs_bits(r0) & 0xFFFF0000u, m1 = gs_bits(r1) & 0xFFFF0000u;
+    const float s0 = r0 - gs_float(m0), s1 = r1 - gs_float(m1);                 // exact, <= 8 significant bits left
+    hi = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+    mid = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+    lo = __builtin_amdgcn_perm(gs_bits(s1), gs_bits(s0), 0x07060302u);
+}
+
+// eight consecutive contraction indices -> one 16-byte row segment per piece plane
+__device__ __forceinline__ void gs_store8(unsigned char *dst, int plane, const float (&v)[8]) {
+    uint4 hi, mid, lo;
+    gs_split2(v[0], v[1], hi.x, mid.x, lo.x);
+    gs_split2(v[2], v[3], hi.y, mid.y, lo.y);
+    gs_split2(v[4], v[5], hi.z, mid.z, lo.z);
+    gs_split2(v[6], v[7], hi.w, mid.w, lo.w);
+    *reinterpret_cast<uint4 *>(dst) = hi;
+    *reinterpret_cast<uint4 *>(dst + plane) = mid;
+    *reinterpret_cast<uint4 *>(dst + 2 * plane) = lo;
+}
+
+// Workgroup tile BM x BN, 4 waves as 2 x 2, wave tile (BM/2) x (BN/2).
+template <int BM, int BN, bool BKC>
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 4) void gemm_split_kernel(GconvParams p) {
+    constexpr int WTM = BM / 2, WTN = BN / 2;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int PA = BM / 64, PB = BN / 64;      // staging passes of the k-contiguous form: 64 rows x 4 eight-float groups
+    constexpr int KPT = BN / 8;                     // [k][n] weight staging: one output column, KPT consecutive k per thread
+    constexpr int APLANE = BM * GS_PITCH, BPLANE = BN * GS_PITCH;
+    static_assert(TM >= 1 && TN >= 1 && (BN == 64 || BN == 128), "tile");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * (APLANE + BPLANE)];
+    unsigned char *sA = smem, *sB = smem + 3 * APLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int q = tid & 3, r = tid >> 2;
+    const int bcol = tid % BN, kg = tid / BN;       // [k][n] staging coordinates
+
+    int n, t;
+    cape_map_block(blockIdx.x, p.N, p.row_tiles * p.col_tiles, n, t);
+    const int r0 = (t / p.col_tiles) * BM;
+    const int f0 = (t % p.col_tiles) * BN;
+
+    f32x16 acc[TM][TN];
+    f32x16 acc2[1][1];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+
+    int total = 0;
+    for (int si = 0; si < p.nsrc; ++si) total += p.s[si].C / GS_KC;
+
+    // clamped rows / columns (tile parts beyond Mo / F are computed on valid data and never stored)
+    int rc[PA], fc[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) rc[i] = min(r0 + r + 64 * i, p.Mo - 1);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) fc[i] = min(f0 + r + 64 * i, p.F - 1);
+    const int fcol = min(f0 + bcol, p.F - 1);
+
+    // ---- loader cursor: source l_si, channel offset l_c0 (every source is a whole number of chunks)
+    int l_si = 0, l_c0 = 0, l_C = 0;
+    const float *l_x = nullptr, *l_w = nullptr;
+    long long l_wrs = 0;
+    int arow[PA], brow[PB];
+    auto open_source = [&]() {
+        const SrcDev &S = p.s[l_si];
+        l_C = S.C;
+        l_x = S.x + (long long)n * S.xs;
+        l_w = S.w;
+        l_wrs = S.wrs;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) arow[i] = rc[i] * S.ldx;
+        if constexpr (BKC) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) brow[i] = fc[i] * (int)S.wcs;
+        }
+    };
+
+    float4 ra[PA][2];
+    float rbv[BKC ? PB : 1][BKC ? 8 : KPT];
+    auto load_regs = [&]() {
+        const int c = l_c0 + 8 * q;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            ra[i][0] = *reinterpret_cast<const float4 *>(l_x + arow[i] + c);
+            ra[i][1] = *reinterpret_cast<const float4 *>(l_x + arow[i] + c + 4);
+        }
+        if constexpr (BKC) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const float4 u = *reinterpret_cast<const float4 *>(l_w + brow[i] + c);
+                const float4 v = *reinterpret_cast<const float4 *>(l_w + brow[i] + c + 4);
+                rbv[i][0] = u.x; rbv[i][1] = u.y; rbv[i][2] = u.z; rbv[i][3] = u.w;
+                rbv[i][4] = v.x; rbv[i][5] = v.y; rbv[i][6] = v.z; rbv[i][7] = v.w;
+            }
+        } else {
+            const float *wk = l_w + (long long)(l_c0 + kg * KPT) * l_wrs + fcol;
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) rbv[0][j] = wk[(long long)j * l_wrs];
+        }
+        l_c0 += GS_KC;
+        if (l_c0 >= l_C) {
+            l_c0 = 0;
+            ++l_si;
+            if (l_si < p.nsrc) open_source();
+        }
+    };
+
+    auto store_regs = [&]() {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const float v[8] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w, ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
+            gs_store8(sA + (r + 64 * i) * GS_PITCH + 16 * q, APLANE, v);
+        }
+        if constexpr (BKC) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) gs_store8(sB + (r + 64 * i) * GS_PITCH + 16 * q, BPLANE, rbv[i]);
+        } else {
+#pragma unroll
+            for (int g = 0; g < KPT / 8; ++g) {
+                const float v[8] = {rbv[0][8 * g + 0], rbv[0][8 * g + 1], rbv[0][8 * g + 2], rbv[0][8 * g + 3],
+                                    rbv[0][8 * g + 4], rbv[0][8 * g + 5], rbv[0][8 * g + 6], rbv[0][8 * g + 7]};
+                gs_store8(sB + bcol * GS_PITCH + 16 * (kg * (KPT / 8) + g), BPLANE, v);
+            }
+        }
+    };
+
+    // ---- multiply one staged chunk.  Lane (li, lh) of v_mfma_f32_32x32x16_bf16 supplies row/column li and the
+    // contraction indices 8*lh .. 8*lh+7 of the k16 step: one 16-byte LDS read per operand piece.
+    auto compute = [&]() {
+        const unsigned char *pa = sA + (wm * WTM + li) * GS_PITCH + 16 * lh;
+        const unsigned char *pb = sB + (wn * WTN + li) * GS_PITCH + 16 * lh;
+#pragma unroll
+        for (int ks = 0; ks < GS_KC / 16; ++ks) {
+            bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    af[a][pc] = *reinterpret_cast<const bf16x8 *>(pa + pc * APLANE + a * 32 * GS_PITCH + 32 * ks);
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    bf[b][pc] = *reinterpret_cast<const bf16x8 *>(pb + pc * BPLANE + b * 32 * GS_PITCH + 32 * ks);
+            // piece indices (0 = hi, 1 = mid, 2 = lo) of the six products, smallest first
+            constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][TA[term]], bf[b][TB[term]], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    open_source();
+    load_regs();
+    store_regs();
+    __syncthreads();
+    for (int it = 0; it < total; ++it) {
+        const bool more = it + 1 < total;
+        if (more) load_regs();          // chunk it+1: global -> registers, in flight during the MFMAs below
+        compute();
+        __syncthreads();
+        if (more) store_regs();         // split + LDS store
+        __syncthreads();
+    }
+
+    if (p.rankR > 0 || p.bias_mode == CAPE_BIAS_VERTEX || p.act == CAPE_ACT_TANH) {
+        gconv_epilogue<BM, BN, 2, 2, false>(p, acc, acc2, n, r0, f0, wm, wn, li, lh);
+        return;
+    }
+    // Short epilogue for the common launches (no rank-1 terms; channel bias or none; identity / ReLU / leaky ReLU as
+    // one negative-side slope).  With two workgroups per CU all tiles of a launch finish together, so the epilogue is
+    // not hidden behind other workgroups' multiplies: the general one (uniform branches per element) cost ~10 us here.
+    const float slope = p.act == CAPE_ACT_LEAKY ? 0.2f : 1.f;
+    const bool relu = p.act == CAPE_ACT_RELU;
+    float *yb = p.y + (long long)n * p.ys;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int f = f0 + wn * WTN + b * 32 + li;
+            const bool fok = f < p.F;
+            const int fm = p.deintK > 1 ? (f % p.deintK) * p.deint_stride + f / p.deintK : f;
+            const float bch = (p.bias_mode == CAPE_BIAS_CHANNEL && fok) ? p.bias[f] : 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row = r0 + wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                float v = acc[a][b][g] + bch;
+                v = v > 0.f ? v : (relu ? 0.f : slope * v);
+                if (fok && row < p.Mo) yb[(long long)row * p.ldy + fm] = v;
+            }
+        }
+}
+
+// Eligibility (on top of gp_weight_layout() >= 0): no second weight set, whole chunks, an output wide enough for
+// the 64-column MFMA tile pair.
+inline bool gs_eligible(const GconvParams &p, bool dual) {
+    if (dual || p.F < 64) return false;
+    for (int i = 0; i < p.nsrc; ++i)
+        if (p.s[i].C % GS_KC != 0 || p.s[i].C < GS_KC) return false;
+    return true;
+}
+
+// 128 x 128 tiles (2 workgroups per CU: 61 KB LDS, ~200 VGPRs) when they still give every CU its two workgroups,
+// 64 x 64 (5 per CU) otherwise -- the faster choice on every layer shape of the model in tools/ubench/gemm_bf16x3.hip.
+inline void gs_tile(int N, int Mo, int F, int &BM, int &BN) {
+    const long long big = (long long)N * ((Mo + 127) / 128) * ((F + 127) / 128);
+    if (F >= 128 && big >= 384) { BM = 128; BN = 128; }
+    else { BM = 64; BN = 64; }
+}
+
+inline void gs_launch(const GconvParams &p, int BM, int layout, dim3 grid, hipStream_t st) {
+    if (BM == 128) {
+        if (layout == 1) CAPE_LAUNCH((gemm_split_kernel<128, 128, true>), grid, dim3(256), 0, st, p);
+        else CAPE_LAUNCH((gemm_split_kernel<128, 128, false>), grid, dim3(256), 0, st, p);
+    } else {
+        if (layout == 1) CAPE_LAUNCH((gemm_split_kernel<64, 64, true>), grid, dim3(256), 0, st, p);
+        else CAPE_LAUNCH((gemm_split_kernel<64, 64, false>), grid, dim3(256), 0, st, p);
+    }
+}
+
+}  // namespace

@@ -200,7 +200,9 @@ def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=
         check(lib.cape_gconv_fwd_plan(arr, len(entries), N, Mo, F, plan), "cape_gconv_fwd_plan")
         fam, bm, bn, layout = list(plan)
         waves = "2, 2" if (bm, bn) in ((64, 128), (128, 128), (64, 64)) else "4, 1"
-        if fam == 1:
+        if fam == 2:
+            name = "gemm_split_kernel<%d, %d, %s>" % (bm, bn, "true" if layout else "false")
+        elif fam == 1:
             name = "gemm_plain_kernel<%d, %d, %s, %s, %s>" % (bm, bn, waves, "true" if dual else "false", "true" if layout else "false")
         else:
             name = "gconv_fwd_kernel<%d, %d, %s, %s, 32>" % (bm, bn, waves, "true" if dual else "false")

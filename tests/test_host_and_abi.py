@@ -141,11 +141,17 @@ def test_forward_plan_query_is_pure_host_logic():
         assert lib.cape_gconv_fwd_plan(srcs(specs), len(specs), N, Mo, F, out) == 0
         return list(out)
 
+    split = int(os.environ.get("CAPE_GEMM_BF16X6", "1"))     # bf16x6 family (2) replaces the fp32-MFMA family (1) where eligible
+    fam = 2 if split else 1
     # plain aligned sources, forward weight layout (rows c*K+k of [C*K, F], F contiguous) -> pipelined kernel, 64x64
-    assert plan([(64, 64, False, 2 * 128, 1, 0x4000), (64, 64, False, 2 * 128, 1, 0x8000)], 16, 862, 128) == [1, 64, 64, 0]
+    assert plan([(64, 64, False, 2 * 128, 1, 0x4000), (64, 64, False, 2 * 128, 1, 0x8000)], 16, 862, 128) == [fam, 64, 64, 0]
     # data-gradient layout (contraction contiguous)
-    assert plan([(128, 128, False, 1, 2 * 128, 0x4000)], 16, 862, 64)[:2] == [1, 64] and \
-        plan([(128, 128, False, 1, 2 * 128, 0x4000)], 16, 862, 64)[3] == 1
+    assert plan([(128, 128, False, 1, 2 * 128, 0x4000)], 16, 862, 64) == [fam, 64, 64, 1]
+    # wide coarse-level layer: 128x128 tiles for the split family once every CU gets two of them
+    assert plan([(512, 512, False, 512, 1, 0x4000)] * 2, 16, 862, 512) == ([2, 128, 128, 0] if split else [1, 64, 64, 0])
+    assert plan([(512, 512, False, 256, 1, 0x4000)], 16, 862, 256) == [fam, 64, 64, 0]
+    # a source that is not a whole number of 32-wide chunks, or a second weight set, stays on the fp32-MFMA family
+    assert plan([(48, 48, False, 128, 1, 0x4000)], 16, 862, 128)[0] == 1
     # narrow output -> 128 x 32 tiles
     assert plan([(64, 64, False, 32, 1, 0x4000)], 16, 6890, 32) == [1, 128, 32, 0]
     # gathered source, unaligned base, or unpadded odd channel count -> gather kernel

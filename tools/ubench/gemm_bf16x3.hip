@@ -1,0 +1,359 @@
+// Experiment: fp32 GEMM on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the f32-MFMA rate) by splitting every
+// fp32 operand EXACTLY into three bf16 pieces (x = hi + mid + lo, 8 + 8 + 8 significand bits, truncation split) while
+// it is staged into LDS, and accumulating the cross products in the MFMA's fp32 accumulator:
+//   NT = 6:  hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi   (dropped terms <= 2^-24 relative: fp32-level)
+//   NT = 9:  all nine products (every product of two fp32 inputs exact before accumulation)
+//   NT = 3:  hi*hi + hi*mid + mid*hi                              (~2^-16: tf32x3-like, for reference)
+// Shape of the work: the trailing contraction of chebyshev5 (reference lib/models.py:99-102) in its data-gradient
+// layout -- C[n] = A[n] (Mo x K) * B^T with B stored [F][K] (contraction-contiguous), per sample n.
+// Standalone (no library):  hipcc --offload-arch=gfx950 -O3 gemm_bf16x3.hip -o gemm_bf16x3
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int KC = 32;              // contraction indices per staged chunk (two k16 MFMA steps)
+constexpr int PITCH = 80;           // bytes per LDS row of one piece plane: 32 bf16 + 16 B pad (conflict-free b128 reads)
+
+__device__ __forceinline__ unsigned fbits(float v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ float bitsf(unsigned v) { return __builtin_bit_cast(float, v); }
+
+// two fp32 -> their three bf16 pieces, packed pairwise (element 0 in the low half)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
+    const unsigned h0 = fbits(x0) & 0xFFFF0000u, h1 = fbits(x1) & 0xFFFF0000u;
+    const float r0 = x0 - bitsf(h0), r1 = x1 - bitsf(h1);                 // exact
+    const unsigned m0 = fbits(r0) & 0xFFFF0000u, m1 = fbits(r1) & 0xFFFF0000u;
+    const float s0 = r0 - bitsf(m0), s1 = r1 - bitsf(m1);                 // exact, <= 8 significant bits left
+    hi = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+    mid = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+    lo = __builtin_amdgcn_perm(fbits(s1), fbits(s0), 0x07060302u);
+}
+
+__device__ __forceinline__ void split8(const float4 &u, const float4 &v, uint4 &hi, uint4 &mid, uint4 &lo) {
+    split2(u.x, u.y, hi.x, mid.x, lo.x);
+    split2(u.z, u.w, hi.y, mid.y, lo.y);
+    split2(v.x, v.y, hi.z, mid.z, lo.z);
+    split2(v.z, v.w, hi.w, mid.w, lo.w);
+}
+
+// piece indices (0 = hi, 1 = mid, 2 = lo) of the A and B factor of term t, smallest products first
+__host__ __device__ constexpr int term_count(int nt) { return nt; }
+__host__ __device__ constexpr int term_pa(int nt, int t) {
+    return nt == 3 ? (t == 0 ? 0 : t == 1 ? 1 : 0)
+         : nt == 6 ? (t == 0 ? 0 : t == 1 ? 2 : t == 2 ? 1 : t == 3 ? 0 : t == 4 ? 1 : 0)
+                   : (t == 0 ? 2 : t == 1 ? 1 : t == 2 ? 2 : t == 3 ? 0 : t == 4 ? 2 : t == 5 ? 1 : t == 6 ? 0 : t == 7 ? 1 : 0);
+}
+__host__ __device__ constexpr int term_pb(int nt, int t) {
+    return nt == 3 ? (t == 0 ? 1 : t == 1 ? 0 : 0)
+         : nt == 6 ? (t == 0 ? 2 : t == 1 ? 0 : t == 2 ? 1 : t == 3 ? 1 : t == 4 ? 0 : 0)
+                   : (t == 0 ? 2 : t == 1 ? 2 : t == 2 ? 1 : t == 3 ? 2 : t == 4 ? 0 : t == 5 ? 1 : t == 6 ? 1 : t == 7 ? 0 : 0);
+}
+
+// block -> (sample, tile): all tiles of a sample on one XCD (blocks are dispatched round robin over the 8 XCDs)
+__device__ __forceinline__ void map_block(int b, int N, int T, int &n, int &t) {
+    if ((N & 7) == 0) {
+        const int per = N >> 3, local = b >> 3;
+        n = (b & 7) * per + local / T;
+        t = local % T;
+    } else {
+        n = b / T;
+        t = b % T;
+    }
+}
+
+// WG tile BM x BN, 4 waves as 2 x 2, wave tile (BM/2) x (BN/2)
+// PF = chunks of global loads in flight during a multiply (1 or 2); DBG: 1 = no global loads inside the loop, 2 = no split
+// arithmetic (raw bits stored; wrong results), 3 = both -- timing decomposition only
+template <int BM, int BN, int NT, int MINB, int PF, int DBG>
+__global__ __launch_bounds__(256, MINB) void gemm_bf16x3_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                                float *__restrict__ C, int N, int Mo, int K, int F,
+                                                                int row_tiles, int col_tiles) {
+    constexpr int WTM = BM / 2, WTN = BN / 2;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int PA = BM / 64, PB = BN / 64;            // staging passes (64 rows x 4 eight-float groups per pass)
+    constexpr int APLANE = BM * PITCH, BPLANE = BN * PITCH;
+    constexpr bool NEED_LO = NT != 3;
+    constexpr int NP = NEED_LO ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NP * (APLANE + BPLANE)];
+    unsigned char *sA = smem, *sB = smem + NP * APLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int q = tid & 3, r = tid >> 2;
+
+    int n, t;
+    map_block(blockIdx.x, N, row_tiles * col_tiles, n, t);
+    const int r0 = (t / col_tiles) * BM, f0 = (t % col_tiles) * BN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+
+    const float *ap[PA], *bp[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) ap[i] = A + ((long long)n * Mo + min(r0 + r + 64 * i, Mo - 1)) * K + 8 * q;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) bp[i] = B + (long long)min(f0 + r + 64 * i, F - 1) * K + 8 * q;
+
+    float4 ra[PF][PA][2], rb[PF][PB][2];
+    auto load_regs = [&](auto slot, int k0) {
+        constexpr int S = decltype(slot)::value;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            ra[S][i][0] = *reinterpret_cast<const float4 *>(ap[i] + k0);
+            ra[S][i][1] = *reinterpret_cast<const float4 *>(ap[i] + k0 + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            rb[S][i][0] = *reinterpret_cast<const float4 *>(bp[i] + k0);
+            rb[S][i][1] = *reinterpret_cast<const float4 *>(bp[i] + k0 + 4);
+        }
+    };
+    auto split = [&](const float4 &u, const float4 &v, uint4 &hi, uint4 &mid, uint4 &lo) {
+        if (DBG & 2) {
+            hi = uint4{fbits(u.x), fbits(u.y), fbits(u.z), fbits(u.w)};
+            mid = uint4{fbits(v.x), fbits(v.y), fbits(v.z), fbits(v.w)};
+            lo = hi;
+        } else {
+            split8(u, v, hi, mid, lo);
+        }
+    };
+    auto store_regs = [&](auto slot) {
+        constexpr int S = decltype(slot)::value;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            uint4 hi, mid, lo;
+            split(ra[S][i][0], ra[S][i][1], hi, mid, lo);
+            unsigned char *d = sA + (r + 64 * i) * PITCH + 16 * q;
+            *reinterpret_cast<uint4 *>(d) = hi;
+            *reinterpret_cast<uint4 *>(d + APLANE) = mid;
+            if (NEED_LO) *reinterpret_cast<uint4 *>(d + 2 * APLANE) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            uint4 hi, mid, lo;
+            split(rb[S][i][0], rb[S][i][1], hi, mid, lo);
+            unsigned char *d = sB + (r + 64 * i) * PITCH + 16 * q;
+            *reinterpret_cast<uint4 *>(d) = hi;
+            *reinterpret_cast<uint4 *>(d + BPLANE) = mid;
+            if (NEED_LO) *reinterpret_cast<uint4 *>(d + 2 * BPLANE) = lo;
+        }
+    };
+    auto compute = [&]() {
+        const unsigned char *pa = sA + (wm * WTM + li) * PITCH + 16 * lh;
+        const unsigned char *pb = sB + (wn * WTN + li) * PITCH + 16 * lh;
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            bf16x8 af[TM][NP], bf[TN][NP];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    af[a][p] = *reinterpret_cast<const bf16x8 *>(pa + p * APLANE + a * 32 * PITCH + 32 * ks);
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    bf[b][p] = *reinterpret_cast<const bf16x8 *>(pb + p * BPLANE + b * 32 * PITCH + 32 * ks);
+#pragma unroll
+            for (int term = 0; term < NT; ++term)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][term_pa(NT, term)], bf[b][term_pb(NT, term)],
+                                                                            acc[a][b], 0, 0, 0);
+        }
+    };
+
+    auto sync = [&]() { if (!(DBG & 8)) __syncthreads(); };
+    const int total = K / KC;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, PF - 1>;
+    load_regs(S0{}, 0);
+    store_regs(S0{});
+    __syncthreads();
+    if (PF == 1) {
+        for (int it = 0; it < total; ++it) {
+            const bool more = it + 1 < total;
+            if (more && !(DBG & 1)) load_regs(S0{}, (it + 1) * KC);
+            compute();
+            sync();
+            if (more) store_regs(S0{});
+            sync();
+        }
+    } else {
+        // LDS holds chunk `it`; slot A carries chunk it+1, slot B chunk it+2 (loads of two chunks in flight)
+        if (1 < total) load_regs(S0{}, KC);
+        for (int it = 0; it < total; it += 2) {
+            if (it + 2 < total && !(DBG & 1)) load_regs(S1{}, (it + 2) * KC);
+            compute();
+            sync();
+            if (it + 1 < total) store_regs(S0{});
+            sync();
+            if (it + 1 < total) {
+                if (it + 3 < total && !(DBG & 1)) load_regs(S0{}, (it + 3) * KC);
+                compute();
+                sync();
+                if (it + 2 < total) store_regs(S1{});
+                sync();
+            }
+        }
+    }
+
+    // C/D layout of the 32x32 MFMA tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    float *cn = C + (long long)n * Mo * F;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = f0 + wn * WTN + b * 32 + li;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row = r0 + wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                if (row < Mo && col < F) cn[(long long)row * F + col] = acc[a][b][g];
+            }
+        }
+}
+
+// sustained v_mfma_f32_32x32x16_bf16 rate, no memory traffic (NACC independent accumulators per wave)
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_bf16_loop(float *out, int iters) {
+    f32x16 acc[NACC];
+    for (int a = 0; a < NACC; ++a)
+        for (int g = 0; g < 16; ++g) acc[a][g] = 0.f;
+    bf16x8 av, bv;
+    for (int j = 0; j < 8; ++j) { av[j] = (__bf16)(1e-3f * (1 + (threadIdx.x + j) % 7)); bv[j] = (__bf16)(1e-3f * (2 + (threadIdx.x + j) % 5)); }
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[a], 0, 0, 0);
+    }
+    float sum = 0.f;
+    for (int a = 0; a < NACC; ++a)
+        for (int g = 0; g < 16; ++g) sum += acc[a][g];
+    out[blockIdx.x * 256 + threadIdx.x] = sum;
+}
+
+static void peak(int blocks, int iters, float *out) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    mfma_bf16_loop<4><<<blocks, 256>>>(out, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    mfma_bf16_loop<4><<<blocks, 256>>>(out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double fl = (double)blocks * 4 * iters * 4 * 32768.0;
+    printf("bf16 MFMA peak: %d blocks (%.0f waves/SIMD) x %d iters: %.3f ms  %.0f TFLOP/s (/6 = %.0f fp32-equivalent)\n", blocks,
+           blocks / 256.0, iters, ms, fl / ms / 1e9, fl / ms / 1e9 / 6);
+}
+
+struct Shape { int N, Mo, K, F; };
+
+static void fill(std::vector<float> &h, unsigned seed, float scale) {
+    unsigned s = seed * 2654435761u + 12345u;
+    for (size_t i = 0; i < h.size(); ++i) {
+        s = s * 1664525u + 1013904223u;
+        // full 24-bit mantissas, mixed magnitudes (a few octaves) so that the low pieces matter
+        const float m = ((int)(s >> 8) % 16777216) / 16777216.0f - 0.5f;
+        s = s * 1664525u + 1013904223u;
+        h[i] = scale * m * (1 << ((s >> 28) & 3));
+    }
+}
+
+template <int BM, int BN, int NT, int MINB, int PF = 1, int DBG = 0>
+static double run(const Shape &s, const float *A, const float *B, float *C, int iters) {
+    const int rt = (s.Mo + BM - 1) / BM, ct = (s.F + BN - 1) / BN;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    auto launch = [&]() { gemm_bf16x3_kernel<BM, BN, NT, MINB, PF, DBG><<<s.N * rt * ct, 256>>>(A, B, C, s.N, s.Mo, s.K, s.F, rt, ct); };
+    launch();
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < iters; ++i) launch();
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return 1e3 * ms / iters;
+}
+
+// error of rows [ra, rb) of sample n against a float64 reference; also the error an fp32 sequential dot makes
+static void check(const Shape &s, const std::vector<float> &hA, const std::vector<float> &hB, const float *dC, int n, int ra, int rb,
+                  double &err_max, double &err_rms, double &f32_rms) {
+    std::vector<float> hC((size_t)(rb - ra) * s.F);
+    hipMemcpy(hC.data(), dC + ((size_t)n * s.Mo + ra) * s.F, hC.size() * 4, hipMemcpyDeviceToHost);
+    double se = 0, sf = 0, sr = 0;
+    err_max = 0;
+    for (int r = ra; r < rb; ++r)
+        for (int f = 0; f < s.F; ++f) {
+            const float *a = &hA[((size_t)n * s.Mo + r) * s.K], *b = &hB[(size_t)f * s.K];
+            double ref = 0;
+            float f32 = 0.f;
+            for (int k = 0; k < s.K; ++k) { ref += (double)a[k] * (double)b[k]; f32 = fmaf(a[k], b[k], f32); }
+            const double e = (double)hC[(size_t)(r - ra) * s.F + f] - ref;
+            se += e * e; sf += ((double)f32 - ref) * ((double)f32 - ref); sr += ref * ref;
+            if (fabs(e) > err_max) err_max = fabs(e);
+        }
+    const double cnt = (double)(rb - ra) * s.F;
+    const double scale = sqrt(sr / cnt);
+    err_max /= scale; err_rms = sqrt(se / cnt) / scale; f32_rms = sqrt(sf / cnt) / scale;
+}
+
+int main(int argc, char **argv) {
+    std::vector<Shape> shapes = {{16, 862, 1024, 512}, {16, 862, 768, 512}, {16, 862, 512, 512}, {16, 862, 512, 256},
+                                 {16, 1723, 256, 256}};
+    const int iters = 20;
+    {
+        float *o; hipMalloc(&o, 2048 * 256 * 4);
+        peak(256, 20000, o); peak(512, 10000, o); peak(512, 50, o); peak(1024, 5000, o);
+        hipFree(o);
+    }
+    const char *names[] = {"128x128 pf1", "neither", "neither+nobar", "nobar only", "x3 neither", "x9 neither", "64x64 neither", "128x64 neither"};
+    constexpr int NV = 8;
+    printf("%-22s", "shape (N Mo K F)");
+    for (int i = 0; i < NV; ++i) printf(" %16s", names[i]);
+    printf("\n");
+    for (const Shape &s : shapes) {
+        std::vector<float> hA((size_t)s.N * s.Mo * s.K), hB((size_t)s.F * s.K);
+        fill(hA, 7, 1.0f);
+        fill(hB, 100, 0.05f);
+        float *A, *B, *C;
+        hipMalloc(&A, hA.size() * 4); hipMalloc(&B, hB.size() * 4); hipMalloc(&C, (size_t)s.N * s.Mo * s.F * 4);
+        hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
+        const double fl = 2.0 * s.N * s.Mo * (double)s.K * s.F;
+        double us[NV], emax[NV], erms[NV], f32rms = 0;
+        auto chk = [&](int i) { check(s, hA, hB, C, s.N - 1, s.Mo - 24, s.Mo, emax[i], erms[i], f32rms); };
+        auto clr = [&]() { hipMemset(C, 0xFF, (size_t)s.N * s.Mo * s.F * 4); };
+        clr(); us[0] = run<128, 128, 6, 2, 1, 0>(s, A, B, C, iters); chk(0);
+        clr(); us[1] = run<128, 128, 6, 2, 1, 3>(s, A, B, C, iters); chk(1);
+        clr(); us[2] = run<128, 128, 6, 2, 1, 11>(s, A, B, C, iters); chk(2);
+        clr(); us[3] = run<128, 128, 6, 2, 1, 8>(s, A, B, C, iters); chk(3);
+        clr(); us[4] = run<128, 128, 3, 2, 1, 3>(s, A, B, C, iters); chk(4);
+        clr(); us[5] = run<128, 128, 9, 2, 1, 3>(s, A, B, C, iters); chk(5);
+        clr(); us[6] = run<64, 64, 6, 5, 1, 3>(s, A, B, C, iters); chk(6);
+        clr(); us[7] = run<128, 64, 6, 2, 1, 3>(s, A, B, C, iters); chk(7);
+        char name[64];
+        snprintf(name, sizeof name, "%d %d %d %d", s.N, s.Mo, s.K, s.F);
+        printf("%-22s", name);
+        for (int i = 0; i < NV; ++i) printf(" %6.1fus %5.1fTF", us[i], fl / us[i] / 1e6);
+        printf("\n%-22s", "  rms err/rms(ref)");
+        for (int i = 0; i < NV; ++i) printf(" %16.2e", erms[i]);
+        printf("   fp32 fma chain: %.2e\n", f32rms);
+        hipFree(A); hipFree(B); hipFree(C);
+    }
+    return 0;
+}
