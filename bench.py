@@ -231,6 +231,8 @@ def main():
                                   args.batch, " (BASELINE configs[2])" if args.config.startswith("CAPE-affineconv_nz64") else ""),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "graph_replay": runner._gA is not None,
                    "inputs": "host numpy per step (PCIe-inclusive)" if args.host_inputs else "resident in HBM",
+                   "arithmetic": "fp32 in/out/accumulate; eligible GEMMs as 6 bf16 MFMA products per multiply-add on an "
+                                 "exact 3-way bf16 split of each fp32 operand (fp32 accuracy), exact-fp32 MFMA elsewhere",
                    "final_loss_g": loss},
         "roofline": roof,
     }

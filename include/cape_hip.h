@@ -143,6 +143,11 @@ int cape_csr_validate(int32_t rows, int32_t cols, int64_t nnz, const int32_t *ro
  *   k * round_up(F/K, 4) + c, i.e. the reference's fin*K + k weight-row order (lib/models.py:97-101) comes out as
  *   K contiguous channel blocks -- ONE launch  G = dz W^T  for all K orders of a data gradient, each block then
  *   being the operand of its S_k^T (ldy >= K * round_up(F/K, 4)).  0 / 1 = off.
+ * Arithmetic: fp32 in, fp32 out, fp32 accumulation.  Single-mode launches on plain (no CSR) sources whose channel
+ *   counts are multiples of 32, with F >= 64, multiply on the bf16 matrix pipe: each fp32 operand is split exactly
+ *   into three bf16 pieces and six cross products per multiply-add are accumulated in fp32 -- as accurate as an fp32
+ *   FMA chain, not bit-identical to the other kernels' exact-fp32 MFMA, and an inf operand gives
+ *   NaN.  Environment CAPE_GEMM_BF16X6=0 (read once per process) keeps every launch on the exact-fp32 MFMA.
  */
 int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, int64_t y_sample_stride,
                    int32_t ldy, int32_t N, int32_t Mo, int32_t F, const float *bias,
@@ -150,8 +155,9 @@ int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, int64_t y_sam
                    int32_t out_deinterleave, void *stream);
 
 /* Which kernel cape_gconv_fwd would run for these arguments (pure query, no launch):
- * plan[0] = family (0: gather-GEMM gconv_fwd_kernel, 1: pipelined plain-source gemm_plain_kernel),
- * plan[1], plan[2] = workgroup tile rows x columns, plan[3] = weight layout of family 1
+ * plan[0] = family (0: gather-GEMM gconv_fwd_kernel, 1: pipelined plain-source gemm_plain_kernel, 2: the same on
+ * the bf16 pipe with the exact three-way operand split, gemm_split_kernel),
+ * plan[1], plan[2] = workgroup tile rows x columns, plan[3] = weight layout of families 1 and 2
  * (1: contraction-contiguous, 0: output-contiguous).  Used by bench.py to attribute per-launch work to
  * the kernel names rocprofv3 reports. */
 int cape_gconv_fwd_plan(const cape_src_t *srcs, int32_t nsrc, int32_t N, int32_t Mo, int32_t F, int32_t plan[4]);

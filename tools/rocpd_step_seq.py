@@ -19,7 +19,7 @@ def tag(n):
         return 'rocblas:' + re.search(r'MT\d+x\d+x\d+', n).group(0)
     m = re.match(r'(\w+)(<[^(]*>)?', n)
     base = m.group(1)
-    if base in ('gconv_fwd_kernel', 'gemm_plain_kernel', 'gconv_dw_kernel'):
+    if base in ('gconv_fwd_kernel', 'gemm_plain_kernel', 'gemm_split_kernel', 'gconv_dw_kernel', 'dw_plain_kernel', 'dw_packed_kernel'):
         return base.replace('_kernel', '') + (m.group(2) or '')
     f = re.search(r'(CUDAFunctor_add|CUDAFunctorOnSelf_add|MulFunctor|addcmul|NormTwo|sum_functor|FillFunctor|pow_tensor|'
                   r'leaky_relu_backward|leaky_relu|reciprocal|exp_kernel|clamp|direct_copy|gather|sqrt|DivFunctor)', n)
