@@ -818,6 +818,9 @@ extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *
     bool c4 = true;
     for (int i = 0; i < nsrc; ++i) c4 = c4 && (srcs[i].C & 3) == 0;
     const bool packed = plain && c4 && !(dz2 && dz2_mask) && nsrc > 1 && sumC <= 128 && F <= 64;
+    // CAPE_DW_BF16X6=1: un-packed plain launches on the bf16 pipe (dw_split_kernel)
+    static const int dws_on = getenv("CAPE_DW_BF16X6") ? atoi(getenv("CAPE_DW_BF16X6")) : CAPE_DW_BF16X6_DEFAULT;
+    const bool dw_split = dws_on && plain && !packed && c4 && (F & 1) == 0;
     if (packed) plan_dw_plain(srcs, nsrc, N, Mo, F, true, pl);
     else plan_dw(srcs, nsrc, N, Mo, F, pl);
     const long long need = pl.slab * pl.ngroups * pl.rsplit * (long long)sizeof(float);
@@ -853,6 +856,11 @@ extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *
         else if (pl.ct == 64) CAPE_LAUNCH((dw_packed_kernel<64, 128, 2, 2>), grid, block, 0, st, p);
         else if (pl.ft == 64) CAPE_LAUNCH((dw_packed_kernel<128, 64, 2, 2>), grid, block, 0, st, p);
         else CAPE_LAUNCH((dw_packed_kernel<128, 128, 2, 2>), grid, block, 0, st, p);
+    } else if (plain && dw_split) {
+        if (pl.ct == 64 && pl.ft == 64) CAPE_LAUNCH((dw_split_kernel<64, 64>), grid, block, 0, st, p);
+        else if (pl.ct == 64) CAPE_LAUNCH((dw_split_kernel<64, 128>), grid, block, 0, st, p);
+        else if (pl.ft == 64) CAPE_LAUNCH((dw_split_kernel<128, 64>), grid, block, 0, st, p);
+        else CAPE_LAUNCH((dw_split_kernel<128, 128>), grid, block, 0, st, p);
     } else if (plain) {
         if (pl.ct == 64 && pl.ft == 64) CAPE_LAUNCH((dw_plain_kernel<64, 64, 2, 2>), grid, block, 0, st, p);
         else if (pl.ct == 64) CAPE_LAUNCH((dw_plain_kernel<64, 128, 2, 2>), grid, block, 0, st, p);

@@ -24,6 +24,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef CAPE_GEMM_BF16X6_DEFAULT
 #define CAPE_GEMM_BF16X6_DEFAULT 1
 #endif
+#ifndef CAPE_DW_BF16X6_DEFAULT
+#define CAPE_DW_BF16X6_DEFAULT 0      // weight gradient on the bf16 pipe: written, not yet validated on the GPU test suite
+#endif
 
 constexpr int GS_KC = 32;       // contraction indices per staged chunk = two k16 MFMA steps
 constexpr int GS_PITCH = 80;    // bytes per LDS row of one piece plane: 32 bf16 + 16 B pad (conflict-free ds_read_b128)
@@ -232,6 +235,163 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 4) void gemm_spli
                 float v = acc[a][b][g] + bch;
                 v = v > 0.f ? v : (relu ? 0.f : slope * v);
                 if (fok && row < p.Mo) yb[(long long)row * p.ldy + fm] = v;
+            }
+        }
+}
+
+// =============================================================================================================
+// Weight gradient of plain sources on the bf16 pipe:  dW_s[c, f] = sum_{n, r} X_s[n, r, c] * dz[n, r, f].
+// Same decomposition and partial-slab output as dw_plain_kernel (gemm_plain.h); the contraction runs over the
+// vertices, so BOTH operands are transposed in the stage: a thread reads 8 consecutive rows of its 1-2 channels
+// (loads coalesced over the channels), splits them and writes one 16-byte row segment per piece plane [channel][row].
+// Requires: sources plain, C % 4 == 0, 16-byte aligned rows; dz likewise with F % 2 == 0.
+// =============================================================================================================
+template <int CT, int FT>
+__global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? 2 : 3) void dw_split_kernel(DwParams p) {
+    constexpr int RK = 32;
+    constexpr int WTM = CT / 2, WTN = FT / 2;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int CPA = CT / 64, CPB = FT / 64;      // channels per thread (8 rows each): 64 lanes x CP channels = one tile row
+    constexpr int APLANE = CT * GS_PITCH, BPLANE = FT * GS_PITCH;
+    static_assert(TM >= 1 && TN >= 1 && (CT == 64 || CT == 128) && (FT == 64 || FT == 128), "tile");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * (APLANE + BPLANE)];
+    unsigned char *sA = smem, *sB = smem + 3 * APLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int rg = tid >> 6;                          // rows 8*rg .. 8*rg+7 of the 32-row chunk
+    const int ca = (tid & 63) * CPA, fb = (tid & 63) * CPB;
+
+    const int ntiles = p.tile_off[p.nsrc];
+    const int tile = blockIdx.x % ntiles;
+    const int split = blockIdx.x / ntiles;            // split = group * rsplit + rs
+    const int grp = split / p.rsplit;
+    const int rs = split % p.rsplit;
+    const int n_begin = grp * p.samples_per_group;
+    const int n_end = min(p.N, n_begin + p.samples_per_group);
+    int si = 0;
+    while (si + 1 < p.nsrc && tile >= p.tile_off[si + 1]) ++si;
+    const SrcDev &S = p.s[si];
+    const int lt = tile - p.tile_off[si];
+    const int c0 = (lt / p.ftiles) * CT;
+    const int f0 = (lt % p.ftiles) * FT;
+    const int ra = rs * p.rows_per_split;
+    const int rb = min(p.Mo, ra + p.rows_per_split);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+
+    // columns beyond C / F are read from column 0 and feed output rows / columns that are never stored
+    const int a_col = (c0 + ca < S.C) ? c0 + ca : 0;
+    const int b_col = (f0 + fb < p.F) ? f0 + fb : 0;
+    const float *dz0 = ((p.dz2_mask >> si) & 1u) ? p.dz2 : p.dz;
+
+    const int chunks = (rb - ra + RK - 1) / RK;
+    const int total = (n_end - n_begin) * chunks;
+    int l_n = n_begin, l_r = ra;                      // loader cursor
+    float xa[CPA][8], xz[CPB][8];
+    unsigned ok = 0;
+
+    auto load_regs = [&]() {
+        const float *xb = S.x + (long long)l_n * S.xs + a_col;
+        const float *zb = dz0 + (long long)l_n * p.dzs + b_col;
+        ok = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = l_r + 8 * rg + j;
+            ok |= (r < rb ? 1u : 0u) << j;
+            const int rr = min(r, rb - 1);
+            if constexpr (CPA == 2) {
+                const float2 v = *reinterpret_cast<const float2 *>(xb + (long long)rr * S.ldx);
+                xa[0][j] = v.x; xa[1][j] = v.y;
+            } else {
+                xa[0][j] = xb[(long long)rr * S.ldx];
+            }
+            if constexpr (CPB == 2) {
+                const float2 v = *reinterpret_cast<const float2 *>(zb + (long long)rr * p.lddz);
+                xz[0][j] = v.x; xz[1][j] = v.y;
+            } else {
+                xz[0][j] = zb[(long long)rr * p.lddz];
+            }
+        }
+        l_r += RK;
+        if (l_r >= rb) { l_r = ra; ++l_n; }
+    };
+    auto store_regs = [&]() {
+        // rows beyond the split's range contribute zero (they were read from the clamped last row)
+#pragma unroll
+        for (int ch = 0; ch < CPA; ++ch) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ((ok >> j) & 1u) ? xa[ch][j] : 0.f;
+            gs_store8(sA + (ca + ch) * GS_PITCH + 16 * rg, APLANE, v);
+        }
+#pragma unroll
+        for (int ch = 0; ch < CPB; ++ch) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ((ok >> j) & 1u) ? xz[ch][j] : 0.f;
+            gs_store8(sB + (fb + ch) * GS_PITCH + 16 * rg, BPLANE, v);
+        }
+    };
+    auto compute = [&]() {
+        const unsigned char *pa = sA + (wm * WTM + li) * GS_PITCH + 16 * lh;
+        const unsigned char *pb = sB + (wn * WTN + li) * GS_PITCH + 16 * lh;
+#pragma unroll
+        for (int ks = 0; ks < RK / 16; ++ks) {
+            bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    af[a][pc] = *reinterpret_cast<const bf16x8 *>(pa + pc * APLANE + a * 32 * GS_PITCH + 32 * ks);
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    bf[b][pc] = *reinterpret_cast<const bf16x8 *>(pb + pc * BPLANE + b * 32 * GS_PITCH + 32 * ks);
+            constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][TA[term]], bf[b][TB[term]], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    if (total > 0) {
+        load_regs();
+        store_regs();
+        __syncthreads();
+        for (int it = 0; it < total; ++it) {
+            const bool more = it + 1 < total;
+            if (more) load_regs();
+            compute();
+            __syncthreads();
+            if (more) store_regs();
+            __syncthreads();
+        }
+    }
+
+    // partial slab layout: [split][part_off[si] + c*F + f]
+    float *out = p.ws + (long long)split * p.slab + p.part_off[si];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int f = f0 + wn * WTN + b * 32 + li;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int c = c0 + wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                if (c < S.C && f < p.F) out[(long long)c * p.F + f] = acc[a][b][g];
             }
         }
 }
