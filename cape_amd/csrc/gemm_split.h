@@ -4,9 +4,11 @@
 //     x = hi + mid + lo      (8 + 8 + 8 significand bits; truncation split, both subtractions exact)
 // and six of the nine cross products accumulated in the fp32 accumulator of v_mfma_f32_32x32x16_bf16
 // (smallest first):  hi*lo + lo*hi + mid*mid + hi*mid + mid*hi + hi*hi.
-// The three dropped products are <= 2^-24 relative to the exact product, i.e. below the rounding of an fp32
-// multiply; measured against float64 the result is as accurate as an fp32 FMA chain (tools/ubench/gemm_bf16x3.hip:
-// rms error 4.96e-07 vs 5.74e-07 of rms(ref) at K = 1024; all nine products: 4.95e-07).  The bf16 pipe sustains
+// The three dropped products (mid*lo, lo*mid, lo*lo) amount to 2^-24 of the exact product in the rms -- one fp32
+// rounding -- and at most 2^-21 (truncation split: |mid| < 2^-7 |x|, |lo| < 2^-15 |x|; tests/test_bf16_split_numerics.py);
+// measured against float64 a contraction is as accurate as an fp32 FMA chain (tools/ubench/gemm_bf16x3.hip:
+// rms error 4.96e-07 vs 5.74e-07 of rms(ref) at K = 1024; all nine products: 4.95e-07).  The identity x = hi+mid+lo
+// is exact for every finite x; lo is a bf16 number for |x| >= 2^-110 (below, <= 2^-133 is lost).  The bf16 pipe sustains
 // ~1.7-1.85 PFLOP/s on this chip (same ubench), /6 = ~290 TFLOP/s fp32-equivalent against the 142 TFLOP/s the
 // exact-fp32 MFMA sustains.
 //

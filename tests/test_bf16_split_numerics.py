@@ -1,0 +1,98 @@
+"""Host-side (numpy) restatement of the operand split used by cape_amd/csrc/gemm_split.h, pinning the two
+numerical claims DESIGN.md section 4 makes for the GEMMs on the bf16 pipe:
+  1. x = hi + mid + lo holds EXACTLY for every finite fp32 x, each piece being a bf16 number for |x| >= 2^-110
+     (below that the third piece loses at most 2^-133 absolute when it is truncated to 16 bits);
+  2. dropping the three smallest of the nine cross products loses 2^-24 (rms; at most 2^-21) relative to |a||b| per
+     product, and a contraction computed from six products per multiply-add has the error of an fp32 FMA chain.
+The device results themselves are compared with the float64 oracle by the GPU parity tests (tests/test_gpu_*.py)."""
+import numpy as np
+
+MASK = np.uint32(0xFFFF0000)
+
+
+def split3(x):
+    x = np.asarray(x, dtype=np.float32)
+    hi = (x.view(np.uint32) & MASK).view(np.float32)
+    r1 = x - hi                                            # exact in fp32
+    mid = (r1.view(np.uint32) & MASK).view(np.float32)
+    lo = r1 - mid                                          # exact in fp32, <= 8 significant bits
+    return hi, mid, lo
+
+
+def is_bf16(v):
+    return np.all((np.asarray(v, dtype=np.float32).view(np.uint32) & np.uint32(0xFFFF)) == 0)
+
+
+def sample(rng, n):
+    # full 24-bit mantissas over the whole normal exponent range, both signs, plus the awkward values
+    bits = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    x = bits.view(np.float32)
+    x = x[np.isfinite(x)]
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.finfo(np.float32).max, -np.finfo(np.float32).max,
+                        np.finfo(np.float32).tiny, 1e-40, -1e-45, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24, 0.1, 3.0e38],
+                       dtype=np.float32)
+    return np.concatenate([x, special])
+
+
+def bf16_trunc(v):
+    return (np.asarray(v, dtype=np.float32).view(np.uint32) & MASK).view(np.float32)
+
+
+def test_three_way_split_is_exact_and_bf16():
+    rng = np.random.default_rng(0)
+    x = sample(rng, 400000)
+    with np.errstate(all='raise'):                         # no overflow / invalid anywhere in the split
+        hi, mid, lo = split3(x)
+    s = hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64)
+    assert np.array_equal(s, x.astype(np.float64))         # the fp32 identity holds for every finite x
+    assert is_bf16(hi) and is_bf16(mid)
+    # lo is a bf16 number whenever its last bit is at or above the bf16 subnormal spacing 2^-133, i.e. |x| >= 2^-110;
+    # below that (|x| < 7.8e-34) the kernel's 16-bit truncation of lo loses at most 2^-133 absolute
+    big = np.abs(x) >= 2.0 ** -110
+    assert is_bf16(lo[big]) and big.sum() > 0.8 * x.size
+    lost = np.abs(lo.astype(np.float64) - bf16_trunc(lo).astype(np.float64))
+    assert lost[big].max() == 0.0 and lost.max() <= 2.0 ** -133
+    # the pieces do not overlap: each is at most 2^-8 of the previous one
+    nz = (hi != 0) & big
+    assert np.all(np.abs(mid[nz]) <= np.abs(hi[nz]) * 2.0 ** -7)
+    assert np.all(np.abs(lo[nz]) <= np.abs(hi[nz]) * 2.0 ** -15)
+
+
+def test_six_products_are_an_fp32_multiply():
+    rng = np.random.default_rng(1)
+    a = (rng.standard_normal(200000) * 10.0 ** rng.integers(-6, 6, 200000)).astype(np.float32)
+    b = (rng.standard_normal(200000) * 10.0 ** rng.integers(-6, 6, 200000)).astype(np.float32)
+    pa = [p.astype(np.float64) for p in split3(a)]
+    pb = [p.astype(np.float64) for p in split3(b)]
+    exact = a.astype(np.float64) * b.astype(np.float64)
+    six = sum(pa[i] * pb[j] for i, j in ((0, 2), (2, 0), (1, 1), (0, 1), (1, 0), (0, 0)))   # the kernel's terms
+    nine = sum(pa[i] * pb[j] for i in range(3) for j in range(3))
+    assert np.array_equal(nine, exact)                     # all nine products reproduce the fp32 x fp32 product exactly
+    rel = np.abs(six - exact) / np.abs(exact)
+    # dropped: mid*lo + lo*mid + lo*lo.  The truncation split leaves |mid| < 2^-7 |x| and |lo| < 2^-15 |x|, so a single
+    # product can lose up to 2^-21 (8 fp32 roundings, operands just above a power of two); the rms loss is one fp32
+    # rounding (2^-24), and in a contraction the signed losses average out (next test)
+    assert rel.max() < 2.0 ** -21
+    assert np.sqrt(np.mean(rel ** 2)) < 2.0 ** -23.5
+
+
+def test_contraction_error_matches_fp32():
+    """K = 1024 dot products: six-term products accumulated in fp32 (as the MFMA accumulator does, here in
+    index order) against float64 -- the error is that of an fp32 FMA chain, as measured on the device
+    (profiles/r01_ubench_bf16x6_tiles_accuracy.txt: 4.96e-07 vs 5.74e-07 of rms(ref))."""
+    rng = np.random.default_rng(2)
+    K, M = 1024, 512
+    A = ((rng.random((M, K)) - 0.5) * 2.0 ** rng.integers(0, 4, (M, K))).astype(np.float32)
+    B = (0.05 * (rng.random((M, K)) - 0.5) * 2.0 ** rng.integers(0, 4, (M, K))).astype(np.float32)
+    ref = np.einsum('mk,mk->m', A.astype(np.float64), B.astype(np.float64))
+    pa, pb = split3(A), split3(B)
+    acc6 = np.zeros(M, dtype=np.float32)
+    acc32 = np.zeros(M, dtype=np.float32)
+    for k in range(K):
+        for i, j in ((0, 2), (2, 0), (1, 1), (0, 1), (1, 0), (0, 0)):
+            acc6 += pa[i][:, k] * pb[j][:, k]              # bf16 x bf16 is exact in fp32; the add rounds
+        acc32 = (acc32.astype(np.float64) + A[:, k].astype(np.float64) * B[:, k]).astype(np.float32)   # fma chain
+    scale = np.sqrt(np.mean(ref ** 2))
+    e6 = np.sqrt(np.mean((acc6 - ref) ** 2)) / scale
+    e32 = np.sqrt(np.mean((acc32 - ref) ** 2)) / scale
+    assert e32 < 2e-6 and e6 < 4 * e32, (e6, e32)
