@@ -1,13 +1,19 @@
-"""Graph-Laplacian construction for the Chebyshev hot path (host side, scipy).
+"""Operator precompute for the Chebyshev hot path (host side, numpy/scipy): same names, argument meaning and
+return values as the reference's lib/mesh_sampling.py, without its psbody dependency, so ``main.py:39-44`` /
+``lib/load_data.py:17,31`` style callers keep working:
 
-Mirrors the two dependency-free functions of the reference's operator precompute
-layer (reference lib/mesh_sampling.py:10-29 ``laplacian`` and :31-38 ``rescale_L``):
-same names, same argument meaning, same dtype behaviour, so ``main.py:44`` /
-``lib/load_data.py:17,31`` style callers keep working.  The QSlim decimation part of
-that file (:40-263) is out of scope (offline, needs psbody).
+  * ``laplacian`` (reference :10-29) and ``rescale_L`` (:31-38) -- defined here;
+  * ``generate_transform_matrices``, ``qslim_decimator_transformer``, ``setup_deformation_transfer``,
+    ``vertex_quadrics``, ``_get_sparse_transform`` (:40-263) -- implemented in ``cape_amd.mesh_operators`` and
+    re-exported; they regenerate the operators the reference ships for the SMPL template exactly
+    (tests/test_mesh_operators.py).
 """
 import numpy as np
 import scipy.sparse as sp
+
+from .mesh_operators import (Mesh, _get_sparse_transform, generate_transform_matrices, get_vert_connectivity,  # noqa: F401
+                             get_vertices_per_edge, qslim_decimator_transformer, setup_deformation_transfer,
+                             vertex_quadrics)
 
 
 def laplacian(W, normalized=True):
