@@ -691,7 +691,7 @@ inline FwdPlan plan_fwd(const GconvParams &p, const cape_src_t *srcs, bool dual)
         static const int gs_on = getenv("CAPE_GEMM_BF16X6") ? atoi(getenv("CAPE_GEMM_BF16X6")) : CAPE_GEMM_BF16X6_DEFAULT;
         if (gs_on && gs_eligible(p, dual)) {
             pl.family = 2;
-            gs_tile(p.N, p.Mo, p.F, pl.BM, pl.BN);
+            gs_tile(dual, p.N, p.Mo, p.F, pl.BM, pl.BN);
             return pl;
         }
         pl.family = 1;
@@ -769,7 +769,7 @@ extern "C" int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, in
     dim3 grid((unsigned)(N * p.row_tiles * p.col_tiles)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (pl.family == 2) {
-        gs_launch(p, pl.BM, pl.layout, grid, st);
+        gs_launch(p, dual, pl.BM, pl.layout, grid, st);
     } else if (pl.family == 1) {
         gp_launch(p, dual, pl.BM, pl.BN, pl.layout, grid, st);
     } else if (!dual) {

@@ -59,17 +59,20 @@ __device__ __forceinline__ void gs_store8(unsigned char *dst, int plane, const f
     *reinterpret_cast<uint4 *>(dst + 2 * plane) = lo;
 }
 
-// Workgroup tile BM x BN, 4 waves as 2 x 2, wave tile (BM/2) x (BN/2).
-template <int BM, int BN, bool BKC>
-__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 4) void gemm_split_kernel(GconvParams p) {
+// Workgroup tile BM x BN, 4 waves as 2 x 2, wave tile (BM/2) x (BN/2).  DUAL: sources may carry a second weight set
+// (w2) accumulated into a second tile, combined as relu(acc) + acc2 by the shared epilogue (res_block_affine,
+// reference lib/models.py:776-793); its LDS holds a third group of planes, so the DUAL tile is 128 x 64.
+template <int BM, int BN, bool BKC, bool DUAL = false>
+__global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? 2 : 4) void gemm_split_kernel(GconvParams p) {
     constexpr int WTM = BM / 2, WTN = BN / 2;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int PA = BM / 64, PB = BN / 64;      // staging passes of the k-contiguous form: 64 rows x 4 eight-float groups
     constexpr int KPT = BN / 8;                     // [k][n] weight staging: one output column, KPT consecutive k per thread
     constexpr int APLANE = BM * GS_PITCH, BPLANE = BN * GS_PITCH;
     static_assert(TM >= 1 && TN >= 1 && (BN == 64 || BN == 128), "tile");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * (APLANE + BPLANE)];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * (APLANE + (DUAL ? 2 : 1) * BPLANE)];
     unsigned char *sA = smem, *sB = smem + 3 * APLANE;
+    unsigned char *sB2 = sB + 3 * BPLANE;           // DUAL only
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
@@ -82,13 +85,16 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 4) void gemm_spli
     const int f0 = (t % p.col_tiles) * BN;
 
     f32x16 acc[TM][TN];
-    f32x16 acc2[1][1];
+    f32x16 acc2[DUAL ? TM : 1][DUAL ? TN : 1];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+            for (int g = 0; g < 16; ++g) {
+                acc[a][b][g] = 0.f;
+                if constexpr (DUAL) acc2[a][b][g] = 0.f;
+            }
 
     int total = 0;
     for (int si = 0; si < p.nsrc; ++si) total += p.s[si].C / GS_KC;
@@ -103,25 +109,34 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 4) void gemm_spli
 
     // ---- loader cursor: source l_si, channel offset l_c0 (every source is a whole number of chunks)
     int l_si = 0, l_c0 = 0, l_C = 0;
-    const float *l_x = nullptr, *l_w = nullptr;
-    long long l_wrs = 0;
-    int arow[PA], brow[PB];
+    const float *l_x = nullptr, *l_w = nullptr, *l_w2 = nullptr;
+    long long l_wrs = 0, l_w2rs = 0;
+    int arow[PA], brow[PB], brow2[DUAL ? PB : 1];
     auto open_source = [&]() {
         const SrcDev &S = p.s[l_si];
         l_C = S.C;
         l_x = S.x + (long long)n * S.xs;
         l_w = S.w;
         l_wrs = S.wrs;
+        if constexpr (DUAL) {
+            l_w2 = S.w2;
+            l_w2rs = S.w2rs;
+        }
 #pragma unroll
         for (int i = 0; i < PA; ++i) arow[i] = rc[i] * S.ldx;
         if constexpr (BKC) {
 #pragma unroll
-            for (int i = 0; i < PB; ++i) brow[i] = fc[i] * (int)S.wcs;
+            for (int i = 0; i < PB; ++i) {
+                brow[i] = fc[i] * (int)S.wcs;
+                if constexpr (DUAL) brow2[i] = fc[i] * (int)S.w2cs;
+            }
         }
     };
 
     float4 ra[PA][2];
     float rbv[BKC ? PB : 1][BKC ? 8 : KPT];
+    float rbv2[DUAL ? (BKC ? PB : 1) : 1][DUAL ? (BKC ? 8 : KPT) : 1];
+    bool s_has2 = false;                            // of the chunk held in the staging registers
     auto load_regs = [&]() {
         const int c = l_c0 + 8 * q;
 #pragma unroll
@@ -141,6 +156,24 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 4) void gemm_spli
             const float *wk = l_w + (long long)(l_c0 + kg * KPT) * l_wrs + fcol;
 #pragma unroll
             for (int j = 0; j < KPT; ++j) rbv[0][j] = wk[(long long)j * l_wrs];
+        }
+        if constexpr (DUAL) {
+            s_has2 = l_w2 != nullptr;
+            if (s_has2) {
+                if constexpr (BKC) {
+#pragma unroll
+                    for (int i = 0; i < PB; ++i) {
+                        const float4 u = *reinterpret_cast<const float4 *>(l_w2 + brow2[i] + c);
+                        const float4 v = *reinterpret_cast<const float4 *>(l_w2 + brow2[i] + c + 4);
+                        rbv2[i][0] = u.x; rbv2[i][1] = u.y; rbv2[i][2] = u.z; rbv2[i][3] = u.w;
+                        rbv2[i][4] = v.x; rbv2[i][5] = v.y; rbv2[i][6] = v.z; rbv2[i][7] = v.w;
+                    }
+                } else {
+                    const float *wk2 = l_w2 + (long long)(l_c0 + kg * KPT) * l_w2rs + fcol;
+#pragma unroll
+                    for (int j = 0; j < KPT; ++j) rbv2[0][j] = wk2[(long long)j * l_w2rs];
+                }
+            }
         }
         l_c0 += GS_KC;
         if (l_c0 >= l_C) {
@@ -167,11 +200,26 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 4) void gemm_spli
                 gs_store8(sB + bcol * GS_PITCH + 16 * (kg * (KPT / 8) + g), BPLANE, v);
             }
         }
+        if constexpr (DUAL) {
+            if (s_has2) {
+                if constexpr (BKC) {
+#pragma unroll
+                    for (int i = 0; i < PB; ++i) gs_store8(sB2 + (r + 64 * i) * GS_PITCH + 16 * q, BPLANE, rbv2[i]);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < KPT / 8; ++g) {
+                        const float v[8] = {rbv2[0][8 * g + 0], rbv2[0][8 * g + 1], rbv2[0][8 * g + 2], rbv2[0][8 * g + 3],
+                                            rbv2[0][8 * g + 4], rbv2[0][8 * g + 5], rbv2[0][8 * g + 6], rbv2[0][8 * g + 7]};
+                        gs_store8(sB2 + bcol * GS_PITCH + 16 * (kg * (KPT / 8) + g), BPLANE, v);
+                    }
+                }
+            }
+        }
     };
 
     // ---- multiply one staged chunk.  Lane (li, lh) of v_mfma_f32_32x32x16_bf16 supplies row/column li and the
     // contraction indices 8*lh .. 8*lh+7 of the k16 step: one 16-byte LDS read per operand piece.
-    auto compute = [&]() {
+    auto compute = [&](bool has2) {
         const unsigned char *pa = sA + (wm * WTM + li) * GS_PITCH + 16 * lh;
         const unsigned char *pb = sB + (wn * WTN + li) * GS_PITCH + 16 * lh;
 #pragma unroll
@@ -197,24 +245,43 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 2 : 4) void gemm_spli
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][TA[term]], bf[b][TB[term]], acc[a][b], 0, 0, 0);
+            if constexpr (DUAL) {
+                if (has2) {
+                    bf16x8 bf2[TN][3];
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc)
+                            bf2[b][pc] = *reinterpret_cast<const bf16x8 *>(pb + 3 * BPLANE + pc * BPLANE + b * 32 * GS_PITCH + 32 * ks);
+#pragma unroll
+                    for (int term = 0; term < 6; ++term)
+#pragma unroll
+                        for (int a = 0; a < TM; ++a)
+#pragma unroll
+                            for (int b = 0; b < TN; ++b)
+                                acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][TA[term]], bf2[b][TB[term]], acc2[a][b], 0, 0, 0);
+                }
+            }
         }
     };
 
     open_source();
     load_regs();
     store_regs();
+    bool c_has2 = s_has2;               // of the chunk staged in LDS
     __syncthreads();
     for (int it = 0; it < total; ++it) {
         const bool more = it + 1 < total;
         if (more) load_regs();          // chunk it+1: global -> registers, in flight during the MFMAs below
-        compute();
+        compute(c_has2);
         __syncthreads();
         if (more) store_regs();         // split + LDS store
+        c_has2 = s_has2;
         __syncthreads();
     }
 
-    if (p.rankR > 0 || p.bias_mode == CAPE_BIAS_VERTEX || p.act == CAPE_ACT_TANH) {
-        gconv_epilogue<BM, BN, 2, 2, false>(p, acc, acc2, n, r0, f0, wm, wn, li, lh);
+    if (DUAL || p.rankR > 0 || p.bias_mode == CAPE_BIAS_VERTEX || p.act == CAPE_ACT_TANH) {
+        gconv_epilogue<BM, BN, 2, 2, DUAL>(p, acc, acc2, n, r0, f0, wm, wn, li, lh);
         return;
     }
     // Short epilogue for the common launches (no rank-1 terms; channel bias or none; identity / ReLU / leaky ReLU as
@@ -401,7 +468,9 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? 2 : 3) void dw_split_
 // Eligibility (on top of gp_weight_layout() >= 0): no second weight set, whole chunks, an output wide enough for
 // the 64-column MFMA tile pair.
 inline bool gs_eligible(const GconvParams &p, bool dual) {
-    if (dual || p.F < 64) return false;
+    // DUAL launches: written, checked for compilation only -- CAPE_GEMM_BF16X6_DUAL=1 enables them
+    static const int dual_on = getenv("CAPE_GEMM_BF16X6_DUAL") ? atoi(getenv("CAPE_GEMM_BF16X6_DUAL")) : 0;
+    if ((dual && !dual_on) || p.F < 64) return false;
     for (int i = 0; i < p.nsrc; ++i)
         if (p.s[i].C % GS_KC != 0 || p.s[i].C < GS_KC) return false;
     return true;
@@ -409,14 +478,18 @@ inline bool gs_eligible(const GconvParams &p, bool dual) {
 
 // 128 x 128 tiles (2 workgroups per CU: 61 KB LDS, ~200 VGPRs) when they still give every CU its two workgroups,
 // 64 x 64 (5 per CU) otherwise -- the faster choice on every layer shape of the model in tools/ubench/gemm_bf16x3.hip.
-inline void gs_tile(int N, int Mo, int F, int &BM, int &BN) {
+inline void gs_tile(bool dual, int N, int Mo, int F, int &BM, int &BN) {
+    if (dual) { BM = 128; BN = 64; return; }
     const long long big = (long long)N * ((Mo + 127) / 128) * ((F + 127) / 128);
     if (F >= 128 && big >= 384) { BM = 128; BN = 128; }
     else { BM = 64; BN = 64; }
 }
 
-inline void gs_launch(const GconvParams &p, int BM, int layout, dim3 grid, hipStream_t st) {
-    if (BM == 128) {
+inline void gs_launch(const GconvParams &p, bool dual, int BM, int layout, dim3 grid, hipStream_t st) {
+    if (dual) {
+        if (layout == 1) CAPE_LAUNCH((gemm_split_kernel<128, 64, true, true>), grid, dim3(256), 0, st, p);
+        else CAPE_LAUNCH((gemm_split_kernel<128, 64, false, true>), grid, dim3(256), 0, st, p);
+    } else if (BM == 128) {
         if (layout == 1) CAPE_LAUNCH((gemm_split_kernel<128, 128, true>), grid, dim3(256), 0, st, p);
         else CAPE_LAUNCH((gemm_split_kernel<128, 128, false>), grid, dim3(256), 0, st, p);
     } else {
