@@ -26,6 +26,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef CAPE_GEMM_BF16X6_DEFAULT
 #define CAPE_GEMM_BF16X6_DEFAULT 1
 #endif
+#ifndef CAPE_SPLIT_RN
+#define CAPE_SPLIT_RN 0                   // 1: round-to-nearest operand split (see gs_split2)
+#endif
 #ifndef CAPE_DW_BF16X6_DEFAULT
 #define CAPE_DW_BF16X6_DEFAULT 0      // weight gradient on the bf16 pipe: written, not yet validated on the GPU test suite
 #endif
@@ -37,6 +40,22 @@ __device__ __forceinline__ unsigned gs_bits(float v) { return __builtin_bit_cast
 __device__ __forceinline__ float gs_float(unsigned v) { return __builtin_bit_cast(float, v); }
 
 // two fp32 -> their three bf16 pieces, packed pairwise (first element in the low half)
+#if CAPE_SPLIT_RN
+// Round-to-nearest pieces (v_cvt_pk_bf16_f32): x = hi + mid + lo still exactly, |mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|, so the
+// dropped products are bounded by 2^-23 |ab| instead of 2^-21; 9 VALU ops per pair (cvt_pk, shift, and, packed subtract)
+// against 11 for the truncation form.  Written and checked on the host (tests/test_bf16_split_numerics.py) and for
+// code generation only: not yet run on the GPU, hence not the default.
+typedef __bf16 gs_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float gs_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gs_split2(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
+    const gs_f32x2 x = {x0, x1};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, gs_bf16x2));
+    const gs_f32x2 r = {x0 - gs_float(hi << 16), x1 - gs_float(hi & 0xFFFF0000u)};                 // exact
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r, gs_bf16x2));
+    const gs_f32x2 s = {r[0] - gs_float(mid << 16), r[1] - gs_float(mid & 0xFFFF0000u)};           // exact, <= 7 significant bits
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(s, gs_bf16x2));
+}
+#else
 __device__ __forceinline__ void gs_split2(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
     const unsigned h0 = gs_bits(x0) & 0xFFFF0000u, h1 = gs_bits(x1) & 0xFFFF0000u;
     const float r0 = x0 - gs_float(h0), r1 = x1 - gs_float(h1);                 // exact
@@ -46,6 +65,7 @@ __device__ __forceinline__ void gs_split2(float x0, float x1, unsigned &hi, unsi
     mid = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
     lo = __builtin_amdgcn_perm(gs_bits(s1), gs_bits(s0), 0x07060302u);
 }
+#endif
 
 // eight consecutive contraction indices -> one 16-byte row segment per piece plane
 __device__ __forceinline__ void gs_store8(unsigned char *dst, int plane, const float (&v)[8]) {

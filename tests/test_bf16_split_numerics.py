@@ -96,3 +96,43 @@ def test_contraction_error_matches_fp32():
     e6 = np.sqrt(np.mean((acc6 - ref) ** 2)) / scale
     e32 = np.sqrt(np.mean((acc32 - ref) ** 2)) / scale
     assert e32 < 2e-6 and e6 < 4 * e32, (e6, e32)
+
+
+# ---- round-to-nearest variant (gemm_split.h, CAPE_SPLIT_RN=1; v_cvt_pk_bf16_f32 rounds to nearest even) -------------
+def bf16_rne(x):
+    u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def split3_rn(x):
+    x = np.asarray(x, dtype=np.float32)
+    hi = bf16_rne(x)
+    r1 = x - hi
+    mid = bf16_rne(r1)
+    r2 = r1 - mid
+    return hi, mid, bf16_rne(r2), r2
+
+
+def test_round_to_nearest_split_is_exact_with_tighter_pieces():
+    rng = np.random.default_rng(3)
+    x = sample(rng, 400000)
+    x = x[np.abs(x) < 3.0e38]                              # rounding hi up must not overflow to inf
+    hi, mid, lo, r2 = split3_rn(x)
+    big = np.abs(x) >= 2.0 ** -100
+    assert np.array_equal(lo[big], r2[big])                # the third piece needs no rounding
+    s = hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64)
+    assert np.array_equal(s[big], x[big].astype(np.float64))
+    nz = big & (x != 0)
+    assert np.all(np.abs(mid[nz]) <= np.abs(x[nz]) * 2.0 ** -8)
+    assert np.all(np.abs(lo[nz]) <= np.abs(x[nz]) * 2.0 ** -16)
+    # dropped products mid*lo + lo*mid + lo*lo: at most 2^-23 |ab| (truncation split: 2^-21)
+    a, b = x[nz][:100000], x[nz][100000:200000]
+    keep = (np.abs(a) < 1e18) & (np.abs(b) < 1e18) & (np.abs(a) > 1e-18) & (np.abs(b) > 1e-18)
+    a, b = a[keep], b[keep]
+    pa = [p.astype(np.float64) for p in split3_rn(a)[:3]]
+    pb = [p.astype(np.float64) for p in split3_rn(b)[:3]]
+    exact = a.astype(np.float64) * b.astype(np.float64)
+    six = sum(pa[i] * pb[j] for i, j in ((0, 2), (2, 0), (1, 1), (0, 1), (1, 0), (0, 0)))
+    rel = np.abs(six - exact) / np.abs(exact)
+    assert rel.max() < 2.0 ** -22.9 and np.sqrt(np.mean(rel ** 2)) < 2.0 ** -25
