@@ -11,6 +11,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 #include <vector>
 
@@ -259,6 +260,158 @@ static void peak(int blocks, int iters, float *out) {
            blocks / 256.0, iters, ms, fl / ms / 1e9, fl / ms / 1e9 / 6);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Second-generation variants (six products, one chunk of prefetch), parameterised for the next measurements:
+//   WM x WN waves per workgroup (64 * WM * WN threads), wave tile (BM / WM) x (BN / WN);
+//   RN   1: round-to-nearest pieces through v_cvt_pk_bf16_f32 (9 VALU ops per pair instead of 11, dropped terms 2^-23);
+//   SWZ  1: unpadded 64-byte LDS rows with the 16-byte segment index XOR-ed by (row >> 2) & 3 (conflict-free for the
+//           ds_read_b128 lane groups {0-3,12-15,20-27}...) -- 48 KB instead of 60 KB per 128 x 128 tile, i.e. three
+//           workgroups per CU if the registers allow (MINB = 3).
+// ---------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+template <bool RN>
+__device__ __forceinline__ void split2v(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
+    if constexpr (RN) {
+        const f32x2_t x = {x0, x1};
+        hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2_t));
+        const f32x2_t r = {x0 - bitsf(hi << 16), x1 - bitsf(hi & 0xFFFF0000u)};
+        mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+        const f32x2_t s = {r[0] - bitsf(mid << 16), r[1] - bitsf(mid & 0xFFFF0000u)};
+        lo = __builtin_bit_cast(unsigned, __builtin_convertvector(s, bf16x2_t));
+    } else {
+        split2(x0, x1, hi, mid, lo);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int MINB, bool RN, bool SWZ>
+__global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_v2_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                                      float *__restrict__ C, int N, int Mo, int K, int F,
+                                                                      int row_tiles, int col_tiles) {
+    constexpr int NTH = 64 * WM * WN;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int RPP = NTH / 4;                          // rows per staging pass (4 eight-float groups per row)
+    constexpr int PA = BM / RPP, PB = BN / RPP;
+    constexpr int LP = SWZ ? 64 : PITCH;                  // LDS row pitch in bytes
+    constexpr int APLANE = BM * LP, BPLANE = BN * LP;
+    static_assert(TM >= 1 && TN >= 1 && PA >= 1 && PB >= 1, "tile");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * (APLANE + BPLANE)];
+    unsigned char *sA = smem, *sB = smem + 3 * APLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
+    const int q = tid & 3, r = tid >> 2;
+    auto seg = [](int row, int s) { return SWZ ? (s ^ ((row >> 2) & 3)) : s; };
+
+    int n, t;
+    map_block(blockIdx.x, N, row_tiles * col_tiles, n, t);
+    const int r0 = (t / col_tiles) * BM, f0 = (t % col_tiles) * BN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+
+    const float *ap[PA], *bp[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) ap[i] = A + ((long long)n * Mo + min(r0 + r + RPP * i, Mo - 1)) * K + 8 * q;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) bp[i] = B + (long long)min(f0 + r + RPP * i, F - 1) * K + 8 * q;
+
+    float4 ra[PA][2], rb[PB][2];
+    auto load_regs = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            ra[i][0] = *reinterpret_cast<const float4 *>(ap[i] + k0);
+            ra[i][1] = *reinterpret_cast<const float4 *>(ap[i] + k0 + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            rb[i][0] = *reinterpret_cast<const float4 *>(bp[i] + k0);
+            rb[i][1] = *reinterpret_cast<const float4 *>(bp[i] + k0 + 4);
+        }
+    };
+    auto store8 = [&](unsigned char *base, int plane, int row, const float4 &u, const float4 &v) {
+        uint4 hi, mid, lo;
+        split2v<RN>(u.x, u.y, hi.x, mid.x, lo.x);
+        split2v<RN>(u.z, u.w, hi.y, mid.y, lo.y);
+        split2v<RN>(v.x, v.y, hi.z, mid.z, lo.z);
+        split2v<RN>(v.z, v.w, hi.w, mid.w, lo.w);
+        unsigned char *d = base + row * LP + 16 * seg(row, q);
+        *reinterpret_cast<uint4 *>(d) = hi;
+        *reinterpret_cast<uint4 *>(d + plane) = mid;
+        *reinterpret_cast<uint4 *>(d + 2 * plane) = lo;
+    };
+    auto store_regs = [&]() {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) store8(sA, APLANE, r + RPP * i, ra[i][0], ra[i][1]);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) store8(sB, BPLANE, r + RPP * i, rb[i][0], rb[i][1]);
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int row = wm * WTM + a * 32 + li;
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    af[a][p] = *reinterpret_cast<const bf16x8 *>(sA + p * APLANE + row * LP + 16 * seg(row, lh + 2 * ks));
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int row = wn * WTN + b * 32 + li;
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    bf[b][p] = *reinterpret_cast<const bf16x8 *>(sB + p * BPLANE + row * LP + 16 * seg(row, lh + 2 * ks));
+            }
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][term_pa(6, term)], bf[b][term_pb(6, term)],
+                                                                            acc[a][b], 0, 0, 0);
+        }
+    };
+
+    const int total = K / KC;
+    load_regs(0);
+    store_regs();
+    __syncthreads();
+    for (int it = 0; it < total; ++it) {
+        const bool more = it + 1 < total;
+        if (more) load_regs((it + 1) * KC);
+        compute();
+        __syncthreads();
+        if (more) store_regs();
+        __syncthreads();
+    }
+
+    float *cn = C + (long long)n * Mo * F;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = f0 + wn * WTN + b * 32 + li;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row = r0 + wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                if (row < Mo && col < F) cn[(long long)row * F + col] = acc[a][b][g];
+            }
+        }
+}
+
+template <int BM, int BN, int WM, int WN, int MINB, bool RN, bool SWZ>
+static double run_v2(const struct Shape &s, const float *A, const float *B, float *C, int iters);
+
 struct Shape { int N, Mo, K, F; };
 
 static void fill(std::vector<float> &h, unsigned seed, float scale) {
@@ -278,6 +431,26 @@ static double run(const Shape &s, const float *A, const float *B, float *C, int 
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     auto launch = [&]() { gemm_bf16x3_kernel<BM, BN, NT, MINB, PF, DBG><<<s.N * rt * ct, 256>>>(A, B, C, s.N, s.Mo, s.K, s.F, rt, ct); };
+    launch();
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < iters; ++i) launch();
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return 1e3 * ms / iters;
+}
+
+template <int BM, int BN, int WM, int WN, int MINB, bool RN, bool SWZ>
+static double run_v2(const Shape &s, const float *A, const float *B, float *C, int iters) {
+    const int rt = (s.Mo + BM - 1) / BM, ct = (s.F + BN - 1) / BN;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    auto launch = [&]() {
+        gemm_v2_kernel<BM, BN, WM, WN, MINB, RN, SWZ><<<s.N * rt * ct, 64 * WM * WN>>>(A, B, C, s.N, s.Mo, s.K, s.F, rt, ct);
+    };
     launch();
     hipDeviceSynchronize();
     hipEventRecord(e0);
@@ -320,6 +493,42 @@ int main(int argc, char **argv) {
         float *o; hipMalloc(&o, 2048 * 256 * 4);
         peak(256, 20000, o); peak(512, 10000, o); peak(512, 50, o); peak(1024, 5000, o);
         hipFree(o);
+    }
+    if (argc > 1 && !strcmp(argv[1], "v2")) {
+        const char *vn[] = {"128x128 2x2 trunc", "128x128 2x2 RN", "2x2 RN swz occ3", "4x2 RN (8 waves)", "2x4 RN (8 waves)", "64x64 2x2 RN occ5"};
+        constexpr int NV2 = 6;
+        printf("%-22s", "shape (N Mo K F)");
+        for (int i = 0; i < NV2; ++i) printf(" %18s", vn[i]);
+        printf("\n");
+        for (const Shape &s : std::vector<Shape>{{16, 862, 1024, 512}, {16, 862, 512, 512}, {16, 862, 512, 256}, {16, 1723, 256, 256},
+                                                 {16, 3445, 128, 128}, {16, 3445, 192, 64}}) {
+            std::vector<float> hA((size_t)s.N * s.Mo * s.K), hB((size_t)s.F * s.K);
+            fill(hA, 7, 1.0f);
+            fill(hB, 100, 0.05f);
+            float *A, *B, *C;
+            hipMalloc(&A, hA.size() * 4); hipMalloc(&B, hB.size() * 4); hipMalloc(&C, (size_t)s.N * s.Mo * s.F * 4);
+            hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
+            hipMemcpy(B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
+            const double fl = 2.0 * s.N * s.Mo * (double)s.K * s.F;
+            double us[NV2], emax[NV2], erms[NV2], f32rms = 0;
+            auto chk = [&](int i) { check(s, hA, hB, C, s.N - 1, s.Mo - 24, s.Mo, emax[i], erms[i], f32rms); };
+            auto clr = [&]() { hipMemset(C, 0xFF, (size_t)s.N * s.Mo * s.F * 4); };
+            clr(); us[0] = run_v2<128, 128, 2, 2, 2, false, false>(s, A, B, C, iters); chk(0);
+            clr(); us[1] = run_v2<128, 128, 2, 2, 2, true, false>(s, A, B, C, iters); chk(1);
+            clr(); us[2] = run_v2<128, 128, 2, 2, 3, true, true>(s, A, B, C, iters); chk(2);
+            clr(); us[3] = run_v2<128, 128, 4, 2, 1, true, false>(s, A, B, C, iters); chk(3);
+            clr(); us[4] = run_v2<128, 128, 2, 4, 1, true, false>(s, A, B, C, iters); chk(4);
+            clr(); us[5] = run_v2<64, 64, 2, 2, 5, true, false>(s, A, B, C, iters); chk(5);
+            char name[64];
+            snprintf(name, sizeof name, "%d %d %d %d", s.N, s.Mo, s.K, s.F);
+            printf("%-22s", name);
+            for (int i = 0; i < NV2; ++i) printf(" %8.1fus %5.1fTF", us[i], fl / us[i] / 1e6);
+            printf("\n%-22s", "  rms err/rms(ref)");
+            for (int i = 0; i < NV2; ++i) printf(" %18.2e", erms[i]);
+            printf("   fp32 fma chain: %.2e\n", f32rms);
+            hipFree(A); hipFree(B); hipFree(C);
+        }
+        return 0;
     }
     const char *names[] = {"128x128 pf1", "neither", "neither+nobar", "nobar only", "x3 neither", "x9 neither", "64x64 neither", "128x64 neither"};
     constexpr int NV = 8;
