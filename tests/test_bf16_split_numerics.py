@@ -136,3 +136,19 @@ def test_round_to_nearest_split_is_exact_with_tighter_pieces():
     six = sum(pa[i] * pb[j] for i, j in ((0, 2), (2, 0), (1, 1), (0, 1), (1, 0), (0, 0)))
     rel = np.abs(six - exact) / np.abs(exact)
     assert rel.max() < 2.0 ** -22.9 and np.sqrt(np.mean(rel ** 2)) < 2.0 ** -25
+
+
+def test_lds_layouts_of_the_split_kernels_are_conflict_free_on_reads():
+    """tools/lds_bank_check.py models the gfx950 ds_read_b128 / ds_write_b128 lane groups: the MFMA operand reads of
+    gemm_split_kernel / dw_split_kernel (row pitch 80 bytes) and of the prepared swizzled 64-byte layout must be
+    conflict-free; an unpadded, unswizzled layout would be 4-way."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import lds_bank_check
+    rows = dict(lds_bank_check.main())
+    assert rows["operand read, pitch 80, k16 step 0"] == 1 and rows["operand read, pitch 80, k16 step 1"] == 1
+    assert rows["operand read, pitch 64, no swizzle"] == 4
+    assert rows["operand read, pitch 64, seg ^ (row>>2)&3, step 0"] == 1
+    assert rows["stage store k-contiguous, pitch 64 swizzled"] == 1
+    assert rows["stage store k-contiguous, pitch 80"] <= 2 and rows["stage store transposed, 1 row per lane, pitch 80"] == 1
