@@ -33,8 +33,23 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define CAPE_DW_BF16X6_DEFAULT 0      // weight gradient on the bf16 pipe: written, not yet validated on the GPU test suite
 #endif
 
+#ifndef CAPE_SPLIT_SWZ
+#define CAPE_SPLIT_SWZ 0                  // 1: unpadded 64-byte LDS rows, 16-byte segment index XOR-ed with (row >> 2) & 3
+#endif
+
 constexpr int GS_KC = 32;       // contraction indices per staged chunk = two k16 MFMA steps
+#if CAPE_SPLIT_SWZ
+// Conflict-free for the ds_read_b128 lane groups and for the k-contiguous staging stores (tools/lds_bank_check.py); 48 KB
+// instead of 60 KB per 128 x 128 tile, i.e. three workgroups per CU when the registers fit (launch bounds below).
+// Compiled and modelled only -- not yet run on the GPU.
+constexpr int GS_PITCH = 64;
+__device__ __forceinline__ int gs_seg(int row, int seg) { return seg ^ ((row >> 2) & 3); }
+constexpr int GS_BIG_MINB = 3;
+#else
 constexpr int GS_PITCH = 80;    // bytes per LDS row of one piece plane: 32 bf16 + 16 B pad (conflict-free ds_read_b128)
+__device__ __forceinline__ int gs_seg(int, int seg) { return seg; }
+constexpr int GS_BIG_MINB = 2;
+#endif
 
 __device__ __forceinline__ unsigned gs_bits(float v) { return __builtin_bit_cast(unsigned, v); }
 __device__ __forceinline__ float gs_float(unsigned v) { return __builtin_bit_cast(float, v); }
@@ -83,7 +98,7 @@ __device__ __forceinline__ void gs_store8(unsigned char *dst, int plane, const f
 // (w2) accumulated into a second tile, combined as relu(acc) + acc2 by the shared epilogue (res_block_affine,
 // reference lib/models.py:776-793); its LDS holds a third group of planes, so the DUAL tile is 128 x 64.
 template <int BM, int BN, bool BKC, bool DUAL = false>
-__global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? 2 : 4) void gemm_split_kernel(GconvParams p) {
+__global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_BIG_MINB : 4) void gemm_split_kernel(GconvParams p) {
     constexpr int WTM = BM / 2, WTN = BN / 2;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int PA = BM / 64, PB = BN / 64;      // staging passes of the k-contiguous form: 64 rows x 4 eight-float groups
@@ -207,30 +222,30 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? 2 : 
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const float v[8] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w, ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
-            gs_store8(sA + (r + 64 * i) * GS_PITCH + 16 * q, APLANE, v);
+            gs_store8(sA + (r + 64 * i) * GS_PITCH + 16 * gs_seg(r + 64 * i, q), APLANE, v);
         }
         if constexpr (BKC) {
 #pragma unroll
-            for (int i = 0; i < PB; ++i) gs_store8(sB + (r + 64 * i) * GS_PITCH + 16 * q, BPLANE, rbv[i]);
+            for (int i = 0; i < PB; ++i) gs_store8(sB + (r + 64 * i) * GS_PITCH + 16 * gs_seg(r + 64 * i, q), BPLANE, rbv[i]);
         } else {
 #pragma unroll
             for (int g = 0; g < KPT / 8; ++g) {
                 const float v[8] = {rbv[0][8 * g + 0], rbv[0][8 * g + 1], rbv[0][8 * g + 2], rbv[0][8 * g + 3],
                                     rbv[0][8 * g + 4], rbv[0][8 * g + 5], rbv[0][8 * g + 6], rbv[0][8 * g + 7]};
-                gs_store8(sB + bcol * GS_PITCH + 16 * (kg * (KPT / 8) + g), BPLANE, v);
+                gs_store8(sB + bcol * GS_PITCH + 16 * gs_seg(bcol, kg * (KPT / 8) + g), BPLANE, v);
             }
         }
         if constexpr (DUAL) {
             if (s_has2) {
                 if constexpr (BKC) {
 #pragma unroll
-                    for (int i = 0; i < PB; ++i) gs_store8(sB2 + (r + 64 * i) * GS_PITCH + 16 * q, BPLANE, rbv2[i]);
+                    for (int i = 0; i < PB; ++i) gs_store8(sB2 + (r + 64 * i) * GS_PITCH + 16 * gs_seg(r + 64 * i, q), BPLANE, rbv2[i]);
                 } else {
 #pragma unroll
                     for (int g = 0; g < KPT / 8; ++g) {
                         const float v[8] = {rbv2[0][8 * g + 0], rbv2[0][8 * g + 1], rbv2[0][8 * g + 2], rbv2[0][8 * g + 3],
                                             rbv2[0][8 * g + 4], rbv2[0][8 * g + 5], rbv2[0][8 * g + 6], rbv2[0][8 * g + 7]};
-                        gs_store8(sB2 + bcol * GS_PITCH + 16 * (kg * (KPT / 8) + g), BPLANE, v);
+                        gs_store8(sB2 + bcol * GS_PITCH + 16 * gs_seg(bcol, kg * (KPT / 8) + g), BPLANE, v);
                     }
                 }
             }
@@ -240,21 +255,23 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? 2 : 
     // ---- multiply one staged chunk.  Lane (li, lh) of v_mfma_f32_32x32x16_bf16 supplies row/column li and the
     // contraction indices 8*lh .. 8*lh+7 of the k16 step: one 16-byte LDS read per operand piece.
     auto compute = [&](bool has2) {
-        const unsigned char *pa = sA + (wm * WTM + li) * GS_PITCH + 16 * lh;
-        const unsigned char *pb = sB + (wn * WTN + li) * GS_PITCH + 16 * lh;
+        // rows wm*WTM + a*32 + li: all tile offsets are multiples of 32, so the swizzle term (row >> 2) & 3 is that of li
+        const unsigned char *pa = sA + (wm * WTM + li) * GS_PITCH;
+        const unsigned char *pb = sB + (wn * WTN + li) * GS_PITCH;
 #pragma unroll
         for (int ks = 0; ks < GS_KC / 16; ++ks) {
+            const int so = 16 * gs_seg(li, lh + 2 * ks);             // byte offset of this lane's 16-byte segment
             bf16x8 af[TM][3], bf[TN][3];
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc)
-                    af[a][pc] = *reinterpret_cast<const bf16x8 *>(pa + pc * APLANE + a * 32 * GS_PITCH + 32 * ks);
+                    af[a][pc] = *reinterpret_cast<const bf16x8 *>(pa + pc * APLANE + a * 32 * GS_PITCH + so);
 #pragma unroll
             for (int b = 0; b < TN; ++b)
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc)
-                    bf[b][pc] = *reinterpret_cast<const bf16x8 *>(pb + pc * BPLANE + b * 32 * GS_PITCH + 32 * ks);
+                    bf[b][pc] = *reinterpret_cast<const bf16x8 *>(pb + pc * BPLANE + b * 32 * GS_PITCH + so);
             // piece indices (0 = hi, 1 = mid, 2 = lo) of the six products, smallest first
             constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
             constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
@@ -272,7 +289,7 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? 2 : 
                     for (int b = 0; b < TN; ++b)
 #pragma unroll
                         for (int pc = 0; pc < 3; ++pc)
-                            bf2[b][pc] = *reinterpret_cast<const bf16x8 *>(pb + 3 * BPLANE + pc * BPLANE + b * 32 * GS_PITCH + 32 * ks);
+                            bf2[b][pc] = *reinterpret_cast<const bf16x8 *>(pb + 3 * BPLANE + pc * BPLANE + b * 32 * GS_PITCH + so);
 #pragma unroll
                     for (int term = 0; term < 6; ++term)
 #pragma unroll
@@ -336,7 +353,7 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? 2 : 
 // Requires: sources plain, C % 4 == 0, 16-byte aligned rows; dz likewise with F % 2 == 0.
 // =============================================================================================================
 template <int CT, int FT>
-__global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? 2 : 3) void dw_split_kernel(DwParams p) {
+__global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? GS_BIG_MINB : 3) void dw_split_kernel(DwParams p) {
     constexpr int RK = 32;
     constexpr int WTM = CT / 2, WTN = FT / 2;
     constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -418,32 +435,33 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? 2 : 3) void dw_split_
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = ((ok >> j) & 1u) ? xa[ch][j] : 0.f;
-            gs_store8(sA + (ca + ch) * GS_PITCH + 16 * rg, APLANE, v);
+            gs_store8(sA + (ca + ch) * GS_PITCH + 16 * gs_seg(ca + ch, rg), APLANE, v);
         }
 #pragma unroll
         for (int ch = 0; ch < CPB; ++ch) {
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = ((ok >> j) & 1u) ? xz[ch][j] : 0.f;
-            gs_store8(sB + (fb + ch) * GS_PITCH + 16 * rg, BPLANE, v);
+            gs_store8(sB + (fb + ch) * GS_PITCH + 16 * gs_seg(fb + ch, rg), BPLANE, v);
         }
     };
     auto compute = [&]() {
-        const unsigned char *pa = sA + (wm * WTM + li) * GS_PITCH + 16 * lh;
-        const unsigned char *pb = sB + (wn * WTN + li) * GS_PITCH + 16 * lh;
+        const unsigned char *pa = sA + (wm * WTM + li) * GS_PITCH;
+        const unsigned char *pb = sB + (wn * WTN + li) * GS_PITCH;
 #pragma unroll
         for (int ks = 0; ks < RK / 16; ++ks) {
+            const int so = 16 * gs_seg(li, lh + 2 * ks);
             bf16x8 af[TM][3], bf[TN][3];
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc)
-                    af[a][pc] = *reinterpret_cast<const bf16x8 *>(pa + pc * APLANE + a * 32 * GS_PITCH + 32 * ks);
+                    af[a][pc] = *reinterpret_cast<const bf16x8 *>(pa + pc * APLANE + a * 32 * GS_PITCH + so);
 #pragma unroll
             for (int b = 0; b < TN; ++b)
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc)
-                    bf[b][pc] = *reinterpret_cast<const bf16x8 *>(pb + pc * BPLANE + b * 32 * GS_PITCH + 32 * ks);
+                    bf[b][pc] = *reinterpret_cast<const bf16x8 *>(pb + pc * BPLANE + b * 32 * GS_PITCH + so);
             constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
             constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
