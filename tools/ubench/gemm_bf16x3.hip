@@ -285,10 +285,25 @@ __device__ __forceinline__ void split2v(float x0, float x1, unsigned &hi, unsign
     }
 }
 
-template <int BM, int BN, int WM, int WN, int MINB, bool RN, bool SWZ>
+// operand already split by its producer: three bf16 planes [3][rows][K] in HBM (1.5x the bytes, no split in the GEMM)
+template <bool RN>
+__global__ void presplit_kernel(const float *__restrict__ x, unsigned *__restrict__ planes, long long n_pairs) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+    unsigned hi, mid, lo;
+    split2v<RN>(x[2 * i], x[2 * i + 1], hi, mid, lo);
+    planes[i] = hi;
+    planes[n_pairs + i] = mid;
+    planes[2 * n_pairs + i] = lo;
+}
+
+// PRE_A / PRE_B: that operand is read as pre-split planes (A3 / B3) instead of fp32
+template <int BM, int BN, int WM, int WN, int MINB, bool RN, bool SWZ, bool PRE_A = false, bool PRE_B = false>
 __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_v2_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                                       float *__restrict__ C, int N, int Mo, int K, int F,
-                                                                      int row_tiles, int col_tiles) {
+                                                                      int row_tiles, int col_tiles,
+                                                                      const unsigned short *__restrict__ A3 = nullptr,
+                                                                      const unsigned short *__restrict__ B3 = nullptr) {
     constexpr int NTH = 64 * WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -324,17 +339,37 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_v2_kernel(const float
     for (int i = 0; i < PB; ++i) bp[i] = B + (long long)min(f0 + r + RPP * i, F - 1) * K + 8 * q;
 
     float4 ra[PA][2], rb[PB][2];
+    uint4 pa3[PRE_A ? PA : 1][3], pb3[PRE_B ? PB : 1][3];            // pre-split operands: 8 bf16 per plane per pass
+    const long long a_plane = (long long)N * Mo * K, b_plane = (long long)F * K;   // elements per plane
     auto load_regs = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            ra[i][0] = *reinterpret_cast<const float4 *>(ap[i] + k0);
-            ra[i][1] = *reinterpret_cast<const float4 *>(ap[i] + k0 + 4);
+            if constexpr (PRE_A) {
+                const long long e = (ap[i] - A) + k0;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) pa3[i][p] = *reinterpret_cast<const uint4 *>(A3 + p * a_plane + e);
+            } else {
+                ra[i][0] = *reinterpret_cast<const float4 *>(ap[i] + k0);
+                ra[i][1] = *reinterpret_cast<const float4 *>(ap[i] + k0 + 4);
+            }
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            rb[i][0] = *reinterpret_cast<const float4 *>(bp[i] + k0);
-            rb[i][1] = *reinterpret_cast<const float4 *>(bp[i] + k0 + 4);
+            if constexpr (PRE_B) {
+                const long long e = (bp[i] - B) + k0;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) pb3[i][p] = *reinterpret_cast<const uint4 *>(B3 + p * b_plane + e);
+            } else {
+                rb[i][0] = *reinterpret_cast<const float4 *>(bp[i] + k0);
+                rb[i][1] = *reinterpret_cast<const float4 *>(bp[i] + k0 + 4);
+            }
         }
+    };
+    auto store3 = [&](unsigned char *base, int plane, int row, const uint4 (&v)[3]) {
+        unsigned char *d = base + row * LP + 16 * seg(row, q);
+        *reinterpret_cast<uint4 *>(d) = v[0];
+        *reinterpret_cast<uint4 *>(d + plane) = v[1];
+        *reinterpret_cast<uint4 *>(d + 2 * plane) = v[2];
     };
     auto store8 = [&](unsigned char *base, int plane, int row, const float4 &u, const float4 &v) {
         uint4 hi, mid, lo;
@@ -349,9 +384,15 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_v2_kernel(const float
     };
     auto store_regs = [&]() {
 #pragma unroll
-        for (int i = 0; i < PA; ++i) store8(sA, APLANE, r + RPP * i, ra[i][0], ra[i][1]);
+        for (int i = 0; i < PA; ++i) {
+            if constexpr (PRE_A) store3(sA, APLANE, r + RPP * i, pa3[i]);
+            else store8(sA, APLANE, r + RPP * i, ra[i][0], ra[i][1]);
+        }
 #pragma unroll
-        for (int i = 0; i < PB; ++i) store8(sB, BPLANE, r + RPP * i, rb[i][0], rb[i][1]);
+        for (int i = 0; i < PB; ++i) {
+            if constexpr (PRE_B) store3(sB, BPLANE, r + RPP * i, pb3[i]);
+            else store8(sB, BPLANE, r + RPP * i, rb[i][0], rb[i][1]);
+        }
     };
     auto compute = [&]() {
 #pragma unroll
@@ -409,7 +450,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_v2_kernel(const float
         }
 }
 
-template <int BM, int BN, int WM, int WN, int MINB, bool RN, bool SWZ>
+template <int BM, int BN, int WM, int WN, int MINB, bool RN, bool SWZ, bool PRE_A = false, bool PRE_B = false>
 static double run_v2(const struct Shape &s, const float *A, const float *B, float *C, int iters);
 
 struct Shape { int N, Mo, K, F; };
@@ -443,13 +484,23 @@ static double run(const Shape &s, const float *A, const float *B, float *C, int 
     return 1e3 * ms / iters;
 }
 
-template <int BM, int BN, int WM, int WN, int MINB, bool RN, bool SWZ>
+template <int BM, int BN, int WM, int WN, int MINB, bool RN, bool SWZ, bool PRE_A, bool PRE_B>
 static double run_v2(const Shape &s, const float *A, const float *B, float *C, int iters) {
     const int rt = (s.Mo + BM - 1) / BM, ct = (s.F + BN - 1) / BN;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
+    unsigned short *A3 = nullptr, *B3 = nullptr;
+    const long long na = (long long)s.N * s.Mo * s.K, nb = (long long)s.F * s.K;
+    if (PRE_A) {          // the producer-side split is not part of the timed region (it would ride in the producer's epilogue)
+        hipMalloc(&A3, na * 6);
+        presplit_kernel<RN><<<(unsigned)((na / 2 + 255) / 256), 256>>>(A, (unsigned *)A3, na / 2);
+    }
+    if (PRE_B) {
+        hipMalloc(&B3, nb * 6);
+        presplit_kernel<RN><<<(unsigned)((nb / 2 + 255) / 256), 256>>>(B, (unsigned *)B3, nb / 2);
+    }
     auto launch = [&]() {
-        gemm_v2_kernel<BM, BN, WM, WN, MINB, RN, SWZ><<<s.N * rt * ct, 64 * WM * WN>>>(A, B, C, s.N, s.Mo, s.K, s.F, rt, ct);
+        gemm_v2_kernel<BM, BN, WM, WN, MINB, RN, SWZ, PRE_A, PRE_B><<<s.N * rt * ct, 64 * WM * WN>>>(A, B, C, s.N, s.Mo, s.K, s.F, rt, ct, A3, B3);
     };
     launch();
     hipDeviceSynchronize();
@@ -460,6 +511,8 @@ static double run_v2(const Shape &s, const float *A, const float *B, float *C, i
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     hipEventDestroy(e0); hipEventDestroy(e1);
+    if (A3) hipFree(A3);
+    if (B3) hipFree(B3);
     return 1e3 * ms / iters;
 }
 
@@ -495,8 +548,9 @@ int main(int argc, char **argv) {
         hipFree(o);
     }
     if (argc > 1 && !strcmp(argv[1], "v2")) {
-        const char *vn[] = {"128x128 2x2 trunc", "128x128 2x2 RN", "2x2 RN swz occ3", "4x2 RN (8 waves)", "2x4 RN (8 waves)", "64x64 2x2 RN occ5"};
-        constexpr int NV2 = 6;
+        const char *vn[] = {"128x128 2x2 trunc", "128x128 2x2 RN", "2x2 RN swz occ3", "4x2 RN (8 waves)", "2x4 RN (8 waves)", "64x64 2x2 RN occ5",
+                            "swz occ2 B presplit", "swz occ2 A+B presplit"};
+        constexpr int NV2 = 8;
         printf("%-22s", "shape (N Mo K F)");
         for (int i = 0; i < NV2; ++i) printf(" %18s", vn[i]);
         printf("\n");
@@ -519,6 +573,8 @@ int main(int argc, char **argv) {
             clr(); us[3] = run_v2<128, 128, 4, 2, 1, true, false>(s, A, B, C, iters); chk(3);
             clr(); us[4] = run_v2<128, 128, 2, 4, 1, true, false>(s, A, B, C, iters); chk(4);
             clr(); us[5] = run_v2<64, 64, 2, 2, 5, true, false>(s, A, B, C, iters); chk(5);
+            clr(); us[6] = run_v2<128, 128, 2, 2, 2, true, true, false, true>(s, A, B, C, iters); chk(6);
+            clr(); us[7] = run_v2<128, 128, 2, 2, 2, true, true, true, true>(s, A, B, C, iters); chk(7);
             char name[64];
             snprintf(name, sizeof name, "%d %d %d %d", s.N, s.Mo, s.K, s.F);
             printf("%-22s", name);
