@@ -365,11 +365,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_v2_kernel(const float
             }
         }
     };
-    auto store3 = [&](unsigned char *base, int plane, int row, const uint4 (&v)[3]) {
+    auto store3 = [&](unsigned char *base, int plane, int row, uint4 v0, uint4 v1, uint4 v2) {
         unsigned char *d = base + row * LP + 16 * seg(row, q);
-        *reinterpret_cast<uint4 *>(d) = v[0];
-        *reinterpret_cast<uint4 *>(d + plane) = v[1];
-        *reinterpret_cast<uint4 *>(d + 2 * plane) = v[2];
+        *reinterpret_cast<uint4 *>(d) = v0;
+        *reinterpret_cast<uint4 *>(d + plane) = v1;
+        *reinterpret_cast<uint4 *>(d + 2 * plane) = v2;
     };
     auto store8 = [&](unsigned char *base, int plane, int row, const float4 &u, const float4 &v) {
         uint4 hi, mid, lo;
@@ -385,12 +385,12 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_v2_kernel(const float
     auto store_regs = [&]() {
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            if constexpr (PRE_A) store3(sA, APLANE, r + RPP * i, pa3[i]);
+            if constexpr (PRE_A) store3(sA, APLANE, r + RPP * i, pa3[i][0], pa3[i][1], pa3[i][2]);
             else store8(sA, APLANE, r + RPP * i, ra[i][0], ra[i][1]);
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            if constexpr (PRE_B) store3(sB, BPLANE, r + RPP * i, pb3[i]);
+            if constexpr (PRE_B) store3(sB, BPLANE, r + RPP * i, pb3[i][0], pb3[i][1], pb3[i][2]);
             else store8(sB, BPLANE, r + RPP * i, rb[i][0], rb[i][1]);
         }
     };
