@@ -166,3 +166,41 @@ def test_cli_lists_tensors(tmp_path, capsys):
     tc.main([str(tmp_path)])
     out = capsys.readouterr().out
     assert 'a/w' in out and '[2, 3]' in out and '1 tensors' in out
+
+
+def test_property_round_trips(tmp_path):
+    """Random tables (keys with long shared prefixes, empty values, every block size) and random bundles (names, shapes,
+    dtypes) survive a write/read cycle; hypothesis drives the generators."""
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+
+    key = st.binary(min_size=1, max_size=40).map(lambda b: b"generator/decoder/" + b)
+    table = st.dictionaries(key, st.binary(max_size=300), min_size=1, max_size=60)
+
+    @settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+    @given(table, st.sampled_from([16, 100, 1000, tc._BLOCK_SIZE]))
+    def tables(entries, block_size):
+        items = sorted(entries.items())
+        fn = str(tmp_path / "p.index")
+        tc.write_table(fn, items, block_size=block_size)
+        assert tc.read_table(fn) == items
+
+    names = st.text(alphabet="abcdefghijklmnopqrstuvwxyz_/0123456789", min_size=1, max_size=30)
+    dtypes = st.sampled_from([np.float32, np.float64, np.int32, np.int64, np.uint8, np.bool_, np.float16])
+    shapes = st.lists(st.integers(0, 5), max_size=4).map(tuple)
+
+    @settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+    @given(st.dictionaries(names, st.tuples(dtypes, shapes, st.integers(0, 2 ** 31 - 1)), min_size=1, max_size=12))
+    def bundles(spec):
+        arrays = {}
+        for name, (dt, shape, seed) in spec.items():
+            a = np.random.default_rng(seed).integers(0, 200, size=shape)
+            arrays[name] = a.astype(dt)
+        prefix = tc.write_bundle(str(tmp_path / "b" / "model-1"), arrays)
+        got = tc.BundleReader(prefix).read_all()
+        assert set(got) == set(arrays)
+        for k, a in arrays.items():
+            assert got[k].dtype == a.dtype and got[k].shape == a.shape and np.array_equal(got[k], a)
+
+    tables()
+    bundles()
