@@ -292,3 +292,33 @@ def load_obj(path):
             elif line.startswith('f '):
                 f.append([int(t.split('/')[0]) - 1 for t in line.split()[1:4]])
     return Mesh(np.asarray(v, dtype=np.float64), np.asarray(f, dtype=np.int64))
+
+
+def save_transform_matrices(out_dir, A, D, U):
+    """Write ``A.npy``, ``D.npy``, ``U.npy`` the way the reference ships them (``data/transform_matrices/<set>/``:
+    pickled object arrays of scipy matrices, read back by ``lib/load_data.py:9-11,22-24`` with ``np.load``)."""
+    import os
+    os.makedirs(out_dir, exist_ok=True)
+    for name, mats in (("A", A), ("D", D), ("U", U)):
+        arr = np.empty(len(mats), dtype=object)
+        for i, m in enumerate(mats):
+            arr[i] = sp.csc_matrix(m)
+        np.save(os.path.join(out_dir, name + ".npy"), arr, allow_pickle=True)
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(description="generate the mesh down-/up-sampling operators of a template mesh "
+                                             "(the precompute of the reference's main.py:31-44, without psbody)")
+    ap.add_argument("obj", help="template mesh (.obj, triangles)")
+    ap.add_argument("--factors", type=int, nargs="+", default=[1, 2, 1, 2, 1, 2, 1, 1],
+                    help="down-sampling factor per conv layer (main.py:31-36)")
+    ap.add_argument("--out", required=True, help="directory for A.npy / D.npy / U.npy")
+    a = ap.parse_args(argv)
+    M, A, D, U, E = generate_transform_matrices(load_obj(a.obj), a.factors)
+    save_transform_matrices(a.out, A, D, U)
+    print("levels:", " -> ".join(str(m.v.shape[0]) for m in M), " written to", a.out)
+
+
+if __name__ == "__main__":
+    main()

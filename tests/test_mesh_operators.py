@@ -104,3 +104,38 @@ def test_decimation_argument_errors(template):
     tet = mo.Mesh(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1.0]]), np.array([[0, 2, 1], [0, 1, 3], [1, 2, 3], [0, 3, 2]]))
     f, D = mo.qslim_decimator_transformer(tet, n_verts_desired=4)           # nothing to do
     assert D.shape == (4, 4) and len(f) == 4
+
+
+def test_saved_operator_files_load_like_the_shipped_ones(tmp_path):
+    """A.npy / D.npy / U.npy written for a small mesh are read back the way lib/load_data.py:9-15 reads the shipped
+    files (np.load of a pickled list, astype float32)."""
+    # an octahedron subdivided once: 18 vertices, 32 faces
+    v = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], dtype=np.float64)
+    f = np.array([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]])
+    mid, verts, faces = {}, [list(p) for p in v], []
+
+    def m(a, b):
+        k = (min(a, b), max(a, b))
+        if k not in mid:
+            p = (v[a] + v[b]) / 2
+            verts.append(list(p / np.linalg.norm(p)))
+            mid[k] = len(verts) - 1
+        return mid[k]
+
+    for a, b, c in f:
+        ab, bc, ca = m(a, b), m(b, c), m(c, a)
+        faces += [[a, ab, ca], [ab, b, bc], [ca, bc, c], [ab, bc, ca]]
+    mesh = mo.Mesh(np.array(verts), np.array(faces))
+    M, A, D, U, E = mo.generate_transform_matrices(mesh, [1, 2])
+    assert [x.v.shape[0] for x in M] == [18, 18, 9]
+    mo.save_transform_matrices(str(tmp_path / "ops"), A, D, U)
+    for name, want in (("A", A), ("D", D), ("U", U)):
+        got = list(np.load(str(tmp_path / "ops" / (name + ".npy")), encoding='latin1', allow_pickle=True))
+        got = [g.astype('float32') for g in got]
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert sp.issparse(g) and g.shape == w.shape and abs(g - w.astype('float32')).max() < 1e-6
+    # the coarse level is a closed manifold again and up-sampling reproduces the kept vertices
+    assert M[2].v.shape[0] - len(E[2]) + len(M[2].f) == 2
+    kept = D[1].tocsr().indices
+    assert np.abs(U[1].dot(M[2].v)[kept] - M[1].v[kept]).max() < 1e-9
