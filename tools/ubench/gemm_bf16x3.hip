@@ -17,6 +17,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int KC = 32;              // contraction indices per staged chunk (two k16 MFMA steps)
 constexpr int PITCH = 80;           // bytes per LDS row of one piece plane: 32 bf16 + 16 B pad (conflict-free b128 reads)
@@ -450,6 +451,116 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_v2_kernel(const float
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16-STORAGE contraction (BASELINE configs[4]: activations and weights kept in bf16, fp32 accumulate): one MFMA product
+// per multiply-add, operands copied global -> LDS as they are (64 contraction indices = 128 bytes per row and chunk,
+// swizzled 16-byte segments), fp32 or bf16 output.  A projection of what the bf16 path of the library would reach.
+// ---------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int MINB, bool OUT16>
+__global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_bf16_kernel(const unsigned short *__restrict__ A,
+                                                                        const unsigned short *__restrict__ B, void *__restrict__ Cv,
+                                                                        int N, int Mo, int K, int F, int row_tiles, int col_tiles) {
+    constexpr int NTH = 64 * WM * WN;
+    constexpr int KB = 64;                                // contraction indices per chunk
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int RPP = NTH / 8;                          // rows per staging pass (8 sixteen-byte segments per row)
+    constexpr int PA = BM / RPP, PB = BN / RPP;
+    constexpr int LP = 128;                               // bytes per LDS row, unpadded: segment s of row r at s ^ (r & 7)
+    static_assert(TM >= 1 && TN >= 1 && PA >= 1 && PB >= 1, "tile");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * LP];
+    unsigned char *sA = smem, *sB = smem + BM * LP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
+    const int q = tid & 7, r = tid >> 3;
+    int n, t;
+    map_block(blockIdx.x, N, row_tiles * col_tiles, n, t);
+    const int r0 = (t / col_tiles) * BM, f0 = (t % col_tiles) * BN;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+    long long ao[PA], bo[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) ao[i] = ((long long)n * Mo + min(r0 + r + RPP * i, Mo - 1)) * K + 8 * q;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) bo[i] = (long long)min(f0 + r + RPP * i, F - 1) * K + 8 * q;
+    u32x4 ra[PA], rb[PB];
+    auto load_regs = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) ra[i] = *reinterpret_cast<const u32x4 *>(A + ao[i] + k0);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) rb[i] = *reinterpret_cast<const u32x4 *>(B + bo[i] + k0);
+    };
+    auto store_regs = [&]() {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int row = r + RPP * i;
+            *reinterpret_cast<u32x4 *>(sA + row * LP + 16 * (q ^ (row & 7))) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int row = r + RPP * i;
+            *reinterpret_cast<u32x4 *>(sB + row * LP + 16 * (q ^ (row & 7))) = rb[i];
+        }
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < KB / 16; ++ks) {
+            bf16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int row = wm * WTM + a * 32 + li;
+                af[a] = *reinterpret_cast<const bf16x8 *>(sA + row * LP + 16 * ((lh + 2 * ks) ^ (row & 7)));
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int row = wn * WTN + b * 32 + li;
+                bf[b] = *reinterpret_cast<const bf16x8 *>(sB + row * LP + 16 * ((lh + 2 * ks) ^ (row & 7)));
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+    };
+    const int total = K / KB;
+    load_regs(0);
+    store_regs();
+    __syncthreads();
+    for (int it = 0; it < total; ++it) {
+        const bool more = it + 1 < total;
+        if (more) load_regs((it + 1) * KB);
+        compute();
+        __syncthreads();
+        if (more) store_regs();
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = f0 + wn * WTN + b * 32 + li;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row = r0 + wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                if (row < Mo && col < F) {
+                    const long long o = ((long long)n * Mo + row) * F + col;
+                    if constexpr (OUT16) reinterpret_cast<__bf16 *>(Cv)[o] = (__bf16)acc[a][b][g];
+                    else reinterpret_cast<float *>(Cv)[o] = acc[a][b][g];
+                }
+            }
+        }
+}
+
+__global__ void to_bf16_kernel(const float *__restrict__ x, __bf16 *__restrict__ y, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = (__bf16)x[i];
+}
+
 template <int BM, int BN, int WM, int WN, int MINB, bool RN, bool SWZ, bool PRE_A = false, bool PRE_B = false>
 static double run_v2(const struct Shape &s, const float *A, const float *B, float *C, int iters);
 
@@ -546,6 +657,50 @@ int main(int argc, char **argv) {
         float *o; hipMalloc(&o, 2048 * 256 * 4);
         peak(256, 20000, o); peak(512, 10000, o); peak(512, 50, o); peak(1024, 5000, o);
         hipFree(o);
+    }
+    if (argc > 1 && !strcmp(argv[1], "bf16")) {
+        printf("%-22s %22s %22s %22s   %s\n", "shape (N Mo K F)", "128x128 fp32 out", "128x128 bf16 out", "64x64 bf16 out", "rms err vs float64 of the fp32 inputs");
+        for (const Shape &s : std::vector<Shape>{{16, 862, 1024, 512}, {16, 862, 512, 256}, {16, 1723, 256, 256}, {16, 3445, 128, 128},
+                                                 {16, 6890, 64, 64}}) {
+            std::vector<float> hA((size_t)s.N * s.Mo * s.K), hB((size_t)s.F * s.K);
+            fill(hA, 7, 1.0f);
+            fill(hB, 100, 0.05f);
+            float *A, *B, *C;
+            __bf16 *A16, *B16;
+            const long long na = (long long)hA.size(), nb = (long long)hB.size(), nc = (long long)s.N * s.Mo * s.F;
+            hipMalloc(&A, na * 4); hipMalloc(&B, nb * 4); hipMalloc(&C, nc * 4); hipMalloc(&A16, na * 2); hipMalloc(&B16, nb * 2);
+            hipMemcpy(A, hA.data(), na * 4, hipMemcpyHostToDevice);
+            hipMemcpy(B, hB.data(), nb * 4, hipMemcpyHostToDevice);
+            to_bf16_kernel<<<(unsigned)((na + 255) / 256), 256>>>(A, A16, na);
+            to_bf16_kernel<<<(unsigned)((nb + 255) / 256), 256>>>(B, B16, nb);
+            const double fl = 2.0 * s.N * s.Mo * (double)s.K * s.F;
+            auto timeit = [&](auto launch) {
+                hipEvent_t e0, e1;
+                hipEventCreate(&e0); hipEventCreate(&e1);
+                launch();
+                hipDeviceSynchronize();
+                hipEventRecord(e0);
+                for (int i = 0; i < iters; ++i) launch();
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                float ms;
+                hipEventElapsedTime(&ms, e0, e1);
+                return 1e3 * ms / iters;
+            };
+            const int rt = (s.Mo + 127) / 128, ct = (s.F + 127) / 128, rt6 = (s.Mo + 63) / 64, ct6 = (s.F + 63) / 64;
+            double emax, erms, f32rms;
+            const double u0 = timeit([&]() { gemm_bf16_kernel<128, 128, 2, 2, 2, false><<<s.N * rt * ct, 256>>>((const unsigned short *)A16, (const unsigned short *)B16, C, s.N, s.Mo, s.K, s.F, rt, ct); });
+            check(s, hA, hB, C, s.N - 1, s.Mo - 24, s.Mo, emax, erms, f32rms);
+            const double u1 = timeit([&]() { gemm_bf16_kernel<128, 128, 2, 2, 2, true><<<s.N * rt * ct, 256>>>((const unsigned short *)A16, (const unsigned short *)B16, C, s.N, s.Mo, s.K, s.F, rt, ct); });
+            const double u2 = timeit([&]() { gemm_bf16_kernel<64, 64, 2, 2, 4, true><<<s.N * rt6 * ct6, 256>>>((const unsigned short *)A16, (const unsigned short *)B16, C, s.N, s.Mo, s.K, s.F, rt6, ct6); });
+            char name[64];
+            snprintf(name, sizeof name, "%d %d %d %d", s.N, s.Mo, s.K, s.F);
+            const double by32 = 2.0 * (na + nb) + 4.0 * nc, by16 = 2.0 * (na + nb + nc);
+            printf("%-22s %7.1fus %5.0fTF %4.1fTB/s %7.1fus %5.0fTF %4.1fTB/s %7.1fus %5.0fTF %4.1fTB/s   %.2e\n", name, u0, fl / u0 / 1e6,
+                   by32 / u0 / 1e6, u1, fl / u1 / 1e6, by16 / u1 / 1e6, u2, fl / u2 / 1e6, by16 / u2 / 1e6, erms);
+            hipFree(A); hipFree(B); hipFree(C); hipFree(A16); hipFree(B16);
+        }
+        return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "v2")) {
         const char *vn[] = {"128x128 2x2 trunc", "128x128 2x2 RN", "2x2 RN swz occ3", "4x2 RN (8 waves)", "2x4 RN (8 waves)", "64x64 2x2 RN occ5",
