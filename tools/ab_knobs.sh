@@ -17,6 +17,8 @@ env CAPE_GEMM_BF16X6=1 CAPE_GEMM_BF16X6_DUAL=0 ./gemm_bench > $O/gemm_split.txt 
 env CAPE_GEMM_BF16X6=1 CAPE_GEMM_BF16X6_DUAL=1 ./gemm_bench > $O/gemm_split_dual.txt 2>&1
 env CAPE_DW_BF16X6=0 ./dw_bench > $O/dw_fp32.txt 2>&1
 env CAPE_DW_BF16X6=1 ./dw_bench > $O/dw_split.txt 2>&1
+./gemm_bf16x3 v2 > $O/ubench_split_v2.txt 2>&1        # prepared kernel variants (RN split, swizzle/occ3, 8 waves, pre-split operands)
+./gemm_bf16x3 bf16 > $O/ubench_bf16_storage.txt 2>&1  # bf16-storage contraction projection
 cd $R
 python tools/ab_compare.py $O/gemm_fp32.txt $O/gemm_split.txt $O/gemm_split_dual.txt | tee $O/compare_gemm.txt
 python tools/ab_compare.py $O/dw_fp32.txt $O/dw_split.txt | tee $O/compare_dw.txt
@@ -28,6 +30,7 @@ for i in $(seq 1 $PAIRS); do
   python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 >> $O/bench_default.jsonl
   env $KNOBS python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 >> $O/bench_knobs.jsonl
 done
+tail -n +1 $O/ubench_split_v2.txt $O/ubench_bf16_storage.txt | cut -c1-230
 python - <<PY
 import json
 for name in ("default", "knobs"):
