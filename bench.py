@@ -151,6 +151,26 @@ def cpu_baseline(batch=2, iters=2):
                        "median of %d passes" % (batch, iters))
 
 
+def exact_fp32_run(args):
+    """The same step with every contraction on the exact-fp32 MFMA (CAPE_GEMM_BF16X6=0; the library reads the knob once
+    per process, hence a child process): reported NEXT TO the headline so that both arithmetic paths are measured by the
+    same bench invocation.  Never replaces ``value``; any failure is reported as a string instead of aborting the line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(min(args.steps, 30)), '--warmup', str(min(args.warmup, 5)),
+           '--batch', str(args.batch), '--config', args.config, '--no-cpu-baseline', '--no-roofline', '--no-ab']
+    if args.gan:
+        cmd.append('--gan')
+    try:
+        env = dict(os.environ, CAPE_GEMM_BF16X6='0')
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=180, check=True)
+        line = [l for l in out.stdout.decode().splitlines() if l.startswith('{')][-1]
+        r = json.loads(line)
+        return {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+                "note": "same step, CAPE_GEMM_BF16X6=0: all contractions on v_mfma_f32_32x32x2_f32"}
+    except Exception as e:                                  # noqa: BLE001 -- the comparison is optional
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -162,6 +182,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-ab', action='store_true',
+                    help='skip the short exact-fp32-MFMA comparison run (a child process with CAPE_GEMM_BF16X6=0)')
     ap.add_argument('--host-inputs', action='store_true',
                     help='hand every step a fresh batch of HOST numpy arrays (as fit() does): the PCIe-inclusive rate '
                          'quoted in DESIGN.md; never the headline value')
@@ -242,6 +264,8 @@ def main():
         result["cpu_baseline"] = cpu_baseline()
     else:
         result["cpu_baseline"] = None
+    if world == 1 and not args.no_ab and not args.host_inputs and os.environ.get("CAPE_GEMM_BF16X6", "1") != "0":
+        result["exact_fp32_mfma"] = exact_fp32_run(args)
     print(json.dumps(result))
 
 

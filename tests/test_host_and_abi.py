@@ -164,3 +164,32 @@ def test_forward_plan_query_is_pure_host_logic():
     w1 = lib.cape_gconv_dw_workspace_bytes(srcs([(64, 64, False, 64, 1, 0x4000)]), 1, 16, 862, 64)
     w2 = lib.cape_gconv_dw_workspace_bytes(srcs([(512, 512, False, 512, 1, 0x4000)] * 2), 2, 16, 862, 512)
     assert 0 < w1 < w2 and lib.cape_gconv_dw_workspace_bytes(None, 1, 16, 862, 64) == -1
+
+
+def test_bench_exact_fp32_comparison_is_fault_tolerant(monkeypatch):
+    """bench.py's optional child run (exact-fp32 MFMA comparison) must never break the JSON line: a failing child gives
+    an error record, a good child gives its numbers."""
+    import subprocess
+    import types
+    import bench
+    args = types.SimpleNamespace(steps=30, warmup=5, batch=16, config='CAPE-affineconv_nz64_pose32_clotype32_male', gan=False)
+
+    def fail(*a, **k):
+        raise subprocess.CalledProcessError(1, a[0])
+    monkeypatch.setattr(subprocess, "run", fail)
+    r = bench.exact_fp32_run(args)
+    assert set(r) == {"error"} and "CalledProcessError" in r["error"]
+
+    seen = {}
+
+    def good(cmd, env=None, **k):
+        seen["cmd"], seen["env"] = cmd, env
+        line = '{"value": 4000.5, "unit": "meshes/s", "ms_per_step": 3.9995, "steps": 30}'
+        return types.SimpleNamespace(stdout=("warning: x\n" + line + "\n").encode())
+    monkeypatch.setattr(subprocess, "run", good)
+    r = bench.exact_fp32_run(args)
+    assert r["value"] == 4000.5 and r["ms_per_step"] == 3.9995 and "CAPE_GEMM_BF16X6=0" in r["note"]
+    assert seen["env"]["CAPE_GEMM_BF16X6"] == "0" and "--no-ab" in seen["cmd"] and "--no-roofline" in seen["cmd"]
+
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: types.SimpleNamespace(stdout=b"no json here\n"))
+    assert "error" in bench.exact_fp32_run(args)

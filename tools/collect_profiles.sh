@@ -10,14 +10,14 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 python $R/bench.py --gan --no-cpu-baseline > $O/${TAG}_bench_gan.json 2>> $O/${TAG}_bench.err
-rm -rf /tmp/prof_ks && rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -o r -- python $R/bench.py --no-cpu-baseline --no-roofline --steps 20 --warmup 3 > $O/${TAG}_bench_under_rocprof.json 2>/dev/null
+rm -rf /tmp/prof_ks && rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -o r -- python $R/bench.py --no-cpu-baseline --no-roofline --no-ab --steps 20 --warmup 3 > $O/${TAG}_bench_under_rocprof.json 2>/dev/null
 DB=$(ls /tmp/prof_ks/*.db /tmp/prof_ks/*/*.db 2>/dev/null | head -1)
 python $R/tools/rocpd_summary.py $DB $O/${TAG}_bench_kernel_stats.txt
 python $R/tools/rocpd_step_seq.py $DB $O/${TAG}_step_sequence.txt
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   name=${pass%%:*}; ctrs=${pass#*:}
   rm -rf /tmp/prof_$name
-  rocprofv3 --pmc $ctrs -d /tmp/prof_$name -o r -- python $R/bench.py --no-cpu-baseline --no-roofline --no-graph --steps 2 --warmup 1 > /dev/null 2>&1
+  rocprofv3 --pmc $ctrs -d /tmp/prof_$name -o r -- python $R/bench.py --no-cpu-baseline --no-roofline --no-ab --no-graph --steps 2 --warmup 1 > /dev/null 2>&1
   DBP=$(ls /tmp/prof_$name/*.db /tmp/prof_$name/*/*.db 2>/dev/null | head -1)
   python $R/tools/pmc_summary.py $DBP $O/pmc_$name.json
 done
