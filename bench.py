@@ -60,15 +60,55 @@ def synthetic_batch(model, seed):
                 cond2_g=clo, cond2_d=clo.roll(1, 0), eps=r(B, int(model.nz)))
 
 
+# SURVEY.md section 8(d), config 3 (affine-nz64 generator fwd+bwd at N = 16, reference formulation, fp32):
+# 256.5 GFLOP and 5.75 GB algorithmic per step -> per mesh 16.03 GFLOP and 359.6 MB
+STEP_ALG_GFLOP_PER_MESH = 16.03
+STEP_ALG_MB_PER_MESH = 359.6
+# one discriminator pass (SURVEY 8d row "3 + one D pass"): fwd+bwd 21.9 GFLOP, 0.57 GB at N = 16; the adversarial step
+# runs D on the real and on the generated batch
+DPASS_ALG_GFLOP_PER_MESH = 1.37
+DPASS_ALG_MB_PER_MESH = 35.5
+
+
+def _csrc_fingerprint():
+    """sha256 over the kernel sources: PMC traffic figures are only attached to a bench line when they were collected
+    from exactly this code (tools/pmc_merge.py stamps the same fingerprint into the summary)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "cape_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h", ".cpp")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _pmc_traffic(kernel):
+    """HBM bytes per launch of ``kernel`` from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes, tools/collect_profiles.sh; counters cannot be read from inside this process), or None when the
+    summary was collected from different kernel code."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+        if pmc.get("_meta", {}).get("csrc_sha") != _csrc_fingerprint():
+            return None
+        key = next((k for k in pmc if k.replace(" ", "") == kernel.replace(" ", "")), None)
+        return None if key is None else pmc[key].get("hbm_bytes_per_dispatch")
+    except Exception:
+        return None
+
+
 def kernel_roofline(runner):
-    """Per-launch HIP-event timing of every gather-GEMM launch in ONE eager pass of the same step
-    (graph replays cannot be bracketed per kernel); returns the roofline object of the kernel
-    instantiation with the largest total time."""
+    """Per-launch HIP-event timing of EVERY library launch (contractions fwd / dX / dW, slab reductions, sparse
+    operators, backward-prep, dense layers, loss, optimiser) in three eager passes of the same step (graph replays
+    cannot be bracketed per kernel; kernels and shapes are identical); returns the roofline object of the kernel
+    with the largest total time and the per-kernel table."""
     from cape_amd import ops
     ops.LAUNCH_LOG = []
     torch.cuda.synchronize()
-    for _ in range(3):
+    reps = 3
+    for _ in range(reps):
         runner._fwd_bwd()
+        runner._update()
     torch.cuda.synchronize()
     log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
     # an event pair around NOTHING still measures the record-to-record gap of the stream (a few us): calibrate
@@ -92,36 +132,50 @@ def kernel_roofline(runner):
         return None, {}
     dom = max(agg, key=lambda k: agg[k][1])
     n, t, fl, by = agg[dom]
-    achieved = fl / t / 1e12
-    table = {k: dict(launches=v[0] // 3, avg_us=1e6 * v[1] / v[0], tflops=v[2] / v[1] / 1e12, alg_gbs=v[3] / v[1] / 1e9)
-             for k, v in agg.items()}
-    # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected separately and
-    # committed as profiles/r01_pmc_summary.json -- counters cannot be read from inside this process)
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-        key = dom.replace(",", ", ")
-        key = next((k for k in pmc if k.replace(" ", "") == dom.replace(" ", "")), key)
-        traffic = pmc[key]["hbm_bytes_per_dispatch"]
-    except Exception:
-        traffic = None
-    split = dom.startswith("gemm_split_kernel")
-    peak = BF16X6_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
-    roof = dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=round(peak, 1), unit="TFLOP/s",
-                frac=round(achieved / peak, 4), traffic=traffic,
-                peak_basis=("fp32 result on the bf16 MFMA pipe, 6 bf16 products per multiply-add: dense bf16 peak 2500 / 6; "
-                            "achieved counts algorithmic fp32 flops (x6 = bf16 MFMA flops executed)") if split
-                else "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)",
-                frac_of_fp32_mfma_peak=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                launches_per_step=n // 3, avg_launch_us=round(1e6 * t / n, 2),
+    table = {k: dict(launches=v[0] // reps, avg_us=1e6 * v[1] / v[0], total_us=1e6 * v[1] / reps, tflops=v[2] / v[1] / 1e12,
+                     alg_gbs=v[3] / v[1] / 1e9) for k, v in agg.items()}
+    split = dom.startswith(("gemm_split_kernel", "dw_split_kernel"))
+    mfma_peak = BF16X6_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+    # the bound of THIS kernel: time at the HBM peak vs time at its matrix-pipe peak for its algorithmic work
+    t_hbm, t_mfma = by / n / (HBM_PEAK_GBS * 1e9), fl / n / (mfma_peak * 1e12)
+    bound = "mfma" if t_mfma >= t_hbm else "hbm"
+    if bound == "mfma":
+        achieved, peak, unit = fl / t / 1e12, mfma_peak, "TFLOP/s"
+        basis = ("fp32 result on the bf16 MFMA pipe, 6 bf16 products per multiply-add: dense bf16 peak 2500 / 6; "
+                 "achieved counts algorithmic fp32 flops (x6 = bf16 MFMA flops executed)") if split \
+            else "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)"
+    else:
+        achieved, peak, unit = by / t / 1e9, HBM_PEAK_GBS, "GB/s"
+        basis = "HBM3E 8 TB/s; achieved counts algorithmic bytes (operands touched once)"
+    roof = dict(bound=bound, kernel=dom, achieved=round(achieved, 2), peak=round(peak, 1), unit=unit,
+                frac=round(achieved / peak, 4), traffic=_pmc_traffic(dom), peak_basis=basis,
+                launches_per_step=n // reps, avg_launch_us=round(1e6 * t / n, 2),
                 alg_flop_per_launch=fl / n, alg_bytes_per_launch=by / n,
-                hbm_alg_gbs=round(by / t / 1e9, 1), hbm_frac=round(by / t / 1e9 / HBM_PEAK_GBS, 4))
+                tflops=round(fl / t / 1e12, 2), frac_of_fp32_mfma_peak=round(fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                hbm_alg_gbs=round(by / t / 1e9, 1), hbm_frac=round(by / t / 1e9 / HBM_PEAK_GBS, 4),
+                share_of_logged_time=round(t / sum(v[1] for v in agg.values()), 4))
     return roof, table
 
 
-def cpu_baseline(batch=2, iters=2):
+def step_roofline(ms_per_step, batch, gan):
+    """Step-level fraction: t_roof = max(alg. bytes / HBM peak, alg. flops / fp32-MFMA peak) of the
+    reference formulation of the step, over the measured step time."""
+    gf = STEP_ALG_GFLOP_PER_MESH + (2 * DPASS_ALG_GFLOP_PER_MESH if gan else 0.0)
+    mb = STEP_ALG_MB_PER_MESH + (2 * DPASS_ALG_MB_PER_MESH if gan else 0.0)
+    t_mfma = batch * gf * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3
+    t_hbm = batch * mb * 1e6 / (HBM_PEAK_GBS * 1e9) * 1e3
+    t_roof = max(t_mfma, t_hbm)
+    return dict(t_roof_ms=round(t_roof, 4), t_mfma_fp32_ms=round(t_mfma, 4), t_hbm_ms=round(t_hbm, 4),
+                frac=round(t_roof / ms_per_step, 4), frac_hbm=round(t_hbm / ms_per_step, 4),
+                basis="SURVEY 8(d) reference-formulation work per mesh: %.2f GFLOP, %.1f MB fwd+bwd; fp32-MFMA peak %.1f TF, "
+                      "HBM %.0f GB/s" % (gf, mb, FP32_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS))
+
+
+def cpu_baseline(batch=16, iters=5, budget_s=150.0):
     """The CPU oracle (numpy/torch restatement of the reference's TF1 graph, reference op order, fp32)
-    timed on this host: forward+backward of the same CVAE step on a bounded sample."""
+    timed on this host: forward+backward of the same CVAE step at the benchmarked batch (BASELINE.md section 3:
+    same batch, >= 5 timed passes after one untimed pass that builds the variables).  ``budget_s`` bounds the
+    sample on a slow host: timing stops early (never below 2 passes) once it is spent."""
     from cape_amd.load_data import load_graph_mtx, load_pack
     from oracle.torch_twin import TwinCAPE
     from oracle.configs import cape_params as oracle_params
@@ -136,6 +190,7 @@ def cpu_baseline(batch=2, iters=2):
     clo = np.eye(4, dtype=np.float32)[np.arange(batch) % 4]
     eps = rng.standard_normal((batch, P['nz'])).astype(np.float32)
     times = []
+    t_begin = time.time()
     for it in range(iters + 1):
         t0 = time.time()
         y, y2 = twin.cond_embeddings(cond, clo)
@@ -145,10 +200,12 @@ def cpu_baseline(batch=2, iters=2):
                             allow_unused=True)
         if it:                        # first pass builds the variables
             times.append(time.time() - t0)
+        if len(times) >= 2 and time.time() - t_begin > budget_s:
+            break
     t = float(np.median(times))
     return dict(value=round(batch / t, 3), unit="meshes/s", cores=int(torch.get_num_threads()), kind="port",
                 sample="torch-CPU fp32 restatement of the TF1 graph (reference op order), CVAE fwd+bwd, batch %d, "
-                       "median of %d passes" % (batch, iters))
+                       "median of %d timed passes (%.1f s of CPU work)" % (batch, len(times), sum(times)))
 
 
 def exact_fp32_run(args):
@@ -253,15 +310,18 @@ def main():
                                   args.batch, " (BASELINE configs[2])" if args.config.startswith("CAPE-affineconv_nz64") else ""),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "graph_replay": runner._gA is not None,
                    "inputs": "host numpy per step (PCIe-inclusive)" if args.host_inputs else "resident in HBM",
-                   "arithmetic": "fp32 in/out/accumulate; eligible GEMMs as 6 bf16 MFMA products per multiply-add on an "
-                                 "exact 3-way bf16 split of each fp32 operand (fp32 accuracy), exact-fp32 MFMA elsewhere",
+                   "arithmetic": "fp32 in/out/accumulate; eligible contractions (forward incl. the affine DUAL form, data "
+                                 "gradient, weight gradient) as 6 bf16 MFMA products per multiply-add on an exact 3-way "
+                                 "bf16 split of each fp32 operand (fp32 accuracy, not bit-identical to an fp32 FMA chain; "
+                                 "inf operands give NaN), exact-fp32 MFMA for odd-channel / packed launches",
                    "final_loss_g": loss},
         "roofline": roof,
+        "step_roofline": step_roofline(ms, args.batch, args.gan) if args.config.startswith("CAPE-affineconv_nz64") else None,
     }
     if table:
         result["kernels"] = {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in table.items()}
     if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline()
+        result["cpu_baseline"] = cpu_baseline(batch=args.batch)
     else:
         result["cpu_baseline"] = None
     if world == 1 and not args.no_ab and not args.host_inputs and os.environ.get("CAPE_GEMM_BF16X6", "1") != "0":

@@ -68,6 +68,8 @@ SIGNATURES = {
     "cape_rowscale_reduce": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _i32, _i32, _p, _p, _i64, _p]),
     "cape_gconv_dw_workspace_bytes": (_i64, [_SRCP, _i32, _i32, _i32, _i32]),
     "cape_gconv_dw": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _p, C.c_uint32, _i32, _i32, _i32, _i32, _p, _i64, _p]),
+    "cape_gconv_dw_stage": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _p, C.c_uint32, _i32, _i32, _i32, _i32, _p, _i64, _i32, _p]),
+    "cape_gconv_dw_plan": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _p, C.c_uint32, _i32, _i32, _i32, C.POINTER(_i32)]),
     "cape_bwd_prep_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "cape_bwd_prep": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p, _i32, _p,
                                 _i64, _i32, _i32, _i32, _i32, _p, _i64, _p]),

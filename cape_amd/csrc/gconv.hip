@@ -670,6 +670,34 @@ inline bool dw_srcs_plain(const cape_src_t *srcs, int nsrc) {
 }
 
 
+inline bool dw_dz_vec(const float *dz, int64_t dz_sample_stride, int32_t lddz, const float *dz2) {
+    return ((lddz & 3) == 0) && ((dz_sample_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dz) & 15) == 0) &&
+           (!dz2 || (reinterpret_cast<uintptr_t>(dz2) & 15) == 0);
+}
+
+// Kernel choice of one weight-gradient launch (pure function of the arguments): 0 = gather form (gconv_dw_kernel),
+// 1 = pipelined plain kernel on the exact-fp32 MFMA (dw_plain_kernel), 2 = packed narrow sources (dw_packed_kernel),
+// 3 = plain sources on the bf16 pipe with the exact three-way operand split (dw_split_kernel).  Fills the tile plan.
+inline int choose_dw(const cape_src_t *srcs, int nsrc, const float *dz, int64_t dz_sample_stride, int32_t lddz,
+                     const float *dz2, uint32_t dz2_mask, int N, int Mo, int F, DwPlan &pl) {
+    static const int dwp_on = getenv("CAPE_DW_PLAIN") ? atoi(getenv("CAPE_DW_PLAIN")) : 1;      // 0: A/B against the gather kernel
+    const bool dzvec = dw_dz_vec(dz, dz_sample_stride, lddz, dz2);
+    const bool plain = dwp_on && dzvec && (((F + 3) & ~3) <= lddz) && dw_srcs_plain(srcs, nsrc);
+    int sumC = 0;
+    for (int i = 0; i < nsrc; ++i) sumC += srcs[i].C;
+    // packing pays where several sources fit ONE tile (narrow layers of the fine mesh levels)
+    // (and the output is narrow: with F > 64 the single packed tile over-splits the rows -- measured 1.8x slower)
+    bool c4 = true;
+    for (int i = 0; i < nsrc; ++i) c4 = c4 && (srcs[i].C & 3) == 0;
+    const bool packed = plain && c4 && !(dz2 && dz2_mask) && nsrc > 1 && sumC <= 128 && F <= 64;
+    // un-packed plain launches run on the bf16 pipe (dw_split_kernel); CAPE_DW_BF16X6=0 keeps them on the fp32 MFMA
+    static const int dws_on = getenv("CAPE_DW_BF16X6") ? atoi(getenv("CAPE_DW_BF16X6")) : CAPE_DW_BF16X6_DEFAULT;
+    const bool dw_split = dws_on && plain && !packed && c4 && (F & 1) == 0;
+    if (packed) plan_dw_plain(srcs, nsrc, N, Mo, F, true, pl);
+    else plan_dw(srcs, nsrc, N, Mo, F, pl);
+    return packed ? 2 : dw_split ? 3 : plain ? 1 : 0;
+}
+
 // Kernel choice of one forward launch (pure function of the arguments).
 struct FwdPlan {
     int family;   // 0: gather-GEMM (gconv_fwd_kernel), 1: pipelined plain GEMM (gemm_plain_kernel),
@@ -799,30 +827,36 @@ extern "C" int64_t cape_gconv_dw_workspace_bytes(const cape_src_t *srcs, int32_t
     return (int64_t)need * (int64_t)sizeof(float);
 }
 
+extern "C" int cape_gconv_dw_plan(const cape_src_t *srcs, int32_t nsrc, const float *dz, int64_t dz_sample_stride,
+                                  int32_t lddz, const float *dz2, uint32_t dz2_mask, int32_t N, int32_t Mo, int32_t F,
+                                  int32_t plan[4]) {
+    if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || !dz || N < 1 || Mo < 1 || F < 1 || lddz < F || !plan) return CAPE_EINVAL;
+    DwPlan pl;
+    plan[0] = choose_dw(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, N, Mo, F, pl);
+    plan[1] = pl.ct; plan[2] = pl.ft; plan[3] = pl.ngroups * pl.rsplit;
+    return CAPE_OK;
+}
+
 extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *dz,
                              int64_t dz_sample_stride, int32_t lddz, const float *dz2, uint32_t dz2_mask,
                              int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
                              int64_t workspace_bytes, void *stream) {
+    return cape_gconv_dw_stage(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, N, Mo, F, accumulate, workspace,
+                               workspace_bytes, 0, stream);
+}
+
+extern "C" int cape_gconv_dw_stage(const cape_src_t *srcs, int32_t nsrc, const float *dz,
+                                   int64_t dz_sample_stride, int32_t lddz, const float *dz2, uint32_t dz2_mask,
+                                   int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
+                                   int64_t workspace_bytes, int32_t stage, void *stream) {
+    if (stage < 0 || stage > 2) return CAPE_EINVAL;
     if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || !dz || N < 1 || Mo < 1 || F < 1 || lddz < F || !workspace)
         return CAPE_EINVAL;
     if (dz2_mask && !dz2) return CAPE_EINVAL;
-    static const int dwp_on = getenv("CAPE_DW_PLAIN") ? atoi(getenv("CAPE_DW_PLAIN")) : 1;      // 0: A/B against the gather kernel
-    const bool dzvec = ((lddz & 3) == 0) && ((dz_sample_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dz) & 15) == 0) &&
-                       (!dz2 || (reinterpret_cast<uintptr_t>(dz2) & 15) == 0);
-    const bool plain = dwp_on && dzvec && (((F + 3) & ~3) <= lddz) && dw_srcs_plain(srcs, nsrc);
     DwPlan pl;
-    int sumC = 0;
-    for (int i = 0; i < nsrc; ++i) sumC += srcs[i].C;
-    // packing pays where several sources fit ONE tile (narrow layers of the fine mesh levels)
-    // (and the output is narrow: with F > 64 the single packed tile over-splits the rows -- measured 1.8x slower)
-    bool c4 = true;
-    for (int i = 0; i < nsrc; ++i) c4 = c4 && (srcs[i].C & 3) == 0;
-    const bool packed = plain && c4 && !(dz2 && dz2_mask) && nsrc > 1 && sumC <= 128 && F <= 64;
-    // CAPE_DW_BF16X6=1: un-packed plain launches on the bf16 pipe (dw_split_kernel)
-    static const int dws_on = getenv("CAPE_DW_BF16X6") ? atoi(getenv("CAPE_DW_BF16X6")) : CAPE_DW_BF16X6_DEFAULT;
-    const bool dw_split = dws_on && plain && !packed && c4 && (F & 1) == 0;
-    if (packed) plan_dw_plain(srcs, nsrc, N, Mo, F, true, pl);
-    else plan_dw(srcs, nsrc, N, Mo, F, pl);
+    const int fam = choose_dw(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, N, Mo, F, pl);
+    const bool packed = fam == 2, plain = fam != 0, dw_split = fam == 3;
+    const bool dzvec = dw_dz_vec(dz, dz_sample_stride, lddz, dz2);
     const long long need = pl.slab * pl.ngroups * pl.rsplit * (long long)sizeof(float);
     if (workspace_bytes < need) return CAPE_EWORKSPACE;
     DwParams p;
@@ -850,6 +884,9 @@ extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *
     p.ws = (float *)workspace; p.slab = pl.slab;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(pl.ntiles * pl.ngroups * pl.rsplit)), block(256);
+    if (stage == 2) {
+        // reduction only: the partial slabs of an earlier stage-1 call with the same arguments are in the workspace
+    } else
     if (packed) {
         if (pl.ft == 32) CAPE_LAUNCH((dw_packed_kernel<128, 32, 4, 1>), grid, block, 0, st, p);
         else if (pl.ct == 64 && pl.ft == 64) CAPE_LAUNCH((dw_packed_kernel<64, 64, 2, 2>), grid, block, 0, st, p);
@@ -872,6 +909,7 @@ extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *
     else if (pl.ft == 64) CAPE_LAUNCH((gconv_dw_kernel<128, 64>), grid, block, 0, st, p);
     else CAPE_LAUNCH((gconv_dw_kernel<128, 128>), grid, block, 0, st, p);
     CAPE_LAUNCH_CHECK();
+    if (stage == 1) return CAPE_OK;
     rp.F = F; rp.nsplit = pl.ngroups * pl.rsplit; rp.accumulate = accumulate; rp.ws = (const float *)workspace; rp.slab = pl.slab;
     long long total = poff;
     int rblocks = (int)((total + 15) / 16);

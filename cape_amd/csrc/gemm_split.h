@@ -30,7 +30,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define CAPE_SPLIT_RN 0                   // 1: round-to-nearest operand split (see gs_split2)
 #endif
 #ifndef CAPE_DW_BF16X6_DEFAULT
-#define CAPE_DW_BF16X6_DEFAULT 0      // weight gradient on the bf16 pipe: written, not yet validated on the GPU test suite
+#define CAPE_DW_BF16X6_DEFAULT 1      // weight gradient on the bf16 pipe (dw_split_kernel); CAPE_DW_BF16X6=0 -> exact-fp32 MFMA
 #endif
 
 #ifndef CAPE_SPLIT_SWZ
@@ -506,8 +506,8 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? GS_BIG_MINB : 3) void
 // Eligibility (on top of gp_weight_layout() >= 0): no second weight set, whole chunks, an output wide enough for
 // the 64-column MFMA tile pair.
 inline bool gs_eligible(const GconvParams &p, bool dual) {
-    // DUAL launches: written, checked for compilation only -- CAPE_GEMM_BF16X6_DUAL=1 enables them
-    static const int dual_on = getenv("CAPE_GEMM_BF16X6_DUAL") ? atoi(getenv("CAPE_GEMM_BF16X6_DUAL")) : 0;
+    // DUAL launches (affine blocks' forward) take the 128 x 64 DUAL tile; CAPE_GEMM_BF16X6_DUAL=0 keeps them on the fp32 MFMA
+    static const int dual_on = getenv("CAPE_GEMM_BF16X6_DUAL") ? atoi(getenv("CAPE_GEMM_BF16X6_DUAL")) : 1;
     if ((dual && !dual_on) || p.F < 64) return false;
     for (int i = 0; i < p.nsrc; ++i)
         if (p.s[i].C % GS_KC != 0 || p.s[i].C < GS_KC) return false;

@@ -5,7 +5,7 @@ same return tuples).  Two sources:
 
 * a CAPE checkout (``project_dir/data/transform_matrices/{ds2,for_demo}/*.npy``), read
   exactly the way the reference reads them (pickled scipy ``csc_matrix`` lists), or
-* the repo's plain-array pack ``tests/golden/smpl_mesh_pack.npz`` (made by
+* the package's plain-array pack ``cape_amd/data/smpl_mesh_pack.npz`` (made by
   tools/make_operator_pack.py from those same files) -- what the GPU box uses, since
   /root/reference does not exist there.
 
@@ -17,7 +17,7 @@ import scipy.sparse as sp
 
 from .mesh_sampling import laplacian
 
-_PACK_DEFAULT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden",
+_PACK_DEFAULT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data",
                              "smpl_mesh_pack.npz")
 
 

@@ -129,10 +129,15 @@ def _mk_srcs(entries):
 
 
 # --------------------------------------------------------------------------------------------
-# per-launch timing hook (bench.py roofline leg): when LAUNCH_LOG is a list every gather-GEMM launch
-# is bracketed by HIP events on the launch stream and logged with its algorithmic work.
+# per-launch instrumentation (bench.py's roofline leg and the kernel-coverage parity test)
+#   LAUNCH_LOG: a list -> every C-ABI compute call is bracketed by HIP events on the launch stream and logged as
+#               (kernel name as rocprofv3 prints it, algorithmic flops, algorithmic bytes, event0, event1)
+#   PLAN_LOG:   a set  -> the kernel selection the library reports for every contraction launch is recorded as
+#               ("fwd", family, BM, BN, layout, dual) / ("dw", family, CT, FT)
+# Both None (the default): no overhead, no extra calls.
 # --------------------------------------------------------------------------------------------
 LAUNCH_LOG = None
+PLAN_LOG = None
 
 
 def _gconv_work(entries, N, Mo, F):
@@ -156,6 +161,26 @@ def _gconv_work(entries, N, Mo, F):
     return flops, byts
 
 
+def _dw_work(entries, N, Mo, F, two_dz):
+    """Weight-gradient launch: 2*N*Mo*C*F per source; every distinct source and gradient operand read once, every
+    gradient block written once."""
+    flops, byts = 0, 4 * N * Mo * F * (2 if two_dz else 1)
+    seen = set()
+    for e in entries:
+        Cs = int(e.get("C", e["x"].shape[2]))
+        flops += 2 * N * Mo * Cs * F
+        byts += 4 * Cs * F
+        key = e["x"].data_ptr()
+        if key not in seen:
+            seen.add(key)
+            byts += 4 * N * e["x"].shape[1] * Cs
+    return flops, byts
+
+
+def _csr_bytes(csr):
+    return 0 if (csr is None or csr.identity) else 8 * csr.nnz + 4 * (csr.shape[0] + 1)
+
+
 def _log_launch(name, flops, byts, fn):
     if LAUNCH_LOG is None:
         return fn()
@@ -163,8 +188,30 @@ def _log_launch(name, flops, byts, fn):
     e0.record()
     out = fn()
     e1.record()
-    LAUNCH_LOG.append((name, flops, byts, e0, e1))
+    LAUNCH_LOG.append((name, int(flops), int(byts), e0, e1))
     return out
+
+
+_FWD_FAMILY = {0: "gconv_fwd_kernel", 1: "gemm_plain_kernel", 2: "gemm_split_kernel"}
+_DW_FAMILY = {0: "gconv_dw_kernel", 1: "dw_plain_kernel", 2: "dw_packed_kernel", 3: "dw_split_kernel"}
+
+
+def fwd_kernel_name(fam, bm, bn, layout, dual):
+    """Kernel instantiation name as rocprofv3 prints it."""
+    waves = "2, 2" if (bm, bn) in ((64, 128), (128, 128), (64, 64)) else "4, 1"
+    tf = lambda b: "true" if b else "false"
+    if fam == 2:
+        return "gemm_split_kernel<%d, %d, %s%s>" % (bm, bn, tf(layout), ", true" if dual else "")
+    if fam == 1:
+        return "gemm_plain_kernel<%d, %d, %s, %s, %s>" % (bm, bn, waves, tf(dual), tf(layout))
+    return "gconv_fwd_kernel<%d, %d, %s, %s, 32>" % (bm, bn, waves, tf(dual))
+
+
+def dw_kernel_name(fam, ct, ft):
+    if fam == 3 or fam == 0:
+        return "%s<%d, %d>" % (_DW_FAMILY[fam], ct, ft)
+    waves = "4, 1" if (fam == 2 and ft == 32) else "2, 2"
+    return "%s<%d, %d, %s>" % (_DW_FAMILY[fam], ct, ft, waves)
 
 
 # --------------------------------------------------------------------------------------------
@@ -191,7 +238,7 @@ def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=
                                 _ptr(mask), C.byref(rk) if rk is not None else None, int(deinterleave), _stream())
         check(rc, "cape_gconv_fwd")
 
-    if LAUNCH_LOG is None:
+    if LAUNCH_LOG is None and PLAN_LOG is None:
         launch()
     else:
         # the library reports the kernel it selects; names as rocprofv3 prints them
@@ -199,15 +246,10 @@ def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=
         plan = (C.c_int32 * 4)()
         check(lib.cape_gconv_fwd_plan(arr, len(entries), N, Mo, F, plan), "cape_gconv_fwd_plan")
         fam, bm, bn, layout = list(plan)
-        waves = "2, 2" if (bm, bn) in ((64, 128), (128, 128), (64, 64)) else "4, 1"
-        if fam == 2:
-            name = "gemm_split_kernel<%d, %d, %s>" % (bm, bn, "true" if layout else "false")
-        elif fam == 1:
-            name = "gemm_plain_kernel<%d, %d, %s, %s, %s>" % (bm, bn, waves, "true" if dual else "false", "true" if layout else "false")
-        else:
-            name = "gconv_fwd_kernel<%d, %d, %s, %s, 32>" % (bm, bn, waves, "true" if dual else "false")
+        if PLAN_LOG is not None:
+            PLAN_LOG.add(("fwd", fam, bm, bn, layout, int(dual)))
         flops, byts = _gconv_work(entries, N, Mo, F)
-        _log_launch(name, flops, byts, launch)
+        _log_launch(fwd_kernel_name(fam, bm, bn, layout, dual), flops, byts, launch)
     return y
 
 
@@ -229,9 +271,31 @@ def gconv_dw(entries, dz, accumulate=False, dz2=None):
         for i, e in enumerate(entries):
             if e.get("use_dz2"):
                 mask |= 1 << i
-    rc = lib.cape_gconv_dw(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, 1 if accumulate else 0,
-                           C.c_void_p(ws.data_ptr()), need, _stream())
-    check(rc, "cape_gconv_dw")
+    def launch():
+        rc = lib.cape_gconv_dw(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, 1 if accumulate else 0,
+                               C.c_void_p(ws.data_ptr()), need, _stream())
+        check(rc, "cape_gconv_dw")
+
+    if LAUNCH_LOG is None and PLAN_LOG is None:
+        launch()
+    else:
+        plan = (C.c_int32 * 4)()
+        check(lib.cape_gconv_dw_plan(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, plan), "cape_gconv_dw_plan")
+        fam, ct, ft, nslab = list(plan)
+        if PLAN_LOG is not None:
+            PLAN_LOG.add(("dw", fam, ct, ft))
+        if LAUNCH_LOG is None:
+            launch()
+            return
+        flops, byts = _dw_work(entries, N, Mo, F, bool(mask))
+        sumCF = sum(int(e.get("C", e["x"].shape[2])) for e in entries) * F
+
+        def stage(which):
+            check(lib.cape_gconv_dw_stage(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, 1 if accumulate else 0,
+                                          C.c_void_p(ws.data_ptr()), need, which, _stream()), "cape_gconv_dw_stage")
+        # the contraction kernel and its fixed-order slab reduction, each with its own bracket
+        _log_launch(dw_kernel_name(fam, ct, ft), flops, byts, lambda: stage(1))
+        _log_launch("dw_reduce", 0, 4 * sumCF * (nslab + 1), lambda: stage(2))
 
 
 def spmm(x, csr, y=None, alpha=1.0, z=None, beta=0.0):
@@ -246,11 +310,14 @@ def spmm(x, csr, y=None, alpha=1.0, z=None, beta=0.0):
         zp, zs, zl = _v(z)
     else:
         zp, zs, zl = None, 0, 0
-    rc = lib.cape_spmm(xp, xs, xl, C.c_void_p(csr.rowptr_t.data_ptr()), C.c_void_p(csr.colidx_t.data_ptr()),
-                       C.c_void_p(csr.vals_t.data_ptr()), int(csr.max_row if (csr.min_row >= 1 and SPMM_BOUNDED) else 0), float(alpha),
-                       zp, zs, zl, float(beta),
-                       yp, ys, yl, N, Mo, Cn, _stream())
-    check(rc, "cape_spmm")
+    def launch():
+        rc = lib.cape_spmm(xp, xs, xl, C.c_void_p(csr.rowptr_t.data_ptr()), C.c_void_p(csr.colidx_t.data_ptr()),
+                           C.c_void_p(csr.vals_t.data_ptr()), int(csr.max_row if (csr.min_row >= 1 and SPMM_BOUNDED) else 0),
+                           float(alpha), zp, zs, zl, float(beta), yp, ys, yl, N, Mo, Cn, _stream())
+        check(rc, "cape_spmm")
+
+    _log_launch("spmm_kernel", 2 * N * csr.nnz * Cn, 4 * N * Cn * (Mi + Mo * (2 if z is not None else 1)) + 8 * csr.nnz + 4 * (Mo + 1),
+                launch)
     return y
 
 
@@ -287,7 +354,10 @@ def spmm_multi(xs, csrs, sum=False, scales=None):
         yp, ys, yl = _v(y)
     else:
         y, yp, ys, yl = None, None, 0, 0
-    check(lib.cape_spmm_multi(arr, n, 1 if sum else 0, yp, ys, yl, N, Mo, Cn, _stream()), "cape_spmm_multi")
+    flops = sum(2 * N * (Mo if ident[k] else csrs[k].nnz) * Cn for k in range(n))
+    byts = sum(4 * N * Cn * xs[k].shape[1] + (0 if ident[k] else _csr_bytes(csrs[k])) for k in range(n)) + 4 * N * Mo * Cn * (1 if sum else n)
+    _log_launch("spmm_multi_kernel", flops, byts,
+                lambda: check(lib.cape_spmm_multi(arr, n, 1 if sum else 0, yp, ys, yl, N, Mo, Cn, _stream()), "cape_spmm_multi"))
     return y if sum else outs
 
 
@@ -315,9 +385,13 @@ def spmm_combine(xs, csrs, y, to_acc2=0, rank=None, bias=None, bias_mode=_lib.BI
         assert coef.is_contiguous() and rowscale.is_contiguous() and coef.shape[0] == N and coef.shape[2] == F
         rk = _lib.CapeRank(int(coef.shape[1]), rowscale.data_ptr(), coef.data_ptr(), int(to2))
     yp, ys, yl = _v(y)
-    check(lib.cape_spmm_combine(arr, n, int(to_acc2), C.byref(rk) if rk is not None else None, _ptr(bias),
-                                bias_mode if bias is not None else _lib.BIAS_NONE, _lib.ACT[act], 1 if dual else 0, _ptr(mask),
-                                yp, ys, yl, N, Mo, F, _stream()), "cape_spmm_combine")
+    flops = sum(2 * N * (Mo if (c is None or c.identity) else c.nnz) * F for c in csrs)
+    byts = sum(4 * N * F * xs[k].shape[1] + _csr_bytes(csrs[k]) for k in range(n)) + 4 * N * Mo * F
+    _log_launch("spmm_combine_kernel", flops, byts,
+                lambda: check(lib.cape_spmm_combine(arr, n, int(to_acc2), C.byref(rk) if rk is not None else None, _ptr(bias),
+                                                    bias_mode if bias is not None else _lib.BIAS_NONE, _lib.ACT[act],
+                                                    1 if dual else 0, _ptr(mask), yp, ys, yl, N, Mo, F, _stream()),
+                              "cape_spmm_combine"))
     return y
 
 
@@ -453,10 +527,15 @@ def bwd_prep(g, y=None, act="none", mask=None, want_bias=False, rowscale=None, R
         yp, ys, yl = _v(y)
     else:
         yp, ys, yl = None, 0, 0
-    rc = lib.cape_bwd_prep(gp, gs, gl, yp, ys, yl, _lib.ACT[act] if mask is None else 0, _ptr(mask), zp, zs, zl,
-                           _ptr(dbias), _ptr(rowscale), R, _ptr(dcoef), 0 if rg is None else int(rg), _ptr(dcoef_g),
-                           cstride, 0 if (defer and DEFERRED is not None) else 1, N, Mo, F, _ptr(ws), need, _stream())
-    check(rc, "cape_bwd_prep")
+    def launch():
+        rc = lib.cape_bwd_prep(gp, gs, gl, yp, ys, yl, _lib.ACT[act] if mask is None else 0, _ptr(mask), zp, zs, zl,
+                               _ptr(dbias), _ptr(rowscale), R, _ptr(dcoef), 0 if rg is None else int(rg), _ptr(dcoef_g),
+                               cstride, 0 if (defer and DEFERRED is not None) else 1, N, Mo, F, _ptr(ws), need, _stream())
+        check(rc, "cape_bwd_prep")
+
+    # one pass: read g (+ y or the 1-bit mask), write dz
+    _log_launch("bwd_prep", 0, 4 * N * Mo * F * (3 if yp is not None else 2) + (N * Mo * ((F + 31) // 32) * 4 if mask is not None else 0),
+                launch)
     if defer and DEFERRED is not None and (dbias is not None or R or rg is not None):
         DEFERRED.append(dict(ws=ws, N=N, Mo=Mo, F=F, R=R, dbias=dbias, dcoef=dcoef, dcoef_g=dcoef_g, cstride=cstride))
     return dz, dbias, dcoef, dcoef_g
@@ -872,9 +951,9 @@ class GroupNormFn(torch.autograd.Function):
         stats = torch.empty((N, G, 2), device=x.device, dtype=torch.float32)
         xp, xs, xl = _v(x)
         yp, ys, yl = _v(y)
-        rc = lib.cape_groupnorm_fwd(xp, xs, xl, _ptr(gamma), _ptr(beta), float(eps), int(G), int(relu), yp, ys, yl,
-                                    _ptr(stats), N, V, Cn, _stream())
-        check(rc, "cape_groupnorm_fwd")
+        _log_launch("groupnorm_fwd", 0, 2 * 4 * N * V * Cn,
+                    lambda: check(lib.cape_groupnorm_fwd(xp, xs, xl, _ptr(gamma), _ptr(beta), float(eps), int(G), int(relu), yp, ys, yl,
+                                                         _ptr(stats), N, V, Cn, _stream()), "cape_groupnorm_fwd"))
         ctx.G, ctx.relu = G, relu
         ctx.save_for_backward(x, y, gamma, stats)
         return y
@@ -892,9 +971,10 @@ class GroupNormFn(torch.autograd.Function):
         yp, ys, yl = _v(y)
         gp, gs, gl = _v(g)
         dp, ds, dl = _v(dx)
-        rc = lib.cape_groupnorm_bwd(xp, xs, xl, yp, ys, yl, gp, gs, gl, _ptr(gamma), _ptr(stats), int(ctx.G),
-                                    int(ctx.relu), dp, ds, dl, _ptr(dgp), _ptr(dbp), _ptr(gst), N, V, Cn, _stream())
-        check(rc, "cape_groupnorm_bwd")
+        _log_launch("groupnorm_bwd", 0, 3 * 4 * N * V * Cn,
+                    lambda: check(lib.cape_groupnorm_bwd(xp, xs, xl, yp, ys, yl, gp, gs, gl, _ptr(gamma), _ptr(stats), int(ctx.G),
+                                                         int(ctx.relu), dp, ds, dl, _ptr(dgp), _ptr(dbp), _ptr(gst), N, V, Cn,
+                                                         _stream()), "cape_groupnorm_bwd"))
         return dx, dgp.sum(0), dbp.sum(0), None, None, None
 
 
@@ -913,10 +993,11 @@ class ReconEdgeLossFn(torch.autograd.Function):
         out = torch.empty(2, device=pred.device, dtype=torch.float32)
         total = torch.empty((), device=pred.device, dtype=torch.float32)
         dpred = torch.empty_like(pred)
-        rc = lib.cape_recon_edge_loss_fwd_bwd(_ptr(pred), _ptr(gt), _ptr(verts_ref), _ptr(edges), _ptr(vptr), _ptr(vidx),
-                                              N, M, E, float(w_recon), float(w_edge), _ptr(out), _ptr(total), _ptr(dpred),
-                                              _ptr(ws), need, _stream())
-        check(rc, "cape_recon_edge_loss_fwd_bwd")
+        _log_launch("recon_edge_loss", 0, N * (E * 24 + M * 36),
+                    lambda: check(lib.cape_recon_edge_loss_fwd_bwd(_ptr(pred), _ptr(gt), _ptr(verts_ref), _ptr(edges), _ptr(vptr),
+                                                                   _ptr(vidx), N, M, E, float(w_recon), float(w_edge), _ptr(out),
+                                                                   _ptr(total), _ptr(dpred), _ptr(ws), need, _stream()),
+                                  "cape_recon_edge_loss_fwd_bwd"))
         ctx.save_for_backward(dpred)
         ctx.mark_non_differentiable(out)
         return total, out
@@ -1070,8 +1151,9 @@ class FcLongFn(torch.autograd.Function):
         if need < 0:
             check(need, "cape_fc_long_workspace_bytes")
         ws = torch.empty((need + 3) // 4, device=x.device, dtype=torch.float32)
-        check(lib.cape_fc_long_fwd(C.c_void_p(x.data_ptr()), kin, N, kin, out, nmat, _parr(Ws), _parr(bs), _parr(ys),
-                                   C.c_void_p(ws.data_ptr()), need, _stream()), "cape_fc_long_fwd")
+        _log_launch("fc_long_fwd", 2 * N * kin * out * nmat, 4 * (kin * out * nmat + N * kin + N * out * nmat),
+                    lambda: check(lib.cape_fc_long_fwd(C.c_void_p(x.data_ptr()), kin, N, kin, out, nmat, _parr(Ws), _parr(bs), _parr(ys),
+                                                       C.c_void_p(ws.data_ptr()), need, _stream()), "cape_fc_long_fwd"))
         ctx.gbufs, ctx.nmat, ctx.has_b = gbufs, nmat, [b is not None for b in bs]
         ctx.save_for_backward(x, *Ws)
         return tuple(ys)
@@ -1093,8 +1175,9 @@ class FcLongFn(torch.autograd.Function):
             else:
                 dbs.append(None)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        check(lib.cape_fc_long_bwd(C.c_void_p(x.data_ptr()), kin, N, kin, out, nmat, _parr(Ws), _parr(gs), _parr(dWs), _parr(dbs),
-                                   _ptr(dx), kin, _stream()), "cape_fc_long_bwd")
+        _log_launch("fc_long_bwd", 4 * N * kin * out * nmat, 4 * (2 * kin * out * nmat + 2 * N * kin + N * out * nmat),
+                    lambda: check(lib.cape_fc_long_bwd(C.c_void_p(x.data_ptr()), kin, N, kin, out, nmat, _parr(Ws), _parr(gs), _parr(dWs),
+                                                       _parr(dbs), _ptr(dx), kin, _stream()), "cape_fc_long_bwd"))
         grads = [dx, None]
         for m in range(nmat):
             grads += [dWs[m], dbs[m]]
@@ -1113,8 +1196,9 @@ class FcWideFn(torch.autograd.Function):
         out = int(W.shape[1])
         assert W.is_contiguous() and W.shape[0] == kin
         y = torch.empty((N, out), device=x.device, dtype=torch.float32)
-        check(lib.cape_fc_wide_fwd(C.c_void_p(x.data_ptr()), kin, N, kin, out, C.c_void_p(W.data_ptr()), _ptr(b), _lib.ACT[act],
-                                   C.c_void_p(y.data_ptr()), out, _stream()), "cape_fc_wide_fwd")
+        _log_launch("fc_wide_fwd", 2 * N * kin * out, 4 * (kin * out + N * kin + N * out),
+                    lambda: check(lib.cape_fc_wide_fwd(C.c_void_p(x.data_ptr()), kin, N, kin, out, C.c_void_p(W.data_ptr()), _ptr(b),
+                                                       _lib.ACT[act], C.c_void_p(y.data_ptr()), out, _stream()), "cape_fc_wide_fwd"))
         ctx.act, ctx.gW, ctx.gb, ctx.has_b = act, gW, gb, b is not None
         ctx.save_for_backward(x, W, y)
         return y
@@ -1136,9 +1220,10 @@ class FcWideFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             need = int(lib.cape_fc_wide_bwd_workspace_bytes(N, kin, out))
             ws = torch.empty((need + 3) // 4, device=x.device, dtype=torch.float32)
-        check(lib.cape_fc_wide_bwd(C.c_void_p(x.data_ptr()), kin, C.c_void_p(g.data_ptr()), out, C.c_void_p(y.data_ptr()), out,
-                                   _lib.ACT[ctx.act], N, kin, out, C.c_void_p(W.data_ptr()), _ptr(dW), _ptr(db), _ptr(dx), kin,
-                                   _ptr(ws), need, _stream()), "cape_fc_wide_bwd")
+        _log_launch("fc_wide_bwd", 4 * N * kin * out, 4 * (2 * kin * out + 2 * N * kin + 2 * N * out),
+                    lambda: check(lib.cape_fc_wide_bwd(C.c_void_p(x.data_ptr()), kin, C.c_void_p(g.data_ptr()), out, C.c_void_p(y.data_ptr()),
+                                                       out, _lib.ACT[ctx.act], N, kin, out, C.c_void_p(W.data_ptr()), _ptr(dW), _ptr(db),
+                                                       _ptr(dx), kin, _ptr(ws), need, _stream()), "cape_fc_wide_bwd"))
         return dx, dW, db, None, None, None
 
 
@@ -1184,9 +1269,10 @@ def flat_gradnorm(g, w, ranges, coef, sumsq_out, ws):
     """sumsq_out <- sum (g + coef*w on ``ranges``)^2 over a flat bucket (two deterministic launches)."""
     _lib.require_gpu()
     arr, nr = _ranges_arg(ranges)
-    check(lib.cape_flat_gradnorm(C.c_void_p(g.data_ptr()), _ptr(w), g.numel(), arr, nr, float(coef),
-                                 C.c_void_p(sumsq_out.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel() * 4, _stream()),
-          "cape_flat_gradnorm")
+    _log_launch("flat_gradnorm", 0, 4 * g.numel(),
+                lambda: check(lib.cape_flat_gradnorm(C.c_void_p(g.data_ptr()), _ptr(w), g.numel(), arr, nr, float(coef),
+                                                     C.c_void_p(sumsq_out.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel() * 4,
+                                                     _stream()), "cape_flat_gradnorm"))
     return sumsq_out
 
 
@@ -1194,10 +1280,11 @@ def flat_momentum_update(w, g, m, momentum, clip, sumsq, neg_lr, ranges, coef):
     """clip-by-global-norm + momentum update of a flat bucket in one launch (csrc/optim.hip)."""
     _lib.require_gpu()
     arr, nr = _ranges_arg(ranges)
-    check(lib.cape_flat_momentum_update(C.c_void_p(w.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
-                                        w.numel(), float(momentum), float(clip), C.c_void_p(sumsq.data_ptr()),
-                                        C.c_void_p(neg_lr.data_ptr()), arr, nr, float(coef), _stream()),
-          "cape_flat_momentum_update")
+    _log_launch("flat_momentum_update", 0, 5 * 4 * w.numel(),
+                lambda: check(lib.cape_flat_momentum_update(C.c_void_p(w.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
+                                                            w.numel(), float(momentum), float(clip), C.c_void_p(sumsq.data_ptr()),
+                                                            C.c_void_p(neg_lr.data_ptr()), arr, nr, float(coef), _stream()),
+                              "cape_flat_momentum_update"))
 
 
 def sumsq_ranges(x, ranges, scale, ws):

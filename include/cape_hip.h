@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CAPE_ABI_VERSION 6
+#define CAPE_ABI_VERSION 7
 #define CAPE_MAX_SRC 8
 
 /* error codes (negative = argument error; positive values are hipError_t) */
@@ -186,6 +186,22 @@ int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *dz,
                   int64_t dz_sample_stride, int32_t lddz, const float *dz2, uint32_t dz2_mask,
                   int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
                   int64_t workspace_bytes, void *stream);
+
+/* The two stages of cape_gconv_dw separately (stage 1: contraction into the partial slabs of the workspace; stage 2:
+ * their fixed-order reduction into the gradient blocks; stage 0 = both, identical to cape_gconv_dw).  Lets a caller
+ * bracket each kernel with its own events (bench.py's per-kernel roofline). */
+int cape_gconv_dw_stage(const cape_src_t *srcs, int32_t nsrc, const float *dz,
+                        int64_t dz_sample_stride, int32_t lddz, const float *dz2, uint32_t dz2_mask,
+                        int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
+                        int64_t workspace_bytes, int32_t stage, void *stream);
+
+/* Which kernel cape_gconv_dw would run for these arguments (pure query, no launch): plan[0] = family (0: gather form
+ * gconv_dw_kernel, 1: dw_plain_kernel on the exact-fp32 MFMA, 2: dw_packed_kernel, 3: dw_split_kernel on the bf16 pipe
+ * with the exact three-way operand split), plan[1], plan[2] = tile channels x output columns, plan[3] = number of
+ * partial slabs the fixed-order reduction sums.  The parity tests use it to prove that every kernel the benchmarked
+ * step launches is exercised by a passing comparison against the oracle. */
+int cape_gconv_dw_plan(const cape_src_t *srcs, int32_t nsrc, const float *dz, int64_t dz_sample_stride, int32_t lddz,
+                       const float *dz2, uint32_t dz2_mask, int32_t N, int32_t Mo, int32_t F, int32_t plan[4]);
 
 /*
  * One pass over the incoming gradient g [N, Mo, F] that produces everything the backward of a conv

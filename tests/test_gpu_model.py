@@ -83,9 +83,14 @@ CONFIGS = [
 
 @pytest.mark.parametrize("cfg,overrides", CONFIGS, ids=["affine_nz64", "cmr_nz18", "resblock_udn_tanh"])
 def test_full_model_forward_backward(cfg, overrides, mesh_ops):
-    N = 2
+    _full_model_parity(cfg, overrides, mesh_ops, N=2)
+
+
+def _full_model_parity(cfg, overrides, mesh_ops, N, inputs=None):
+    """Forward values, all losses and every parameter gradient of the HIP model against the fp64 twin (same named
+    weights, same inputs).  Returns the model (variables loaded) for further use."""
     P, twin, model = _build(cfg, mesh_ops, N, overrides)
-    x, gt, xd, cond, cond_d, clo, clo_d, eps = _inputs(N, P["nz"])
+    x, gt, xd, cond, cond_d, clo, clo_d, eps = inputs if inputs is not None else _inputs(N, P["nz"])
     xh, zm, zl, d_real, d_fake, ls = _run_twin(twin, x, gt, xd, cond, cond_d, clo, clo_d, eps)
     # same variable set (names + shapes) as the restated reference graph, then identical values
     assert set(model._vars) == set(twin.vs.vars), set(model._vars) ^ set(twin.vs.vars)
@@ -129,6 +134,62 @@ def test_full_model_forward_backward(cfg, overrides, mesh_ops):
     print("gradient error: worst var %.3g (fp32 CPU worst %.3g); global L2 %.3g (fp32 CPU %.3g)"
           % (max(r[1] for r in rows), noise, gl, gl32))
     assert gl < max(1e-5, 4 * gl32), (gl, gl32)
+    return model, out
+
+
+def test_batch16_parity_covers_every_bench_kernel(mesh_ops):
+    """BASELINE configs[2] AT its stated batch: static batch 16 is part of the reference contract
+    (lib/models.py:272-282, config_parser.py:33) and the library picks its large-tile kernels only at that size
+    (gemm_split_kernel<128,128,*>, dw_split_kernel<128,128>).  (1) full CAPE-affineconv_nz64 + discriminator at N = 16:
+    forward, losses and all gradients against the fp64 twin, forward also against the golden vectors the reference's own
+    lib/models.py produced at batch 16 (oracle/make_golden.py, case affine_nz64_b16); (2) every kernel instantiation the
+    library reports (cape_gconv_fwd_plan / cape_gconv_dw_plan) for the step bench.py times -- CVAE step and adversarial
+    step, through the same graph runner -- must have been launched by (1)."""
+    from cape_amd import ops
+    from cape_amd.runtime import GraphedTrainStep
+    from oracle.golden_inputs import golden_inputs
+    from test_oracle_golden import load_case
+    g, meta = load_case("affine_nz64_b16")
+    N = int(meta["N"])
+    assert N == 16
+    inp = golden_inputs(N, 64, meta["seed"], mesh_ops["pack"]["demo_rot"])
+    inputs = tuple(np.asarray(inp[k], np.float64) for k in ("x", "gt", "xd", "cond", "cond_d", "clo", "clo_d", "eps"))
+    ops.PLAN_LOG = set()
+    try:
+        model, out = _full_model_parity("affine_nz64", None, mesh_ops, N=N, inputs=inputs)
+        parity_plans = set(ops.PLAN_LOG)
+    finally:
+        ops.PLAN_LOG = None
+    # the reference's own graph code at batch 16 (numpy TF1 shim), same weights by name (checked by CRC in
+    # tests/test_oracle_golden.py), same inputs
+    assert vertex_err(out['prediction'].detach().cpu().numpy(), g["out_op_prediction"].astype(np.float64)) < 1e-4
+    assert rel_err(out['z_mean'].detach().cpu().numpy(), g["out_z_mean"]) < 1e-4
+    assert rel_err(out['z_logvar'].detach().cpu().numpy(), g["out_z_logvar"]) < 1e-4
+    for key, name in (("recon", "recon_loss"), ("latent", "latent_loss"), ("edge", "edge_loss"),
+                      ("gan_g", "loss_g"), ("gan_d", "loss_d"), ("loss_g", "op_loss_g"), ("loss_d", "op_loss_d")):
+        assert abs(float(out[key]) - float(g["out_" + name])) < 1e-4 * max(abs(float(g["out_" + name])), 1e-3), key
+    del out
+
+    # the step bench.py times (eager pass of the graph runner's body), CVAE-only and adversarial
+    bench_plans = set()
+    for gan in (False, True):
+        runner = GraphedTrainStep(model, with_gan=gan, use_graph=False)
+        runner.load_batch(data_g=inputs[0], gt=inputs[1], data_d=inputs[2], cond_g=inputs[3], cond_d=inputs[4],
+                          cond2_g=inputs[5], cond2_d=inputs[6], eps=inputs[7])
+        ops.PLAN_LOG = set()
+        try:
+            runner._fwd_bwd()
+            torch.cuda.synchronize()
+            bench_plans |= ops.PLAN_LOG
+        finally:
+            ops.PLAN_LOG = None
+    missing = bench_plans - parity_plans
+    assert not missing, "kernels launched by the benchmarked step without a parity case: %s" % sorted(missing)
+    # the instantiations VERDICT r01 named: 128 x 128 split tiles in both weight layouts, the 128 x 128 split dW
+    for need in (("fwd", 2, 128, 128, 0, 0), ("fwd", 2, 128, 128, 1, 0), ("dw", 3, 128, 128)):
+        assert need in bench_plans, (need, sorted(bench_plans))
+    print("kernel instantiations of the benchmarked step, all covered at batch 16:",
+          sorted(ops.fwd_kernel_name(*p[1:]) if p[0] == "fwd" else ops.dw_kernel_name(*p[1:]) for p in bench_plans))
 
 
 def test_encode_decode_api_padding(mesh_ops):

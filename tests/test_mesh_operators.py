@@ -1,6 +1,6 @@
 """Operator generation without psbody (cape_amd/mesh_operators.py, reference lib/mesh_sampling.py:40-263): the
 hierarchy regenerated from the SMPL template must reproduce the operators the reference SHIPS for it
-(data/transform_matrices/for_demo/{A,D,U}.npy, re-encoded in tests/golden/smpl_mesh_pack.npz) -- identical
+(data/transform_matrices/for_demo/{A,D,U}.npy, re-encoded in cape_amd/data/smpl_mesh_pack.npz) -- identical
 down-sampling selections, identical adjacencies, up-sampling weights to the float32 precision they are stored in.
 CPU only."""
 import os

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["affine_nz64", "cmr_nz18", "resblock_udn_tanh"]
+CASES = ["affine_nz64", "cmr_nz18", "resblock_udn_tanh", "affine_nz64_b16"]
 
 
 def load_case(tag):
@@ -61,9 +61,10 @@ def test_oracle_reproduces_reference_graph(tag, mesh_ops):
         assert abs(float(val) - float(g["out_" + key])) <= 1e-9 * max(1.0, abs(float(g["out_" + key]))), key
     # demo-phase ops: encoder outputs and the decoder-only path (model.decode)
     assert rel(zm, g["out_op_vae_mean"]) < 1e-10
-    zt = np.concatenate([g["out_op_vae_mean"], g["out_op_cond_latent"], g["out_op_cond2_latent"]], 1)
-    dec = orc.decoder_cond_vert(zt, g["out_op_cond_latent"], g["out_op_cond2_latent"])
-    assert rel(dec, g["out_op_decoder"].astype(np.float64)) < 5e-7
+    if "out_op_decoder" in g.files:          # (not stored for the batch-16 case: same decoder graph, 1.3 MB)
+        zt = np.concatenate([g["out_op_vae_mean"], g["out_op_cond_latent"], g["out_op_cond2_latent"]], 1)
+        dec = orc.decoder_cond_vert(zt, g["out_op_cond_latent"], g["out_op_cond2_latent"])
+        assert rel(dec, g["out_op_decoder"].astype(np.float64)) < 5e-7
 
 
 def test_fp32_tier_close_to_fp64(mesh_ops):

@@ -23,7 +23,7 @@ cd $R
 python tools/ab_compare.py $O/gemm_fp32.txt $O/gemm_split.txt $O/gemm_split_dual.txt | tee $O/compare_gemm.txt
 python tools/ab_compare.py $O/dw_fp32.txt $O/dw_split.txt | tee $O/compare_dw.txt
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-  env CAPE_RUN_NEW_GPU_TESTS=1 python -m pytest tests/test_gpu_split_ragged.py -x -q 2>&1 | tail -3 | tee $O/pytest_split_ragged.txt
+  python -m pytest tests/test_gpu_split_ragged.py -x -q 2>&1 | tail -3 | tee $O/pytest_split_ragged.txt
   env $KNOBS python -m pytest tests -x -q -m gpu 2>&1 | tail -3 | tee $O/pytest_knobs.txt
 fi
 for i in $(seq 1 $PAIRS); do

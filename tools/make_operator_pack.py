@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build tests/golden/smpl_mesh_pack.npz (and tests/golden/template_faces.npy) from the reference's shipped data assets.
+"""Build cape_amd/data/smpl_mesh_pack.npz (and tests/golden/template_faces.npy) from the reference's shipped data assets.
 
 Runs ONLY in the build container (needs /root/reference, which does not exist on
 the GPU box).  The pack is a plain-array re-encoding (no pickles) of
@@ -21,8 +21,9 @@ import sys
 import numpy as np
 
 REF = os.environ.get("CAPE_REFERENCE", "/root/reference")
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden",
-                   "smpl_mesh_pack.npz")
+_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+OUT = os.path.join(_ROOT, "cape_amd", "data", "smpl_mesh_pack.npz")          # product data (operators the package loads)
+FACES = os.path.join(_ROOT, "tests", "golden", "template_faces.npy")           # test fixture
 
 
 def main():
@@ -50,7 +51,7 @@ def main():
     faces = np.asarray(faces, dtype=np.int32)
     assert faces.shape == (13776, 3) and faces.min() == 0 and faces.max() == 6889
     if "--faces-only" in sys.argv:
-        np.save(os.path.join(os.path.dirname(OUT), "template_faces.npy"), faces)
+        np.save(FACES, faces)
         print("wrote template_faces.npy", faces.shape)
         return
     pack["template_verts"] = np.asarray(verts, dtype=np.float64)
@@ -58,7 +59,7 @@ def main():
     pose = np.load(os.path.join(REF, "data", "demo_data", "demo_pose_params.npz"))
     pack["demo_rot"] = pose["rot"].astype(np.float64)
     np.savez_compressed(OUT, **pack)
-    np.save(os.path.join(os.path.dirname(OUT), "template_faces.npy"), faces)
+    np.save(FACES, faces)
     print("wrote", OUT, os.path.getsize(OUT), "bytes,", len(pack), "arrays")
 
 

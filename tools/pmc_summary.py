@@ -19,7 +19,7 @@ def main(db, out):
     agg = collections.defaultdict(dict)
     for k, cn, v, n in rows:
         agg[short(k)][cn] = dict(avg_per_dispatch=v / n, dispatches=n)
-    keep = {k: v for k, v in agg.items() if any(t in k for t in ('gconv', 'gemm_', 'dw_plain', 'dw_packed', 'spmm', 'bwd_prep', 'dw_reduce', 'edge', 'vert_', 'fc_', 'cond_coef', 'momentum', 'gradnorm'))}
+    keep = {k: v for k, v in agg.items() if any(t in k for t in ('gconv', 'gemm_', 'dw_', 'spmm', 'bwd_prep', 'edge', 'vert_', 'fc_', 'cond_coef', 'momentum', 'gradnorm', 'gn_', 'cheb'))}
     json.dump(keep, open(out, 'w'), indent=1, sort_keys=True)
     print("wrote", out, len(keep), "kernels")
 
