@@ -234,6 +234,9 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=16, help='meshes per GPU per step')
+    ap.add_argument('--global-batch', type=int, default=0,
+                    help='strong scaling (SURVEY 8e: 16 -> 16/8/4/2 per GPU): the GLOBAL batch is fixed and sharded over the '
+                         'ranks (per-GPU batch = global / world); default 0 = weak scaling with --batch per GPU')
     ap.add_argument('--config', default='CAPE-affineconv_nz64_pose32_clotype32_male')
     ap.add_argument('--gan', action='store_true', help='include the discriminator passes/update (adversarial step)')
     ap.add_argument('--no-graph', action='store_true')
@@ -256,6 +259,10 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local)
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit("--global-batch %d is not divisible by the %d ranks" % (args.global_batch, world))
+        args.batch = args.global_batch // world
     model = build_model(args.batch, local, args.config)
     hook = None
     if world > 1:
@@ -303,7 +310,7 @@ def main():
         "metric": "meshes/sec fwd+bwd, CAPE-affineconv nz64 @ batch 16, 1/2/4/8 MI355X",
         "value": round(args.batch * world * args.steps / elapsed, 2), "unit": "meshes/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s Mesh-CVAE%s: fwd+bwd+clip+momentum update, batch %d per GPU, "
                                "6890-vertex SMPL hierarchy%s"
                                % (args.config.replace("_pose32_clotype32_male", ""), " + mesh-patch discriminator (adversarial step)" if args.gan else "",

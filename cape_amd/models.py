@@ -12,6 +12,7 @@ name.  All mesh-tensor arithmetic runs in the HIP kernels (cape_amd.ops); PyTorc
 autograd / optimizer shell.  There is no CPU fallback.
 """
 import collections
+import contextlib
 import glob
 import os
 import shutil
@@ -846,6 +847,19 @@ class CAPE(base_model):
         finally:
             ops.DEFERRED = None
 
+    @contextlib.contextmanager
+    def _data_grad_only_through_d(self, active):
+        """The generator sweep passes through D(fake) only for its data gradient: name the discriminator variables so
+        that their layers skip the weight/bias-gradient kernels in this sweep (the discriminator sweep computes them)."""
+        if not active:
+            yield
+            return
+        ops.NO_WEIGHT_GRAD = {p.data_ptr() for p in self._opt_state['d']['params']}
+        try:
+            yield
+        finally:
+            ops.NO_WEIGHT_GRAD = None
+
     def backward_phase1(self, out):
         """First half of the two-phase backward (``split_backward``): everything downstream of the encoder's
         convolution stack -- decoder, dense layers, discriminator.  Afterwards the EARLY part of the G bucket
@@ -855,7 +869,8 @@ class CAPE(base_model):
         one = self._one_scalar()
         self._deferred_begin()
         heads = [t for t in (self._enc_feat_cut,) + tuple(self._y_pair) if t.requires_grad]
-        res = torch.autograd.grad(out['loss_g'], st['params'][:ne] + heads, grad_outputs=one, retain_graph=True, allow_unused=True)
+        with self._data_grad_only_through_d('loss_d' in out):
+            res = torch.autograd.grad(out['loss_g'], st['params'][:ne] + heads, grad_outputs=one, retain_graph=True, allow_unused=True)
         self.store_grads('g', res[:ne], 0, ne)
         self._phase_heads = (heads, list(res[ne:]))
         if 'loss_d' in out:
@@ -863,6 +878,10 @@ class CAPE(base_model):
                                           allow_unused=True)
             self.store_grads('d', grads_d)
         self._deferred_end()
+        # Adam path: the regularised dense kernels are all EARLY variables, so their regulariser gradient must be in
+        # the bucket before the early range is handed to the asynchronous all-reduce (adding it in phase 2 would race
+        # with the collective that reduces the same range in place)
+        self._add_reg_grads()
 
     def backward_phase2(self):
         """Second half: from the cut (and the condition embeddings) through the encoder convolutions and the
@@ -882,7 +901,6 @@ class CAPE(base_model):
             self.store_grads('g', res, ne, None)
         self._deferred_end()
         self._phase_heads = self._enc_feat = self._enc_feat_cut = None
-        self._add_reg_grads()
 
     def backward_to_flat(self, out):
         """Gradients of loss_g w.r.t. the G group and loss_d w.r.t. the D group -> flat gradient buffers."""
@@ -911,7 +929,8 @@ class CAPE(base_model):
         else:
             # two sweeps over the shared D(fake) graph: the first needs only data gradients inside D, the second only
             # reaches the discriminator variables
-            grads_g = torch.autograd.grad(out['loss_g'], g_params, grad_outputs=one, retain_graph=True, allow_unused=True)
+            with self._data_grad_only_through_d(True):
+                grads_g = torch.autograd.grad(out['loss_g'], g_params, grad_outputs=one, retain_graph=True, allow_unused=True)
             grads_d = torch.autograd.grad(out['loss_d'], d_params, grad_outputs=one, allow_unused=True)
         self.store_grads('g', grads_g)
         self._add_reg_grads()
@@ -938,7 +957,11 @@ class CAPE(base_model):
         arrays['training/global_step'] = np.asarray(self.global_step, dtype=np.int64)
         if self._opt_state is not None:
             for grp in ('g', 'd'):
-                arrays['training/momentum_' + grp] = self._opt_state[grp]['m'].detach().cpu().numpy()
+                st = self._opt_state[grp]
+                arrays['training/momentum_' + grp] = st['m'].detach().cpu().numpy()
+                if 'v' in st:                        # Adam: second moment and step count (bias correction)
+                    arrays['training/adam_v_' + grp] = st['v'].detach().cpu().numpy()
+                    arrays['training/adam_t_' + grp] = np.asarray(st['t'], dtype=np.int64)
         fn = os.path.join(path, 'model-%d.npz' % step)
         np.savez(fn, **arrays)
         keep = sorted(glob.glob(os.path.join(path, 'model-*.npz')), key=os.path.getmtime)
@@ -986,6 +1009,17 @@ class CAPE(base_model):
                 key = 'training/momentum_' + grp
                 if key in arrays and arrays[key].shape == tuple(st['m'].shape):
                     st['m'].copy_(torch.from_numpy(arrays[key]).to(self.device))
+                    if 'v' in st:
+                        kv, kt = 'training/adam_v_' + grp, 'training/adam_t_' + grp
+                        if kv in arrays and kt in arrays and arrays[kv].shape == tuple(st['v'].shape):
+                            st['v'].copy_(torch.from_numpy(arrays[kv]).to(self.device))
+                            st['t'] = int(arrays[kt])
+                        else:
+                            # first moment without second moment / step count: restart Adam's statistics instead of
+                            # applying the t = 1 bias correction to a warm m (a 10x first step)
+                            st['m'].zero_()
+                            st['v'].zero_()
+                            st['t'] = 0
                     continue
                 for buf in ('m', 'v'):                     # per-variable TF slots -> flat bucket
                     suffix = self._slot_suffix(buf)
@@ -1077,7 +1111,15 @@ class CAPE(base_model):
         self._weights_loaded = True
         losses = []
         indices_g, indices_d = collections.deque(), collections.deque()
-        learning_rate_g = learning_rate_d = 0.0
+        # The step itself runs through the HIP-graph runner (cape_amd.runtime.GraphedTrainStep: the whole adversarial
+        # step captured once and replayed -- the counterpart of the reference's static graph + sess.run, :905-906);
+        # per step the host only stages the batch into the runner's static input buffers and draws eps.  The loss
+        # averages (reference: ExponentialMovingAverage(0.9), :407-411) stay on the device and are read at epoch ends.
+        from .runtime import GraphedTrainStep
+        runner = GraphedTrainStep(self, with_gan=True, grad_hook=getattr(self, 'grad_hook', None))
+        ema = torch.tensor([self._ema['g'], self._ema['d']], device=self.device, dtype=torch.float32)
+        cur = torch.zeros(2, device=self.device, dtype=torch.float32)
+        captured = False
         for step in range(start_step, end_step):
             if len(indices_g) < self.batch_size:
                 indices_g.extend(np.random.permutation(train_data.shape[0]))
@@ -1085,16 +1127,21 @@ class CAPE(base_model):
                 indices_d.extend(np.random.permutation(train_data.shape[0]))
             idx_g = [indices_g.popleft() for _ in range(self.batch_size)]
             idx_d = [indices_d.popleft() for _ in range(self.batch_size)]
-            bg, bd = self._dense_np(train_data[idx_g]), self._dense_np(train_data[idx_d])
-            args = (self._dev(bg), self._dev(train_cond[idx_g]), self._dev(train_cond2[idx_g]),
-                    self._dev(self._dense_np(train_labels[idx_g])), self._dev(bd),
-                    self._dev(train_cond[idx_d]), self._dev(train_cond2[idx_d]))
+            runner.load_batch(data_g=self._dense_np(train_data[idx_g]), cond_g=train_cond[idx_g], cond2_g=train_cond2[idx_g],
+                              gt=self._dense_np(train_labels[idx_g]), data_d=self._dense_np(train_data[idx_d]),
+                              cond_d=train_cond[idx_d], cond2_d=train_cond2[idx_d])
             for _ in range(2 if self.bug_compat else 1):   # quirk C1: two sess.run, each applies both updates
-                out = self.train_step(*args)
-                self._ema['g'] = 0.9 * self._ema['g'] + 0.1 * float(out['loss_g'])
-                self._ema['d'] = 0.9 * self._ema['d'] + 0.1 * float(out['loss_d'])
-            learning_rate_g, learning_rate_d = out['lr_g'], out['lr_d']
+                runner.buf['eps'].normal_()                # tf.random_normal inside the graph (:194): fresh per run
+                if not captured:
+                    runner.capture(preserve_state=True)    # (no-op for Adam: host-side step counter -> eager runner)
+                    captured = True
+                runner.step()
+                torch.stack([runner.losses['loss_g'], runner.losses['loss_d']], out=cur)
+                ema.mul_(0.9).add_(cur, alpha=0.1)
             if step % num_steps_epoch == 0 or step == num_steps:
+                self._ema['g'], self._ema['d'] = (float(v) for v in ema.tolist())
+                learning_rate_g = self._lr_at(self.lr_g, max(self.global_step - 2, 0))
+                learning_rate_d = self._lr_at(self.lr_d, max(self.global_step - 2, 0))
                 epoch = int(step * self.batch_size / train_data.shape[0])
                 print('step {} / {} (epoch {} / {}):'.format(step, num_steps, epoch, self.num_epochs))
                 print('  learning_rate_g = {:.2e}, loss_average_g = {:.2e}'.format(learning_rate_g, self._ema['g']))
@@ -1104,6 +1151,7 @@ class CAPE(base_model):
                 print('  validation {}'.format(string))
                 print('  time: {:.0f}s'.format(time.time() - t_start))
                 self.save_checkpoint(step)
+        self._ema['g'], self._ema['d'] = (float(v) for v in ema.tolist())
         t_step = (time.time() - t_start) / max(num_steps, 1)
         return losses, t_step
 

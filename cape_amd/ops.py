@@ -354,8 +354,10 @@ def spmm_multi(xs, csrs, sum=False, scales=None):
         yp, ys, yl = _v(y)
     else:
         y, yp, ys, yl = None, None, 0, 0
-    flops = sum(2 * N * (Mo if ident[k] else csrs[k].nnz) * Cn for k in range(n))
-    byts = sum(4 * N * Cn * xs[k].shape[1] + (0 if ident[k] else _csr_bytes(csrs[k])) for k in range(n)) + 4 * N * Mo * Cn * (1 if sum else n)
+    flops, byts = 0, 4 * N * Mo * Cn * (1 if sum else n)        # (``sum`` is this function's flag, not the builtin)
+    for k in range(n):
+        flops += 2 * N * (Mo if ident[k] else csrs[k].nnz) * Cn
+        byts += 4 * N * Cn * xs[k].shape[1] + (0 if ident[k] else _csr_bytes(csrs[k]))
     _log_launch("spmm_multi_kernel", flops, byts,
                 lambda: check(lib.cape_spmm_multi(arr, n, 1 if sum else 0, yp, ys, yl, N, Mo, Cn, _stream()), "cape_spmm_multi"))
     return y if sum else outs
@@ -469,6 +471,13 @@ def reduce_cond(dy, scale=None, out=None, accumulate=False):
                               N, M, Cn, 1 if accumulate else 0, _stream())
     check(rc, "cape_reduce_cond")
     return out
+
+
+# Weights (by data pointer) whose layers are differentiated for their DATA gradient only in the current sweep.
+# ``needs_input_grad`` is static (True for every variable), so the generator sweep of the adversarial step -- which passes
+# through D(fake) only to reach the generator -- would compute every discriminator weight gradient and discard it; the
+# training step names the discriminator's variables here around that sweep (cape_amd.models).
+NO_WEIGHT_GRAD = None
 
 
 # Deferred finalisation of bwd_prep's reductions: while DEFERRED is a list (set by the training step around the backward
@@ -718,6 +727,8 @@ class ChebConvFn(torch.autograd.Function):
         gfull = as_act(gfull)
         g = gfull[:, :, :Fout]
         need_x, need_w, need_b, need_wa, need_ci, need_co = (ctx.needs_input_grad[i] for i in range(6))
+        if NO_WEIGHT_GRAD and W.data_ptr() in NO_WEIGHT_GRAD:
+            need_w = need_b = need_wa = False       # data-gradient-only sweep through this layer (see NO_WEIGHT_GRAD)
         dW = dB = dWa = dci = dco = dx = dcoef_out = None
         # one pass over g: dz (activation / ReLU-mask gradient), channel-bias gradient and the rank-1
         # condition-term gradients
@@ -869,14 +880,15 @@ class ChebConvRecurrenceFn(torch.autograd.Function):
         g = as_act(g)
         dz = act_bwd(g, y, act) if act != "none" else g
         dW = dB = dx = None
-        if ctx.needs_input_grad[2] and ctx.has_bias:
+        skip_w = bool(NO_WEIGHT_GRAD) and W.data_ptr() in NO_WEIGHT_GRAD
+        if ctx.needs_input_grad[2] and ctx.has_bias and not skip_w:
             if ctx.bias_mode == _lib.BIAS_VERTEX:
                 dB = torch.empty((1, M, Fout), device=g.device, dtype=torch.float32)
                 colsum(dz, dB, per_vertex=True)
             else:
                 dB = torch.empty((1, 1, Fout), device=g.device, dtype=torch.float32)
                 colsum(dz, dB)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not skip_w:
             dW = torch.empty_like(W)
             gconv_dw([dict(x=xs[k], csr=None, w=(dW, k * Fout, K * Fout, 1)) for k in range(K)], dz)
         if ctx.needs_input_grad[0]:

@@ -129,9 +129,17 @@ class GraphedTrainStep(object):
         self._update()
 
     # ---- capture / replay --------------------------------------------------------------------------
-    def capture(self, warmup=2):
+    def capture(self, warmup=2, preserve_state=False):
+        """Capture the step into HIP graphs (after ``warmup`` eager passes that load every kernel and settle the
+        allocator).  The warm-up passes run real updates (on whatever batch the input buffers hold, with the current
+        learning-rate scalars): ``preserve_state`` snapshots variables and optimiser buffers first and restores them
+        afterwards, so that a training run's trajectory is exactly that of the un-captured step (fit())."""
         if not self.use_graph:
             return self
+        saved = None
+        if preserve_state and warmup > 0:
+            saved = {grp: {k: st[k].detach().clone() for k in ('flat', 'm', 'v') if k in st}
+                     for grp, st in self.model._opt_state.items()}
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -144,6 +152,12 @@ class GraphedTrainStep(object):
                     self._update()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        if saved is not None:
+            with torch.no_grad():
+                for grp, bufs in saved.items():
+                    for k, v in bufs.items():
+                        self.model._opt_state[grp][k].copy_(v)
+            torch.cuda.synchronize()
         self._gA = torch.cuda.CUDAGraph()
         if self.split:
             with torch.cuda.graph(self._gA):

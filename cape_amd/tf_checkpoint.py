@@ -470,8 +470,33 @@ class BundleReader(object):
             arr = (arr.astype(np.uint32) << 16).view(np.float32)
         return np.array(arr)
 
-    def read_all(self):
-        return {k: self.get_tensor(k) for k in self.keys()}
+    def readable(self, name):
+        """True if ``get_tensor(name)`` can decode the entry: a whole (unsliced) tensor of a numeric dtype.  String
+        tensors (e.g. the ``_CHECKPOINTABLE_OBJECT_GRAPH`` entry newer TF 1.x savers add) and partitioned variables
+        are not."""
+        e = self.entries.get(name)
+        return (e is not None and not e['slices'] and e['dtype'] != DT_STRING and
+                (e['dtype'] == DT_BFLOAT16 or e['dtype'] in _DTYPES))
+
+    def read_all(self, names=None, skip_unreadable=True):
+        """``{name: array}`` of the checkpoint.  ``names``: optional filter (iterable or predicate).  Entries that
+        cannot be decoded (string tensors, slices, unknown dtypes) are skipped -- a checkpoint that carries one must
+        still yield its float variables -- unless ``skip_unreadable`` is False, which raises like ``get_tensor``."""
+        if names is None:
+            want = lambda k: True
+        elif callable(names):
+            want = names
+        else:
+            wanted = set(names)
+            want = wanted.__contains__
+        out = {}
+        for k in self.keys():
+            if not want(k):
+                continue
+            if skip_unreadable and not self.readable(k):
+                continue
+            out[k] = self.get_tensor(k)
+        return out
 
 
 def write_bundle(prefix, arrays):

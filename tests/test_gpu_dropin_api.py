@@ -151,3 +151,50 @@ def test_tf_checkpoint_export_and_restore(tmp_path, mesh_ops):
     za, zb = src.encode(x, c1, c2), dst.encode(x, c1, c2)
     for u, v in zip(za, zb):
         assert np.array_equal(u, v)
+
+
+def test_fit_runs_the_graph_runner_and_matches_eager_train_steps(tmp_path, mesh_ops):
+    """fit() drives the captured HIP-graph step (ADVICE r01: the public training API must be what is benchmarked);
+    its trajectory equals eager train_step() calls on the same batches and the same eps draws."""
+    import torch
+    from cape_amd import models
+    from cape_amd.load_data import load_graph_mtx
+    L, D, U, p, L_ds2, D_ds2, U_ds2 = load_graph_mtx(None, load_for_demo=True)
+    B, n_train = 2, 4
+    rng = np.random.default_rng(5)
+    data = types.SimpleNamespace(
+        vertices_train=rng.standard_normal((n_train, 6890, 3)).astype(np.float32),
+        cond1_train=rng.standard_normal((n_train, 126)).astype(np.float32),
+        cond2_train=np.eye(4, dtype=np.float32)[rng.integers(0, 4, n_train)],
+        vertices_val=rng.standard_normal((B, 6890, 3)).astype(np.float32),
+        cond1_val=rng.standard_normal((B, 126)).astype(np.float32),
+        cond2_val=np.eye(4, dtype=np.float32)[rng.integers(0, 4, B)])
+    ad = dict(_args_dict(), batch_size=B, lr_warmup=0, name='fit_graph')
+    params = _params(ad, p, decay_steps=1000)
+    a = models.CAPE(L=L, D=D, U=U, L_d=L_ds2, D_d=D_ds2, project_dir=str(tmp_path), **params)
+    a.build_graph(6890, 3, phase='train')
+    init = {k: v.copy() for k, v in a.variables().items()}
+    np.random.seed(3)
+    torch.manual_seed(3)
+    a.fit(data)                                          # 2 steps of the captured adversarial step
+    assert a.global_step == 4
+
+    b = models.CAPE(L=L, D=D, U=U, L_d=L_ds2, D_d=D_ds2, project_dir=str(tmp_path), **dict(params, name='fit_eager'))
+    b.build_graph(6890, 3, phase='train')
+    b.load_variables(init)
+    np.random.seed(3)
+    torch.manual_seed(3)
+    idx_g, idx_d = list(np.random.permutation(n_train)), list(np.random.permutation(n_train))
+    dev = b.device
+    t = lambda arr: torch.as_tensor(np.ascontiguousarray(arr), dtype=torch.float32).to(dev)
+    for s_ in range(n_train // B):
+        ig, id_ = idx_g[s_ * B:(s_ + 1) * B], idx_d[s_ * B:(s_ + 1) * B]
+        eps = torch.zeros((B, int(b.nz)), device=dev).normal_()
+        b.train_step(t(data.vertices_train[ig]), t(data.cond1_train[ig]), t(data.cond2_train[ig]), t(data.vertices_train[ig]),
+                     t(data.vertices_train[id_]), t(data.cond1_train[id_]), t(data.cond2_train[id_]), eps=eps)
+    for grp in ('g', 'd'):
+        fa, fb = a._opt_state[grp]['flat'], b._opt_state[grp]['flat']
+        d = (fa - fb).abs().max().item()
+        assert d <= 1e-6 * max(fb.abs().max().item(), 1.0), (grp, d)
+    # and the weights did move (the comparison is not vacuous)
+    assert any(not np.array_equal(init[k], v) for k, v in b.variables().items())

@@ -123,16 +123,20 @@ def _full_model_parity(cfg, overrides, mesh_ops, N, inputs=None):
                 assert b is None or float(b.abs().max()) == 0.0, n
                 continue
             a64, b64, c64 = a.numpy(), b.cpu().numpy().astype(np.float64), c.numpy().astype(np.float64)
-            rows.append((n, rel_err(b64, a64), rel_err(c64, a64)))
+            rows.append((n, rel_err(b64, a64), rel_err(c64, a64), ((b64 - a64) ** 2).sum(), (a64 ** 2).sum(),
+                         ((c64 - a64) ** 2).sum()))
             num += ((b64 - a64) ** 2).sum()
             num32 += ((c64 - a64) ** 2).sum()
             den += (a64 ** 2).sum()
     noise = max(r[2] for r in rows)          # worst variable of the fp32 CPU evaluation (ReLU-flip noise level)
-    for n, e, e32 in rows:
-        assert e < max(1e-3, 4 * e32, 2 * noise), (n, e, e32, noise)
     gl, gl32 = np.sqrt(num / den), np.sqrt(num32 / den)
     print("gradient error: worst var %.3g (fp32 CPU worst %.3g); global L2 %.3g (fp32 CPU %.3g)"
           % (max(r[1] for r in rows), noise, gl, gl32))
+    for r in sorted(rows, key=lambda r: -r[3])[:6]:
+        print("   %-58s max-norm err %.2e (cpu32 %.2e)  L2 err/|var| %.2e (cpu32 %.2e)  share of global err^2 %.2f"
+              % (r[0], r[1], r[2], np.sqrt(r[3] / max(r[4], 1e-300)), np.sqrt(r[5] / max(r[4], 1e-300)), r[3] / max(num, 1e-300)))
+    for n, e, e32 in [r[:3] for r in rows]:
+        assert e < max(1e-3, 4 * e32, 2 * noise), (n, e, e32, noise)
     assert gl < max(1e-5, 4 * gl32), (gl, gl32)
     return model, out
 

@@ -152,6 +152,37 @@ def test_bundle_round_trip_and_state_file(tmp_path):
     assert tc.BundleReader(os.path.join(d, 'model-1400'), verify=False).get_tensor('x') != np.float32(1400)
 
 
+def test_read_all_skips_string_and_sliced_entries(tmp_path):
+    """A checkpoint that carries a non-numeric entry (newer TF 1.x savers add the DT_STRING tensor
+    ``_CHECKPOINTABLE_OBJECT_GRAPH``) must still yield its float variables: read_all() skips what get_tensor()
+    cannot decode, get_tensor() on such an entry still raises, and a names filter restricts the result."""
+    w = np.arange(12, dtype=np.float32).reshape(3, 4)
+    step = np.asarray(7, dtype=np.int64)
+    blob = b'\x0a\x04root'                                  # some serialized proto stored as ONE string element
+    str_payload = bytes([len(blob)]) + blob                   # (length varints, then the bytes; never decoded here)
+    prefix = str(tmp_path / 'model-7')
+    data = w.tobytes() + step.tobytes() + str_payload
+    open(prefix + '.data-00000-of-00001', 'wb').write(data)
+    items = [(b'', tc.encode_header(1)),
+             (b'_CHECKPOINTABLE_OBJECT_GRAPH', tc.encode_entry(tc.DT_STRING, (), 0, len(w.tobytes()) + 8, len(str_payload),
+                                                               tc.crc_mask(tc.crc32c(str_payload)))),
+             (b'generator/decoder/outputs/weights', tc.encode_entry(1, w.shape, 0, 0, w.nbytes, tc.crc_mask(tc.crc32c(w.tobytes())))),
+             (b'training/global_step', tc.encode_entry(9, (), 0, w.nbytes, 8, tc.crc_mask(tc.crc32c(step.tobytes()))))]
+    tc.write_table(prefix + '.index', items)
+    r = tc.BundleReader(prefix)
+    assert r.keys() == ['_CHECKPOINTABLE_OBJECT_GRAPH', 'generator/decoder/outputs/weights', 'training/global_step']
+    assert not r.readable('_CHECKPOINTABLE_OBJECT_GRAPH') and r.readable('training/global_step')
+    got = r.read_all()
+    assert sorted(got) == ['generator/decoder/outputs/weights', 'training/global_step']
+    assert np.array_equal(got['generator/decoder/outputs/weights'], w) and int(got['training/global_step']) == 7
+    assert sorted(r.read_all(names=lambda k: k.startswith('generator/'))) == ['generator/decoder/outputs/weights']
+    assert sorted(r.read_all(names=['training/global_step'])) == ['training/global_step']
+    with pytest.raises(tc.CheckpointError, match="string"):
+        r.get_tensor('_CHECKPOINTABLE_OBJECT_GRAPH')
+    with pytest.raises(tc.CheckpointError, match="string"):
+        r.read_all(skip_unreadable=False)
+
+
 def test_snappy_block_decoder():
     # literal "abcd", then a 1-byte-offset copy (len 8, offset 4), then a 2-byte-offset copy (len 4, offset 12)
     src = bytes([16]) + bytes([3 << 2]) + b'abcd' + bytes([((8 - 4) << 2) | 1, 4]) + bytes([((4 - 1) << 2) | 2, 12, 0])
