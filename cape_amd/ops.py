@@ -201,7 +201,7 @@ def fwd_kernel_name(fam, bm, bn, layout, dual):
     waves = "2, 2" if (bm, bn) in ((64, 128), (128, 128), (64, 64)) else "4, 1"
     tf = lambda b: "true" if b else "false"
     if fam == 2:
-        return "gemm_split_kernel<%d, %d, %s%s>" % (bm, bn, tf(layout), ", true" if dual else "")
+        return "gemm_split_kernel<%d, %d, %s, %s>" % (bm, bn, tf(layout), tf(dual))
     if fam == 1:
         return "gemm_plain_kernel<%d, %d, %s, %s, %s>" % (bm, bn, waves, tf(dual), tf(layout))
     return "gconv_fwd_kernel<%d, %d, %s, %s, 32>" % (bm, bn, waves, tf(dual))
