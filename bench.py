@@ -34,7 +34,7 @@ BF16X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 HBM_PEAK_GBS = 8000.0
 
 
-def build_model(batch, local_rank, config):
+def build_model(batch, local_rank, config, act_dtype='fp32'):
     from cape_amd.configs import cape_params
     from cape_amd.load_data import load_graph_mtx
     from cape_amd.models import CAPE
@@ -44,7 +44,7 @@ def build_model(batch, local_rank, config):
     # the warm-up (lr_warmup: 1) spans 8 * decay_steps steps -- i.e. the timed steps run at the small learning
     # rates a real run starts with (a 0.008 step on N(0,1) data diverges from the reference initialisers).
     decay_steps = 2 * (31036 - 100) / 16
-    params = cape_params(config, p=p, batch_size=batch, name='bench', decay_steps=decay_steps)
+    params = cape_params(config, p=p, batch_size=batch, name='bench', decay_steps=decay_steps, act_dtype=act_dtype)
     model = CAPE(L=L, D=D, U=U, L_d=L_d, D_d=D_d, device='cuda:%d' % local_rank, **params)
     model.build_graph(model.input_num_verts, model.nn_input_channel, phase='train')
     return model
@@ -135,14 +135,16 @@ def kernel_roofline(runner):
     table = {k: dict(launches=v[0] // reps, avg_us=1e6 * v[1] / v[0], total_us=1e6 * v[1] / reps, tflops=v[2] / v[1] / 1e12,
                      alg_gbs=v[3] / v[1] / 1e9) for k, v in agg.items()}
     split = dom.startswith(("gemm_split_kernel", "dw_split_kernel"))
-    mfma_peak = BF16X6_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+    one_product = split and "unsigned short" in dom          # bf16 storage: one bf16 MFMA product per multiply-add
+    mfma_peak = BF16_MFMA_PEAK_TFLOPS if one_product else BF16X6_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
     # the bound of THIS kernel: time at the HBM peak vs time at its matrix-pipe peak for its algorithmic work
     t_hbm, t_mfma = by / n / (HBM_PEAK_GBS * 1e9), fl / n / (mfma_peak * 1e12)
     bound = "mfma" if t_mfma >= t_hbm else "hbm"
     if bound == "mfma":
         achieved, peak, unit = fl / t / 1e12, mfma_peak, "TFLOP/s"
-        basis = ("fp32 result on the bf16 MFMA pipe, 6 bf16 products per multiply-add: dense bf16 peak 2500 / 6; "
-                 "achieved counts algorithmic fp32 flops (x6 = bf16 MFMA flops executed)") if split \
+        basis = "bf16 operands, fp32 accumulate: dense bf16 MFMA peak" if one_product else \
+            ("fp32 result on the bf16 MFMA pipe, 6 bf16 products per multiply-add: dense bf16 peak 2500 / 6; "
+             "achieved counts algorithmic fp32 flops (x6 = bf16 MFMA flops executed)") if split \
             else "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)"
     else:
         achieved, peak, unit = by / t / 1e9, HBM_PEAK_GBS, "GB/s"
@@ -157,18 +159,21 @@ def kernel_roofline(runner):
     return roof, table
 
 
-def step_roofline(ms_per_step, batch, gan):
-    """Step-level fraction: t_roof = max(alg. bytes / HBM peak, alg. flops / fp32-MFMA peak) of the
-    reference formulation of the step, over the measured step time."""
+def step_roofline(ms_per_step, batch, gan, bf16=False):
+    """Step-level fraction: t_roof = max(alg. bytes / HBM peak, alg. flops / matrix-pipe peak of the dtype)
+    of the reference formulation of the step, over the measured step time.  bf16 storage (SURVEY 8d cfg 5): half the
+    bytes, dense bf16 MFMA peak -> HBM-bound."""
     gf = STEP_ALG_GFLOP_PER_MESH + (2 * DPASS_ALG_GFLOP_PER_MESH if gan else 0.0)
-    mb = STEP_ALG_MB_PER_MESH + (2 * DPASS_ALG_MB_PER_MESH if gan else 0.0)
-    t_mfma = batch * gf * 1e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3
+    mb = (STEP_ALG_MB_PER_MESH + (2 * DPASS_ALG_MB_PER_MESH if gan else 0.0)) * (0.5 if bf16 else 1.0)
+    t_mfma = batch * gf * 1e9 / ((BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS) * 1e12) * 1e3
     t_hbm = batch * mb * 1e6 / (HBM_PEAK_GBS * 1e9) * 1e3
     t_roof = max(t_mfma, t_hbm)
-    return dict(t_roof_ms=round(t_roof, 4), t_mfma_fp32_ms=round(t_mfma, 4), t_hbm_ms=round(t_hbm, 4),
+    return dict(t_roof_ms=round(t_roof, 4), t_mfma_ms=round(t_mfma, 4), t_hbm_ms=round(t_hbm, 4),
+                bound="hbm" if t_hbm >= t_mfma else "mfma",
                 frac=round(t_roof / ms_per_step, 4), frac_hbm=round(t_hbm / ms_per_step, 4),
-                basis="SURVEY 8(d) reference-formulation work per mesh: %.2f GFLOP, %.1f MB fwd+bwd; fp32-MFMA peak %.1f TF, "
-                      "HBM %.0f GB/s" % (gf, mb, FP32_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS))
+                basis="SURVEY 8(d) reference-formulation work per mesh: %.2f GFLOP, %.1f MB fwd+bwd; %s MFMA peak %.1f TF, "
+                      "HBM %.0f GB/s" % (gf, mb, "bf16" if bf16 else "fp32", BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS,
+                                         HBM_PEAK_GBS))
 
 
 def cpu_baseline(batch=16, iters=5, budget_s=150.0):
@@ -238,6 +243,9 @@ def main():
                     help='strong scaling (SURVEY 8e: 16 -> 16/8/4/2 per GPU): the GLOBAL batch is fixed and sharded over the '
                          'ranks (per-GPU batch = global / world); default 0 = weak scaling with --batch per GPU')
     ap.add_argument('--config', default='CAPE-affineconv_nz64_pose32_clotype32_male')
+    ap.add_argument('--dtype', choices=('fp32', 'bf16'), default='fp32',
+                    help="storage type of the mesh activations: fp32 (the headline, parity path) or bf16 (BASELINE configs[4]: "
+                         "bf16 activations / bf16 operands with fp32 accumulation and fp32 master weights)")
     ap.add_argument('--gan', action='store_true', help='include the discriminator passes/update (adversarial step)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -263,7 +271,7 @@ def main():
         if args.global_batch % world:
             raise SystemExit("--global-batch %d is not divisible by the %d ranks" % (args.global_batch, world))
         args.batch = args.global_batch // world
-    model = build_model(args.batch, local, args.config)
+    model = build_model(args.batch, local, args.config, act_dtype=args.dtype)
     hook = None
     if world > 1:
         for grp in ('g', 'd'):
@@ -310,20 +318,23 @@ def main():
         "metric": "meshes/sec fwd+bwd, CAPE-affineconv nz64 @ batch 16, 1/2/4/8 MI355X",
         "value": round(args.batch * world * args.steps / elapsed, 2), "unit": "meshes/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
-        "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == 'fp32' else "bf16", "data": "synthetic",
         "config": {"workload": "%s Mesh-CVAE%s: fwd+bwd+clip+momentum update, batch %d per GPU, "
                                "6890-vertex SMPL hierarchy%s"
                                % (args.config.replace("_pose32_clotype32_male", ""), " + mesh-patch discriminator (adversarial step)" if args.gan else "",
                                   args.batch, " (BASELINE configs[2])" if args.config.startswith("CAPE-affineconv_nz64") else ""),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "graph_replay": runner._gA is not None,
                    "inputs": "host numpy per step (PCIe-inclusive)" if args.host_inputs else "resident in HBM",
-                   "arithmetic": "fp32 in/out/accumulate; eligible contractions (forward incl. the affine DUAL form, data "
+                   "arithmetic": "bf16 activation storage (BASELINE configs[4] per-GPU shard): bf16 operands, one bf16 MFMA product "
+                                 "per multiply-add, fp32 accumulate, fp32 master weights / dense layers / losses / optimiser"
+                   if args.dtype == 'bf16' else
+                                 "fp32 in/out/accumulate; eligible contractions (forward incl. the affine DUAL form, data "
                                  "gradient, weight gradient) as 6 bf16 MFMA products per multiply-add on an exact 3-way "
                                  "bf16 split of each fp32 operand (fp32 accuracy, not bit-identical to an fp32 FMA chain; "
                                  "inf operands give NaN), exact-fp32 MFMA for odd-channel / packed launches",
                    "final_loss_g": loss},
         "roofline": roof,
-        "step_roofline": step_roofline(ms, args.batch, args.gan) if args.config.startswith("CAPE-affineconv_nz64") else None,
+        "step_roofline": step_roofline(ms, args.batch, args.gan, args.dtype == 'bf16') if args.config.startswith("CAPE-affineconv_nz64") else None,
     }
     if table:
         result["kernels"] = {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in table.items()}
@@ -331,7 +342,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(batch=args.batch)
     else:
         result["cpu_baseline"] = None
-    if world == 1 and not args.no_ab and not args.host_inputs and os.environ.get("CAPE_GEMM_BF16X6", "1") != "0":
+    if world == 1 and not args.no_ab and not args.host_inputs and args.dtype == 'fp32' and os.environ.get("CAPE_GEMM_BF16X6", "1") != "0":
         result["exact_fp32_mfma"] = exact_fp32_run(args)
     print(json.dumps(result))
 

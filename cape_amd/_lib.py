@@ -70,6 +70,12 @@ SIGNATURES = {
     "cape_gconv_dw": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _p, C.c_uint32, _i32, _i32, _i32, _i32, _p, _i64, _p]),
     "cape_gconv_dw_stage": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _p, C.c_uint32, _i32, _i32, _i32, _i32, _p, _i64, _i32, _p]),
     "cape_gconv_dw_plan": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _p, C.c_uint32, _i32, _i32, _i32, C.POINTER(_i32)]),
+    "cape_gconv_fwd_bf16": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p, _i32, _i32, _p,
+                                      C.POINTER(CapeRank), _i32, _p]),
+    "cape_gconv_fwd_plan_bf16": (C.c_int, [_SRCP, _i32, _i32, _i32, _i32, C.POINTER(_i32)]),
+    "cape_gconv_dw_bf16": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _p, C.c_uint32, _i32, _i32, _i32, _i32, _p, _i64, _p]),
+    "cape_gconv_dw_stage_bf16": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _p, C.c_uint32, _i32, _i32, _i32, _i32, _p, _i64, _i32, _p]),
+    "cape_gconv_dw_plan_bf16": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _p, C.c_uint32, _i32, _i32, _i32, C.POINTER(_i32)]),
     "cape_bwd_prep_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "cape_bwd_prep": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p, _i32, _p,
                                 _i64, _i32, _i32, _i32, _i32, _p, _i64, _p]),
@@ -109,6 +115,11 @@ SIGNATURES = {
     "cape_recon_edge_loss_fwd_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _f32,
                                                _p, _p, _p, _p, _i64, _p]),
 }
+
+# bf16-storage variants with the argument list of their fp32 namesake (include/cape_hip.h, last section)
+for _name in ("cape_bwd_prep", "cape_spmm", "cape_spmm_multi", "cape_spmm_combine"):
+    SIGNATURES[_name + "_bf16"] = SIGNATURES[_name]
+SIGNATURES["cape_colsum_vertex_bf16"] = (C.c_int, [_p, _i64, _i32, _i32, _i32, _i32, _i32, _p, _p])
 
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)

@@ -50,4 +50,6 @@ def cape_params(config='CAPE-affineconv_nz64_pose32_clotype32_male', p=None, bat
         lambda_recon=a['lambda_recon'], lambda_edge=a['lambda_edge'], lambda_latent=a['lambda_latent'],
         lambda_gan=a['lambda_gan'], decay_steps=decay_steps, name=name or config,
     )
+    if 'act_dtype' in overrides:          # extension: storage type of the mesh activations ('fp32' | 'bf16')
+        params['act_dtype'] = overrides['act_dtype']
     return params

@@ -7,6 +7,45 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- activation storage types -------------------------------------------------------------------------------
+// Activations [N, M, ld] are stored as fp32 (the parity path) or as bf16 (BASELINE configs[4]: bf16 storage, fp32
+// accumulate; the "_bf16" entry points of cape_hip.h).  Kernels that exist for both are templates over the element
+// type AT in {float, cape_bf16}; every load widens to fp32, every store rounds to nearest even (v_cvt_pk_bf16_f32).
+typedef unsigned short cape_bf16;
+typedef __bf16 cape_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float cape_f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned cape_pack_bf16(float a, float b) {      // a -> low half, b -> high half
+    const cape_f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, cape_bf16x2_t));
+}
+__device__ __forceinline__ float cape_ld(const float *p) { return *p; }
+__device__ __forceinline__ float cape_ld(const cape_bf16 *p) { return __builtin_bit_cast(float, (unsigned)(*p) << 16); }
+__device__ __forceinline__ void cape_st(float *p, float v) { *p = v; }
+__device__ __forceinline__ void cape_st(cape_bf16 *p, float v) { *p = (cape_bf16)(cape_pack_bf16(v, 0.f) & 0xFFFFu); }
+__device__ __forceinline__ float4 cape_ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 cape_ld4(const cape_bf16 *p) {           // 8-byte aligned
+    const uint2 u = *reinterpret_cast<const uint2 *>(p);
+    float4 r;
+    r.x = __builtin_bit_cast(float, u.x << 16); r.y = __builtin_bit_cast(float, u.x & 0xFFFF0000u);
+    r.z = __builtin_bit_cast(float, u.y << 16); r.w = __builtin_bit_cast(float, u.y & 0xFFFF0000u);
+    return r;
+}
+__device__ __forceinline__ void cape_st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ void cape_st4(cape_bf16 *p, float4 v) {
+    uint2 u;
+    u.x = cape_pack_bf16(v.x, v.y); u.y = cape_pack_bf16(v.z, v.w);
+    *reinterpret_cast<uint2 *>(p) = u;
+}
+// two consecutive elements (4-byte aligned for bf16, 8-byte for fp32)
+__device__ __forceinline__ float2 cape_ld2(const float *p) { return *reinterpret_cast<const float2 *>(p); }
+__device__ __forceinline__ float2 cape_ld2(const cape_bf16 *p) {
+    const unsigned u = *reinterpret_cast<const unsigned *>(p);
+    return make_float2(__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xFFFF0000u));
+}
+template <typename AT> struct cape_is_bf16 { static constexpr bool value = false; };
+template <> struct cape_is_bf16<cape_bf16> { static constexpr bool value = true; };
+
 // hipGetLastError() is sticky per thread: clear whatever another runtime user (e.g. torch's device
 // probing) left behind before launching, so that CAPE_LAUNCH_CHECK reports OUR launch only.
 #define CAPE_LAUNCH(...)            \
@@ -54,4 +93,17 @@ __device__ __forceinline__ void cape_map_block(int b, int N, int T, int &n, int 
         n = b / T;
         t = b % T;
     }
+}
+
+// Weight-gradient launches: block -> (output tile, contraction split).  All tiles of one split read the same rows of
+// the sources and of dz; with blocks dispatched round robin over the 8 XCDs (block b -> XCD b % 8) the natural order
+// (tile fastest) spreads those re-reads over all eight L2s -- measured 173 MB of L2-miss traffic per launch against
+// 58 MB algorithmic on the widest layer.  Here XCD x runs ALL tiles of split 8*g + x, so the re-reads of a row range
+// hit one L2.  The grid is rounded up to whole groups of 8 splits; blocks of a split beyond nsplit exit at once.
+__device__ __forceinline__ bool cape_map_dw_block(int b, int ntiles, int nsplit, int &tile, int &split) {
+    const int per = ntiles << 3;
+    const int g = b / per, loc = b - g * per;
+    split = (g << 3) + (loc & 7);
+    tile = loc >> 3;
+    return split < nsplit;
 }

@@ -6,25 +6,28 @@
 
 namespace {
 
-struct View {
-    float *p;
+template <typename T> struct ViewT {
+    T *p;
     long long ss;
     int ld;
 };
-struct CView {
-    const float *p;
+template <typename T> struct CViewT {
+    const T *p;
     long long ss;
     int ld;
 };
+typedef ViewT<float> View;
+typedef CViewT<float> CView;
 
-__host__ __device__ inline bool aligned4(const void *p, long long ss, int ld, int C) {
-    return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && ((ss & 3) == 0) && ((ld & 3) == 0) && ((C & 3) == 0);
+// four consecutive elements addressable as one vector access (16 bytes of fp32, 8 bytes of bf16)
+__host__ __device__ inline bool aligned4(const void *p, long long ss, int ld, int C, int es = 4) {
+    return ((reinterpret_cast<uintptr_t>(p) & (4 * es - 1)) == 0) && ((ss & 3) == 0) && ((ld & 3) == 0) && ((C & 3) == 0);
 }
 
 // ---- spmm: y[n,r,:] = alpha * S x[n] + beta * z[n,r,:] ------------------------------------
-template <bool VEC>
-__global__ __launch_bounds__(256) void spmm_kernel(CView x, const int *rp, const int *ci, const float *va,
-                                                   float alpha, CView z, float beta, View y, int N, int Mo, int C) {
+template <bool VEC, typename T = float>
+__global__ __launch_bounds__(256) void spmm_kernel(CViewT<T> x, const int *rp, const int *ci, const float *va,
+                                                   float alpha, CViewT<T> z, float beta, ViewT<T> y, int N, int Mo, int C) {
     const int W = VEC ? 4 : 1;
     const int cq = (C + W - 1) / W;
     const long long total = (long long)N * Mo * cq;
@@ -34,30 +37,30 @@ __global__ __launch_bounds__(256) void spmm_kernel(CView x, const int *rp, const
         const int r = (int)(nr % Mo);
         const int n = (int)(nr / Mo);
         const int c = q * W;
-        const float *xb = x.p + (long long)n * x.ss + c;
+        const T *xb = x.p + (long long)n * x.ss + c;
         if (VEC) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             const int e1 = rp[r + 1];
             for (int e = rp[r]; e < e1; ++e) {
                 const float v = va[e];
-                const float4 xv = *reinterpret_cast<const float4 *>(xb + (long long)ci[e] * x.ld);
+                const float4 xv = cape_ld4(xb + (long long)ci[e] * x.ld);
                 acc.x = fmaf(v, xv.x, acc.x); acc.y = fmaf(v, xv.y, acc.y);
                 acc.z = fmaf(v, xv.z, acc.z); acc.w = fmaf(v, xv.w, acc.w);
             }
             acc.x *= alpha; acc.y *= alpha; acc.z *= alpha; acc.w *= alpha;
             if (z.p) {
-                const float4 zv = *reinterpret_cast<const float4 *>(z.p + (long long)n * z.ss + (long long)r * z.ld + c);
+                const float4 zv = cape_ld4(z.p + (long long)n * z.ss + (long long)r * z.ld + c);
                 acc.x = fmaf(beta, zv.x, acc.x); acc.y = fmaf(beta, zv.y, acc.y);
                 acc.z = fmaf(beta, zv.z, acc.z); acc.w = fmaf(beta, zv.w, acc.w);
             }
-            *reinterpret_cast<float4 *>(y.p + (long long)n * y.ss + (long long)r * y.ld + c) = acc;
+            cape_st4(y.p + (long long)n * y.ss + (long long)r * y.ld + c, acc);
         } else {
             float acc = 0.f;
             const int e1 = rp[r + 1];
-            for (int e = rp[r]; e < e1; ++e) acc = fmaf(va[e], xb[(long long)ci[e] * x.ld], acc);
+            for (int e = rp[r]; e < e1; ++e) acc = fmaf(va[e], cape_ld(xb + (long long)ci[e] * x.ld), acc);
             acc *= alpha;
-            if (z.p) acc = fmaf(beta, z.p[(long long)n * z.ss + (long long)r * z.ld + c], acc);
-            y.p[(long long)n * y.ss + (long long)r * y.ld + c] = acc;
+            if (z.p) acc = fmaf(beta, cape_ld(z.p + (long long)n * z.ss + (long long)r * z.ld + c), acc);
+            cape_st(y.p + (long long)n * y.ss + (long long)r * y.ld + c, acc);
         }
     }
 }
@@ -69,16 +72,16 @@ __global__ __launch_bounds__(256) void spmm_kernel(CView x, const int *rp, const
 // terms' gathers of one neighbourhood hit the same L1/L2 lines.
 struct SpmmTerms {
     struct T {
-        const float *x; long long xs; int ldx;
+        const void *x; long long xs; int ldx;       // elements of the launch's storage type
         const int *rp; const int *ci; const float *va;
-        float *y; long long ys; int ldy;
+        void *y; long long ys; int ldy;
         float scale;
     } t[CAPE_MAX_SPMM_TERMS];
     int n;
 };
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void spmm_multi_kernel(SpmmTerms P, int sum, View y, int N, int Mo, int C) {
+template <bool VEC, typename T = float>
+__global__ __launch_bounds__(256) void spmm_multi_kernel(SpmmTerms P, int sum, ViewT<T> y, int N, int Mo, int C) {
     const int W = VEC ? 4 : 1;
     const int cq = (C + W - 1) / W;
     const long long total = (long long)N * Mo * cq;
@@ -90,37 +93,37 @@ __global__ __launch_bounds__(256) void spmm_multi_kernel(SpmmTerms P, int sum, V
         const int c = q * W;
         float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int k = 0; k < P.n; ++k) {
-            const SpmmTerms::T &T = P.t[k];
-            const float *xb = T.x + (long long)n * T.xs + c;
+            const SpmmTerms::T &Tm = P.t[k];
+            const T *xb = reinterpret_cast<const T *>(Tm.x) + (long long)n * Tm.xs + c;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!T.rp) {
-                if (VEC) acc = *reinterpret_cast<const float4 *>(xb + (long long)r * T.ldx);
-                else acc.x = xb[(long long)r * T.ldx];
+            if (!Tm.rp) {
+                if (VEC) acc = cape_ld4(xb + (long long)r * Tm.ldx);
+                else acc.x = cape_ld(xb + (long long)r * Tm.ldx);
             } else {
-                const int e1 = T.rp[r + 1];
-                for (int e = T.rp[r]; e < e1; ++e) {
-                    const float v = T.va[e];
+                const int e1 = Tm.rp[r + 1];
+                for (int e = Tm.rp[r]; e < e1; ++e) {
+                    const float v = Tm.va[e];
                     if (VEC) {
-                        const float4 xv = *reinterpret_cast<const float4 *>(xb + (long long)T.ci[e] * T.ldx);
+                        const float4 xv = cape_ld4(xb + (long long)Tm.ci[e] * Tm.ldx);
                         acc.x = fmaf(v, xv.x, acc.x); acc.y = fmaf(v, xv.y, acc.y);
                         acc.z = fmaf(v, xv.z, acc.z); acc.w = fmaf(v, xv.w, acc.w);
                     } else {
-                        acc.x = fmaf(v, xb[(long long)T.ci[e] * T.ldx], acc.x);
+                        acc.x = fmaf(v, cape_ld(xb + (long long)Tm.ci[e] * Tm.ldx), acc.x);
                     }
                 }
             }
-            acc.x *= T.scale; acc.y *= T.scale; acc.z *= T.scale; acc.w *= T.scale;
+            acc.x *= Tm.scale; acc.y *= Tm.scale; acc.z *= Tm.scale; acc.w *= Tm.scale;
             if (sum) {
                 tot.x += acc.x; tot.y += acc.y; tot.z += acc.z; tot.w += acc.w;
             } else if (VEC) {
-                *reinterpret_cast<float4 *>(T.y + (long long)n * T.ys + (long long)r * T.ldy + c) = acc;
+                cape_st4(reinterpret_cast<T *>(Tm.y) + (long long)n * Tm.ys + (long long)r * Tm.ldy + c, acc);
             } else {
-                T.y[(long long)n * T.ys + (long long)r * T.ldy + c] = acc.x;
+                cape_st(reinterpret_cast<T *>(Tm.y) + (long long)n * Tm.ys + (long long)r * Tm.ldy + c, acc.x);
             }
         }
         if (sum) {
-            if (VEC) *reinterpret_cast<float4 *>(y.p + (long long)n * y.ss + (long long)r * y.ld + c) = tot;
-            else y.p[(long long)n * y.ss + (long long)r * y.ld + c] = tot.x;
+            if (VEC) cape_st4(y.p + (long long)n * y.ss + (long long)r * y.ld + c, tot);
+            else cape_st(y.p + (long long)n * y.ss + (long long)r * y.ld + c, tot.x);
         }
     }
 }
@@ -143,8 +146,8 @@ struct CombineParams {
     int mask_words;
 };
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void spmm_combine_kernel(CombineParams Q, View y, int N, int Mo, int F) {
+template <bool VEC, typename T = float>
+__global__ __launch_bounds__(256) void spmm_combine_kernel(CombineParams Q, ViewT<T> y, int N, int Mo, int F) {
     const int W = VEC ? 4 : 1;
     const int cq = (F + W - 1) / W;
     const long long total = (long long)N * Mo * cq;
@@ -159,28 +162,28 @@ __global__ __launch_bounds__(256) void spmm_combine_kernel(CombineParams Q, View
         const int c = q * W;
         float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < Q.P.n; ++k) {
-            const SpmmTerms::T &T = Q.P.t[k];
-            const float *xb = T.x + (long long)n * T.xs + c;
+            const SpmmTerms::T &Tm = Q.P.t[k];
+            const T *xb = reinterpret_cast<const T *>(Tm.x) + (long long)n * Tm.xs + c;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!T.rp) {
-                if (VEC) acc = *reinterpret_cast<const float4 *>(xb + (long long)r * T.ldx);
-                else acc.x = xb[(long long)r * T.ldx];
+            if (!Tm.rp) {
+                if (VEC) acc = cape_ld4(xb + (long long)r * Tm.ldx);
+                else acc.x = cape_ld(xb + (long long)r * Tm.ldx);
             } else {
-                const int e1 = T.rp[r + 1];
-                for (int e = T.rp[r]; e < e1; ++e) {
-                    const float v = T.va[e];
+                const int e1 = Tm.rp[r + 1];
+                for (int e = Tm.rp[r]; e < e1; ++e) {
+                    const float v = Tm.va[e];
                     if (VEC) {
-                        const float4 xv = *reinterpret_cast<const float4 *>(xb + (long long)T.ci[e] * T.ldx);
+                        const float4 xv = cape_ld4(xb + (long long)Tm.ci[e] * Tm.ldx);
                         acc.x = fmaf(v, xv.x, acc.x); acc.y = fmaf(v, xv.y, acc.y);
                         acc.z = fmaf(v, xv.z, acc.z); acc.w = fmaf(v, xv.w, acc.w);
                     } else {
-                        acc.x = fmaf(v, xb[(long long)T.ci[e] * T.ldx], acc.x);
+                        acc.x = fmaf(v, cape_ld(xb + (long long)Tm.ci[e] * Tm.ldx), acc.x);
                     }
                 }
             }
             float *dst = ((Q.to2 >> k) & 1u) ? a2 : a1;
-            dst[0] = fmaf(T.scale, acc.x, dst[0]); dst[1] = fmaf(T.scale, acc.y, dst[1]);
-            dst[2] = fmaf(T.scale, acc.z, dst[2]); dst[3] = fmaf(T.scale, acc.w, dst[3]);
+            dst[0] = fmaf(Tm.scale, acc.x, dst[0]); dst[1] = fmaf(Tm.scale, acc.y, dst[1]);
+            dst[2] = fmaf(Tm.scale, acc.z, dst[2]); dst[3] = fmaf(Tm.scale, acc.w, dst[3]);
         }
         for (int j = 0; j < Q.rankR; ++j) {
             const float rs = Q.rowscale[(long long)j * Mo + r];
@@ -213,8 +216,8 @@ __global__ __launch_bounds__(256) void spmm_combine_kernel(CombineParams Q, View
             if (live && (q & 7) == 0) Q.mask[((long long)n * Mo + r) * Q.mask_words + (q >> 3)] = w;
         }
         if (live) {
-            if (VEC) *reinterpret_cast<float4 *>(y.p + (long long)n * y.ss + (long long)r * y.ld + c) = make_float4(o[0], o[1], o[2], o[3]);
-            else y.p[(long long)n * y.ss + (long long)r * y.ld + c] = o[0];
+            if (VEC) cape_st4(y.p + (long long)n * y.ss + (long long)r * y.ld + c, make_float4(o[0], o[1], o[2], o[3]));
+            else cape_st(y.p + (long long)n * y.ss + (long long)r * y.ld + c, o[0]);
         }
     }
 }
@@ -391,13 +394,14 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float *part, in
     }
 }
 
-__global__ __launch_bounds__(256) void sum_over_samples_kernel(CView x, int N, int M, int C, int accumulate, float *out) {
+template <typename T = float>
+__global__ __launch_bounds__(256) void sum_over_samples_kernel(CViewT<T> x, int N, int M, int C, int accumulate, float *out) {
     const long long total = (long long)M * C;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % C);
         const long long m = i / C;
         float s = 0.f;
-        for (int n = 0; n < N; ++n) s += x.p[(long long)n * x.ss + m * x.ld + c];
+        for (int n = 0; n < N; ++n) s += cape_ld(x.p + (long long)n * x.ss + m * x.ld + c);
         out[i] = accumulate ? out[i] + s : s;
     }
 }
@@ -543,7 +547,8 @@ inline int bp_rows(int N, int Mo) {
 }
 constexpr int BP_MAXT = RSR_MAXR + 2;       // reduction terms: [0]=sum dz, [1..R]=rowscale_j*dz, [R+1]=rowscale_rg*g
 
-__global__ __launch_bounds__(256) void bwd_prep_kernel(CView g, CView y, int act, const unsigned *mask, View dz,
+template <typename AT = float>
+__global__ __launch_bounds__(256) void bwd_prep_kernel(CViewT<AT> g, CViewT<AT> y, int act, const unsigned *mask, ViewT<AT> dz,
                                                        const float *rowscale, int R, int rg, int want_bias, int want_g,
                                                        int N, int Mo, int F, float *part, int chunks, int RB) {
     __shared__ float red[BP_MAXT][256];
@@ -559,12 +564,12 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(CView g, CView y, int act
         for (int j = 0; j < BP_MAXT; ++j) acc[j] = 0.f;
         if (f < F)
             for (int r = ra + rl; r < rb; r += 4) {
-                const float gv = g.p[(long long)n * g.ss + (long long)r * g.ld + f];
+                const float gv = cape_ld(g.p + (long long)n * g.ss + (long long)r * g.ld + f);
                 float d;
                 if (mask) d = ((mask[((long long)n * Mo + r) * words + (f >> 5)] >> (f & 31)) & 1u) ? gv : 0.f;
-                else if (act != CAPE_ACT_NONE) d = gv * cape_act_grad_from_out(y.p[(long long)n * y.ss + (long long)r * y.ld + f], act);
+                else if (act != CAPE_ACT_NONE) d = gv * cape_act_grad_from_out(cape_ld(y.p + (long long)n * y.ss + (long long)r * y.ld + f), act);
                 else d = gv;
-                dz.p[(long long)n * dz.ss + (long long)r * dz.ld + f] = d;
+                cape_st(dz.p + (long long)n * dz.ss + (long long)r * dz.ld + f, d);
                 acc[0] += d;
 #pragma unroll
                 for (int j = 0; j < RSR_MAXR; ++j)
@@ -588,7 +593,8 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(CView g, CView y, int act
 }
 
 // float4 variant (F % 4 == 0, 16-byte aligned views, F <= 1024): thread = (float4 column, row lane)
-__global__ __launch_bounds__(256) void bwd_prep_vec_kernel(CView g, CView y, int act, const unsigned *mask, View dz,
+template <typename AT = float>
+__global__ __launch_bounds__(256) void bwd_prep_vec_kernel(CViewT<AT> g, CViewT<AT> y, int act, const unsigned *mask, ViewT<AT> dz,
                                                            const float *rowscale, int R, int rg, int want_bias, int want_g,
                                                            int N, int Mo, int F, float *part, int chunks, int RB) {
     __shared__ float4 red[256];
@@ -608,17 +614,17 @@ __global__ __launch_bounds__(256) void bwd_prep_vec_kernel(CView g, CView y, int
         for (int j = 0; j < BP_MAXT; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (rl < lanes)
             for (int r = ra + rl; r < rb; r += lanes) {
-                const float4 gv = *reinterpret_cast<const float4 *>(g.p + (long long)n * g.ss + (long long)r * g.ld + f);
+                const float4 gv = cape_ld4(g.p + (long long)n * g.ss + (long long)r * g.ld + f);
                 float4 d = gv;
                 if (mask) {
                     const unsigned w = mask[((long long)n * Mo + r) * words + (f >> 5)] >> (f & 31);
                     d.x = (w & 1u) ? gv.x : 0.f; d.y = (w & 2u) ? gv.y : 0.f; d.z = (w & 4u) ? gv.z : 0.f; d.w = (w & 8u) ? gv.w : 0.f;
                 } else if (act != CAPE_ACT_NONE) {
-                    const float4 o = *reinterpret_cast<const float4 *>(y.p + (long long)n * y.ss + (long long)r * y.ld + f);
+                    const float4 o = cape_ld4(y.p + (long long)n * y.ss + (long long)r * y.ld + f);
                     d.x = gv.x * cape_act_grad_from_out(o.x, act); d.y = gv.y * cape_act_grad_from_out(o.y, act);
                     d.z = gv.z * cape_act_grad_from_out(o.z, act); d.w = gv.w * cape_act_grad_from_out(o.w, act);
                 }
-                *reinterpret_cast<float4 *>(dz.p + (long long)n * dz.ss + (long long)r * dz.ld + f) = d;
+                cape_st4(dz.p + (long long)n * dz.ss + (long long)r * dz.ld + f, d);
                 acc[0].x += d.x; acc[0].y += d.y; acc[0].z += d.z; acc[0].w += d.w;
 #pragma unroll
                 for (int j = 0; j < RSR_MAXR; ++j)
@@ -739,41 +745,69 @@ inline int grid_for(long long total) {
 
 }  // namespace
 
-extern "C" int cape_spmm(const float *x, int64_t x_sample_stride, int32_t ldx, const int32_t *rowptr,
-                         const int32_t *colidx, const float *vals, int32_t max_row_nnz, float alpha, const float *z,
-                         int64_t z_sample_stride, int32_t ldz, float beta, float *y, int64_t y_sample_stride,
-                         int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
+namespace {
+template <typename T>
+int spmm_impl(const T *x, int64_t x_sample_stride, int32_t ldx, const int32_t *rowptr,
+              const int32_t *colidx, const float *vals, int32_t max_row_nnz, float alpha, const T *z,
+              int64_t z_sample_stride, int32_t ldz, float beta, T *y, int64_t y_sample_stride,
+              int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
     if (!x || !rowptr || !colidx || !vals || !y || N < 1 || Mo < 1 || C < 1 || ldx < C || ldy < C) return CAPE_EINVAL;
     if (z && ldz < C) return CAPE_EINVAL;
-    CView xv{x, x_sample_stride, ldx}, zv{z, z_sample_stride, ldz};
-    View yv{y, y_sample_stride, ldy};
-    const bool vec = aligned4(x, x_sample_stride, ldx, C) && aligned4(y, y_sample_stride, ldy, C) &&
-                     (!z || aligned4(z, z_sample_stride, ldz, C));
+    constexpr int es = (int)sizeof(T);
+    CViewT<T> xv{x, x_sample_stride, ldx}, zv{z, z_sample_stride, ldz};
+    ViewT<T> yv{y, y_sample_stride, ldy};
+    const bool vec = aligned4(x, x_sample_stride, ldx, C, es) && aligned4(y, y_sample_stride, ldy, C, es) &&
+                     (!z || aligned4(z, z_sample_stride, ldz, C, es));
     hipStream_t st = (hipStream_t)stream;
-    if (vec && max_row_nnz >= 1 && max_row_nnz <= 16) {
+    if constexpr (es == 4) {
+        if (vec && max_row_nnz >= 1 && max_row_nnz <= 16) {
+            const long long total = (long long)N * Mo * (C / 4);
+            const dim3 g(grid_for(total)), b(256);
+            if (max_row_nnz <= 4) CAPE_LAUNCH(spmm_bounded_kernel<4>, g, b, 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
+            else if (max_row_nnz <= 8) CAPE_LAUNCH(spmm_bounded_kernel<8>, g, b, 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
+            else CAPE_LAUNCH(spmm_bounded_kernel<16>, g, b, 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
+            CAPE_LAUNCH_CHECK();
+            return CAPE_OK;
+        }
+    }
+    if (vec) {
         const long long total = (long long)N * Mo * (C / 4);
-        const dim3 g(grid_for(total)), b(256);
-        if (max_row_nnz <= 4) CAPE_LAUNCH(spmm_bounded_kernel<4>, g, b, 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
-        else if (max_row_nnz <= 8) CAPE_LAUNCH(spmm_bounded_kernel<8>, g, b, 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
-        else CAPE_LAUNCH(spmm_bounded_kernel<16>, g, b, 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
-    } else if (vec) {
-        const long long total = (long long)N * Mo * (C / 4);
-        CAPE_LAUNCH(spmm_kernel<true>, dim3(grid_for(total)), dim3(256), 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
+        CAPE_LAUNCH((spmm_kernel<true, T>), dim3(grid_for(total)), dim3(256), 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
     } else {
         const long long total = (long long)N * Mo * C;
-        CAPE_LAUNCH(spmm_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
+        CAPE_LAUNCH((spmm_kernel<false, T>), dim3(grid_for(total)), dim3(256), 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
     }
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }
+}  // namespace
 
-extern "C" int cape_spmm_multi(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, float *y, int64_t y_sample_stride,
-                               int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
+extern "C" int cape_spmm(const float *x, int64_t x_sample_stride, int32_t ldx, const int32_t *rowptr,
+                         const int32_t *colidx, const float *vals, int32_t max_row_nnz, float alpha, const float *z,
+                         int64_t z_sample_stride, int32_t ldz, float beta, float *y, int64_t y_sample_stride,
+                         int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
+    return spmm_impl<float>(x, x_sample_stride, ldx, rowptr, colidx, vals, max_row_nnz, alpha, z, z_sample_stride, ldz, beta, y,
+                            y_sample_stride, ldy, N, Mo, C, stream);
+}
+
+extern "C" int cape_spmm_bf16(const void *x, int64_t x_sample_stride, int32_t ldx, const int32_t *rowptr,
+                              const int32_t *colidx, const float *vals, int32_t max_row_nnz, float alpha, const void *z,
+                              int64_t z_sample_stride, int32_t ldz, float beta, void *y, int64_t y_sample_stride,
+                              int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
+    return spmm_impl<cape_bf16>((const cape_bf16 *)x, x_sample_stride, ldx, rowptr, colidx, vals, max_row_nnz, alpha,
+                                (const cape_bf16 *)z, z_sample_stride, ldz, beta, (cape_bf16 *)y, y_sample_stride, ldy, N, Mo, C, stream);
+}
+
+namespace {
+template <typename T>
+int spmm_multi_impl(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, T *y, int64_t y_sample_stride,
+                    int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
     if (!terms || nterms < 1 || nterms > CAPE_MAX_SPMM_TERMS || N < 1 || Mo < 1 || C < 1) return CAPE_EINVAL;
     if (sum && (!y || ldy < C)) return CAPE_EINVAL;
+    constexpr int es = (int)sizeof(T);
     SpmmTerms P;
     P.n = nterms;
-    bool vec = !sum || aligned4(y, y_sample_stride, ldy, C);
+    bool vec = !sum || aligned4(y, y_sample_stride, ldy, C, es);
     for (int k = 0; k < nterms; ++k) {
         const cape_spmm_term_t &t = terms[k];
         if (!t.x || t.ldx < C) return CAPE_EINVAL;
@@ -783,19 +817,33 @@ extern "C" int cape_spmm_multi(const cape_spmm_term_t *terms, int32_t nterms, in
         P.t[k].rp = t.rowptr; P.t[k].ci = t.colidx; P.t[k].va = t.vals;
         P.t[k].y = t.y; P.t[k].ys = t.y_sample_stride; P.t[k].ldy = t.ldy;
         P.t[k].scale = t.scale;
-        vec = vec && aligned4(t.x, t.x_sample_stride, t.ldx, C) && (sum || aligned4(t.y, t.y_sample_stride, t.ldy, C));
+        vec = vec && aligned4(t.x, t.x_sample_stride, t.ldx, C, es) && (sum || aligned4(t.y, t.y_sample_stride, t.ldy, C, es));
     }
-    View yv{y, y_sample_stride, ldy};
+    ViewT<T> yv{y, y_sample_stride, ldy};
     hipStream_t st = (hipStream_t)stream;
-    if (vec) CAPE_LAUNCH(spmm_multi_kernel<true>, dim3(grid_for((long long)N * Mo * (C / 4))), dim3(256), 0, st, P, sum, yv, N, Mo, C);
-    else CAPE_LAUNCH(spmm_multi_kernel<false>, dim3(grid_for((long long)N * Mo * C)), dim3(256), 0, st, P, sum, yv, N, Mo, C);
+    if (vec) CAPE_LAUNCH((spmm_multi_kernel<true, T>), dim3(grid_for((long long)N * Mo * (C / 4))), dim3(256), 0, st, P, sum, yv, N, Mo, C);
+    else CAPE_LAUNCH((spmm_multi_kernel<false, T>), dim3(grid_for((long long)N * Mo * C)), dim3(256), 0, st, P, sum, yv, N, Mo, C);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }
+}  // namespace
 
-extern "C" int cape_spmm_combine(const cape_spmm_term_t *terms, int32_t nterms, uint32_t to_acc2, const cape_rank_t *rank,
-                                 const float *bias, int32_t bias_mode, int32_t act, int32_t dual, uint32_t *mask_out, float *y,
-                                 int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t F, void *stream) {
+extern "C" int cape_spmm_multi(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, float *y, int64_t y_sample_stride,
+                               int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
+    return spmm_multi_impl<float>(terms, nterms, sum, y, y_sample_stride, ldy, N, Mo, C, stream);
+}
+
+extern "C" int cape_spmm_multi_bf16(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, void *y, int64_t y_sample_stride,
+                                    int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
+    return spmm_multi_impl<cape_bf16>(terms, nterms, sum, (cape_bf16 *)y, y_sample_stride, ldy, N, Mo, C, stream);
+}
+
+namespace {
+template <typename T>
+int spmm_combine_impl(const cape_spmm_term_t *terms, int32_t nterms, uint32_t to_acc2, const cape_rank_t *rank,
+                      const float *bias, int32_t bias_mode, int32_t act, int32_t dual, uint32_t *mask_out, T *y,
+                      int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t F, void *stream) {
+    constexpr int es = (int)sizeof(T);
     if (!terms || nterms < 1 || nterms > CAPE_MAX_SPMM_TERMS || !y || N < 1 || Mo < 1 || F < 1 || ldy < F) return CAPE_EINVAL;
     if (bias_mode != CAPE_BIAS_NONE && !bias) return CAPE_EINVAL;
     if (act < CAPE_ACT_NONE || act > CAPE_ACT_TANH) return CAPE_EINVAL;
@@ -803,7 +851,7 @@ extern "C" int cape_spmm_combine(const cape_spmm_term_t *terms, int32_t nterms, 
     if (!dual && (to_acc2 || mask_out)) return CAPE_EINVAL;
     CombineParams Q;
     Q.P.n = nterms;
-    bool vec = aligned4(y, y_sample_stride, ldy, F);
+    bool vec = aligned4(y, y_sample_stride, ldy, F, es);
     for (int k = 0; k < nterms; ++k) {
         const cape_spmm_term_t &t = terms[k];
         if (!t.x || t.ldx < F) return CAPE_EINVAL;
@@ -812,7 +860,7 @@ extern "C" int cape_spmm_combine(const cape_spmm_term_t *terms, int32_t nterms, 
         Q.P.t[k].rp = t.rowptr; Q.P.t[k].ci = t.colidx; Q.P.t[k].va = t.vals;
         Q.P.t[k].y = nullptr; Q.P.t[k].ys = 0; Q.P.t[k].ldy = 0;
         Q.P.t[k].scale = t.scale;
-        vec = vec && aligned4(t.x, t.x_sample_stride, t.ldx, F);
+        vec = vec && aligned4(t.x, t.x_sample_stride, t.ldx, F, es);
     }
     Q.to2 = to_acc2;
     Q.rankR = 0; Q.rowscale = nullptr; Q.coef = nullptr; Q.rank_to2 = 0;
@@ -823,12 +871,27 @@ extern "C" int cape_spmm_combine(const cape_spmm_term_t *terms, int32_t nterms, 
     Q.bias = bias; Q.bias_mode = bias ? bias_mode : CAPE_BIAS_NONE; Q.act = act; Q.dual = dual ? 1 : 0;
     Q.mask = mask_out; Q.mask_words = (F + 31) / 32;
     if (mask_out && (!vec || (F & 31))) return CAPE_EINVAL;      // sign words are assembled from 8 float4 lanes
-    View yv{y, y_sample_stride, ldy};
+    ViewT<T> yv{y, y_sample_stride, ldy};
     hipStream_t st = (hipStream_t)stream;
-    if (vec) CAPE_LAUNCH(spmm_combine_kernel<true>, dim3(grid_for((long long)N * Mo * (F / 4))), dim3(256), 0, st, Q, yv, N, Mo, F);
-    else CAPE_LAUNCH(spmm_combine_kernel<false>, dim3(grid_for((long long)N * Mo * F)), dim3(256), 0, st, Q, yv, N, Mo, F);
+    if (vec) CAPE_LAUNCH((spmm_combine_kernel<true, T>), dim3(grid_for((long long)N * Mo * (F / 4))), dim3(256), 0, st, Q, yv, N, Mo, F);
+    else CAPE_LAUNCH((spmm_combine_kernel<false, T>), dim3(grid_for((long long)N * Mo * F)), dim3(256), 0, st, Q, yv, N, Mo, F);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
+}
+}  // namespace
+
+extern "C" int cape_spmm_combine(const cape_spmm_term_t *terms, int32_t nterms, uint32_t to_acc2, const cape_rank_t *rank,
+                                 const float *bias, int32_t bias_mode, int32_t act, int32_t dual, uint32_t *mask_out, float *y,
+                                 int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t F, void *stream) {
+    return spmm_combine_impl<float>(terms, nterms, to_acc2, rank, bias, bias_mode, act, dual, mask_out, y, y_sample_stride, ldy,
+                                    N, Mo, F, stream);
+}
+
+extern "C" int cape_spmm_combine_bf16(const cape_spmm_term_t *terms, int32_t nterms, uint32_t to_acc2, const cape_rank_t *rank,
+                                      const float *bias, int32_t bias_mode, int32_t act, int32_t dual, uint32_t *mask_out, void *y,
+                                      int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t F, void *stream) {
+    return spmm_combine_impl<cape_bf16>(terms, nterms, to_acc2, rank, bias, bias_mode, act, dual, mask_out, (cape_bf16 *)y,
+                                        y_sample_stride, ldy, N, Mo, F, stream);
 }
 
 extern "C" int cape_bias_act_fwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *bias,
@@ -875,7 +938,7 @@ extern "C" int cape_colsum(const float *x, int64_t x_sample_stride, int32_t ldx,
     CView xv{x, x_sample_stride, ldx};
     hipStream_t st = (hipStream_t)stream;
     if (per_vertex) {
-        CAPE_LAUNCH(sum_over_samples_kernel, dim3(grid_for((long long)M * C)), dim3(256), 0, st, xv, N, M, C, accumulate, out);
+        CAPE_LAUNCH((sum_over_samples_kernel<float>), dim3(grid_for((long long)M * C)), dim3(256), 0, st, xv, N, M, C, accumulate, out);
         CAPE_LAUNCH_CHECK();
         return CAPE_OK;
     }
@@ -888,6 +951,17 @@ extern "C" int cape_colsum(const float *x, int64_t x_sample_stride, int32_t ldx,
         CAPE_LAUNCH(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, xv, N, M, C, (float *)workspace);
     CAPE_LAUNCH_CHECK();
     CAPE_LAUNCH(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, (const float *)workspace, nblk, C, accumulate, out);
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}
+
+/* per-vertex column sums of a bf16 tensor: out[m, c] (+)= sum_n x[n, m, c]  (gradient of the [1, M, F] output bias) */
+extern "C" int cape_colsum_vertex_bf16(const void *x, int64_t x_sample_stride, int32_t ldx, int32_t N, int32_t M, int32_t C,
+                                       int32_t accumulate, float *out, void *stream) {
+    if (!x || !out || N < 1 || M < 1 || C < 1 || ldx < C) return CAPE_EINVAL;
+    CViewT<cape_bf16> xv{(const cape_bf16 *)x, x_sample_stride, ldx};
+    CAPE_LAUNCH((sum_over_samples_kernel<cape_bf16>), dim3(grid_for((long long)M * C)), dim3(256), 0, (hipStream_t)stream, xv, N, M, C,
+                accumulate, out);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }
@@ -953,11 +1027,14 @@ extern "C" int64_t cape_bwd_prep_workspace_bytes(int32_t N, int32_t Mo, int32_t 
     return (int64_t)N * chunks * (R + 2) * F * (int64_t)sizeof(float);
 }
 
-extern "C" int cape_bwd_prep(const float *g, int64_t g_sample_stride, int32_t ldg, const float *y, int64_t y_sample_stride,
-                             int32_t ldy, int32_t act, const uint32_t *mask, float *dz, int64_t dz_sample_stride, int32_t lddz,
-                             float *dbias, const float *rowscale, int32_t R, float *dcoef, int32_t rg, float *dcoef_g,
-                             int64_t dcoef_sample_stride, int32_t finalize, int32_t N, int32_t Mo, int32_t F, void *workspace,
-                             int64_t workspace_bytes, void *stream) {
+namespace {
+template <typename T>
+int bwd_prep_impl(const T *g, int64_t g_sample_stride, int32_t ldg, const T *y, int64_t y_sample_stride,
+                  int32_t ldy, int32_t act, const uint32_t *mask, T *dz, int64_t dz_sample_stride, int32_t lddz,
+                  float *dbias, const float *rowscale, int32_t R, float *dcoef, int32_t rg, float *dcoef_g,
+                  int64_t dcoef_sample_stride, int32_t finalize, int32_t N, int32_t Mo, int32_t F, void *workspace,
+                  int64_t workspace_bytes, void *stream) {
+    constexpr int es = (int)sizeof(T);
     if (!g || !dz || !workspace || N < 1 || Mo < 1 || F < 1 || ldg < F || lddz < F || R < 0 || R > RSR_MAXR) return CAPE_EINVAL;
     if (act < CAPE_ACT_NONE || act > CAPE_ACT_TANH) return CAPE_EINVAL;
     if (!mask && act != CAPE_ACT_NONE && (!y || ldy < F)) return CAPE_EINVAL;
@@ -966,17 +1043,17 @@ extern "C" int cape_bwd_prep(const float *g, int64_t g_sample_stride, int32_t ld
     if (workspace_bytes < cape_bwd_prep_workspace_bytes(N, Mo, F, R)) return CAPE_EWORKSPACE;
     const int RB = bp_rows(N, Mo);
     const int chunks = (Mo + RB - 1) / RB;
-    CView gv{g, g_sample_stride, ldg}, yv{y, y_sample_stride, ldy};
-    View zv{dz, dz_sample_stride, lddz};
+    CViewT<T> gv{g, g_sample_stride, ldg}, yv{y, y_sample_stride, ldy};
+    ViewT<T> zv{dz, dz_sample_stride, lddz};
     hipStream_t st = (hipStream_t)stream;
-    const bool vec = aligned4(g, g_sample_stride, ldg, F) && aligned4(dz, dz_sample_stride, lddz, F) &&
-                     (mask || act == CAPE_ACT_NONE || aligned4(y, y_sample_stride, ldy, F)) &&
+    const bool vec = aligned4(g, g_sample_stride, ldg, F, es) && aligned4(dz, dz_sample_stride, lddz, F, es) &&
+                     (mask || act == CAPE_ACT_NONE || aligned4(y, y_sample_stride, ldy, F, es)) &&
                      (F >= 256 ? (F % 256) == 0 : (256 % (F / 4)) == 0) && ((F & 31) == 0 || !mask);
     if (vec)
-        CAPE_LAUNCH(bwd_prep_vec_kernel, dim3(N * chunks), dim3(256), 0, st, gv, yv, act, mask, zv, rowscale, R, rg, dbias ? 1 : 0,
+        CAPE_LAUNCH((bwd_prep_vec_kernel<T>), dim3(N * chunks), dim3(256), 0, st, gv, yv, act, mask, zv, rowscale, R, rg, dbias ? 1 : 0,
                     dcoef_g ? 1 : 0, N, Mo, F, (float *)workspace, chunks, RB);
     else
-        CAPE_LAUNCH(bwd_prep_kernel, dim3(N * chunks), dim3(256), 0, st, gv, yv, act, mask, zv, rowscale, R, rg, dbias ? 1 : 0,
+        CAPE_LAUNCH((bwd_prep_kernel<T>), dim3(N * chunks), dim3(256), 0, st, gv, yv, act, mask, zv, rowscale, R, rg, dbias ? 1 : 0,
                     dcoef_g ? 1 : 0, N, Mo, F, (float *)workspace, chunks, RB);
     CAPE_LAUNCH_CHECK();
     if (finalize && (dbias || R > 0 || dcoef_g)) {
@@ -988,6 +1065,26 @@ extern "C" int cape_bwd_prep(const float *g, int64_t g_sample_stride, int32_t ld
         CAPE_LAUNCH_CHECK();
     }
     return CAPE_OK;
+}
+}  // namespace
+
+extern "C" int cape_bwd_prep(const float *g, int64_t g_sample_stride, int32_t ldg, const float *y, int64_t y_sample_stride,
+                             int32_t ldy, int32_t act, const uint32_t *mask, float *dz, int64_t dz_sample_stride, int32_t lddz,
+                             float *dbias, const float *rowscale, int32_t R, float *dcoef, int32_t rg, float *dcoef_g,
+                             int64_t dcoef_sample_stride, int32_t finalize, int32_t N, int32_t Mo, int32_t F, void *workspace,
+                             int64_t workspace_bytes, void *stream) {
+    return bwd_prep_impl<float>(g, g_sample_stride, ldg, y, y_sample_stride, ldy, act, mask, dz, dz_sample_stride, lddz, dbias,
+                                rowscale, R, dcoef, rg, dcoef_g, dcoef_sample_stride, finalize, N, Mo, F, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cape_bwd_prep_bf16(const void *g, int64_t g_sample_stride, int32_t ldg, const void *y, int64_t y_sample_stride,
+                                  int32_t ldy, int32_t act, const uint32_t *mask, void *dz, int64_t dz_sample_stride, int32_t lddz,
+                                  float *dbias, const float *rowscale, int32_t R, float *dcoef, int32_t rg, float *dcoef_g,
+                                  int64_t dcoef_sample_stride, int32_t finalize, int32_t N, int32_t Mo, int32_t F, void *workspace,
+                                  int64_t workspace_bytes, void *stream) {
+    return bwd_prep_impl<cape_bf16>((const cape_bf16 *)g, g_sample_stride, ldg, (const cape_bf16 *)y, y_sample_stride, ldy, act, mask,
+                                    (cape_bf16 *)dz, dz_sample_stride, lddz, dbias, rowscale, R, dcoef, rg, dcoef_g,
+                                    dcoef_sample_stride, finalize, N, Mo, F, workspace, workspace_bytes, stream);
 }
 
 extern "C" int cape_bwd_prep_finalize(const cape_bwd_prep_item_t *items, int32_t nitems, void *stream) {

@@ -21,7 +21,7 @@ namespace {
 constexpr int KC_DEFAULT = 32;   // contraction chunk staged per iteration
 
 // ---- A-tile staging: gathered rows -> LDS [ROWS][KC+4] -----------------------------------
-template <int ROWS, int LDA, int KC>
+template <int ROWS, int LDA, int KC, typename AT = float>
 __device__ __forceinline__ void stage_gather(float *sA, const SrcDev &S, int n, int r0, int Mo,
                                               int c0, int tid) {
     constexpr int QPR = KC / 4;            // float4 columns per row of the chunk
@@ -29,7 +29,8 @@ __device__ __forceinline__ void stage_gather(float *sA, const SrcDev &S, int n, 
     const int q = tid % QPR;
     const int rl0 = tid / QPR;
     const int c = c0 + 4 * q;
-    const float *xb = S.x + (long long)n * S.xs + c;
+    const AT *x0 = reinterpret_cast<const AT *>(S.x) + (long long)n * S.xs;
+    const AT *xb = x0 + c;
     const int nvalid = S.C - c;   // channels available from c
     constexpr int P = ROWS / RP;
     if (!S.rp && S.vec && (nvalid >= 4 || (nvalid > 0 && c + 4 <= S.ldx) || nvalid <= 0)) {
@@ -43,7 +44,7 @@ __device__ __forceinline__ void stage_gather(float *sA, const SrcDev &S, int n, 
             // unconditional load from a clamped (always valid) row, zeroed by a select afterwards:
             // a branch around each load would make hipcc wait vmcnt(0) per load (serialised round trips)
             const int rc = r < Mo ? r : Mo - 1;
-            v[pass] = *reinterpret_cast<const float4 *>((nvalid > 0 ? xb : S.x + (long long)n * S.xs) + (long long)rc * S.ldx);
+            v[pass] = cape_ld4((nvalid > 0 ? xb : x0) + (long long)rc * S.ldx);
         }
 #pragma unroll
         for (int pass = 0; pass < P; ++pass) {
@@ -67,18 +68,18 @@ __device__ __forceinline__ void stage_gather(float *sA, const SrcDev &S, int n, 
                 int e = S.rp[r];
                 for (; e + 1 < e1; e += 2) {
                     const float v0 = S.va[e], v1 = S.va[e + 1];
-                    const float4 x0 = *reinterpret_cast<const float4 *>(xb + (long long)S.ci[e] * S.ldx);
-                    const float4 x1 = *reinterpret_cast<const float4 *>(xb + (long long)S.ci[e + 1] * S.ldx);
-                    acc.x = fmaf(v0, x0.x, acc.x); acc.y = fmaf(v0, x0.y, acc.y);
-                    acc.z = fmaf(v0, x0.z, acc.z); acc.w = fmaf(v0, x0.w, acc.w);
-                    acc.x = fmaf(v1, x1.x, acc.x); acc.y = fmaf(v1, x1.y, acc.y);
-                    acc.z = fmaf(v1, x1.z, acc.z); acc.w = fmaf(v1, x1.w, acc.w);
+                    const float4 xa = cape_ld4(xb + (long long)S.ci[e] * S.ldx);
+                    const float4 xc = cape_ld4(xb + (long long)S.ci[e + 1] * S.ldx);
+                    acc.x = fmaf(v0, xa.x, acc.x); acc.y = fmaf(v0, xa.y, acc.y);
+                    acc.z = fmaf(v0, xa.z, acc.z); acc.w = fmaf(v0, xa.w, acc.w);
+                    acc.x = fmaf(v1, xc.x, acc.x); acc.y = fmaf(v1, xc.y, acc.y);
+                    acc.z = fmaf(v1, xc.z, acc.z); acc.w = fmaf(v1, xc.w, acc.w);
                 }
                 if (e < e1) {
                     const float v0 = S.va[e];
-                    const float4 x0 = *reinterpret_cast<const float4 *>(xb + (long long)S.ci[e] * S.ldx);
-                    acc.x = fmaf(v0, x0.x, acc.x); acc.y = fmaf(v0, x0.y, acc.y);
-                    acc.z = fmaf(v0, x0.z, acc.z); acc.w = fmaf(v0, x0.w, acc.w);
+                    const float4 xa = cape_ld4(xb + (long long)S.ci[e] * S.ldx);
+                    acc.x = fmaf(v0, xa.x, acc.x); acc.y = fmaf(v0, xa.y, acc.y);
+                    acc.z = fmaf(v0, xa.z, acc.z); acc.w = fmaf(v0, xa.w, acc.w);
                 }
             } else {
                 float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -86,16 +87,16 @@ __device__ __forceinline__ void stage_gather(float *sA, const SrcDev &S, int n, 
                     const int e1 = S.rp[r + 1];
                     for (int e = S.rp[r]; e < e1; ++e) {
                         const float v = S.va[e];
-                        const float *xr = xb + (long long)S.ci[e] * S.ldx;
+                        const AT *xr = xb + (long long)S.ci[e] * S.ldx;
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
-                            if (u < nvalid) a[u] = fmaf(v, xr[u], a[u]);
+                            if (u < nvalid) a[u] = fmaf(v, cape_ld(xr + u), a[u]);
                     }
                 } else {
-                    const float *xr = xb + (long long)r * S.ldx;
+                    const AT *xr = xb + (long long)r * S.ldx;
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        if (u < nvalid) a[u] = xr[u];
+                        if (u < nvalid) a[u] = cape_ld(xr + u);
                 }
                 acc = make_float4(a[0], a[1], a[2], a[3]);
             }
@@ -178,7 +179,7 @@ __device__ __forceinline__ void stage_weights(float *sB, const float *w, long lo
 // weight chunk, then multiplies.  3-4 resident workgroups per CU overlap each other's staging and MFMA
 // phases (measured faster here than a loader/MFMA wave split and than a register-prefetch pipeline, which
 // cost occupancy on the gather path; plain sources take the pipelined kernel of gemm_plain.h instead).
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool DUAL, int KC = KC_DEFAULT>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool DUAL, int KC = KC_DEFAULT, typename AT = float>
 __global__ __launch_bounds__(256, 4) void gconv_fwd_kernel(GconvParams p) {
     constexpr int LDA = KC + 4;
     constexpr int LDB = BN + 4;
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256, 4) void gconv_fwd_kernel(GconvParams p) {
         const SrcDev &S = p.s[l_si];
         float *sA = smem + buf * BUF_SZ;
         float *sB = sA + A_SZ;
-        stage_gather<BM, LDA, KC>(sA, S, n, r0, p.Mo, l_c0, ltid);
+        stage_gather<BM, LDA, KC, AT>(sA, S, n, r0, p.Mo, l_c0, ltid);
         stage_weights<BN, LDB, 256, KC>(sB, S.w, S.wrs, S.wcs, S.C, p.F, l_c0, f0, ltid);
         if (DUAL && S.w2) stage_weights<BN, LDB, 256, KC>(sB + B_SZ, S.w2, S.w2rs, S.w2cs, S.C, p.F, l_c0, f0, ltid);
         l_c0 += KC;
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(256, 4) void gconv_fwd_kernel(GconvParams p) {
         compute(0);
     }
 
-    gconv_epilogue<BM, BN, WAVES_M, WAVES_N, DUAL>(p, acc, acc2, n, r0, f0, wm, wn, li, lh);
+    gconv_epilogue<BM, BN, WAVES_M, WAVES_N, DUAL, AT>(p, acc, acc2, n, r0, f0, wm, wn, li, lh);
 }
 
 // =============================================================================================
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(256, 4) void gconv_fwd_kernel(GconvParams p) {
 // slice of the vertex dimension; partials go to the workspace and are summed in a fixed order
 // by dw_reduce_kernel (deterministic; no float atomics).
 // =============================================================================================
-template <int CT, int FT>
+template <int CT, int FT, typename AT = float>
 __global__ __launch_bounds__(256, 4) void gconv_dw_kernel(DwParams p) {
     constexpr int RK = 32;
     constexpr int LDA = CT + 4, LDB = FT + 4;
@@ -318,8 +319,8 @@ __global__ __launch_bounds__(256, 4) void gconv_dw_kernel(DwParams p) {
     const int li = lane & 31, lh = lane >> 5;
 
     const int ntiles = p.tile_off[p.nsrc];
-    const int tile = blockIdx.x % ntiles;
-    const int split = blockIdx.x / ntiles;   // split = group * rsplit + rs
+    int tile, split;                                  // split = group * rsplit + rs
+    if (!cape_map_dw_block(blockIdx.x, ntiles, p.ngroups * p.rsplit, tile, split)) return;
     const int grp = split / p.rsplit;
     const int rs = split % p.rsplit;
     const int n_begin = grp * p.samples_per_group;
@@ -342,8 +343,8 @@ __global__ __launch_bounds__(256, 4) void gconv_dw_kernel(DwParams p) {
             for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
 
     for (int n = n_begin; n < n_end; ++n) {
-    const float *dzb = (((p.dz2_mask >> si) & 1u) ? p.dz2 : p.dz) + (long long)n * p.dzs;
-    const float *xb = S.x + (long long)n * S.xs;
+    const AT *dzb = reinterpret_cast<const AT *>(((p.dz2_mask >> si) & 1u) ? p.dz2 : p.dz) + (long long)n * p.dzs;
+    const AT *xb = reinterpret_cast<const AT *>(S.x) + (long long)n * S.xs;
 
     for (int rbase = ra; rbase < rb; rbase += RK) {
         __syncthreads();
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(256, 4) void gconv_dw_kernel(DwParams p) {
                 const int r = rbase + rl;
                 const int rc = r < rb ? r : rb - 1;
                 const int cc = (c0 + 4 * q) < S.C ? (c0 + 4 * q) : 0;
-                va4[i] = *reinterpret_cast<const float4 *>(xb + (long long)rc * S.ldx + cc);
+                va4[i] = cape_ld4(xb + (long long)rc * S.ldx + cc);
             }
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
@@ -386,14 +387,14 @@ __global__ __launch_bounds__(256, 4) void gconv_dw_kernel(DwParams p) {
                         const int e1 = S.rp[r + 1];
                         for (int e = S.rp[r]; e < e1; ++e) {
                             const float v = S.va[e];
-                            const float4 xv = *reinterpret_cast<const float4 *>(xb + (long long)S.ci[e] * S.ldx + c);
+                            const float4 xv = cape_ld4(xb + (long long)S.ci[e] * S.ldx + c);
                             v4.x = fmaf(v, xv.x, v4.x);
                             v4.y = fmaf(v, xv.y, v4.y);
                             v4.z = fmaf(v, xv.z, v4.z);
                             v4.w = fmaf(v, xv.w, v4.w);
                         }
                     } else {
-                        v4 = *reinterpret_cast<const float4 *>(xb + (long long)r * S.ldx + c);
+                        v4 = cape_ld4(xb + (long long)r * S.ldx + c);
                     }
                 } else {
                     float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -401,16 +402,16 @@ __global__ __launch_bounds__(256, 4) void gconv_dw_kernel(DwParams p) {
                         const int e1 = S.rp[r + 1];
                         for (int e = S.rp[r]; e < e1; ++e) {
                             const float v = S.va[e];
-                            const float *xr = xb + (long long)S.ci[e] * S.ldx + c;
+                            const AT *xr = xb + (long long)S.ci[e] * S.ldx + c;
 #pragma unroll
                             for (int u = 0; u < 4; ++u)
-                                if (u < nvalid) a[u] = fmaf(v, xr[u], a[u]);
+                                if (u < nvalid) a[u] = fmaf(v, cape_ld(xr + u), a[u]);
                         }
                     } else {
-                        const float *xr = xb + (long long)r * S.ldx + c;
+                        const AT *xr = xb + (long long)r * S.ldx + c;
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
-                            if (u < nvalid) a[u] = xr[u];
+                            if (u < nvalid) a[u] = cape_ld(xr + u);
                     }
                     v4 = make_float4(a[0], a[1], a[2], a[3]);
                 }
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(256, 4) void gconv_dw_kernel(DwParams p) {
                 const int r = rbase + rl;
                 const int rc = r < rb ? r : rb - 1;
                 const int fc = (f0 + 4 * q) < p.F ? (f0 + 4 * q) : 0;
-                vb4[i] = *reinterpret_cast<const float4 *>(dzb + (long long)rc * p.lddz + fc);
+                vb4[i] = cape_ld4(dzb + (long long)rc * p.lddz + fc);
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
@@ -447,14 +448,14 @@ __global__ __launch_bounds__(256, 4) void gconv_dw_kernel(DwParams p) {
             const int nvalid = p.F - f;
             float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < rb && nvalid > 0) {
-                const float *zr = dzb + (long long)r * p.lddz + f;
+                const AT *zr = dzb + (long long)r * p.lddz + f;
                 if (p.dzvec && nvalid >= 4) {
-                    v4 = *reinterpret_cast<const float4 *>(zr);
+                    v4 = cape_ld4(zr);
                 } else {
                     float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        if (u < nvalid) a[u] = zr[u];
+                        if (u < nvalid) a[u] = cape_ld(zr + u);
                     v4 = make_float4(a[0], a[1], a[2], a[3]);
                 }
             }
@@ -580,14 +581,15 @@ __global__ __launch_bounds__(256) void dw_reduce_vec_kernel(DwReduceParams p) {
     *dst = t;
 }
 
-inline int fill_src(SrcDev &d, const cape_src_t &s) {
+// es = bytes per activation element (4: fp32, 2: bf16 storage)
+inline int fill_src(SrcDev &d, const cape_src_t &s, int es = 4) {
     if (!s.x || s.C <= 0 || s.ldx < s.C) return CAPE_EINVAL;
     if (s.rowptr && (!s.colidx || !s.vals)) return CAPE_EINVAL;
     d.x = s.x; d.xs = s.x_sample_stride; d.ldx = s.ldx; d.C = s.C;
     d.rp = s.rowptr; d.ci = s.colidx; d.va = s.vals;
     d.w = s.w; d.wrs = s.w_rs; d.wcs = s.w_cs;
     d.w2 = s.w2; d.w2rs = s.w2_rs; d.w2cs = s.w2_cs;
-    d.vec = ((s.ldx & 3) == 0) && ((s.x_sample_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(s.x) & 15) == 0);
+    d.vec = ((s.ldx & 3) == 0) && ((s.x_sample_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(s.x) & (4 * es - 1)) == 0);
     return CAPE_OK;
 }
 
@@ -661,28 +663,37 @@ inline void plan_dw_plain(const cape_src_t *srcs, int nsrc, int N, int Mo, int F
 // Plain = no gather and float4-addressable rows.  A channel count that is not a multiple of 4 qualifies when the
 // row is padded to one (ld >= round_up(C, 4)): the pad lane only feeds an output row that is never stored
 // (the 3-channel network input / output layers).
-inline bool dw_srcs_plain(const cape_src_t *srcs, int nsrc) {
+inline bool dw_srcs_plain(const cape_src_t *srcs, int nsrc, int es = 4) {
     for (int i = 0; i < nsrc; ++i)
         if (srcs[i].rowptr || (((srcs[i].C + 3) & ~3) > srcs[i].ldx) || (srcs[i].ldx & 3) || (srcs[i].x_sample_stride & 3) ||
-            (reinterpret_cast<uintptr_t>(srcs[i].x) & 15))
+            (reinterpret_cast<uintptr_t>(srcs[i].x) & (4 * es - 1)))
             return false;
     return true;
 }
 
 
-inline bool dw_dz_vec(const float *dz, int64_t dz_sample_stride, int32_t lddz, const float *dz2) {
-    return ((lddz & 3) == 0) && ((dz_sample_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dz) & 15) == 0) &&
-           (!dz2 || (reinterpret_cast<uintptr_t>(dz2) & 15) == 0);
+inline bool dw_dz_vec(const float *dz, int64_t dz_sample_stride, int32_t lddz, const float *dz2, int es = 4) {
+    return ((lddz & 3) == 0) && ((dz_sample_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(dz) & (4 * es - 1)) == 0) &&
+           (!dz2 || (reinterpret_cast<uintptr_t>(dz2) & (4 * es - 1)) == 0);
 }
 
 // Kernel choice of one weight-gradient launch (pure function of the arguments): 0 = gather form (gconv_dw_kernel),
 // 1 = pipelined plain kernel on the exact-fp32 MFMA (dw_plain_kernel), 2 = packed narrow sources (dw_packed_kernel),
 // 3 = plain sources on the bf16 pipe with the exact three-way operand split (dw_split_kernel).  Fills the tile plan.
 inline int choose_dw(const cape_src_t *srcs, int nsrc, const float *dz, int64_t dz_sample_stride, int32_t lddz,
-                     const float *dz2, uint32_t dz2_mask, int N, int Mo, int F, DwPlan &pl) {
+                     const float *dz2, uint32_t dz2_mask, int N, int Mo, int F, DwPlan &pl, bool bf16 = false) {
     static const int dwp_on = getenv("CAPE_DW_PLAIN") ? atoi(getenv("CAPE_DW_PLAIN")) : 1;      // 0: A/B against the gather kernel
-    const bool dzvec = dw_dz_vec(dz, dz_sample_stride, lddz, dz2);
-    const bool plain = dwp_on && dzvec && (((F + 3) & ~3) <= lddz) && dw_srcs_plain(srcs, nsrc);
+    const int es = bf16 ? 2 : 4;
+    const bool dzvec = dw_dz_vec(dz, dz_sample_stride, lddz, dz2, es);
+    const bool plain = dwp_on && dzvec && (((F + 3) & ~3) <= lddz) && dw_srcs_plain(srcs, nsrc, es);
+    if (bf16) {
+        // bf16 storage: the split-pipe kernel with one plane (plain sources, whole float4-equivalent columns), the
+        // generic gather kernel otherwise; the fp32-MFMA plain / packed kernels read fp32 only
+        bool c4b = true;
+        for (int i = 0; i < nsrc; ++i) c4b = c4b && (srcs[i].C & 3) == 0;
+        plan_dw(srcs, nsrc, N, Mo, F, pl);
+        return (plain && c4b && (F & 1) == 0) ? 3 : 0;
+    }
     int sumC = 0;
     for (int i = 0; i < nsrc; ++i) sumC += srcs[i].C;
     // packing pays where several sources fit ONE tile (narrow layers of the fine mesh levels)
@@ -706,10 +717,27 @@ struct FwdPlan {
     int layout;   // family 1: 1 = weights contraction-contiguous, 0 = output-contiguous
 };
 
-inline FwdPlan plan_fwd(const GconvParams &p, const cape_src_t *srcs, bool dual) {
+inline FwdPlan plan_fwd(const GconvParams &p, const cape_src_t *srcs, bool dual, bool bf16 = false) {
     FwdPlan pl;
     static const int gp_on = getenv("CAPE_GEMM_PLAIN") ? atoi(getenv("CAPE_GEMM_PLAIN")) : 1;   // 0: A/B against the gather kernel
     pl.layout = gp_on ? gp_weight_layout(p, dual) : -1;
+    if (bf16) {
+        // bf16 storage: the split-pipe kernel with one plane where its staging applies (plain sources of whole 32-channel
+        // chunks whose rows can be read 8 elements = 16 bytes at a time, F >= 64), the generic gather kernel otherwise
+        bool ok = pl.layout >= 0 && p.F >= 64;
+        for (int i = 0; i < p.nsrc && ok; ++i) {
+            const long long ws = srcs[i].w_cs > srcs[i].w_rs ? srcs[i].w_cs : srcs[i].w_rs;
+            ok = (srcs[i].ldx & 7) == 0 && (srcs[i].x_sample_stride & 7) == 0 && (reinterpret_cast<uintptr_t>(srcs[i].x) & 15) == 0 &&
+                 (long long)p.Mo * srcs[i].ldx < (1LL << 31) && (long long)p.F * ws < (1LL << 31) &&
+                 srcs[i].C % GS_KC == 0 && srcs[i].C >= GS_KC;
+        }
+        if (ok) {
+            pl.family = 2;
+            gs_tile(dual, p.N, p.Mo, p.F, pl.BM, pl.BN);
+            return pl;
+        }
+        pl.layout = -1;
+    }
     for (int i = 0; i < p.nsrc && pl.layout >= 0; ++i) {
         const long long ws = srcs[i].w_cs > srcs[i].w_rs ? srcs[i].w_cs : srcs[i].w_rs;
         if ((long long)p.Mo * srcs[i].ldx >= (1LL << 31) || (long long)p.F * ws >= (1LL << 31)) pl.layout = -1;   // 32-bit offsets
@@ -736,11 +764,11 @@ inline FwdPlan plan_fwd(const GconvParams &p, const cape_src_t *srcs, bool dual)
     return pl;
 }
 
-inline int fill_fwd_srcs(GconvParams &p, const cape_src_t *srcs, int nsrc, bool &dual) {
+inline int fill_fwd_srcs(GconvParams &p, const cape_src_t *srcs, int nsrc, bool &dual, int es = 4) {
     dual = false;
     for (int i = 0; i < nsrc; ++i) {
         if (!srcs[i].w) return CAPE_EINVAL;
-        int rc = fill_src(p.s[i], srcs[i]);
+        int rc = fill_src(p.s[i], srcs[i], es);
         if (rc) return rc;
         dual = dual || (srcs[i].w2 != nullptr);
     }
@@ -750,23 +778,38 @@ inline int fill_fwd_srcs(GconvParams &p, const cape_src_t *srcs, int nsrc, bool 
 
 }  // namespace
 
-extern "C" int cape_gconv_fwd_plan(const cape_src_t *srcs, int32_t nsrc, int32_t N, int32_t Mo, int32_t F,
-                                   int32_t plan[4]) {
+namespace {
+
+int gconv_fwd_plan_impl(const cape_src_t *srcs, int32_t nsrc, int32_t N, int32_t Mo, int32_t F, int32_t plan[4], bool bf16) {
     if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || N < 1 || Mo < 1 || F < 1 || !plan) return CAPE_EINVAL;
     GconvParams p;
     bool dual;
-    int rc = fill_fwd_srcs(p, srcs, nsrc, dual);
+    int rc = fill_fwd_srcs(p, srcs, nsrc, dual, bf16 ? 2 : 4);
     if (rc) return rc;
     p.N = N; p.Mo = Mo; p.F = F;
-    const FwdPlan pl = plan_fwd(p, srcs, dual);
+    const FwdPlan pl = plan_fwd(p, srcs, dual, bf16);
     plan[0] = pl.family; plan[1] = pl.BM; plan[2] = pl.BN; plan[3] = pl.family ? pl.layout : 0;
     return CAPE_OK;
 }
 
-extern "C" int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, int64_t y_sample_stride,
-                              int32_t ldy, int32_t N, int32_t Mo, int32_t F, const float *bias,
-                              int32_t bias_mode, int32_t act, uint32_t *mask_out, const cape_rank_t *rank,
-                              int32_t out_deinterleave, void *stream) {
+template <typename AT>
+void launch_gather_fwd(const GconvParams &p, const FwdPlan &pl, bool dual, dim3 grid, hipStream_t st) {
+    const dim3 block(256);
+    if (!dual) {
+        if (pl.BN == 32) CAPE_LAUNCH((gconv_fwd_kernel<128, 32, 4, 1, false, KC_DEFAULT, AT>), grid, block, 0, st, p);
+        else if (pl.BN == 64) CAPE_LAUNCH((gconv_fwd_kernel<128, 64, 4, 1, false, KC_DEFAULT, AT>), grid, block, 0, st, p);
+        else if (pl.BM == 64) CAPE_LAUNCH((gconv_fwd_kernel<64, 128, 2, 2, false, KC_DEFAULT, AT>), grid, block, 0, st, p);
+        else CAPE_LAUNCH((gconv_fwd_kernel<128, 128, 2, 2, false, KC_DEFAULT, AT>), grid, block, 0, st, p);
+    } else {
+        if (pl.BN == 32) CAPE_LAUNCH((gconv_fwd_kernel<128, 32, 4, 1, true, KC_DEFAULT, AT>), grid, block, 0, st, p);
+        else CAPE_LAUNCH((gconv_fwd_kernel<128, 64, 4, 1, true, KC_DEFAULT, AT>), grid, block, 0, st, p);
+    }
+}
+
+int gconv_fwd_impl(const cape_src_t *srcs, int32_t nsrc, float *y, int64_t y_sample_stride,
+                   int32_t ldy, int32_t N, int32_t Mo, int32_t F, const float *bias,
+                   int32_t bias_mode, int32_t act, uint32_t *mask_out, const cape_rank_t *rank,
+                   int32_t out_deinterleave, void *stream, bool bf16) {
     if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || !y || N < 1 || Mo < 1 || F < 1) return CAPE_EINVAL;
     const int dK = out_deinterleave > 1 ? out_deinterleave : 1;
     const int dstride = dK > 1 ? ((F / dK + 3) & ~3) : 0;
@@ -776,7 +819,7 @@ extern "C" int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, in
     if (act < CAPE_ACT_NONE || act > CAPE_ACT_TANH) return CAPE_EINVAL;
     GconvParams p;
     bool dual;
-    int rc = fill_fwd_srcs(p, srcs, nsrc, dual);
+    int rc = fill_fwd_srcs(p, srcs, nsrc, dual, bf16 ? 2 : 4);
     if (rc) return rc;
     if (mask_out && !dual) return CAPE_EINVAL;
     if (dual && (bias_mode != CAPE_BIAS_NONE || act != CAPE_ACT_NONE)) return CAPE_EINVAL;
@@ -791,26 +834,48 @@ extern "C" int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, in
         if (rank->to_acc2 && !dual) return CAPE_EINVAL;
         p.rankR = rank->R; p.rowscale = rank->rowscale; p.coef = rank->coef; p.rank_to2 = rank->to_acc2;
     }
-    const FwdPlan pl = plan_fwd(p, srcs, dual);
+    const FwdPlan pl = plan_fwd(p, srcs, dual, bf16);
     p.row_tiles = (Mo + pl.BM - 1) / pl.BM;
     p.col_tiles = (F + pl.BN - 1) / pl.BN;
-    dim3 grid((unsigned)(N * p.row_tiles * p.col_tiles)), block(256);
+    dim3 grid((unsigned)(N * p.row_tiles * p.col_tiles));
     hipStream_t st = (hipStream_t)stream;
     if (pl.family == 2) {
-        gs_launch(p, dual, pl.BM, pl.layout, grid, st);
+        gs_launch(p, dual, pl.BM, pl.layout, bf16, grid, st);
     } else if (pl.family == 1) {
         gp_launch(p, dual, pl.BM, pl.BN, pl.layout, grid, st);
-    } else if (!dual) {
-        if (pl.BN == 32) CAPE_LAUNCH((gconv_fwd_kernel<128, 32, 4, 1, false>), grid, block, 0, st, p);
-        else if (pl.BN == 64) CAPE_LAUNCH((gconv_fwd_kernel<128, 64, 4, 1, false>), grid, block, 0, st, p);
-        else if (pl.BM == 64) CAPE_LAUNCH((gconv_fwd_kernel<64, 128, 2, 2, false>), grid, block, 0, st, p);
-        else CAPE_LAUNCH((gconv_fwd_kernel<128, 128, 2, 2, false>), grid, block, 0, st, p);
+    } else if (bf16) {
+        launch_gather_fwd<cape_bf16>(p, pl, dual, grid, st);
     } else {
-        if (pl.BN == 32) CAPE_LAUNCH((gconv_fwd_kernel<128, 32, 4, 1, true>), grid, block, 0, st, p);
-        else CAPE_LAUNCH((gconv_fwd_kernel<128, 64, 4, 1, true>), grid, block, 0, st, p);
+        launch_gather_fwd<float>(p, pl, dual, grid, st);
     }
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
+}
+
+}  // namespace
+
+extern "C" int cape_gconv_fwd_plan(const cape_src_t *srcs, int32_t nsrc, int32_t N, int32_t Mo, int32_t F, int32_t plan[4]) {
+    return gconv_fwd_plan_impl(srcs, nsrc, N, Mo, F, plan, false);
+}
+
+extern "C" int cape_gconv_fwd_plan_bf16(const cape_src_t *srcs, int32_t nsrc, int32_t N, int32_t Mo, int32_t F, int32_t plan[4]) {
+    return gconv_fwd_plan_impl(srcs, nsrc, N, Mo, F, plan, true);
+}
+
+extern "C" int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, int64_t y_sample_stride,
+                              int32_t ldy, int32_t N, int32_t Mo, int32_t F, const float *bias,
+                              int32_t bias_mode, int32_t act, uint32_t *mask_out, const cape_rank_t *rank,
+                              int32_t out_deinterleave, void *stream) {
+    return gconv_fwd_impl(srcs, nsrc, y, y_sample_stride, ldy, N, Mo, F, bias, bias_mode, act, mask_out, rank, out_deinterleave,
+                          stream, false);
+}
+
+extern "C" int cape_gconv_fwd_bf16(const cape_src_t *srcs, int32_t nsrc, void *y, int64_t y_sample_stride,
+                                   int32_t ldy, int32_t N, int32_t Mo, int32_t F, const float *bias,
+                                   int32_t bias_mode, int32_t act, uint32_t *mask_out, const cape_rank_t *rank,
+                                   int32_t out_deinterleave, void *stream) {
+    return gconv_fwd_impl(srcs, nsrc, (float *)y, y_sample_stride, ldy, N, Mo, F, bias, bias_mode, act, mask_out, rank,
+                          out_deinterleave, stream, true);
 }
 
 extern "C" int64_t cape_gconv_dw_workspace_bytes(const cape_src_t *srcs, int32_t nsrc, int32_t N,
@@ -819,7 +884,7 @@ extern "C" int64_t cape_gconv_dw_workspace_bytes(const cape_src_t *srcs, int32_t
     DwPlan pl;
     plan_dw(srcs, nsrc, N, Mo, F, pl);
     long long need = pl.slab * pl.ngroups * pl.rsplit;
-    if (dw_srcs_plain(srcs, nsrc)) {      // whichever kernel the launch ends up taking (depends on dz too)
+    {   // whichever kernel the launch ends up taking (depends on dz and on the storage type too): the larger plan
         plan_dw_plain(srcs, nsrc, N, Mo, F, true, pl);
         const long long n2 = pl.slab * pl.ngroups * pl.rsplit;
         need = n2 > need ? n2 : need;
@@ -827,14 +892,48 @@ extern "C" int64_t cape_gconv_dw_workspace_bytes(const cape_src_t *srcs, int32_t
     return (int64_t)need * (int64_t)sizeof(float);
 }
 
+namespace {
+int gconv_dw_plan_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz, int64_t dz_sample_stride,
+                       int32_t lddz, const float *dz2, uint32_t dz2_mask, int32_t N, int32_t Mo, int32_t F,
+                       int32_t plan[4], bool bf16) {
+    if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || !dz || N < 1 || Mo < 1 || F < 1 || lddz < F || !plan) return CAPE_EINVAL;
+    DwPlan pl;
+    plan[0] = choose_dw(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, N, Mo, F, pl, bf16);
+    plan[1] = pl.ct; plan[2] = pl.ft; plan[3] = pl.ngroups * pl.rsplit;
+    return CAPE_OK;
+}
+int gconv_dw_stage_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz,
+                        int64_t dz_sample_stride, int32_t lddz, const float *dz2, uint32_t dz2_mask,
+                        int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
+                        int64_t workspace_bytes, int32_t stage, void *stream, bool bf16);
+}  // namespace
+
 extern "C" int cape_gconv_dw_plan(const cape_src_t *srcs, int32_t nsrc, const float *dz, int64_t dz_sample_stride,
                                   int32_t lddz, const float *dz2, uint32_t dz2_mask, int32_t N, int32_t Mo, int32_t F,
                                   int32_t plan[4]) {
-    if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || !dz || N < 1 || Mo < 1 || F < 1 || lddz < F || !plan) return CAPE_EINVAL;
-    DwPlan pl;
-    plan[0] = choose_dw(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, N, Mo, F, pl);
-    plan[1] = pl.ct; plan[2] = pl.ft; plan[3] = pl.ngroups * pl.rsplit;
-    return CAPE_OK;
+    return gconv_dw_plan_impl(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, N, Mo, F, plan, false);
+}
+
+extern "C" int cape_gconv_dw_plan_bf16(const cape_src_t *srcs, int32_t nsrc, const void *dz, int64_t dz_sample_stride,
+                                       int32_t lddz, const void *dz2, uint32_t dz2_mask, int32_t N, int32_t Mo, int32_t F,
+                                       int32_t plan[4]) {
+    return gconv_dw_plan_impl(srcs, nsrc, (const float *)dz, dz_sample_stride, lddz, (const float *)dz2, dz2_mask, N, Mo, F, plan, true);
+}
+
+extern "C" int cape_gconv_dw_bf16(const cape_src_t *srcs, int32_t nsrc, const void *dz,
+                                  int64_t dz_sample_stride, int32_t lddz, const void *dz2, uint32_t dz2_mask,
+                                  int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
+                                  int64_t workspace_bytes, void *stream) {
+    return gconv_dw_stage_impl(srcs, nsrc, (const float *)dz, dz_sample_stride, lddz, (const float *)dz2, dz2_mask, N, Mo, F,
+                               accumulate, workspace, workspace_bytes, 0, stream, true);
+}
+
+extern "C" int cape_gconv_dw_stage_bf16(const cape_src_t *srcs, int32_t nsrc, const void *dz,
+                                        int64_t dz_sample_stride, int32_t lddz, const void *dz2, uint32_t dz2_mask,
+                                        int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
+                                        int64_t workspace_bytes, int32_t stage, void *stream) {
+    return gconv_dw_stage_impl(srcs, nsrc, (const float *)dz, dz_sample_stride, lddz, (const float *)dz2, dz2_mask, N, Mo, F,
+                               accumulate, workspace, workspace_bytes, stage, stream, true);
 }
 
 extern "C" int cape_gconv_dw(const cape_src_t *srcs, int32_t nsrc, const float *dz,
@@ -849,14 +948,23 @@ extern "C" int cape_gconv_dw_stage(const cape_src_t *srcs, int32_t nsrc, const f
                                    int64_t dz_sample_stride, int32_t lddz, const float *dz2, uint32_t dz2_mask,
                                    int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
                                    int64_t workspace_bytes, int32_t stage, void *stream) {
+    return gconv_dw_stage_impl(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, N, Mo, F, accumulate, workspace,
+                               workspace_bytes, stage, stream, false);
+}
+
+namespace {
+int gconv_dw_stage_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz,
+                        int64_t dz_sample_stride, int32_t lddz, const float *dz2, uint32_t dz2_mask,
+                        int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
+                        int64_t workspace_bytes, int32_t stage, void *stream, bool bf16) {
     if (stage < 0 || stage > 2) return CAPE_EINVAL;
     if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || !dz || N < 1 || Mo < 1 || F < 1 || lddz < F || !workspace)
         return CAPE_EINVAL;
     if (dz2_mask && !dz2) return CAPE_EINVAL;
     DwPlan pl;
-    const int fam = choose_dw(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, N, Mo, F, pl);
+    const int fam = choose_dw(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, N, Mo, F, pl, bf16);
     const bool packed = fam == 2, plain = fam != 0, dw_split = fam == 3;
-    const bool dzvec = dw_dz_vec(dz, dz_sample_stride, lddz, dz2);
+    const bool dzvec = dw_dz_vec(dz, dz_sample_stride, lddz, dz2, bf16 ? 2 : 4);
     const long long need = pl.slab * pl.ngroups * pl.rsplit * (long long)sizeof(float);
     if (workspace_bytes < need) return CAPE_EWORKSPACE;
     DwParams p;
@@ -866,7 +974,7 @@ extern "C" int cape_gconv_dw_stage(const cape_src_t *srcs, int32_t nsrc, const f
     long long poff = 0;
     for (int i = 0; i < nsrc; ++i) {
         if (!srcs[i].w) return CAPE_EINVAL;
-        int rc = fill_src(p.s[i], srcs[i]);
+        int rc = fill_src(p.s[i], srcs[i], bf16 ? 2 : 4);
         if (rc) return rc;
         p.tile_off[i] = toff; p.part_off[i] = poff; rp.part_off[i] = poff;
         toff += packed ? 0 : pl.ctiles[i] * pl.ftiles;
@@ -883,9 +991,19 @@ extern "C" int cape_gconv_dw_stage(const cape_src_t *srcs, int32_t nsrc, const f
     p.ngroups = pl.ngroups; p.samples_per_group = pl.samples_per_group;
     p.ws = (float *)workspace; p.slab = pl.slab;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)(pl.ntiles * pl.ngroups * pl.rsplit)), block(256);
+    dim3 grid((unsigned)(pl.ntiles * ((pl.ngroups * pl.rsplit + 7) / 8) * 8)), block(256);     // cape_map_dw_block
     if (stage == 2) {
         // reduction only: the partial slabs of an earlier stage-1 call with the same arguments are in the workspace
+    } else if (bf16 && dw_split) {
+        if (pl.ct == 64 && pl.ft == 64) CAPE_LAUNCH((dw_split_kernel<64, 64, cape_bf16>), grid, block, 0, st, p);
+        else if (pl.ct == 64) CAPE_LAUNCH((dw_split_kernel<64, 128, cape_bf16>), grid, block, 0, st, p);
+        else if (pl.ft == 64) CAPE_LAUNCH((dw_split_kernel<128, 64, cape_bf16>), grid, block, 0, st, p);
+        else CAPE_LAUNCH((dw_split_kernel<128, 128, cape_bf16>), grid, block, 0, st, p);
+    } else if (bf16) {
+        if (pl.ct == 64 && pl.ft == 64) CAPE_LAUNCH((gconv_dw_kernel<64, 64, cape_bf16>), grid, block, 0, st, p);
+        else if (pl.ct == 64) CAPE_LAUNCH((gconv_dw_kernel<64, 128, cape_bf16>), grid, block, 0, st, p);
+        else if (pl.ft == 64) CAPE_LAUNCH((gconv_dw_kernel<128, 64, cape_bf16>), grid, block, 0, st, p);
+        else CAPE_LAUNCH((gconv_dw_kernel<128, 128, cape_bf16>), grid, block, 0, st, p);
     } else
     if (packed) {
         if (pl.ft == 32) CAPE_LAUNCH((dw_packed_kernel<128, 32, 4, 1>), grid, block, 0, st, p);
@@ -923,3 +1041,4 @@ extern "C" int cape_gconv_dw_stage(const cape_src_t *srcs, int32_t nsrc, const f
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }
+}  // namespace

@@ -6,7 +6,7 @@
 namespace {
 
 struct SrcDev {
-    const float *x;
+    const float *x;   // activations; reinterpreted as cape_bf16 by the bf16-storage kernels (strides in elements)
     long long xs;
     int ldx, C;
     const int *rp;
@@ -65,14 +65,15 @@ struct DwParams {
 // Epilogue of one workgroup tile: rank-1 condition terms, bias + activation (or, in DUAL mode,
 // relu(acc) + acc2 with the ReLU sign bitmask), store.  Accumulator layout of the 32x32 MFMA:
 // col = lane & 31, row = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5).
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool DUAL>
+// AT = storage type of the OUTPUT (p.y is reinterpreted; strides are in elements of AT).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool DUAL, typename AT = float>
 __device__ __forceinline__ void gconv_epilogue(const GconvParams &p,
                                                f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
                                                f32x16 (&acc2)[DUAL ? BM / WAVES_M / 32 : 1][DUAL ? BN / WAVES_N / 32 : 1],
                                                int n, int r0, int f0, int wm, int wn, int li, int lh) {
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    float *yb = p.y + (long long)n * p.ys;
+    AT *yb = reinterpret_cast<AT *>(p.y) + (long long)n * p.ys;
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -116,7 +117,7 @@ __device__ __forceinline__ void gconv_epilogue(const GconvParams &p,
                     }
                     v = cape_act(v, p.act);
                 }
-                if (ok) yb[(long long)r * p.ldy + fm] = v;
+                if (ok) cape_st(&yb[(long long)r * p.ldy + fm], v);
             }
         }
     }

@@ -283,8 +283,8 @@ __global__ __launch_bounds__(256, 2) void dw_plain_kernel(DwParams p) {
     const int li = lane & 31, lh = lane >> 5;
 
     const int ntiles = p.tile_off[p.nsrc];
-    const int tile = blockIdx.x % ntiles;
-    const int split = blockIdx.x / ntiles;   // split = group * rsplit + rs
+    int tile, split;                                  // split = group * rsplit + rs
+    if (!cape_map_dw_block(blockIdx.x, ntiles, p.ngroups * p.rsplit, tile, split)) return;
     const int grp = split / p.rsplit;
     const int rs = split % p.rsplit;
     const int n_begin = grp * p.samples_per_group;
@@ -440,8 +440,8 @@ __global__ __launch_bounds__(256, 2) void dw_packed_kernel(DwParams p) {
 
     const int V = p.vstart[p.nsrc];
     const int ntiles = ((V + CT - 1) / CT) * p.ftiles;
-    const int tile = blockIdx.x % ntiles;
-    const int split = blockIdx.x / ntiles;   // split = group * rsplit + rs
+    int tile, split;                                  // split = group * rsplit + rs
+    if (!cape_map_dw_block(blockIdx.x, ntiles, p.ngroups * p.rsplit, tile, split)) return;
     const int grp = split / p.rsplit;
     const int rs = split % p.rsplit;
     const int n_begin = grp * p.samples_per_group;

@@ -22,6 +22,7 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned gs_u32x4 __attribute__((ext_vector_type(4)));      // native vector: stays in registers when held in arrays
 
 #ifndef CAPE_GEMM_BF16X6_DEFAULT
 #define CAPE_GEMM_BF16X6_DEFAULT 1
@@ -94,20 +95,44 @@ __device__ __forceinline__ void gs_store8(unsigned char *dst, int plane, const f
     *reinterpret_cast<uint4 *>(dst + 2 * plane) = lo;
 }
 
+// NP = 3: the exact three-way split of fp32 operands above; NP = 1: bf16-storage launches (cape_*_bf16 entry points),
+// one round-to-nearest bf16 value per element (exact when the element already is a bf16 number) and ONE MFMA product
+// per multiply-add.
+// piece indices (0 = hi, 1 = mid, 2 = lo) of the six products, smallest first: A = {0,2,1,0,1,0}, B = {2,0,1,1,0,0};
+// the single product of the one-plane (bf16 storage) form is (0, 0)
+__device__ __forceinline__ constexpr int gs_ta(int np, int t) { return np == 1 ? 0 : (t == 1 ? 2 : ((t == 2 || t == 4) ? 1 : 0)); }
+__device__ __forceinline__ constexpr int gs_tb(int np, int t) { return np == 1 ? 0 : (t == 0 ? 2 : ((t == 2 || t == 3) ? 1 : 0)); }
+
+template <int NP>
+__device__ __forceinline__ void gs_store8_np(unsigned char *dst, int plane, const float (&v)[8]) {
+    if constexpr (NP == 3) {
+        gs_store8(dst, plane, v);
+    } else {
+        uint4 h;
+        h.x = cape_pack_bf16(v[0], v[1]); h.y = cape_pack_bf16(v[2], v[3]);
+        h.z = cape_pack_bf16(v[4], v[5]); h.w = cape_pack_bf16(v[6], v[7]);
+        *reinterpret_cast<uint4 *>(dst) = h;
+    }
+}
+
 // Workgroup tile BM x BN, 4 waves as 2 x 2, wave tile (BM/2) x (BN/2).  DUAL: sources may carry a second weight set
 // (w2) accumulated into a second tile, combined as relu(acc) + acc2 by the shared epilogue (res_block_affine,
 // reference lib/models.py:776-793); its LDS holds a third group of planes, so the DUAL tile is 128 x 64.
-template <int BM, int BN, bool BKC, bool DUAL = false>
+// AT = float: fp32 activations, three bf16 planes per operand, six products.  AT = cape_bf16: activations (sources and
+// output) stored as bf16, weights still fp32 in HBM (rounded to bf16 while staged), one plane, one product, fp32 accumulate.
+template <int BM, int BN, bool BKC, bool DUAL = false, typename AT = float>
 __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_BIG_MINB : 4) void gemm_split_kernel(GconvParams p) {
+    constexpr bool BF = cape_is_bf16<AT>::value;
+    constexpr int NP = BF ? 1 : 3;
     constexpr int WTM = BM / 2, WTN = BN / 2;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int PA = BM / 64, PB = BN / 64;      // staging passes of the k-contiguous form: 64 rows x 4 eight-float groups
     constexpr int KPT = BN / 8;                     // [k][n] weight staging: one output column, KPT consecutive k per thread
     constexpr int APLANE = BM * GS_PITCH, BPLANE = BN * GS_PITCH;
     static_assert(TM >= 1 && TN >= 1 && (BN == 64 || BN == 128), "tile");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * (APLANE + (DUAL ? 2 : 1) * BPLANE)];
-    unsigned char *sA = smem, *sB = smem + 3 * APLANE;
-    unsigned char *sB2 = sB + 3 * BPLANE;           // DUAL only
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NP * (APLANE + (DUAL ? 2 : 1) * BPLANE)];
+    unsigned char *sA = smem, *sB = smem + NP * APLANE;
+    unsigned char *sB2 = sB + NP * BPLANE;          // DUAL only
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
@@ -144,13 +169,14 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_B
 
     // ---- loader cursor: source l_si, channel offset l_c0 (every source is a whole number of chunks)
     int l_si = 0, l_c0 = 0, l_C = 0;
-    const float *l_x = nullptr, *l_w = nullptr, *l_w2 = nullptr;
+    const AT *l_x = nullptr;
+    const float *l_w = nullptr, *l_w2 = nullptr;
     long long l_wrs = 0, l_w2rs = 0;
     int arow[PA], brow[PB], brow2[DUAL ? PB : 1];
     auto open_source = [&]() {
         const SrcDev &S = p.s[l_si];
         l_C = S.C;
-        l_x = S.x + (long long)n * S.xs;
+        l_x = reinterpret_cast<const AT *>(S.x) + (long long)n * S.xs;
         l_w = S.w;
         l_wrs = S.wrs;
         if constexpr (DUAL) {
@@ -169,6 +195,7 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_B
     };
 
     float4 ra[PA][2];
+    gs_u32x4 rab[PA];                                 // bf16 storage: 8 consecutive elements = one 16-byte load, staged as is
     float rbv[BKC ? PB : 1][BKC ? 8 : KPT];
     float rbv2[DUAL ? (BKC ? PB : 1) : 1][DUAL ? (BKC ? 8 : KPT) : 1];
     bool s_has2 = false;                            // of the chunk held in the staging registers
@@ -176,8 +203,12 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_B
         const int c = l_c0 + 8 * q;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            ra[i][0] = *reinterpret_cast<const float4 *>(l_x + arow[i] + c);
-            ra[i][1] = *reinterpret_cast<const float4 *>(l_x + arow[i] + c + 4);
+            if constexpr (BF) {
+                rab[i] = *reinterpret_cast<const gs_u32x4 *>(l_x + arow[i] + c);
+            } else {
+                ra[i][0] = *reinterpret_cast<const float4 *>(l_x + arow[i] + c);
+                ra[i][1] = *reinterpret_cast<const float4 *>(l_x + arow[i] + c + 4);
+            }
         }
         if constexpr (BKC) {
 #pragma unroll
@@ -221,31 +252,36 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_B
     auto store_regs = [&]() {
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            const float v[8] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w, ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
-            gs_store8(sA + (r + 64 * i) * GS_PITCH + 16 * gs_seg(r + 64 * i, q), APLANE, v);
+            unsigned char *dst = sA + (r + 64 * i) * GS_PITCH + 16 * gs_seg(r + 64 * i, q);
+            if constexpr (BF) {
+                *reinterpret_cast<gs_u32x4 *>(dst) = rab[i];
+            } else {
+                const float v[8] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w, ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
+                gs_store8(dst, APLANE, v);
+            }
         }
         if constexpr (BKC) {
 #pragma unroll
-            for (int i = 0; i < PB; ++i) gs_store8(sB + (r + 64 * i) * GS_PITCH + 16 * gs_seg(r + 64 * i, q), BPLANE, rbv[i]);
+            for (int i = 0; i < PB; ++i) gs_store8_np<NP>(sB + (r + 64 * i) * GS_PITCH + 16 * gs_seg(r + 64 * i, q), BPLANE, rbv[i]);
         } else {
 #pragma unroll
             for (int g = 0; g < KPT / 8; ++g) {
                 const float v[8] = {rbv[0][8 * g + 0], rbv[0][8 * g + 1], rbv[0][8 * g + 2], rbv[0][8 * g + 3],
                                     rbv[0][8 * g + 4], rbv[0][8 * g + 5], rbv[0][8 * g + 6], rbv[0][8 * g + 7]};
-                gs_store8(sB + bcol * GS_PITCH + 16 * gs_seg(bcol, kg * (KPT / 8) + g), BPLANE, v);
+                gs_store8_np<NP>(sB + bcol * GS_PITCH + 16 * gs_seg(bcol, kg * (KPT / 8) + g), BPLANE, v);
             }
         }
         if constexpr (DUAL) {
             if (s_has2) {
                 if constexpr (BKC) {
 #pragma unroll
-                    for (int i = 0; i < PB; ++i) gs_store8(sB2 + (r + 64 * i) * GS_PITCH + 16 * gs_seg(r + 64 * i, q), BPLANE, rbv2[i]);
+                    for (int i = 0; i < PB; ++i) gs_store8_np<NP>(sB2 + (r + 64 * i) * GS_PITCH + 16 * gs_seg(r + 64 * i, q), BPLANE, rbv2[i]);
                 } else {
 #pragma unroll
                     for (int g = 0; g < KPT / 8; ++g) {
                         const float v[8] = {rbv2[0][8 * g + 0], rbv2[0][8 * g + 1], rbv2[0][8 * g + 2], rbv2[0][8 * g + 3],
                                             rbv2[0][8 * g + 4], rbv2[0][8 * g + 5], rbv2[0][8 * g + 6], rbv2[0][8 * g + 7]};
-                        gs_store8(sB2 + bcol * GS_PITCH + 16 * gs_seg(bcol, kg * (KPT / 8) + g), BPLANE, v);
+                        gs_store8_np<NP>(sB2 + bcol * GS_PITCH + 16 * gs_seg(bcol, kg * (KPT / 8) + g), BPLANE, v);
                     }
                 }
             }
@@ -261,42 +297,41 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_B
 #pragma unroll
         for (int ks = 0; ks < GS_KC / 16; ++ks) {
             const int so = 16 * gs_seg(li, lh + 2 * ks);             // byte offset of this lane's 16-byte segment
-            bf16x8 af[TM][3], bf[TN][3];
+            bf16x8 af[TM][NP], bf[TN][NP];
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
+                for (int pc = 0; pc < NP; ++pc)
                     af[a][pc] = *reinterpret_cast<const bf16x8 *>(pa + pc * APLANE + a * 32 * GS_PITCH + so);
 #pragma unroll
             for (int b = 0; b < TN; ++b)
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
+                for (int pc = 0; pc < NP; ++pc)
                     bf[b][pc] = *reinterpret_cast<const bf16x8 *>(pb + pc * BPLANE + b * 32 * GS_PITCH + so);
-            // piece indices (0 = hi, 1 = mid, 2 = lo) of the six products, smallest first
-            constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
-            constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
+            // piece indices (0 = hi, 1 = mid, 2 = lo) of the six products, smallest first (bf16 storage: the one product)
+            constexpr int NT = NP == 3 ? 6 : 1;
 #pragma unroll
-            for (int term = 0; term < 6; ++term)
+            for (int term = 0; term < NT; ++term)
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][TA[term]], bf[b][TB[term]], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][gs_ta(NP, term)], bf[b][gs_tb(NP, term)], acc[a][b], 0, 0, 0);
             if constexpr (DUAL) {
                 if (has2) {
-                    bf16x8 bf2[TN][3];
+                    bf16x8 bf2[TN][NP];
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
 #pragma unroll
-                        for (int pc = 0; pc < 3; ++pc)
-                            bf2[b][pc] = *reinterpret_cast<const bf16x8 *>(pb + 3 * BPLANE + pc * BPLANE + b * 32 * GS_PITCH + so);
+                        for (int pc = 0; pc < NP; ++pc)
+                            bf2[b][pc] = *reinterpret_cast<const bf16x8 *>(pb + NP * BPLANE + pc * BPLANE + b * 32 * GS_PITCH + so);
 #pragma unroll
-                    for (int term = 0; term < 6; ++term)
+                    for (int term = 0; term < NT; ++term)
 #pragma unroll
                         for (int a = 0; a < TM; ++a)
 #pragma unroll
                             for (int b = 0; b < TN; ++b)
-                                acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][TA[term]], bf2[b][TB[term]], acc2[a][b], 0, 0, 0);
+                                acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][gs_ta(NP, term)], bf2[b][gs_tb(NP, term)], acc2[a][b], 0, 0, 0);
                 }
             }
         }
@@ -318,7 +353,7 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_B
     }
 
     if (DUAL || p.rankR > 0 || p.bias_mode == CAPE_BIAS_VERTEX || p.act == CAPE_ACT_TANH) {
-        gconv_epilogue<BM, BN, 2, 2, DUAL>(p, acc, acc2, n, r0, f0, wm, wn, li, lh);
+        gconv_epilogue<BM, BN, 2, 2, DUAL, AT>(p, acc, acc2, n, r0, f0, wm, wn, li, lh);
         return;
     }
     // Short epilogue for the common launches (no rank-1 terms; channel bias or none; identity / ReLU / leaky ReLU as
@@ -326,7 +361,7 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_B
     // not hidden behind other workgroups' multiplies: the general one (uniform branches per element) cost ~10 us here.
     const float slope = p.act == CAPE_ACT_LEAKY ? 0.2f : 1.f;
     const bool relu = p.act == CAPE_ACT_RELU;
-    float *yb = p.y + (long long)n * p.ys;
+    AT *yb = reinterpret_cast<AT *>(p.y) + (long long)n * p.ys;
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -340,7 +375,7 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_B
                 const int row = r0 + wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
                 float v = acc[a][b][g] + bch;
                 v = v > 0.f ? v : (relu ? 0.f : slope * v);
-                if (fok && row < p.Mo) yb[(long long)row * p.ldy + fm] = v;
+                if (fok && row < p.Mo) cape_st(&yb[(long long)row * p.ldy + fm], v);
             }
         }
 }
@@ -352,16 +387,17 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_B
 // (loads coalesced over the channels), splits them and writes one 16-byte row segment per piece plane [channel][row].
 // Requires: sources plain, C % 4 == 0, 16-byte aligned rows; dz likewise with F % 2 == 0.
 // =============================================================================================================
-template <int CT, int FT>
+template <int CT, int FT, typename AT = float>
 __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? GS_BIG_MINB : 3) void dw_split_kernel(DwParams p) {
+    constexpr int NP = cape_is_bf16<AT>::value ? 1 : 3;       // see gemm_split_kernel
     constexpr int RK = 32;
     constexpr int WTM = CT / 2, WTN = FT / 2;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int CPA = CT / 64, CPB = FT / 64;      // channels per thread (8 rows each): 64 lanes x CP channels = one tile row
     constexpr int APLANE = CT * GS_PITCH, BPLANE = FT * GS_PITCH;
     static_assert(TM >= 1 && TN >= 1 && (CT == 64 || CT == 128) && (FT == 64 || FT == 128), "tile");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * (APLANE + BPLANE)];
-    unsigned char *sA = smem, *sB = smem + 3 * APLANE;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NP * (APLANE + BPLANE)];
+    unsigned char *sA = smem, *sB = smem + NP * APLANE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
@@ -369,8 +405,8 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? GS_BIG_MINB : 3) void
     const int ca = (tid & 63) * CPA, fb = (tid & 63) * CPB;
 
     const int ntiles = p.tile_off[p.nsrc];
-    const int tile = blockIdx.x % ntiles;
-    const int split = blockIdx.x / ntiles;            // split = group * rsplit + rs
+    int tile, split;                                  // split = group * rsplit + rs
+    if (!cape_map_dw_block(blockIdx.x, ntiles, p.ngroups * p.rsplit, tile, split)) return;
     const int grp = split / p.rsplit;
     const int rs = split % p.rsplit;
     const int n_begin = grp * p.samples_per_group;
@@ -395,7 +431,7 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? GS_BIG_MINB : 3) void
     // columns beyond C / F are read from column 0 and feed output rows / columns that are never stored
     const int a_col = (c0 + ca < S.C) ? c0 + ca : 0;
     const int b_col = (f0 + fb < p.F) ? f0 + fb : 0;
-    const float *dz0 = ((p.dz2_mask >> si) & 1u) ? p.dz2 : p.dz;
+    const AT *dz0 = reinterpret_cast<const AT *>(((p.dz2_mask >> si) & 1u) ? p.dz2 : p.dz);
 
     const int chunks = (rb - ra + RK - 1) / RK;
     const int total = (n_end - n_begin) * chunks;
@@ -404,8 +440,8 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? GS_BIG_MINB : 3) void
     unsigned ok = 0;
 
     auto load_regs = [&]() {
-        const float *xb = S.x + (long long)l_n * S.xs + a_col;
-        const float *zb = dz0 + (long long)l_n * p.dzs + b_col;
+        const AT *xb = reinterpret_cast<const AT *>(S.x) + (long long)l_n * S.xs + a_col;
+        const AT *zb = dz0 + (long long)l_n * p.dzs + b_col;
         ok = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -413,16 +449,16 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? GS_BIG_MINB : 3) void
             ok |= (r < rb ? 1u : 0u) << j;
             const int rr = min(r, rb - 1);
             if constexpr (CPA == 2) {
-                const float2 v = *reinterpret_cast<const float2 *>(xb + (long long)rr * S.ldx);
+                const float2 v = cape_ld2(xb + (long long)rr * S.ldx);
                 xa[0][j] = v.x; xa[1][j] = v.y;
             } else {
-                xa[0][j] = xb[(long long)rr * S.ldx];
+                xa[0][j] = cape_ld(xb + (long long)rr * S.ldx);
             }
             if constexpr (CPB == 2) {
-                const float2 v = *reinterpret_cast<const float2 *>(zb + (long long)rr * p.lddz);
+                const float2 v = cape_ld2(zb + (long long)rr * p.lddz);
                 xz[0][j] = v.x; xz[1][j] = v.y;
             } else {
-                xz[0][j] = zb[(long long)rr * p.lddz];
+                xz[0][j] = cape_ld(zb + (long long)rr * p.lddz);
             }
         }
         l_r += RK;
@@ -435,14 +471,14 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? GS_BIG_MINB : 3) void
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = ((ok >> j) & 1u) ? xa[ch][j] : 0.f;
-            gs_store8(sA + (ca + ch) * GS_PITCH + 16 * gs_seg(ca + ch, rg), APLANE, v);
+            gs_store8_np<NP>(sA + (ca + ch) * GS_PITCH + 16 * gs_seg(ca + ch, rg), APLANE, v);
         }
 #pragma unroll
         for (int ch = 0; ch < CPB; ++ch) {
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = ((ok >> j) & 1u) ? xz[ch][j] : 0.f;
-            gs_store8(sB + (fb + ch) * GS_PITCH + 16 * gs_seg(fb + ch, rg), BPLANE, v);
+            gs_store8_np<NP>(sB + (fb + ch) * GS_PITCH + 16 * gs_seg(fb + ch, rg), BPLANE, v);
         }
     };
     auto compute = [&]() {
@@ -451,26 +487,25 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? GS_BIG_MINB : 3) void
 #pragma unroll
         for (int ks = 0; ks < RK / 16; ++ks) {
             const int so = 16 * gs_seg(li, lh + 2 * ks);
-            bf16x8 af[TM][3], bf[TN][3];
+            bf16x8 af[TM][NP], bf[TN][NP];
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
+                for (int pc = 0; pc < NP; ++pc)
                     af[a][pc] = *reinterpret_cast<const bf16x8 *>(pa + pc * APLANE + a * 32 * GS_PITCH + so);
 #pragma unroll
             for (int b = 0; b < TN; ++b)
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
+                for (int pc = 0; pc < NP; ++pc)
                     bf[b][pc] = *reinterpret_cast<const bf16x8 *>(pb + pc * BPLANE + b * 32 * GS_PITCH + so);
-            constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
-            constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
+            constexpr int NT = NP == 3 ? 6 : 1;
 #pragma unroll
-            for (int term = 0; term < 6; ++term)
+            for (int term = 0; term < NT; ++term)
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][TA[term]], bf[b][TB[term]], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][gs_ta(NP, term)], bf[b][gs_tb(NP, term)], acc[a][b], 0, 0, 0);
         }
     };
 
@@ -523,17 +558,23 @@ inline void gs_tile(bool dual, int N, int Mo, int F, int &BM, int &BN) {
     else { BM = 64; BN = 64; }
 }
 
-inline void gs_launch(const GconvParams &p, bool dual, int BM, int layout, dim3 grid, hipStream_t st) {
+template <typename AT>
+inline void gs_launch_t(const GconvParams &p, bool dual, int BM, int layout, dim3 grid, hipStream_t st) {
     if (dual) {
-        if (layout == 1) CAPE_LAUNCH((gemm_split_kernel<128, 64, true, true>), grid, dim3(256), 0, st, p);
-        else CAPE_LAUNCH((gemm_split_kernel<128, 64, false, true>), grid, dim3(256), 0, st, p);
+        if (layout == 1) CAPE_LAUNCH((gemm_split_kernel<128, 64, true, true, AT>), grid, dim3(256), 0, st, p);
+        else CAPE_LAUNCH((gemm_split_kernel<128, 64, false, true, AT>), grid, dim3(256), 0, st, p);
     } else if (BM == 128) {
-        if (layout == 1) CAPE_LAUNCH((gemm_split_kernel<128, 128, true>), grid, dim3(256), 0, st, p);
-        else CAPE_LAUNCH((gemm_split_kernel<128, 128, false>), grid, dim3(256), 0, st, p);
+        if (layout == 1) CAPE_LAUNCH((gemm_split_kernel<128, 128, true, false, AT>), grid, dim3(256), 0, st, p);
+        else CAPE_LAUNCH((gemm_split_kernel<128, 128, false, false, AT>), grid, dim3(256), 0, st, p);
     } else {
-        if (layout == 1) CAPE_LAUNCH((gemm_split_kernel<64, 64, true>), grid, dim3(256), 0, st, p);
-        else CAPE_LAUNCH((gemm_split_kernel<64, 64, false>), grid, dim3(256), 0, st, p);
+        if (layout == 1) CAPE_LAUNCH((gemm_split_kernel<64, 64, true, false, AT>), grid, dim3(256), 0, st, p);
+        else CAPE_LAUNCH((gemm_split_kernel<64, 64, false, false, AT>), grid, dim3(256), 0, st, p);
     }
+}
+
+inline void gs_launch(const GconvParams &p, bool dual, int BM, int layout, bool bf16, dim3 grid, hipStream_t st) {
+    if (bf16) gs_launch_t<cape_bf16>(p, dual, BM, layout, grid, st);
+    else gs_launch_t<float>(p, dual, BM, layout, grid, st);
 }
 
 }  // namespace

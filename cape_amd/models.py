@@ -353,8 +353,18 @@ class CAPE(base_model):
 
     def __init__(self, L, D, U, L_d, D_d, lr_scaler, lambda_gan, use_res_block, use_res_block_dec, nz_cond2,
                  cond2_dim, Kd, n_layer_cond=1, cond_encoder=True, reduce_dim=True, affine=False,
-                 lr_warmup=False, optim_condnet=True, bug_compat=False, **kwargs):
+                 lr_warmup=False, optim_condnet=True, bug_compat=False, act_dtype='fp32', **kwargs):
         super(CAPE, self).__init__(L, D, U, **kwargs)
+        # Storage type of the mesh activations [N, M, C] (an extension over the reference, whose placeholders are fp32,
+        # :272-282): 'fp32' = the parity path; 'bf16' = BASELINE configs[4] -- activations and their gradients live in HBM
+        # as bf16, the contractions compute with bf16 operands and fp32 accumulation, variables / optimiser state / the
+        # dense layers / losses stay fp32 (master weights).
+        if act_dtype not in ('fp32', 'bf16', torch.float32, torch.bfloat16):
+            raise ValueError("act_dtype must be 'fp32' or 'bf16'")
+        self.act_dtype = torch.bfloat16 if act_dtype in ('bf16', torch.bfloat16) else torch.float32
+        if self.act_dtype == torch.bfloat16 and (use_res_block or (use_res_block_dec and not affine)):
+            raise NotImplementedError("bf16 activation storage covers the cnp encoder with the affine / udn decoders "
+                                      "(the res_block and group-norm kernels read fp32)")
         self.Laplacian_d, self.Downsample_mtx_d = L_d, D_d
         self.Laplacian, self.Downsample_mtx, self.Upsample_mtx = L, D, U
         self.poly_order_d = [Kd] * len(self.out_channels)
@@ -490,6 +500,8 @@ class CAPE(base_model):
         cond_in = torch.cat([y, y2], 1) if use_cond else None
         if cond_in is not None and use_res_block:
             x, cond_in = ops.ConcatCondFn.apply(x, cond_in), None      # res_block reads its input twice
+        if x.dtype != self.act_dtype:
+            x = x.to(self.act_dtype)                                   # bf16 storage: the mesh tensors from here on
         with self.variable_scope('encoder'):
             for i in range(len(self.out_channels)):
                 if use_res_block:
@@ -506,6 +518,8 @@ class CAPE(base_model):
                 x = x.detach().requires_grad_(True)
                 self._enc_feat_cut = x
             x = x.reshape(x.shape[0], -1)
+            if x.dtype != torch.float32:
+                x = x.float()                                          # the dense layers (fp32 master weights) read fp32
             with self.variable_scope('fc_mean'):
                 km, bm, gm = self._dense_vars(int(x.shape[-1]), int(self.nz))
             with self.variable_scope('fc_var'):
@@ -526,6 +540,8 @@ class CAPE(base_model):
                 out_nodes = int(self.p[-1] * self.out_channels[-1]) // self.reduce_rate
                 x = self._dense(x, out_nodes, activation='leaky_relu')
             x = x.reshape(N, int(self.p[-1]), -1)
+            if x.dtype != self.act_dtype:
+                x = x.to(self.act_dtype)
             if self.reduce_dim > 0:
                 with self.variable_scope('1x1-conv'):
                     if self._fusable():
@@ -560,7 +576,7 @@ class CAPE(base_model):
                     x = self.filter(x, self.Laplacian[0], Fo, self.poly_order[0]) + b
         if not materialise:
             self._cond_bank_end()
-        return x
+        return x.float() if x.dtype != torch.float32 else x           # losses and callers see fp32
 
     def generator(self, x, y, y2, eps=None):
         with self.variable_scope('generator'):
@@ -576,6 +592,8 @@ class CAPE(base_model):
 
     def discriminator(self, x, y, y2):
         cond = torch.cat([y, y2], 1)
+        if x.dtype != self.act_dtype:
+            x = x.to(self.act_dtype)
         with self.variable_scope('discriminator'):
             with self.variable_scope('shared'):
                 for i in range(len(self.Downsample_mtx_d)):
@@ -584,7 +602,7 @@ class CAPE(base_model):
                 # poly_order[-1] (=2), not poly_order_d: reference quirk C3 (:676), kept for
                 # checkpoint-shape compatibility
                 pred_map = self.filter(x, self.Laplacian_d[-1], 1, self.poly_order[-1])
-        return pred_map
+        return pred_map.float() if pred_map.dtype != torch.float32 else pred_map
 
     # ======================= losses (reference :354-416) ==========================================
     def _edge_tables(self):

@@ -34,16 +34,25 @@ def _pad4(c):
     return (int(c) + 3) // 4 * 4
 
 
-def alloc_act(N, M, Cn, device, zero=False):
-    """[N, M, C] view of a fresh [N, M, pad4(C)] buffer."""
-    ld = _pad4(Cn)
-    buf = (torch.zeros if zero else torch.empty)((N, M, ld), device=device, dtype=torch.float32)
+ACT_DTYPES = (torch.float32, torch.bfloat16)     # activation storage types (bf16: BASELINE configs[4], the *_bf16 C entry points)
+
+
+def alloc_act(N, M, Cn, device, zero=False, dtype=torch.float32):
+    """[N, M, C] view of a fresh buffer whose rows are padded to 16 bytes (4 fp32 / 8 bf16 elements)."""
+    q = 4 if dtype == torch.float32 else 8
+    ld = (int(Cn) + q - 1) // q * q
+    buf = (torch.zeros if zero else torch.empty)((N, M, ld), device=device, dtype=dtype)
     return buf[:, :, :Cn] if ld != Cn else buf
 
 
+def _fn(name, t):
+    """The C entry point ``name`` for the storage type of activation tensor ``t``."""
+    return getattr(lib, name + "_bf16") if t.dtype == torch.bfloat16 else getattr(lib, name)
+
+
 def as_act(t):
-    """Make ``t`` [N, M, C] usable by the kernels (unit channel stride, fp32, on device)."""
-    assert t.dim() == 3 and t.dtype == torch.float32 and t.is_cuda
+    """Make ``t`` [N, M, C] usable by the kernels (unit channel stride, fp32 or bf16 storage, on device)."""
+    assert t.dim() == 3 and t.dtype in ACT_DTYPES and t.is_cuda
     if t.stride(2) != 1 and t.shape[2] != 1:
         t = t.contiguous()
     if t.shape[1] > 1 and t.stride(1) < t.shape[2]:
@@ -143,7 +152,8 @@ PLAN_LOG = None
 def _gconv_work(entries, N, Mo, F):
     """Algorithmic work of one gather-GEMM launch: dense contraction 2*N*Mo*C*F per weight block plus
     2*N*nnz*C for the sparse operator application; bytes = operands touched once (fp32)."""
-    flops, byts = 0, 4 * N * Mo * F
+    es = entries[0]["x"].element_size()
+    flops, byts = 0, es * N * Mo * F
     seen = set()
     for e in entries:
         Cs = int(e.get("C", e["x"].shape[2]))
@@ -157,14 +167,15 @@ def _gconv_work(entries, N, Mo, F):
         key = e["x"].data_ptr()
         if key not in seen:
             seen.add(key)
-            byts += 4 * N * e["x"].shape[1] * Cs
+            byts += es * N * e["x"].shape[1] * Cs
     return flops, byts
 
 
 def _dw_work(entries, N, Mo, F, two_dz):
     """Weight-gradient launch: 2*N*Mo*C*F per source; every distinct source and gradient operand read once, every
     gradient block written once."""
-    flops, byts = 0, 4 * N * Mo * F * (2 if two_dz else 1)
+    es = entries[0]["x"].element_size()
+    flops, byts = 0, es * N * Mo * F * (2 if two_dz else 1)
     seen = set()
     for e in entries:
         Cs = int(e.get("C", e["x"].shape[2]))
@@ -173,7 +184,7 @@ def _dw_work(entries, N, Mo, F, two_dz):
         key = e["x"].data_ptr()
         if key not in seen:
             seen.add(key)
-            byts += 4 * N * e["x"].shape[1] * Cs
+            byts += es * N * e["x"].shape[1] * Cs
     return flops, byts
 
 
@@ -196,20 +207,21 @@ _FWD_FAMILY = {0: "gconv_fwd_kernel", 1: "gemm_plain_kernel", 2: "gemm_split_ker
 _DW_FAMILY = {0: "gconv_dw_kernel", 1: "dw_plain_kernel", 2: "dw_packed_kernel", 3: "dw_split_kernel"}
 
 
-def fwd_kernel_name(fam, bm, bn, layout, dual):
+def fwd_kernel_name(fam, bm, bn, layout, dual, bf16=False):
     """Kernel instantiation name as rocprofv3 prints it."""
     waves = "2, 2" if (bm, bn) in ((64, 128), (128, 128), (64, 64)) else "4, 1"
     tf = lambda b: "true" if b else "false"
+    at = ", unsigned short" if bf16 else ", float"
     if fam == 2:
-        return "gemm_split_kernel<%d, %d, %s, %s>" % (bm, bn, tf(layout), tf(dual))
+        return "gemm_split_kernel<%d, %d, %s, %s%s>" % (bm, bn, tf(layout), tf(dual), at)
     if fam == 1:
         return "gemm_plain_kernel<%d, %d, %s, %s, %s>" % (bm, bn, waves, tf(dual), tf(layout))
-    return "gconv_fwd_kernel<%d, %d, %s, %s, 32>" % (bm, bn, waves, tf(dual))
+    return "gconv_fwd_kernel<%d, %d, %s, %s, 32%s>" % (bm, bn, waves, tf(dual), at)
 
 
-def dw_kernel_name(fam, ct, ft):
+def dw_kernel_name(fam, ct, ft, bf16=False):
     if fam == 3 or fam == 0:
-        return "%s<%d, %d>" % (_DW_FAMILY[fam], ct, ft)
+        return "%s<%d, %d, %s>" % (_DW_FAMILY[fam], ct, ft, "unsigned short" if bf16 else "float")
     waves = "4, 1" if (fam == 2 and ft == 32) else "2, 2"
     return "%s<%d, %d, %s>" % (_DW_FAMILY[fam], ct, ft, waves)
 
@@ -232,8 +244,10 @@ def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=
         assert rowscale.shape[1] == Mo and rowscale.shape[0] >= coef.shape[1]
         rk = _lib.CapeRank(int(coef.shape[1]), rowscale.data_ptr(), coef.data_ptr(), int(to2))
 
+    assert all(e["x"].dtype == y.dtype for e in entries), "sources and output share one storage type"
+
     def launch():
-        rc = lib.cape_gconv_fwd(arr, len(entries), p, ss, ld, N, Mo, F, _ptr(bias),
+        rc = _fn("cape_gconv_fwd", y)(arr, len(entries), p, ss, ld, N, Mo, F, _ptr(bias),
                                 bias_mode if bias is not None else _lib.BIAS_NONE, _lib.ACT[act],
                                 _ptr(mask), C.byref(rk) if rk is not None else None, int(deinterleave), _stream())
         check(rc, "cape_gconv_fwd")
@@ -244,12 +258,13 @@ def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=
         # the library reports the kernel it selects; names as rocprofv3 prints them
         dual = any(e.get("w2") is not None for e in entries)
         plan = (C.c_int32 * 4)()
-        check(lib.cape_gconv_fwd_plan(arr, len(entries), N, Mo, F, plan), "cape_gconv_fwd_plan")
+        check(_fn("cape_gconv_fwd_plan", y)(arr, len(entries), N, Mo, F, plan), "cape_gconv_fwd_plan")
         fam, bm, bn, layout = list(plan)
+        bf = y.dtype == torch.bfloat16
         if PLAN_LOG is not None:
-            PLAN_LOG.add(("fwd", fam, bm, bn, layout, int(dual)))
+            PLAN_LOG.add(("fwd", fam, bm, bn, layout, int(dual)) + (("bf16",) if bf else ()))
         flops, byts = _gconv_work(entries, N, Mo, F)
-        _log_launch(fwd_kernel_name(fam, bm, bn, layout, dual), flops, byts, launch)
+        _log_launch(fwd_kernel_name(fam, bm, bn, layout, dual, bf), flops, byts, launch)
     return y
 
 
@@ -271,19 +286,22 @@ def gconv_dw(entries, dz, accumulate=False, dz2=None):
         for i, e in enumerate(entries):
             if e.get("use_dz2"):
                 mask |= 1 << i
+    assert all(e["x"].dtype == dz.dtype for e in entries), "sources and gradient share one storage type"
+    bf = dz.dtype == torch.bfloat16
+
     def launch():
-        rc = lib.cape_gconv_dw(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, 1 if accumulate else 0,
-                               C.c_void_p(ws.data_ptr()), need, _stream())
+        rc = _fn("cape_gconv_dw", dz)(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, 1 if accumulate else 0,
+                                      C.c_void_p(ws.data_ptr()), need, _stream())
         check(rc, "cape_gconv_dw")
 
     if LAUNCH_LOG is None and PLAN_LOG is None:
         launch()
     else:
         plan = (C.c_int32 * 4)()
-        check(lib.cape_gconv_dw_plan(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, plan), "cape_gconv_dw_plan")
+        check(_fn("cape_gconv_dw_plan", dz)(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, plan), "cape_gconv_dw_plan")
         fam, ct, ft, nslab = list(plan)
         if PLAN_LOG is not None:
-            PLAN_LOG.add(("dw", fam, ct, ft))
+            PLAN_LOG.add(("dw", fam, ct, ft) + (("bf16",) if bf else ()))
         if LAUNCH_LOG is None:
             launch()
             return
@@ -291,10 +309,10 @@ def gconv_dw(entries, dz, accumulate=False, dz2=None):
         sumCF = sum(int(e.get("C", e["x"].shape[2])) for e in entries) * F
 
         def stage(which):
-            check(lib.cape_gconv_dw_stage(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, 1 if accumulate else 0,
-                                          C.c_void_p(ws.data_ptr()), need, which, _stream()), "cape_gconv_dw_stage")
+            check(_fn("cape_gconv_dw_stage", dz)(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, 1 if accumulate else 0,
+                                                 C.c_void_p(ws.data_ptr()), need, which, _stream()), "cape_gconv_dw_stage")
         # the contraction kernel and its fixed-order slab reduction, each with its own bracket
-        _log_launch(dw_kernel_name(fam, ct, ft), flops, byts, lambda: stage(1))
+        _log_launch(dw_kernel_name(fam, ct, ft, bf), flops, byts, lambda: stage(1))
         _log_launch("dw_reduce", 0, 4 * sumCF * (nslab + 1), lambda: stage(2))
 
 
@@ -303,7 +321,9 @@ def spmm(x, csr, y=None, alpha=1.0, z=None, beta=0.0):
     N, Mi, Cn = x.shape
     Mo = csr.shape[0]
     if y is None:
-        y = alloc_act(N, Mo, Cn, x.device)
+        y = alloc_act(N, Mo, Cn, x.device, dtype=x.dtype)
+    assert y.dtype == x.dtype and (z is None or z.dtype == x.dtype)
+    es = x.element_size()
     xp, xs, xl = _v(x)
     yp, ys, yl = _v(y)
     if z is not None:
@@ -311,12 +331,12 @@ def spmm(x, csr, y=None, alpha=1.0, z=None, beta=0.0):
     else:
         zp, zs, zl = None, 0, 0
     def launch():
-        rc = lib.cape_spmm(xp, xs, xl, C.c_void_p(csr.rowptr_t.data_ptr()), C.c_void_p(csr.colidx_t.data_ptr()),
+        rc = _fn("cape_spmm", x)(xp, xs, xl, C.c_void_p(csr.rowptr_t.data_ptr()), C.c_void_p(csr.colidx_t.data_ptr()),
                            C.c_void_p(csr.vals_t.data_ptr()), int(csr.max_row if (csr.min_row >= 1 and SPMM_BOUNDED) else 0),
                            float(alpha), zp, zs, zl, float(beta), yp, ys, yl, N, Mo, Cn, _stream())
         check(rc, "cape_spmm")
 
-    _log_launch("spmm_kernel", 2 * N * csr.nnz * Cn, 4 * N * Cn * (Mi + Mo * (2 if z is not None else 1)) + 8 * csr.nnz + 4 * (Mo + 1),
+    _log_launch("spmm_kernel", 2 * N * csr.nnz * Cn, es * N * Cn * (Mi + Mo * (2 if z is not None else 1)) + 8 * csr.nnz + 4 * (Mo + 1),
                 launch)
     return y
 
@@ -344,22 +364,24 @@ def spmm_multi(xs, csrs, sum=False, scales=None):
         else:
             assert csrs[k].shape[0] == Mo and csrs[k].shape[1] == xs[k].shape[1]
             t.rowptr, t.colidx, t.vals = csrs[k].rowptr_t.data_ptr(), csrs[k].colidx_t.data_ptr(), csrs[k].vals_t.data_ptr()
+        assert xs[k].dtype == xs[0].dtype
         if not sum:
-            yk = alloc_act(N, Mo, Cn, xs[0].device)
+            yk = alloc_act(N, Mo, Cn, xs[0].device, dtype=xs[0].dtype)
             yp, t.y_sample_stride, t.ldy = _v(yk)
             t.y = yp.value
             outs.append(yk)
     if sum:
-        y = alloc_act(N, Mo, Cn, xs[0].device)
+        y = alloc_act(N, Mo, Cn, xs[0].device, dtype=xs[0].dtype)
         yp, ys, yl = _v(y)
     else:
         y, yp, ys, yl = None, None, 0, 0
-    flops, byts = 0, 4 * N * Mo * Cn * (1 if sum else n)        # (``sum`` is this function's flag, not the builtin)
+    es = xs[0].element_size()
+    flops, byts = 0, es * N * Mo * Cn * (1 if sum else n)       # (``sum`` is this function's flag, not the builtin)
     for k in range(n):
         flops += 2 * N * (Mo if ident[k] else csrs[k].nnz) * Cn
-        byts += 4 * N * Cn * xs[k].shape[1] + (0 if ident[k] else _csr_bytes(csrs[k]))
+        byts += es * N * Cn * xs[k].shape[1] + (0 if ident[k] else _csr_bytes(csrs[k]))
     _log_launch("spmm_multi_kernel", flops, byts,
-                lambda: check(lib.cape_spmm_multi(arr, n, 1 if sum else 0, yp, ys, yl, N, Mo, Cn, _stream()), "cape_spmm_multi"))
+                lambda: check(_fn("cape_spmm_multi", xs[0])(arr, n, 1 if sum else 0, yp, ys, yl, N, Mo, Cn, _stream()), "cape_spmm_multi"))
     return y if sum else outs
 
 
@@ -373,7 +395,7 @@ def spmm_combine(xs, csrs, y, to_acc2=0, rank=None, bias=None, bias_mode=_lib.BI
         t = arr[k]
         xp, t.x_sample_stride, t.ldx = _v(xs[k])
         t.x = xp.value
-        assert xs[k].shape[2] == F
+        assert xs[k].shape[2] == F and xs[k].dtype == y.dtype
         t.scale = 1.0
         if csrs[k] is None or csrs[k].identity:
             t.rowptr = t.colidx = t.vals = None
@@ -388,9 +410,10 @@ def spmm_combine(xs, csrs, y, to_acc2=0, rank=None, bias=None, bias_mode=_lib.BI
         rk = _lib.CapeRank(int(coef.shape[1]), rowscale.data_ptr(), coef.data_ptr(), int(to2))
     yp, ys, yl = _v(y)
     flops = sum(2 * N * (Mo if (c is None or c.identity) else c.nnz) * F for c in csrs)
-    byts = sum(4 * N * F * xs[k].shape[1] + _csr_bytes(csrs[k]) for k in range(n)) + 4 * N * Mo * F
+    es = y.element_size()
+    byts = sum(es * N * F * xs[k].shape[1] + _csr_bytes(csrs[k]) for k in range(n)) + es * N * Mo * F
     _log_launch("spmm_combine_kernel", flops, byts,
-                lambda: check(lib.cape_spmm_combine(arr, n, int(to_acc2), C.byref(rk) if rk is not None else None, _ptr(bias),
+                lambda: check(_fn("cape_spmm_combine", y)(arr, n, int(to_acc2), C.byref(rk) if rk is not None else None, _ptr(bias),
                                                     bias_mode if bias is not None else _lib.BIAS_NONE, _lib.ACT[act],
                                                     1 if dual else 0, _ptr(mask), yp, ys, yl, N, Mo, F, _stream()),
                               "cape_spmm_combine"))
@@ -427,6 +450,12 @@ def colsum(x, out, per_vertex=False, accumulate=False):
     _lib.require_gpu()
     N, M, Cn = x.shape
     xp, xs, xl = _v(x)
+    if x.dtype == torch.bfloat16:
+        if not per_vertex:
+            raise NotImplementedError("channel column sums of a bf16 tensor come from cape_bwd_prep_bf16")
+        check(lib.cape_colsum_vertex_bf16(xp, xs, xl, N, M, Cn, 1 if accumulate else 0, C.c_void_p(out.data_ptr()), _stream()),
+              "cape_colsum_vertex_bf16")
+        return out
     if per_vertex:
         ws, need = None, 0
     else:
@@ -513,7 +542,8 @@ def bwd_prep(g, y=None, act="none", mask=None, want_bias=False, rowscale=None, R
     _lib.require_gpu()
     N, Mo, F = g.shape
     dev = g.device
-    dz = alloc_act(N, Mo, F, dev)
+    dz = alloc_act(N, Mo, F, dev, dtype=g.dtype)
+    assert y is None or y.dtype == g.dtype
     dbias = None
     if want_bias:
         if dbias_out is not None and dbias_out.numel() == F and dbias_out.is_contiguous():
@@ -537,13 +567,13 @@ def bwd_prep(g, y=None, act="none", mask=None, want_bias=False, rowscale=None, R
     else:
         yp, ys, yl = None, 0, 0
     def launch():
-        rc = lib.cape_bwd_prep(gp, gs, gl, yp, ys, yl, _lib.ACT[act] if mask is None else 0, _ptr(mask), zp, zs, zl,
+        rc = _fn("cape_bwd_prep", g)(gp, gs, gl, yp, ys, yl, _lib.ACT[act] if mask is None else 0, _ptr(mask), zp, zs, zl,
                                _ptr(dbias), _ptr(rowscale), R, _ptr(dcoef), 0 if rg is None else int(rg), _ptr(dcoef_g),
                                cstride, 0 if (defer and DEFERRED is not None) else 1, N, Mo, F, _ptr(ws), need, _stream())
         check(rc, "cape_bwd_prep")
 
     # one pass: read g (+ y or the 1-bit mask), write dz
-    _log_launch("bwd_prep", 0, 4 * N * Mo * F * (3 if yp is not None else 2) + (N * Mo * ((F + 31) // 32) * 4 if mask is not None else 0),
+    _log_launch("bwd_prep", 0, g.element_size() * N * Mo * F * (3 if yp is not None else 2) + (N * Mo * ((F + 31) // 32) * 4 if mask is not None else 0),
                 launch)
     if defer and DEFERRED is not None and (dbias is not None or R or rg is not None):
         DEFERRED.append(dict(ws=ws, N=N, Mo=Mo, F=F, R=R, dbias=dbias, dcoef=dcoef, dcoef_g=dcoef_g, cstride=cstride))
@@ -597,7 +627,7 @@ class ChebConvFn(torch.autograd.Function):
         if (x.shape[2] & 3) and (x.stride(1) & 3):
             # e.g. the [N, 6890, 3] network input: re-home it in a row-padded buffer so that the kernels can use
             # aligned float4 accesses (one small copy instead of scalar staging in three GEMM launches)
-            xp = alloc_act(x.shape[0], x.shape[1], x.shape[2], x.device, zero=True)
+            xp = alloc_act(x.shape[0], x.shape[1], x.shape[2], x.device, zero=True, dtype=x.dtype)
             xp.copy_(x)
             x = xp
         N, Mi, Ch = x.shape
@@ -610,7 +640,7 @@ class ChebConvFn(torch.autograd.Function):
         assert ops.fused and W.shape[0] == (Ch + Cc) * K and Mi == ops.Mi
         assert W.is_contiguous() and (W_aff is None or (W_aff.is_contiguous() and W_aff.shape == (Ch + Cc, Fout)))
         Co = 0 if cond_out is None else cond_out.shape[1]
-        yfull = alloc_act(N, ops.Mo, Fout + Co, x.device)
+        yfull = alloc_act(N, ops.Mo, Fout + Co, x.device, dtype=x.dtype)
         y = yfull[:, :, :Fout]
         twopass = (mode == "twopass")
         # up-sampling layer in two-pass mode: contract on the coarse rows, apply the operators to the products
@@ -677,13 +707,13 @@ class ChebConvFn(torch.autograd.Function):
         and the epilogue.  Backward is the ordinary one in its coarse weight-gradient form (needs only x)."""
         N, Mi, Ch = x.shape
         K, Fout = ops.K, W.shape[1]
-        Z = alloc_act(N, Mi, K * Fout, x.device)
+        Z = alloc_act(N, Mi, K * Fout, x.device, dtype=x.dtype)
         gconv_fwd([dict(x=x, csr=None, w=(W, 0, K * Fout, 1))], Z)
         zs = [Z[:, :, k * Fout:(k + 1) * Fout] for k in range(K)]
         csrs = [ops.fwd[k] for k in range(K)]
         to2 = 0
         if W_aff is not None:
-            Za = alloc_act(N, Mi, Fout, x.device)
+            Za = alloc_act(N, Mi, Fout, x.device, dtype=x.dtype)
             gconv_fwd([dict(x=x, csr=None, w=(W_aff, 0, Fout, 1))], Za)
             zs.append(Za)
             csrs.append(ops.fwd[0])
@@ -784,7 +814,7 @@ class ChebConvFn(torch.autograd.Function):
                 if need_ci:
                     dci = dci + torch.mm(dca, W_aff[Ch:].t())
         if need_x:
-            dx = alloc_act(N, Mi, Ch, dev)
+            dx = alloc_act(N, Mi, Ch, dev, dtype=gfull.dtype)
             if not twopass:
                 entries = [dict(x=dz, csr=ops.bwd[k], w=(W, k * Fout, 1, K * Fout), C=Fout) for k in range(K)]
                 # only the first Ch "output" columns (x channels) of W^T are produced: F of this launch = Ch
@@ -801,7 +831,7 @@ class ChebConvFn(torch.autograd.Function):
                     # all K orders in ONE launch: G = dz W[:Ch*K]^T has column c*K + k; the epilogue stores it as K
                     # channel blocks G_k (de-interleave), then dx = sum_k S_k^T G_k
                     ChP = _pad4(Ch)
-                    Gall = alloc_act(N, Mo, K * ChP, dev)
+                    Gall = alloc_act(N, Mo, K * ChP, dev, dtype=gfull.dtype)
                     gconv_fwd([dict(x=dz, csr=None, w=(W, 0, 1, Fout))], Gall, deinterleave=K, F=K * Ch)
                     dx = spmm_multi([Gall[:, :, k * ChP:k * ChP + Ch] for k in range(K)], [ops.bwd[k] for k in range(K)], sum=True)
                 elif contract_first:
@@ -814,7 +844,7 @@ class ChebConvFn(torch.autograd.Function):
                         if ops.bwd[k].identity and first:
                             gconv_fwd(ent, dx)
                         else:
-                            Gk = alloc_act(N, Mo, Ch, dev)
+                            Gk = alloc_act(N, Mo, Ch, dev, dtype=gfull.dtype)
                             gconv_fwd(ent, Gk)
                             if ops.bwd[k].identity:
                                 dx.add_(Gk)

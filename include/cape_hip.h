@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CAPE_ABI_VERSION 7
+#define CAPE_ABI_VERSION 8
 #define CAPE_MAX_SRC 8
 
 /* error codes (negative = argument error; positive values are hipError_t) */
@@ -407,6 +407,54 @@ int64_t cape_fc_wide_bwd_workspace_bytes(int32_t N, int32_t in, int32_t out);
 int cape_fc_wide_bwd(const float *x, int32_t ldx, const float *g, int32_t ldg, const float *y, int32_t ldy,
                      int32_t act, int32_t N, int32_t in, int32_t out, const float *W, float *dW, float *db,
                      float *dx, int32_t lddx, void *workspace, int64_t workspace_bytes, void *stream);
+
+/*
+ * ---- bf16 storage variants (BASELINE configs[4]: "bf16 weights/activations", SURVEY section 8(b) "_bf16") -----------------
+ * Same operators and the same argument meaning as the entry points of the same name without the suffix, with every
+ * ACTIVATION tensor -- sources x, outputs y, gradients g / dz / dz2, the terms of the sparse kernels -- stored as bf16
+ * (uint16_t bit patterns; cape_src_t.x, cape_spmm_term_t.x / .y then point to bf16 data; all strides are in ELEMENTS).
+ * Weights, biases, rank-1 coefficients, CSR values, weight / bias / coefficient gradients and every reduction workspace
+ * stay fp32 (fp32 master weights; the contraction kernels round a weight to bf16 while staging it, i.e. they compute
+ * with bf16 weights).  Arithmetic: bf16 x bf16 products accumulated in fp32 (v_mfma_f32_32x32x16_bf16, ONE product per
+ * multiply-add) where the launch is eligible for the matrix-pipe kernel -- plain sources of whole 32-channel chunks, rows
+ * 16-byte aligned (ldx % 8 == 0), F >= 64 -- and fp32 arithmetic on widened values elsewhere; every store rounds to nearest
+ * even.  Tolerance of the path against the fp32 one: <= 2e-2 relative, tests/test_gpu_bf16.py.
+ * The reference's placeholders are fp32 (lib/models.py:272-282): this storage type is the north_star's own addition.
+ */
+int cape_gconv_fwd_bf16(const cape_src_t *srcs, int32_t nsrc, void *y, int64_t y_sample_stride,
+                        int32_t ldy, int32_t N, int32_t Mo, int32_t F, const float *bias,
+                        int32_t bias_mode, int32_t act, uint32_t *mask_out, const cape_rank_t *rank,
+                        int32_t out_deinterleave, void *stream);
+int cape_gconv_fwd_plan_bf16(const cape_src_t *srcs, int32_t nsrc, int32_t N, int32_t Mo, int32_t F, int32_t plan[4]);
+/* workspace size: cape_gconv_dw_workspace_bytes (the partial slabs are fp32 in both storage types) */
+int cape_gconv_dw_bf16(const cape_src_t *srcs, int32_t nsrc, const void *dz,
+                       int64_t dz_sample_stride, int32_t lddz, const void *dz2, uint32_t dz2_mask,
+                       int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
+                       int64_t workspace_bytes, void *stream);
+int cape_gconv_dw_stage_bf16(const cape_src_t *srcs, int32_t nsrc, const void *dz,
+                             int64_t dz_sample_stride, int32_t lddz, const void *dz2, uint32_t dz2_mask,
+                             int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
+                             int64_t workspace_bytes, int32_t stage, void *stream);
+int cape_gconv_dw_plan_bf16(const cape_src_t *srcs, int32_t nsrc, const void *dz, int64_t dz_sample_stride, int32_t lddz,
+                            const void *dz2, uint32_t dz2_mask, int32_t N, int32_t Mo, int32_t F, int32_t plan[4]);
+int cape_spmm_bf16(const void *x, int64_t x_sample_stride, int32_t ldx, const int32_t *rowptr,
+                   const int32_t *colidx, const float *vals, int32_t max_row_nnz, float alpha, const void *z,
+                   int64_t z_sample_stride, int32_t ldz, float beta, void *y, int64_t y_sample_stride,
+                   int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream);
+int cape_spmm_multi_bf16(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, void *y, int64_t y_sample_stride,
+                         int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream);
+int cape_spmm_combine_bf16(const cape_spmm_term_t *terms, int32_t nterms, uint32_t to_acc2, const cape_rank_t *rank,
+                           const float *bias, int32_t bias_mode, int32_t act, int32_t dual, uint32_t *mask_out, void *y,
+                           int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t F, void *stream);
+/* workspace size and cape_bwd_prep_finalize as for cape_bwd_prep (fp32 partials) */
+int cape_bwd_prep_bf16(const void *g, int64_t g_sample_stride, int32_t ldg, const void *y, int64_t y_sample_stride,
+                       int32_t ldy, int32_t act, const uint32_t *mask, void *dz, int64_t dz_sample_stride, int32_t lddz,
+                       float *dbias, const float *rowscale, int32_t R, float *dcoef, int32_t rg, float *dcoef_g,
+                       int64_t dcoef_sample_stride, int32_t finalize, int32_t N, int32_t Mo, int32_t F, void *workspace,
+                       int64_t workspace_bytes, void *stream);
+/* out[m, c] (+)= sum_n x[n, m, c]: gradient of the per-vertex output bias [1, M, F] (lib/models.py:615) from a bf16 dz */
+int cape_colsum_vertex_bf16(const void *x, int64_t x_sample_stride, int32_t ldx, int32_t N, int32_t M, int32_t C,
+                            int32_t accumulate, float *out, void *stream);
 
 #ifdef __cplusplus
 }
