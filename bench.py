@@ -159,12 +159,22 @@ def kernel_roofline(runner):
     return roof, table
 
 
-def step_roofline(ms_per_step, batch, gan, bf16=False):
+# SURVEY 8(d) config 4 (non-affine GraphCMR/group-norm generator nz18, fp32): 757 GFLOP / 22.0 GB at N = 32 and one
+# discriminator pass 35.2 GFLOP / 1.05 GB
+CMR_ALG_GFLOP_PER_MESH, CMR_ALG_MB_PER_MESH = 23.66, 688.0
+CMR_DPASS_ALG_GFLOP_PER_MESH, CMR_DPASS_ALG_MB_PER_MESH = 1.10, 32.8
+
+
+def step_roofline(ms_per_step, batch, gan, bf16=False, cmr=False):
     """Step-level fraction: t_roof = max(alg. bytes / HBM peak, alg. flops / matrix-pipe peak of the dtype)
     of the reference formulation of the step, over the measured step time.  bf16 storage (SURVEY 8d cfg 5): half the
     bytes, dense bf16 MFMA peak -> HBM-bound."""
-    gf = STEP_ALG_GFLOP_PER_MESH + (2 * DPASS_ALG_GFLOP_PER_MESH if gan else 0.0)
-    mb = (STEP_ALG_MB_PER_MESH + (2 * DPASS_ALG_MB_PER_MESH if gan else 0.0)) * (0.5 if bf16 else 1.0)
+    if cmr:
+        gf = CMR_ALG_GFLOP_PER_MESH + (2 * CMR_DPASS_ALG_GFLOP_PER_MESH if gan else 0.0)
+        mb = CMR_ALG_MB_PER_MESH + (2 * CMR_DPASS_ALG_MB_PER_MESH if gan else 0.0)
+    else:
+        gf = STEP_ALG_GFLOP_PER_MESH + (2 * DPASS_ALG_GFLOP_PER_MESH if gan else 0.0)
+        mb = (STEP_ALG_MB_PER_MESH + (2 * DPASS_ALG_MB_PER_MESH if gan else 0.0)) * (0.5 if bf16 else 1.0)
     t_mfma = batch * gf * 1e9 / ((BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS) * 1e12) * 1e3
     t_hbm = batch * mb * 1e6 / (HBM_PEAK_GBS * 1e9) * 1e3
     t_roof = max(t_mfma, t_hbm)
@@ -322,7 +332,9 @@ def main():
         "config": {"workload": "%s Mesh-CVAE%s: fwd+bwd+clip+momentum update, batch %d per GPU, "
                                "6890-vertex SMPL hierarchy%s"
                                % (args.config.replace("_pose32_clotype32_male", ""), " + mesh-patch discriminator (adversarial step)" if args.gan else "",
-                                  args.batch, " (BASELINE configs[2])" if args.config.startswith("CAPE-affineconv_nz64") else ""),
+                                  args.batch, " (BASELINE configs[2])" if (args.config.startswith("CAPE-affineconv_nz64") and args.dtype == 'fp32') else
+                                  " (BASELINE configs[4], one GPU's shard)" if args.config.startswith("CAPE-affineconv_nz64") else
+                                  " (BASELINE configs[3], one GPU)" if (args.config.startswith("CAPE_nz18") and args.gan) else ""),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "graph_replay": runner._gA is not None,
                    "inputs": "host numpy per step (PCIe-inclusive)" if args.host_inputs else "resident in HBM",
                    "arithmetic": "bf16 activation storage (BASELINE configs[4] per-GPU shard): bf16 operands, one bf16 MFMA product "
@@ -334,7 +346,8 @@ def main():
                                  "inf operands give NaN), exact-fp32 MFMA for odd-channel / packed launches",
                    "final_loss_g": loss},
         "roofline": roof,
-        "step_roofline": step_roofline(ms, args.batch, args.gan, args.dtype == 'bf16') if args.config.startswith("CAPE-affineconv_nz64") else None,
+        "step_roofline": step_roofline(ms, args.batch, args.gan, args.dtype == 'bf16', cmr=args.config.startswith("CAPE_nz18"))
+        if args.config.startswith(("CAPE-affineconv_nz64", "CAPE_nz18")) else None,
     }
     if table:
         result["kernels"] = {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in table.items()}

@@ -1,182 +1,326 @@
 // Group normalisation over mesh activations [N, V, C] (reference lib/models.py:681-712, the
 // norm_type='group' branch used by res_block_decoder :744-774): G = min(32, C) groups of C/G
 // channels, statistics over [C/G, V] per sample, population variance, eps inside the sqrt,
-// per-channel gamma/beta.  Statistics are two-pass (mean, then centred sum of squares) like
-// tf.nn.moments.  Optional fused ReLU (the reference always applies tf.nn.relu right after).
+// per-channel gamma/beta, optional fused ReLU (the reference always applies tf.nn.relu right after).
+//
+// Layout of the work (gfx950): every pass reads WHOLE rows with float4 accesses -- thread = (channel quad, row lane),
+// block = (sample, row chunk) -- instead of one block per (sample, group) walking a [V, C/G] slab of 12..68-byte row
+// segments (the first version: 0.8 TB/s, every cache line fetched by up to five different blocks).
+//   forward : partial sums per (sample, chunk, channel) of d = x - p_c and d^2 with the pivot p_c = x[n, 0, c]
+//             (single pass; the shift keeps sum(d^2) - sum(d)^2/n free of cancellation) -> per (sample, group) mean /
+//             rstd in float64 -> per (sample, channel) scale a = rstd*gamma and shift b = beta - mean*a ->
+//             y = relu(fma(a, x, b)).
+//   backward: the ReLU mask is re-derived as fma(a, x, b) > 0 (bit-identical to the forward decision: same operands, same
+//             fma), so y is not read; partial sums of d' and d'*xhat per (sample, chunk, channel) -> per (sample, group)
+//             sums -> dx = A_c d' - (B_g + xhat C_g).
 #include "common.h"
 
 namespace {
 
-__device__ __forceinline__ float block_sum(float v, float *red) {
-    // 256 threads -> one value, broadcast to all
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) red[w] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
-}
+constexpr int GN_MAXT = 4;       // reduction terms per thread
 
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float *x, long long xs, int ldx, float eps, int G, int V,
-                                                       int C, float *stats) {
-    __shared__ float red[4];
-    const int n = blockIdx.x / G, g = blockIdx.x % G;
-    const int Cg = C / G;
-    const float *xb = x + (long long)n * xs + g * Cg;
-    const int total = V * Cg;
-    float s = 0.f;
-    for (int i = threadIdx.x; i < total; i += 256) s += xb[(long long)(i / Cg) * ldx + (i % Cg)];
-    const float mean = block_sum(s, red) / (float)total;
-    float q = 0.f;
-    for (int i = threadIdx.x; i < total; i += 256) {
-        const float d = xb[(long long)(i / Cg) * ldx + (i % Cg)] - mean;
-        q = fmaf(d, d, q);
-    }
-    const float var = block_sum(q, red) / (float)total;
-    if (threadIdx.x == 0) {
-        stats[2 * blockIdx.x] = mean;
-        stats[2 * blockIdx.x + 1] = 1.0f / sqrtf(var + eps);
-    }
-}
-
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float *x, long long xs, int ldx, const float *gamma,
-                                                       const float *beta, const float *stats, int G, int relu, float *y,
-                                                       long long ys, int ldy, int N, int V, int C) {
-    const int Cg = C / G;
-    const long long total = (long long)N * V * C;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const long long nv = i / C;
-        const int v = (int)(nv % V);
-        const int n = (int)(nv / V);
-        const float *st = stats + 2 * ((long long)n * G + c / Cg);
-        float o = (x[(long long)n * xs + (long long)v * ldx + c] - st[0]) * st[1] * gamma[c] + beta[c];
-        if (relu) o = o > 0.f ? o : 0.f;
-        y[(long long)n * ys + (long long)v * ldy + c] = o;
-    }
-}
-
-// per (n, g): per-channel sums of dy' and dy'*xhat, and the two group sums weighted by gamma.
-// Thread = (row lane, channel of the group): a wave reads whole contiguous channel segments of consecutive rows
-// (the per-channel strided loop this replaces touched every cache line Cg times: 290 us per launch at 862 x 544).
-__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float *x, long long xs, int ldx, const float *y,
-                                                           long long ys, int ldy, const float *dy, long long dys, int lddy,
-                                                           const float *gamma, const float *stats, int G, int relu, int V,
-                                                           int C, float *dgamma_p, float *dbeta_p, float *gstats) {
-    __shared__ float r1[256], r2[256];
-    const int n = blockIdx.x / G, g = blockIdx.x % G;
-    const int Cg = C / G;
-    const float mean = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
-    float S1 = 0.f, S2 = 0.f;
-    // channel tiles of up to 64 (groups are at most a few dozen channels wide in every CAPE configuration)
-    for (int c0 = 0; c0 < Cg; c0 += 64) {
-        const int cw = min(64, Cg - c0);
-        int cp = 1;
-        while (cp < cw) cp <<= 1;                       // lanes per row (power of two >= tile width)
-        const int VL = 256 / cp;
-        const int cc = threadIdx.x % cp, vl = threadIdx.x / cp;
-        const int c = g * Cg + c0 + cc;
-        float s1 = 0.f, s2 = 0.f;
-        if (cc < cw) {
-            for (int v = vl; v < V; v += VL) {
-                float d = dy[(long long)n * dys + (long long)v * lddy + c];
-                if (relu && !(y[(long long)n * ys + (long long)v * ldy + c] > 0.f)) d = 0.f;
-                const float xh = (x[(long long)n * xs + (long long)v * ldx + c] - mean) * rstd;
-                s1 += d;
-                s2 = fmaf(d, xh, s2);
-            }
-        }
-        __syncthreads();
-        r1[threadIdx.x] = s1;
-        r2[threadIdx.x] = s2;
-        __syncthreads();
-        if (threadIdx.x < cw) {                         // fixed-order sum over the row lanes of this channel
-            float t1 = 0.f, t2 = 0.f;
-            for (int l = 0; l < VL; ++l) {
-                t1 += r1[l * cp + threadIdx.x];
-                t2 += r2[l * cp + threadIdx.x];
-            }
-            const int ch = g * Cg + c0 + threadIdx.x;
-            dbeta_p[(long long)n * C + ch] = t1;
-            dgamma_p[(long long)n * C + ch] = t2;
-            r1[threadIdx.x] = gamma[ch] * t1;
-            r2[threadIdx.x] = gamma[ch] * t2;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0)
-            for (int l = 0; l < cw; ++l) {
-                S1 += r1[l];
-                S2 += r2[l];
-            }
-    }
-    if (threadIdx.x == 0) {
-        gstats[2 * blockIdx.x] = S1;
-        gstats[2 * blockIdx.x + 1] = S2;
-    }
-}
-
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *x, long long xs, int ldx, const float *y, long long ys,
-                                                           int ldy, const float *dy, long long dys, int lddy,
-                                                           const float *gamma, const float *stats, const float *gstats, int G,
-                                                           int relu, float *dx, long long dxs, int lddx, int N, int V, int C) {
-    const int Cg = C / G;
-    const float inv = 1.0f / (float)(V * Cg);
-    const long long total = (long long)N * V * C;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const long long nv = i / C;
-        const int v = (int)(nv % V);
-        const int n = (int)(nv / V);
-        const long long sg = (long long)n * G + c / Cg;
-        const float mean = stats[2 * sg], rstd = stats[2 * sg + 1];
-        float d = dy[(long long)n * dys + (long long)v * lddy + c];
-        if (relu && !(y[(long long)n * ys + (long long)v * ldy + c] > 0.f)) d = 0.f;
-        const float xh = (x[(long long)n * xs + (long long)v * ldx + c] - mean) * rstd;
-        dx[(long long)n * dxs + (long long)v * lddx + c] =
-            rstd * (gamma[c] * d - (gstats[2 * sg] + xh * gstats[2 * sg + 1]) * inv);
-    }
+inline int gn_rows(int N, int V) {
+    int rb = 128;
+    while (rb > 16 && (long long)N * ((V + rb - 1) / rb) < 1024) rb >>= 1;
+    return rb;
 }
 
 inline int grid_for(long long total) {
     long long b = (total + 255) / 256;
-    if (b > 4096) b = 4096;
+    if (b > 8192) b = 8192;
     return (int)(b < 1 ? 1 : b);
+}
+
+// coef layout per sample: [4][C] = a (rstd*gamma), b (beta - mean*a), r (rstd of the channel's group), mr (mean*rstd)
+// MODE 0 (forward statistics): terms S = sum(x - p), Q = sum((x - p)^2)
+// MODE 1 (backward):           terms s1 = sum(d'), s2 = sum(d' * xhat)
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float *x, long long xs, int ldx, const float *dy, long long dys,
+                                                         int lddy, const float *coef, int relu, int V, int C, int RB,
+                                                         int chunks, float *part) {
+    __shared__ float4 red[256];
+    const int n = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+    const int ra = ch * RB, rb = min(V, ra + RB);
+    const float *xb = x + (long long)n * xs;
+    float *pp = part + ((long long)n * chunks + ch) * 2 * C;
+    for (int cbase = 0; cbase < C; cbase += 256) {
+        const int cw = min(256, C - cbase);
+        const int c4n = cw >> 2;
+        const int lanes = 256 / c4n;
+        const int q = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+        const int c = cbase + 4 * q;
+        float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
+        if (rl < lanes) {
+            if (MODE == 0) {
+                const float4 p = *reinterpret_cast<const float4 *>(xb + c);           // pivot: row 0 of this sample
+                for (int r = ra + rl; r < rb; r += lanes) {
+                    const float4 v = *reinterpret_cast<const float4 *>(xb + (long long)r * ldx + c);
+                    const float dx_ = v.x - p.x, dy_ = v.y - p.y, dz_ = v.z - p.z, dw_ = v.w - p.w;
+                    t0.x += dx_; t0.y += dy_; t0.z += dz_; t0.w += dw_;
+                    t1.x = fmaf(dx_, dx_, t1.x); t1.y = fmaf(dy_, dy_, t1.y); t1.z = fmaf(dz_, dz_, t1.z); t1.w = fmaf(dw_, dw_, t1.w);
+                }
+            } else {
+                const float *cf = coef + (long long)n * 4 * C + c;
+                const float4 a = *reinterpret_cast<const float4 *>(cf), b = *reinterpret_cast<const float4 *>(cf + C);
+                const float4 rr = *reinterpret_cast<const float4 *>(cf + 2 * C), mr = *reinterpret_cast<const float4 *>(cf + 3 * C);
+                const float *gb = dy + (long long)n * dys;
+                for (int r = ra + rl; r < rb; r += lanes) {
+                    const float4 v = *reinterpret_cast<const float4 *>(xb + (long long)r * ldx + c);
+                    float4 d = *reinterpret_cast<const float4 *>(gb + (long long)r * lddy + c);
+                    if (relu) {
+                        d.x = fmaf(a.x, v.x, b.x) > 0.f ? d.x : 0.f; d.y = fmaf(a.y, v.y, b.y) > 0.f ? d.y : 0.f;
+                        d.z = fmaf(a.z, v.z, b.z) > 0.f ? d.z : 0.f; d.w = fmaf(a.w, v.w, b.w) > 0.f ? d.w : 0.f;
+                    }
+                    t0.x += d.x; t0.y += d.y; t0.z += d.z; t0.w += d.w;
+                    t1.x = fmaf(d.x, fmaf(v.x, rr.x, -mr.x), t1.x); t1.y = fmaf(d.y, fmaf(v.y, rr.y, -mr.y), t1.y);
+                    t1.z = fmaf(d.z, fmaf(v.z, rr.z, -mr.z), t1.z); t1.w = fmaf(d.w, fmaf(v.w, rr.w, -mr.w), t1.w);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __syncthreads();
+            red[threadIdx.x] = j ? t1 : t0;
+            __syncthreads();
+            if (rl == 0) {
+                float4 t = j ? t1 : t0;
+                for (int l = 1; l < lanes; ++l) {                       // fixed order: deterministic
+                    const float4 v = red[l * c4n + q];
+                    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+                }
+                *reinterpret_cast<float4 *>(pp + (long long)j * C + c) = t;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// block = one (sample, group); thread = (channel of the group, chunk lane).  Sums the chunk partials of every channel
+// in float64, combines the channels of the group, writes stats (mean, rstd) and the per-channel coefficients.
+__global__ __launch_bounds__(256) void gn_final_kernel(const float *part, int chunks, const float *x, long long xs,
+                                                       const float *gamma, const float *beta, float eps, int G, int V, int C,
+                                                       float *stats, float *coef) {
+    __shared__ double sS[256], sQ[256];
+    const int n = blockIdx.x / G, g = blockIdx.x % G;
+    const int Cg = C / G;
+    int cp = 1;
+    while (cp < Cg) cp <<= 1;                       // channel lanes (power of two >= group width, <= 256)
+    const int CL = 256 / cp;                        // chunk lanes
+    const int cc = threadIdx.x % cp, cl = threadIdx.x / cp;
+    double S = 0.0, Q = 0.0;
+    if (cc < Cg) {
+        const int c = g * Cg + cc;
+        for (int k = cl; k < chunks; k += CL) {
+            const float *pp = part + ((long long)n * chunks + k) * 2 * C;
+            S += (double)pp[c];
+            Q += (double)pp[C + c];
+        }
+    }
+    sS[threadIdx.x] = S; sQ[threadIdx.x] = Q;
+    __syncthreads();
+    if (cl == 0 && cc < Cg) {
+        for (int l = 1; l < CL; ++l) { S += sS[l * cp + cc]; Q += sQ[l * cp + cc]; }
+        sS[cc] = S; sQ[cc] = Q;                     // per-channel totals of d = x - p_c and d^2
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double T = (double)V * (double)Cg;
+        double sum = 0.0;
+        for (int j = 0; j < Cg; ++j) sum += sS[j] + (double)V * (double)x[(long long)n * xs + g * Cg + j];
+        const double mean = sum / T;
+        double m2 = 0.0;
+        for (int j = 0; j < Cg; ++j) {
+            const double dp = (double)x[(long long)n * xs + g * Cg + j] - mean;      // p_c - mean
+            m2 += sQ[j] + 2.0 * dp * sS[j] + (double)V * dp * dp;
+        }
+        const double var = m2 / T > 0.0 ? m2 / T : 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        stats[2 * blockIdx.x] = (float)mean;
+        stats[2 * blockIdx.x + 1] = rstd;
+        sS[0] = mean; sQ[0] = (double)rstd;
+    }
+    __syncthreads();
+    if (threadIdx.x < Cg) {
+        const int c = g * Cg + threadIdx.x;
+        const float mean = (float)sS[0], rstd = (float)sQ[0];
+        float *cf = coef + (long long)n * 4 * C;
+        const float a = rstd * gamma[c];
+        cf[c] = a;
+        cf[C + c] = fmaf(-mean, a, beta[c]);
+        cf[2 * C + c] = rstd;
+        cf[3 * C + c] = mean * rstd;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float *x, long long xs, int ldx, const float *coef, int relu,
+                                                       float *y, long long ys, int ldy, int N, int V, int C) {
+    const int c4 = C >> 2;
+    const long long total = (long long)N * V * c4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % c4) * 4;
+        const long long nv = i / c4;
+        const int v = (int)(nv % V);
+        const int n = (int)(nv / V);
+        const float *cf = coef + (long long)n * 4 * C + c;
+        const float4 a = *reinterpret_cast<const float4 *>(cf), b = *reinterpret_cast<const float4 *>(cf + C);
+        const float4 xv = *reinterpret_cast<const float4 *>(x + (long long)n * xs + (long long)v * ldx + c);
+        float4 o;
+        o.x = fmaf(a.x, xv.x, b.x); o.y = fmaf(a.y, xv.y, b.y); o.z = fmaf(a.z, xv.z, b.z); o.w = fmaf(a.w, xv.w, b.w);
+        if (relu) {
+            o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+        }
+        *reinterpret_cast<float4 *>(y + (long long)n * ys + (long long)v * ldy + c) = o;
+    }
+}
+
+// block = one (sample, group): per-channel totals of s1 = sum d', s2 = sum d'*xhat -> per-sample gamma / beta gradient
+// partials, the group sums S1 = sum_c gamma_c s1_c, S2 = sum_c gamma_c s2_c, and the coefficients of the apply pass:
+// bcoef[n][3][C] = A_c = rstd*gamma_c, B_g = rstd*S1/T, C_g = rstd*S2/T  (dx = A d' - (B + xhat C)).
+__global__ __launch_bounds__(256) void gn_bwd_final_kernel(const float *part, int chunks, const float *gamma, const float *stats,
+                                                           int G, int V, int C, float *dgamma_p, float *dbeta_p, float *bcoef) {
+    __shared__ double s1s[256], s2s[256];
+    const int n = blockIdx.x / G, g = blockIdx.x % G;
+    const int Cg = C / G;
+    int cp = 1;
+    while (cp < Cg) cp <<= 1;
+    const int CL = 256 / cp;
+    const int cc = threadIdx.x % cp, cl = threadIdx.x / cp;
+    double a1 = 0.0, a2 = 0.0;
+    if (cc < Cg) {
+        const int c = g * Cg + cc;
+        for (int k = cl; k < chunks; k += CL) {
+            const float *pp = part + ((long long)n * chunks + k) * 2 * C;
+            a1 += (double)pp[c];
+            a2 += (double)pp[C + c];
+        }
+    }
+    s1s[threadIdx.x] = a1; s2s[threadIdx.x] = a2;
+    __syncthreads();
+    if (cl == 0 && cc < Cg) {
+        for (int l = 1; l < CL; ++l) { a1 += s1s[l * cp + cc]; a2 += s2s[l * cp + cc]; }
+        const int c = g * Cg + cc;
+        dbeta_p[(long long)n * C + c] = (float)a1;
+        dgamma_p[(long long)n * C + c] = (float)a2;
+        s1s[cc] = a1 * (double)gamma[c]; s2s[cc] = a2 * (double)gamma[c];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S1 = 0.0, S2 = 0.0;
+        for (int j = 0; j < Cg; ++j) { S1 += s1s[j]; S2 += s2s[j]; }
+        const double T = (double)V * (double)Cg;
+        const double rstd = (double)stats[2 * blockIdx.x + 1];
+        s1s[0] = rstd * S1 / T; s2s[0] = rstd * S2 / T;
+    }
+    __syncthreads();
+    if (threadIdx.x < Cg) {
+        const int c = g * Cg + threadIdx.x;
+        float *bc = bcoef + (long long)n * 3 * C;
+        bc[c] = stats[2 * blockIdx.x + 1] * gamma[c];
+        bc[C + c] = (float)s1s[0];
+        bc[2 * C + c] = (float)s2s[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *x, long long xs, int ldx, const float *dy, long long dys,
+                                                           int lddy, const float *coef, const float *bcoef, int relu, float *dx,
+                                                           long long dxs, int lddx, int N, int V, int C) {
+    const int c4 = C >> 2;
+    const long long total = (long long)N * V * c4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % c4) * 4;
+        const long long nv = i / c4;
+        const int v = (int)(nv % V);
+        const int n = (int)(nv / V);
+        const float *cf = coef + (long long)n * 4 * C + c;
+        const float *bc = bcoef + (long long)n * 3 * C + c;
+        const float4 a = *reinterpret_cast<const float4 *>(cf), b = *reinterpret_cast<const float4 *>(cf + C);
+        const float4 rr = *reinterpret_cast<const float4 *>(cf + 2 * C), mr = *reinterpret_cast<const float4 *>(cf + 3 * C);
+        const float4 A = *reinterpret_cast<const float4 *>(bc), B = *reinterpret_cast<const float4 *>(bc + C);
+        const float4 Cc = *reinterpret_cast<const float4 *>(bc + 2 * C);
+        const float4 xv = *reinterpret_cast<const float4 *>(x + (long long)n * xs + (long long)v * ldx + c);
+        float4 d = *reinterpret_cast<const float4 *>(dy + (long long)n * dys + (long long)v * lddy + c);
+        if (relu) {
+            d.x = fmaf(a.x, xv.x, b.x) > 0.f ? d.x : 0.f; d.y = fmaf(a.y, xv.y, b.y) > 0.f ? d.y : 0.f;
+            d.z = fmaf(a.z, xv.z, b.z) > 0.f ? d.z : 0.f; d.w = fmaf(a.w, xv.w, b.w) > 0.f ? d.w : 0.f;
+        }
+        float4 o;
+        o.x = A.x * d.x - fmaf(fmaf(xv.x, rr.x, -mr.x), Cc.x, B.x);
+        o.y = A.y * d.y - fmaf(fmaf(xv.y, rr.y, -mr.y), Cc.y, B.y);
+        o.z = A.z * d.z - fmaf(fmaf(xv.z, rr.z, -mr.z), Cc.z, B.z);
+        o.w = A.w * d.w - fmaf(fmaf(xv.w, rr.w, -mr.w), Cc.w, B.w);
+        *reinterpret_cast<float4 *>(dx + (long long)n * dxs + (long long)v * lddx + c) = o;
+    }
+}
+
+inline bool gn_aligned(const void *p, long long ss, int ld) {
+    return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && ((ss & 3) == 0) && ((ld & 3) == 0);
+}
+
+// the last column tile of a partial-sum pass must have a quad count that leaves at least one row lane
+inline bool gn_shape_ok(int C, int G) {
+    if (C & 3) return false;
+    if (C / G > 256) return false;
+    const int tail = C % 256;
+    return tail == 0 || (tail >> 2) <= 256;
 }
 
 }  // namespace
 
+extern "C" int64_t cape_groupnorm_workspace_bytes(int32_t N, int32_t V, int32_t C) {
+    if (N < 1 || V < 1 || C < 1) return CAPE_EINVAL;
+    const int RB = gn_rows(N, V);
+    const long long chunks = (V + RB - 1) / RB;
+    return (int64_t)N * chunks * 2 * C * (int64_t)sizeof(float);
+}
+
 extern "C" int cape_groupnorm_fwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *gamma,
                                   const float *beta, float eps, int32_t G, int32_t relu, float *y, int64_t y_sample_stride,
-                                  int32_t ldy, float *stats, int32_t N, int32_t V, int32_t C, void *stream) {
-    if (!x || !gamma || !beta || !y || !stats || N < 1 || V < 1 || C < 1 || G < 1 || (C % G) != 0 || ldx < C || ldy < C)
+                                  int32_t ldy, float *stats, float *coef, int32_t N, int32_t V, int32_t C, void *workspace,
+                                  int64_t workspace_bytes, void *stream) {
+    if (!x || !gamma || !beta || !y || !stats || !coef || !workspace || N < 1 || V < 1 || C < 1 || G < 1 || (C % G) != 0 ||
+        ldx < C || ldy < C)
         return CAPE_EINVAL;
+    if (!gn_shape_ok(C, G) || !gn_aligned(x, x_sample_stride, ldx) || !gn_aligned(y, y_sample_stride, ldy)) return CAPE_EINVAL;
+    if (workspace_bytes < cape_groupnorm_workspace_bytes(N, V, C)) return CAPE_EWORKSPACE;
+    const int RB = gn_rows(N, V);
+    const int chunks = (V + RB - 1) / RB;
     hipStream_t st = (hipStream_t)stream;
-    CAPE_LAUNCH(gn_stats_kernel, dim3(N * G), dim3(256), 0, st, x, (long long)x_sample_stride, ldx, eps, G, V, C, stats);
+    CAPE_LAUNCH(gn_partial_kernel<0>, dim3(N * chunks), dim3(256), 0, st, x, (long long)x_sample_stride, ldx, (const float *)nullptr,
+                0LL, 0, (const float *)nullptr, 0, V, C, RB, chunks, (float *)workspace);
     CAPE_LAUNCH_CHECK();
-    CAPE_LAUNCH(gn_apply_kernel, dim3(grid_for((long long)N * V * C)), dim3(256), 0, st, x, (long long)x_sample_stride, ldx,
-                       gamma, beta, stats, G, relu, y, (long long)y_sample_stride, ldy, N, V, C);
+    CAPE_LAUNCH(gn_final_kernel, dim3(N * G), dim3(256), 0, st, (const float *)workspace, chunks, x, (long long)x_sample_stride,
+                gamma, beta, eps, G, V, C, stats, coef);
+    CAPE_LAUNCH_CHECK();
+    CAPE_LAUNCH(gn_apply_kernel, dim3(grid_for((long long)N * V * (C / 4))), dim3(256), 0, st, x, (long long)x_sample_stride, ldx,
+                (const float *)coef, relu, y, (long long)y_sample_stride, ldy, N, V, C);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }
 
-extern "C" int cape_groupnorm_bwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *y, int64_t y_sample_stride,
-                                  int32_t ldy, const float *dy, int64_t dy_sample_stride, int32_t lddy, const float *gamma,
-                                  const float *stats, int32_t G, int32_t relu, float *dx, int64_t dx_sample_stride, int32_t lddx,
-                                  float *dgamma_partial, float *dbeta_partial, float *gstats, int32_t N, int32_t V, int32_t C,
-                                  void *stream) {
-    if (!x || !dy || !gamma || !stats || !dx || !dgamma_partial || !dbeta_partial || !gstats || N < 1 || V < 1 || C < 1 ||
-        G < 1 || (C % G) != 0 || ldx < C || lddy < C || lddx < C)
+extern "C" int cape_groupnorm_bwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *dy,
+                                  int64_t dy_sample_stride, int32_t lddy, const float *gamma, const float *stats,
+                                  const float *coef, int32_t G, int32_t relu, float *dx, int64_t dx_sample_stride, int32_t lddx,
+                                  float *dgamma_partial, float *dbeta_partial, float *bcoef, int32_t N, int32_t V, int32_t C,
+                                  void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!x || !dy || !gamma || !stats || !coef || !dx || !dgamma_partial || !dbeta_partial || !bcoef || !workspace || N < 1 ||
+        V < 1 || C < 1 || G < 1 || (C % G) != 0 || ldx < C || lddy < C || lddx < C)
         return CAPE_EINVAL;
-    if (relu && (!y || ldy < C)) return CAPE_EINVAL;
+    if (!gn_shape_ok(C, G) || !gn_aligned(x, x_sample_stride, ldx) || !gn_aligned(dy, dy_sample_stride, lddy) ||
+        !gn_aligned(dx, dx_sample_stride, lddx))
+        return CAPE_EINVAL;
+    if (workspace_bytes < cape_groupnorm_workspace_bytes(N, V, C)) return CAPE_EWORKSPACE;
+    const int RB = gn_rows(N, V);
+    const int chunks = (V + RB - 1) / RB;
     hipStream_t st = (hipStream_t)stream;
-    CAPE_LAUNCH(gn_bwd_stats_kernel, dim3(N * G), dim3(256), 0, st, x, (long long)x_sample_stride, ldx, y,
-                       (long long)y_sample_stride, ldy, dy, (long long)dy_sample_stride, lddy, gamma, stats, G, relu, V, C,
-                       dgamma_partial, dbeta_partial, gstats);
+    CAPE_LAUNCH(gn_partial_kernel<1>, dim3(N * chunks), dim3(256), 0, st, x, (long long)x_sample_stride, ldx, dy,
+                (long long)dy_sample_stride, lddy, coef, relu, V, C, RB, chunks, (float *)workspace);
     CAPE_LAUNCH_CHECK();
-    CAPE_LAUNCH(gn_bwd_apply_kernel, dim3(grid_for((long long)N * V * C)), dim3(256), 0, st, x, (long long)x_sample_stride,
-                       ldx, y, (long long)y_sample_stride, ldy, dy, (long long)dy_sample_stride, lddy, gamma, stats, gstats, G,
-                       relu, dx, (long long)dx_sample_stride, lddx, N, V, C);
+    CAPE_LAUNCH(gn_bwd_final_kernel, dim3(N * G), dim3(256), 0, st, (const float *)workspace, chunks, gamma, stats, G, V, C,
+                dgamma_partial, dbeta_partial, bcoef);
+    CAPE_LAUNCH_CHECK();
+    CAPE_LAUNCH(gn_bwd_apply_kernel, dim3(grid_for((long long)N * V * (C / 4))), dim3(256), 0, st, x, (long long)x_sample_stride,
+                ldx, dy, (long long)dy_sample_stride, lddy, coef, (const float *)bcoef, relu, dx, (long long)dx_sample_stride, lddx,
+                N, V, C);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }

@@ -982,42 +982,57 @@ class ConcatCondFn(torch.autograd.Function):
 
 class GroupNormFn(torch.autograd.Function):
     """gn(norm_type='group') optionally fused with the following tf.nn.relu
-    (lib/models.py:681-712, 751-760)."""
+    (lib/models.py:681-712, 751-760).  Saved for backward: the input, the per-(sample, group) statistics and the
+    per-(sample, channel) scale / shift -- not the output (the ReLU mask is re-derived from the same fma)."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, G, eps, relu):
         _lib.require_gpu()
         x = as_act(x)
+        assert x.dtype == torch.float32, "group norm reads fp32 activations"
         N, V, Cn = x.shape
+        if (x.stride(1) & 3) or (N > 1 and (x.stride(0) & 3)) or (x.data_ptr() & 15):
+            xa = alloc_act(N, V, Cn, x.device)
+            xa.copy_(x)
+            x = xa
         y = alloc_act(N, V, Cn, x.device)
         stats = torch.empty((N, G, 2), device=x.device, dtype=torch.float32)
+        coef = torch.empty((N, 4, Cn), device=x.device, dtype=torch.float32)
+        need = int(lib.cape_groupnorm_workspace_bytes(N, V, Cn))
+        ws = torch.empty((need + 3) // 4, device=x.device, dtype=torch.float32)
         xp, xs, xl = _v(x)
         yp, ys, yl = _v(y)
-        _log_launch("groupnorm_fwd", 0, 2 * 4 * N * V * Cn,
+        _log_launch("groupnorm_fwd", 0, 3 * 4 * N * V * Cn,
                     lambda: check(lib.cape_groupnorm_fwd(xp, xs, xl, _ptr(gamma), _ptr(beta), float(eps), int(G), int(relu), yp, ys, yl,
-                                                         _ptr(stats), N, V, Cn, _stream()), "cape_groupnorm_fwd"))
+                                                         _ptr(stats), _ptr(coef), N, V, Cn, _ptr(ws), need, _stream()),
+                                  "cape_groupnorm_fwd"))
         ctx.G, ctx.relu = G, relu
-        ctx.save_for_backward(x, y, gamma, stats)
+        ctx.save_for_backward(x, gamma, stats, coef)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, y, gamma, stats = ctx.saved_tensors
+        x, gamma, stats, coef = ctx.saved_tensors
         g = as_act(g)
         N, V, Cn = x.shape
+        if (g.stride(1) & 3) or (N > 1 and (g.stride(0) & 3)) or (g.data_ptr() & 15):
+            ga = alloc_act(N, V, Cn, g.device)
+            ga.copy_(g)
+            g = ga
         dx = alloc_act(N, V, Cn, x.device)
-        dgp = torch.empty((N, Cn), device=x.device, dtype=torch.float32)
-        dbp = torch.empty((N, Cn), device=x.device, dtype=torch.float32)
-        gst = torch.empty((N, ctx.G, 2), device=x.device, dtype=torch.float32)
+        dgb = torch.empty((2, N, Cn), device=x.device, dtype=torch.float32)        # per-sample dgamma / dbeta partials
+        bcoef = torch.empty((N, 3, Cn), device=x.device, dtype=torch.float32)
+        need = int(lib.cape_groupnorm_workspace_bytes(N, V, Cn))
+        ws = torch.empty((need + 3) // 4, device=x.device, dtype=torch.float32)
         xp, xs, xl = _v(x)
-        yp, ys, yl = _v(y)
         gp, gs, gl = _v(g)
         dp, ds, dl = _v(dx)
-        _log_launch("groupnorm_bwd", 0, 3 * 4 * N * V * Cn,
-                    lambda: check(lib.cape_groupnorm_bwd(xp, xs, xl, yp, ys, yl, gp, gs, gl, _ptr(gamma), _ptr(stats), int(ctx.G),
-                                                         int(ctx.relu), dp, ds, dl, _ptr(dgp), _ptr(dbp), _ptr(gst), N, V, Cn,
-                                                         _stream()), "cape_groupnorm_bwd"))
-        return dx, dgp.sum(0), dbp.sum(0), None, None, None
+        _log_launch("groupnorm_bwd", 0, 5 * 4 * N * V * Cn,
+                    lambda: check(lib.cape_groupnorm_bwd(xp, xs, xl, gp, gs, gl, _ptr(gamma), _ptr(stats), _ptr(coef), int(ctx.G),
+                                                         int(ctx.relu), dp, ds, dl, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(bcoef), N, V, Cn,
+                                                         _ptr(ws), need, _stream()), "cape_groupnorm_bwd"))
+        dgb = dgb.sum(1)                                                           # one launch for both parameter gradients
+        return dx, dgb[0], dgb[1], None, None, None
 
 
 class ReconEdgeLossFn(torch.autograd.Function):

@@ -311,22 +311,29 @@ int cape_reduce_cond(const float *dy, int64_t dy_sample_stride, int32_t lddy, co
                      float *dcond, int32_t ldc, int32_t N, int32_t M, int32_t C,
                      int32_t accumulate, void *stream);
 
-/* Group norm over [N, V, C] (G groups of C/G channels, population variance, eps),
- * optional fused ReLU; stats = [N, G, 2] (mean, rstd) saved for backward. */
+/*
+ * Group norm over [C/G, V] per sample (lib/models.py:681-712: G = min(32, C) chosen by the caller, population variance,
+ * eps inside the sqrt) with per-channel gamma / beta and an optional fused ReLU (:751-760):
+ *   y = relu?( (x - mean_{n,g}) * rstd_{n,g} * gamma_c + beta_c )
+ * Every pass reads whole rows (float4): requires C % 4 == 0 and 16-byte aligned, 4-float-padded views.
+ * Outputs kept for the backward pass: stats [N, G, 2] = (mean, rstd) and coef [N, 4, C] = (a = rstd*gamma,
+ * b = beta - mean*a, rstd, mean*rstd) per channel; the forward evaluates y = relu?(fma(a, x, b)) and the backward
+ * re-derives the ReLU mask from the same fma, so it never reads y.  Statistics: one pass of pivot-shifted sums
+ * (pivot = the sample's first row), combined per group in float64.  workspace >= cape_groupnorm_workspace_bytes.
+ */
+int64_t cape_groupnorm_workspace_bytes(int32_t N, int32_t V, int32_t C);
 int cape_groupnorm_fwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *gamma,
                        const float *beta, float eps, int32_t G, int32_t relu, float *y,
-                       int64_t y_sample_stride, int32_t ldy, float *stats, int32_t N, int32_t V,
-                       int32_t C, void *stream);
-/* dx plus per-sample partial parameter gradients dgamma_partial/dbeta_partial [N, C] (the caller
- * sums them over N); y is the forward OUTPUT (only read when relu != 0, may be NULL otherwise);
- * gstats is a [N, G, 2] scratch buffer. */
-int cape_groupnorm_bwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *y,
-                       int64_t y_sample_stride, int32_t ldy, const float *dy,
+                       int64_t y_sample_stride, int32_t ldy, float *stats, float *coef, int32_t N, int32_t V,
+                       int32_t C, void *workspace, int64_t workspace_bytes, void *stream);
+/* dx plus per-sample partial parameter gradients dgamma_partial / dbeta_partial [N, C] (the caller sums them over N);
+ * stats / coef are the forward outputs; bcoef is a [N, 3, C] scratch buffer. */
+int cape_groupnorm_bwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *dy,
                        int64_t dy_sample_stride, int32_t lddy, const float *gamma,
-                       const float *stats, int32_t G, int32_t relu, float *dx,
+                       const float *stats, const float *coef, int32_t G, int32_t relu, float *dx,
                        int64_t dx_sample_stride, int32_t lddx, float *dgamma_partial,
-                       float *dbeta_partial, float *gstats, int32_t N, int32_t V, int32_t C,
-                       void *stream);
+                       float *dbeta_partial, float *bcoef, int32_t N, int32_t V, int32_t C,
+                       void *workspace, int64_t workspace_bytes, void *stream);
 
 /*
  * L1 reconstruction + edge loss (lib/models.py:357-375, lib/losses.py:9-25) and gradient:
