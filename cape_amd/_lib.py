@@ -44,6 +44,13 @@ class CapeBwdPrepItem(C.Structure):
                 ("dbias", C.c_void_p), ("dcoef", C.c_void_p), ("dcoef_g", C.c_void_p), ("dcoef_sample_stride", C.c_int64)]
 
 
+class CapeDwItem(C.Structure):
+    _fields_ = [("srcs", C.c_void_p), ("nsrc", C.c_int32), ("dz", C.c_void_p), ("dz_sample_stride", C.c_int64),
+                ("lddz", C.c_int32), ("dz2", C.c_void_p), ("dz2_mask", C.c_uint32), ("N", C.c_int32), ("Mo", C.c_int32),
+                ("F", C.c_int32), ("accumulate", C.c_int32), ("bf16", C.c_int32), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_int64)]
+
+
 class CapeRank(C.Structure):
     _fields_ = [("R", C.c_int32), ("rowscale", C.c_void_p), ("coef", C.c_void_p), ("to_acc2", C.c_uint32)]
 
@@ -69,6 +76,9 @@ SIGNATURES = {
     "cape_gconv_dw_workspace_bytes": (_i64, [_SRCP, _i32, _i32, _i32, _i32]),
     "cape_gconv_dw": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _p, C.c_uint32, _i32, _i32, _i32, _i32, _p, _i64, _p]),
     "cape_gconv_dw_stage": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _p, C.c_uint32, _i32, _i32, _i32, _i32, _p, _i64, _i32, _p]),
+    "cape_condnet_fwd": (C.c_int, [_p, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "cape_condnet_bwd": (C.c_int, [_p, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "cape_gconv_dw_reduce_batch": (C.c_int, [C.c_void_p, _i32, _p]),
     "cape_gconv_dw_plan": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _p, C.c_uint32, _i32, _i32, _i32, C.POINTER(_i32)]),
     "cape_gconv_fwd_bf16": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p, _i32, _i32, _p,
                                       C.POINTER(CapeRank), _i32, _p]),

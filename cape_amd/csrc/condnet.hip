@@ -1,0 +1,139 @@
+// The two condition networks of CAPE in one launch per direction (reference lib/models.py:479-511 ``condition``, called at
+// :284-290): pose MLP  c1 [N, in1] -> leaky_relu(c1 W1 + b1) [N, hid] -> (.) W2 + b2 [N, out1]   (tf.layers.dense x 2) and the
+// clothing-type layer  c2 [N, in2] -> c2 Wc + bc [N, out2]; the outputs are written side by side as ycat [N, out1 + out2]
+// -- the concatenated condition every consumer wants (:533, :591, :663).  At N = 16 these are ~0.15 MFLOP: as six
+// rocBLAS / elementwise dispatches forward and eight backward they cost ~70 us of a 3.5 ms step in dispatch latency alone.
+// One workgroup, everything staged in LDS, fixed summation order (deterministic).
+#include "common.h"
+
+namespace {
+
+struct CondNetP {
+    const float *c1, *c2;
+    int ld1, ld2;
+    const float *W1, *b1, *W2, *b2, *Wc, *bc;
+    float *h;            // [N, hid] post-activation hidden layer (saved for backward)
+    float *ycat;         // [N, out1 + out2]
+    const float *dycat;  // backward: gradient w.r.t. ycat (contiguous)
+    float *gW1, *gb1, *gW2, *gb2, *gWc, *gbc;
+    int N, in1, hid, out1, in2, out2;
+};
+
+__global__ __launch_bounds__(256) void condnet_fwd_kernel(CondNetP p) {
+    extern __shared__ float sm[];
+    float *s1 = sm;                          // [N][in1]
+    float *sh = sm + p.N * p.in1;            // [N][hid]
+    for (int i = threadIdx.x; i < p.N * p.in1; i += 256) s1[i] = p.c1[(long long)(i / p.in1) * p.ld1 + (i % p.in1)];
+    __syncthreads();
+    for (int o = threadIdx.x; o < p.N * p.hid; o += 256) {
+        const int n = o / p.hid, j = o % p.hid;
+        float a = p.b1[j];
+        for (int i = 0; i < p.in1; ++i) a = fmaf(s1[n * p.in1 + i], p.W1[(long long)i * p.hid + j], a);
+        a = a > 0.f ? a : 0.2f * a;
+        sh[o] = a;
+        p.h[o] = a;
+    }
+    __syncthreads();
+    const int oc = p.out1 + p.out2;
+    for (int o = threadIdx.x; o < p.N * oc; o += 256) {
+        const int n = o / oc, f = o % oc;
+        float a;
+        if (f < p.out1) {
+            a = p.b2[f];
+            for (int j = 0; j < p.hid; ++j) a = fmaf(sh[n * p.hid + j], p.W2[(long long)j * p.out1 + f], a);
+        } else {
+            const int g = f - p.out1;
+            a = p.bc[g];
+            for (int i = 0; i < p.in2; ++i) a = fmaf(p.c2[(long long)n * p.ld2 + i], p.Wc[(long long)i * p.out2 + g], a);
+        }
+        p.ycat[o] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void condnet_bwd_kernel(CondNetP p) {
+    extern __shared__ float sm[];
+    const int oc = p.out1 + p.out2;
+    float *s1 = sm;                          // [N][in1]
+    float *sh = s1 + p.N * p.in1;            // [N][hid]   h, then dh in place
+    float *sd = sh + p.N * p.hid;            // [N][oc]    dycat
+    for (int i = threadIdx.x; i < p.N * p.in1; i += 256) s1[i] = p.c1[(long long)(i / p.in1) * p.ld1 + (i % p.in1)];
+    for (int i = threadIdx.x; i < p.N * p.hid; i += 256) sh[i] = p.h[i];
+    for (int i = threadIdx.x; i < p.N * oc; i += 256) sd[i] = p.dycat[i];
+    __syncthreads();
+    // second pose layer and the clothing-type layer: weight / bias gradients
+    for (int o = threadIdx.x; o < (p.hid + 1) * p.out1; o += 256) {
+        const int j = o / p.out1, f = o % p.out1;          // j == hid: bias row
+        float a = 0.f;
+        for (int n = 0; n < p.N; ++n) a = fmaf(j < p.hid ? sh[n * p.hid + j] : 1.f, sd[n * oc + f], a);
+        if (j < p.hid) p.gW2[o] = a;
+        else p.gb2[f] = a;
+    }
+    for (int o = threadIdx.x; o < (p.in2 + 1) * p.out2; o += 256) {
+        const int i = o / p.out2, g = o % p.out2;
+        float a = 0.f;
+        for (int n = 0; n < p.N; ++n) a = fmaf(i < p.in2 ? p.c2[(long long)n * p.ld2 + i] : 1.f, sd[n * oc + p.out1 + g], a);
+        if (i < p.in2) p.gWc[o] = a;
+        else p.gbc[g] = a;
+    }
+    __syncthreads();
+    // dh = (dy W2^T) * leaky'(h), in place of h
+    for (int o = threadIdx.x; o < p.N * p.hid; o += 256) {
+        const int n = o / p.hid, j = o % p.hid;
+        float a = 0.f;
+        for (int f = 0; f < p.out1; ++f) a = fmaf(sd[n * oc + f], p.W2[(long long)j * p.out1 + f], a);
+        const float hv = sh[o];                            // own element only: the in-place update needs no barrier
+        sh[o] = hv > 0.f ? a : 0.2f * a;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < (p.in1 + 1) * p.hid; o += 256) {
+        const int i = o / p.hid, j = o % p.hid;
+        float a = 0.f;
+        for (int n = 0; n < p.N; ++n) a = fmaf(i < p.in1 ? s1[n * p.in1 + i] : 1.f, sh[n * p.hid + j], a);
+        if (i < p.in1) p.gW1[o] = a;
+        else p.gb1[j] = a;
+    }
+}
+
+inline size_t condnet_lds(const CondNetP &p, bool bwd) {
+    return sizeof(float) * ((size_t)p.N * p.in1 + (size_t)p.N * p.hid + (bwd ? (size_t)p.N * (p.out1 + p.out2) : 0));
+}
+
+inline int condnet_check(const CondNetP &p) {
+    if (!p.c1 || !p.c2 || !p.W1 || !p.b1 || !p.W2 || !p.b2 || !p.Wc || !p.bc || !p.h) return CAPE_EINVAL;
+    if (p.N < 1 || p.N > 64 || p.in1 < 1 || p.hid < 1 || p.out1 < 1 || p.in2 < 1 || p.out2 < 1 || p.ld1 < p.in1 || p.ld2 < p.in2)
+        return CAPE_EINVAL;
+    if (condnet_lds(p, true) > 60 * 1024) return CAPE_EINVAL;
+    return CAPE_OK;
+}
+
+}  // namespace
+
+extern "C" int cape_condnet_fwd(const float *c1, int32_t ld1, const float *c2, int32_t ld2, const float *W1, const float *b1,
+                                const float *W2, const float *b2, const float *Wc, const float *bc, float *h, float *ycat,
+                                int32_t N, int32_t in1, int32_t hid, int32_t out1, int32_t in2, int32_t out2, void *stream) {
+    CondNetP p{};
+    p.c1 = c1; p.c2 = c2; p.ld1 = ld1; p.ld2 = ld2; p.W1 = W1; p.b1 = b1; p.W2 = W2; p.b2 = b2; p.Wc = Wc; p.bc = bc;
+    p.h = h; p.ycat = ycat; p.N = N; p.in1 = in1; p.hid = hid; p.out1 = out1; p.in2 = in2; p.out2 = out2;
+    if (!ycat) return CAPE_EINVAL;
+    const int rc = condnet_check(p);
+    if (rc) return rc;
+    CAPE_LAUNCH(condnet_fwd_kernel, dim3(1), dim3(256), condnet_lds(p, false), (hipStream_t)stream, p);
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}
+
+extern "C" int cape_condnet_bwd(const float *c1, int32_t ld1, const float *c2, int32_t ld2, const float *W2, const float *h,
+                                const float *dycat, float *gW1, float *gb1, float *gW2, float *gb2, float *gWc, float *gbc,
+                                int32_t N, int32_t in1, int32_t hid, int32_t out1, int32_t in2, int32_t out2, void *stream) {
+    CondNetP p{};
+    p.c1 = c1; p.c2 = c2; p.ld1 = ld1; p.ld2 = ld2; p.W2 = W2; p.h = const_cast<float *>(h); p.dycat = dycat;
+    p.gW1 = gW1; p.gb1 = gb1; p.gW2 = gW2; p.gb2 = gb2; p.gWc = gWc; p.gbc = gbc;
+    p.N = N; p.in1 = in1; p.hid = hid; p.out1 = out1; p.in2 = in2; p.out2 = out2;
+    p.W1 = p.b1 = p.b2 = p.Wc = p.bc = W2;      // (unused by the backward kernel; non-null for the shared check)
+    if (!dycat || !gW1 || !gb1 || !gW2 || !gb2 || !gWc || !gbc) return CAPE_EINVAL;
+    const int rc = condnet_check(p);
+    if (rc) return rc;
+    CAPE_LAUNCH(condnet_bwd_kernel, dim3(1), dim3(256), condnet_lds(p, true), (hipStream_t)stream, p);
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}

@@ -509,11 +509,11 @@ struct DwReduceParams {
 };
 
 // block = 16 consecutive output elements x 16 split lanes; fixed summation order (deterministic)
-__global__ __launch_bounds__(256) void dw_reduce_kernel(DwReduceParams p) {
+__device__ __forceinline__ void dw_reduce_body(const DwReduceParams &p, long long block) {
     __shared__ float red[16][17];
     const long long total = p.part_off[p.nsrc];
     const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const long long i = (long long)blockIdx.x * 16 + el;
+    const long long i = block * 16 + el;
     float sum = 0.f;
     if (i < total) {
         float s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -542,12 +542,14 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(DwReduceParams p) {
     }
 }
 
+__global__ __launch_bounds__(256) void dw_reduce_kernel(DwReduceParams p) { dw_reduce_body(p, blockIdx.x); }
+
 // Vector form: thread = 4 consecutive output elements (one float4 of a weight-gradient row), all splits summed
 // in order with four independent partial sums -- fully coalesced slab reads.  Needs F % 4 == 0, unit column
 // stride and 16-byte aligned destinations (the layer weights in the gradient bucket).
-__global__ __launch_bounds__(256) void dw_reduce_vec_kernel(DwReduceParams p) {
+__device__ __forceinline__ void dw_reduce_vec_body(const DwReduceParams &p, long long block) {
     const long long total4 = p.part_off[p.nsrc] >> 2;
-    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long q = block * 256 + threadIdx.x;
     if (q >= total4) return;
     const long long i = q << 2;
     const float4 *src = reinterpret_cast<const float4 *>(p.ws + i);
@@ -579,6 +581,25 @@ __global__ __launch_bounds__(256) void dw_reduce_vec_kernel(DwReduceParams p) {
         t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
     }
     *dst = t;
+}
+
+__global__ __launch_bounds__(256) void dw_reduce_vec_kernel(DwReduceParams p) { dw_reduce_vec_body(p, blockIdx.x); }
+
+// The slab reductions of SEVERAL weight-gradient launches in one dispatch (their partial slabs stay in their workspaces
+// until then): per layer the reduction is a ~5 us dispatch whose result is only needed at the end of the backward pass.
+struct DwReduceBatch {
+    DwReduceParams it[CAPE_MAX_DW_REDUCE_ITEMS];
+    int blk_off[CAPE_MAX_DW_REDUCE_ITEMS + 1];
+    int vec[CAPE_MAX_DW_REDUCE_ITEMS];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void dw_reduce_batch_kernel(DwReduceBatch B) {
+    int i = 0;
+    while (i + 1 < B.n && (int)blockIdx.x >= B.blk_off[i + 1]) ++i;
+    const long long b = (long long)blockIdx.x - B.blk_off[i];
+    if (B.vec[i]) dw_reduce_vec_body(B.it[i], b);       // (uniform per block)
+    else dw_reduce_body(B.it[i], b);
 }
 
 // es = bytes per activation element (4: fp32, 2: bf16 storage)
@@ -902,10 +923,12 @@ int gconv_dw_plan_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz, in
     plan[1] = pl.ct; plan[2] = pl.ft; plan[3] = pl.ngroups * pl.rsplit;
     return CAPE_OK;
 }
+struct DwReduceParams;
 int gconv_dw_stage_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz,
                         int64_t dz_sample_stride, int32_t lddz, const float *dz2, uint32_t dz2_mask,
                         int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
-                        int64_t workspace_bytes, int32_t stage, void *stream, bool bf16);
+                        int64_t workspace_bytes, int32_t stage, void *stream, bool bf16,
+                        DwReduceParams *batch_rp = nullptr, int *batch_vec = nullptr, int *batch_blocks = nullptr);
 }  // namespace
 
 extern "C" int cape_gconv_dw_plan(const cape_src_t *srcs, int32_t nsrc, const float *dz, int64_t dz_sample_stride,
@@ -932,6 +955,7 @@ extern "C" int cape_gconv_dw_stage_bf16(const cape_src_t *srcs, int32_t nsrc, co
                                         int64_t dz_sample_stride, int32_t lddz, const void *dz2, uint32_t dz2_mask,
                                         int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
                                         int64_t workspace_bytes, int32_t stage, void *stream) {
+    if (stage > 2) return CAPE_EINVAL;
     return gconv_dw_stage_impl(srcs, nsrc, (const float *)dz, dz_sample_stride, lddz, (const float *)dz2, dz2_mask, N, Mo, F,
                                accumulate, workspace, workspace_bytes, stage, stream, true);
 }
@@ -948,6 +972,7 @@ extern "C" int cape_gconv_dw_stage(const cape_src_t *srcs, int32_t nsrc, const f
                                    int64_t dz_sample_stride, int32_t lddz, const float *dz2, uint32_t dz2_mask,
                                    int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
                                    int64_t workspace_bytes, int32_t stage, void *stream) {
+    if (stage > 2) return CAPE_EINVAL;
     return gconv_dw_stage_impl(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, N, Mo, F, accumulate, workspace,
                                workspace_bytes, stage, stream, false);
 }
@@ -956,8 +981,9 @@ namespace {
 int gconv_dw_stage_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz,
                         int64_t dz_sample_stride, int32_t lddz, const float *dz2, uint32_t dz2_mask,
                         int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
-                        int64_t workspace_bytes, int32_t stage, void *stream, bool bf16) {
-    if (stage < 0 || stage > 2) return CAPE_EINVAL;
+                        int64_t workspace_bytes, int32_t stage, void *stream, bool bf16,
+                        DwReduceParams *batch_rp, int *batch_vec, int *batch_blocks) {
+    if (stage < 0 || stage > 3 || (stage == 3 && (!batch_rp || !batch_vec || !batch_blocks))) return CAPE_EINVAL;
     if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || !dz || N < 1 || Mo < 1 || F < 1 || lddz < F || !workspace)
         return CAPE_EINVAL;
     if (dz2_mask && !dz2) return CAPE_EINVAL;
@@ -992,7 +1018,7 @@ int gconv_dw_stage_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz,
     p.ws = (float *)workspace; p.slab = pl.slab;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(pl.ntiles * ((pl.ngroups * pl.rsplit + 7) / 8) * 8)), block(256);     // cape_map_dw_block
-    if (stage == 2) {
+    if (stage >= 2) {
         // reduction only: the partial slabs of an earlier stage-1 call with the same arguments are in the workspace
     } else if (bf16 && dw_split) {
         if (pl.ct == 64 && pl.ft == 64) CAPE_LAUNCH((dw_split_kernel<64, 64, cape_bf16>), grid, block, 0, st, p);
@@ -1036,9 +1062,36 @@ int gconv_dw_stage_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz,
     bool rvec = (F & 3) == 0 && (pl.slab & 3) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && total >= 262144;
     for (int i = 0; i < nsrc; ++i)
         rvec = rvec && srcs[i].w_cs == 1 && (srcs[i].w_rs & 3) == 0 && (reinterpret_cast<uintptr_t>(srcs[i].w) & 15) == 0;
+    if (stage == 3) {                  // describe the reduction instead of launching it (cape_gconv_dw_reduce_batch)
+        *batch_rp = rp;
+        *batch_vec = rvec ? 1 : 0;
+        *batch_blocks = rvec ? (int)((total / 4 + 255) / 256) : rblocks;
+        return CAPE_OK;
+    }
     if (rvec) CAPE_LAUNCH(dw_reduce_vec_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, rp);
     else CAPE_LAUNCH(dw_reduce_kernel, dim3(rblocks), dim3(256), 0, st, rp);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }
 }  // namespace
+
+extern "C" int cape_gconv_dw_reduce_batch(const cape_dw_item_t *items, int32_t nitems, void *stream) {
+    if (!items || nitems < 1 || nitems > CAPE_MAX_DW_REDUCE_ITEMS) return CAPE_EINVAL;
+    DwReduceBatch B;
+    B.n = nitems;
+    int off = 0;
+    for (int i = 0; i < nitems; ++i) {
+        const cape_dw_item_t &t = items[i];
+        int blocks = 0;
+        const int rc = gconv_dw_stage_impl(t.srcs, t.nsrc, (const float *)t.dz, t.dz_sample_stride, t.lddz, (const float *)t.dz2,
+                                           t.dz2_mask, t.N, t.Mo, t.F, t.accumulate, t.workspace, t.workspace_bytes, 3, stream,
+                                           t.bf16 != 0, &B.it[i], &B.vec[i], &blocks);
+        if (rc) return rc;
+        B.blk_off[i] = off;
+        off += blocks;
+    }
+    B.blk_off[nitems] = off;
+    CAPE_LAUNCH(dw_reduce_batch_kernel, dim3((unsigned)off), dim3(256), 0, (hipStream_t)stream, B);
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}

@@ -417,9 +417,38 @@ class CAPE(base_model):
         return y
 
     def _conditions(self, cond, cond2):
+        """Pose and clothing-type embeddings (:284-290).  With the default layer counts (pose MLP 2 layers, clothing type 1)
+        both networks run as ONE launch per direction (ops.CondNetsFn) and the embeddings are the two halves of the
+        concatenated condition every consumer needs (``_cat_cond``); variables are created under the reference's names."""
+        self._ycat = None
+        if (self.n_layer_cond == 1 and cond.is_cuda and cond.dim() == 2 and cond.shape[0] <= 64
+                and cond.dtype == torch.float32 and cond2.dtype == torch.float32):
+            y_dim = int(cond.shape[-1])
+            nzc = int(self.nz_cond)
+            hid = y_dim // 2 if nzc < y_dim // 2 else (y_dim if nzc < y_dim * 2 else nzc // 2)       # rule of :498-503
+            with self.variable_scope('condition_pose'):
+                with self.variable_scope('fc1'):
+                    W1, b1, g1 = self._dense_vars(y_dim, hid)
+                with self.variable_scope('fc2'):
+                    W2, b2, g2 = self._dense_vars(hid, nzc)
+            with self.variable_scope('condition_clo_label'):
+                with self.variable_scope('fc1'):
+                    Wc, bc, gc = self._dense_vars(int(cond2.shape[-1]), int(self.nz_cond2))
+            gb = g1 + g2 + gc
+            ycat = ops.CondNetsFn.apply(cond, cond2, W1, b1, W2, b2, Wc, bc, gb if all(v is not None for v in gb) else None)
+            y, y2 = ycat[:, :nzc], ycat[:, nzc:]
+            self._ycat = (y, y2, ycat)
+            return y, y2
         y = self.condition(cond, 'pose', self.nz_cond, nlayers=2)
         y2 = self.condition(cond2, 'clo_label', self.nz_cond2, nlayers=self.n_layer_cond)
         return y, y2
+
+    def _cat_cond(self, y, y2):
+        """tf.concat([y, y2], 1): the tensor the fused condition kernel already produced when y / y2 are its halves."""
+        t = getattr(self, '_ycat', None)
+        if t is not None and y is t[0] and y2 is t[1]:
+            return t[2]
+        return torch.cat([y, y2], 1)
 
     def res_block(self, x_in, i, name):
         with self.variable_scope(name):
@@ -497,7 +526,7 @@ class CAPE(base_model):
         return y.reshape(x.shape[0], 1, y.shape[-1]).expand(x.shape[0], x.shape[1], y.shape[-1])
 
     def encoder(self, x, y, y2, use_res_block=False, use_cond=True):
-        cond_in = torch.cat([y, y2], 1) if use_cond else None
+        cond_in = self._cat_cond(y, y2) if use_cond else None
         if cond_in is not None and use_res_block:
             x, cond_in = ops.ConcatCondFn.apply(x, cond_in), None      # res_block reads its input twice
         if x.dtype != self.act_dtype:
@@ -529,7 +558,7 @@ class CAPE(base_model):
 
     def decoder_cond_vert(self, x, y, y2, use_res_block=False):
         N = x.shape[0]
-        cond = torch.cat([y, y2], 1)
+        cond = self._cat_cond(y, y2)
         # the GraphCMR block group-normalises over the concatenated [features | condition] channels, so it
         # needs the condition materialised; every other consumer takes it as rank-1 ``cond_in`` terms.
         materialise = bool(use_res_block and not self.affine) or not self._fusable()
@@ -586,12 +615,12 @@ class CAPE(base_model):
             # sampling (:193-196) and the KL term (:371-372) share one hand-differentiated op
             z, self._kl_of_last_sample = ops.VaeSampleKLFn.apply(z_mean, z_logvar, eps)
             self._kl_inputs = (z_mean, z_logvar)
-            z_total = torch.cat([z, y, y2], dim=1)
+            z_total = torch.cat([z, self._cat_cond(y, y2)], dim=1)
             x_hat = self.decoder_cond_vert(z_total, y, y2, use_res_block=self.use_res_block_dec)
         return x_hat, z_mean, z_logvar
 
     def discriminator(self, x, y, y2):
-        cond = torch.cat([y, y2], 1)
+        cond = self._cat_cond(y, y2)
         if x.dtype != self.act_dtype:
             x = x.to(self.act_dtype)
         with self.variable_scope('discriminator'):
@@ -825,7 +854,8 @@ class CAPE(base_model):
         self._reg_via_bucket = reg_via_bucket
         self._reg_in_bucket = False
         y_g, y2_g = self._conditions(cond_g, cond2_g)
-        self._y_pair = (y_g, y2_g)
+        # heads of the two-phase backward: the tensors the decoder / discriminator actually consume
+        self._y_pair = (self._ycat[2],) if self._ycat is not None else (y_g, y2_g)
         x_hat, z_mean, z_logvar = self.generator(data_g, y_g, y2_g, eps=eps)
         out = self.loss_terms(x_hat, gt, z_mean, z_logvar)
         out['prediction'] = x_hat

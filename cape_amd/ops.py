@@ -268,9 +268,12 @@ def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=
     return y
 
 
-def gconv_dw(entries, dz, accumulate=False, dz2=None):
+def gconv_dw(entries, dz, accumulate=False, dz2=None, defer=False):
     """entries' ``w`` fields name the gradient blocks to write; entries with ``use_dz2`` contract against
-    ``dz2`` (same shape and strides as ``dz``) instead of ``dz``."""
+    ``dz2`` (same shape and strides as ``dz``) instead of ``dz``.  ``defer`` (honoured while DEFERRED is a list): only
+    the contraction runs now; the fixed-order slab reduction is queued and flush_deferred() performs the reductions of
+    all queued layers in batched launches -- legal when nothing reads the gradient blocks before the flush (they are
+    views of the flat gradient bucket)."""
     _lib.require_gpu()
     arr = _mk_srcs(entries)
     N, Mo, F = dz.shape
@@ -294,6 +297,21 @@ def gconv_dw(entries, dz, accumulate=False, dz2=None):
                                       C.c_void_p(ws.data_ptr()), need, _stream())
         check(rc, "cape_gconv_dw")
 
+    if defer and DEFERRED is not None and LAUNCH_LOG is None:
+        if PLAN_LOG is not None:
+            plan = (C.c_int32 * 4)()
+            check(_fn("cape_gconv_dw_plan", dz)(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, plan), "cape_gconv_dw_plan")
+            PLAN_LOG.add(("dw", plan[0], plan[1], plan[2]) + (("bf16",) if bf else ()))
+        check(_fn("cape_gconv_dw_stage", dz)(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, 1 if accumulate else 0,
+                                             C.c_void_p(ws.data_ptr()), need, 1, _stream()), "cape_gconv_dw_stage")
+        it = _lib.CapeDwItem()
+        it.srcs, it.nsrc = C.addressof(arr), len(entries)
+        it.dz, it.dz_sample_stride, it.lddz = p.value, ss, ld
+        it.dz2, it.dz2_mask = (p2.value if p2 is not None else None), mask
+        it.N, it.Mo, it.F, it.accumulate, it.bf16 = N, Mo, F, 1 if accumulate else 0, 1 if bf else 0
+        it.workspace, it.workspace_bytes = ws.data_ptr(), need
+        DEFERRED_DW.append((it, arr, ws, dz, dz2, [e["x"] for e in entries]))       # keep every buffer alive until the flush
+        return
     if LAUNCH_LOG is None and PLAN_LOG is None:
         launch()
     else:
@@ -513,10 +531,18 @@ NO_WEIGHT_GRAD = None
 # pass) calls with defer=True leave their bias / coefficient-gradient reductions as partial slabs and queue them;
 # flush_deferred() finishes all queued ones in ONE launch (csrc cape_bwd_prep_finalize).  Consumers flush before reading.
 DEFERRED = None
+DEFERRED_DW = []          # queued weight-gradient slab reductions (gconv_dw(defer=True)), same lifetime as DEFERRED
 
 
 def flush_deferred():
     global DEFERRED
+    if DEFERRED_DW:
+        queued, DEFERRED_DW[:] = list(DEFERRED_DW), []
+        nmax = 12                                    # CAPE_MAX_DW_REDUCE_ITEMS
+        for i0 in range(0, len(queued), nmax):
+            chunk = queued[i0:i0 + nmax]
+            arr = (_lib.CapeDwItem * len(chunk))(*[q[0] for q in chunk])
+            check(lib.cape_gconv_dw_reduce_batch(C.addressof(arr), len(chunk), _stream()), "cape_gconv_dw_reduce_batch")
     if not DEFERRED:
         return
     items, DEFERRED[:] = list(DEFERRED), []
@@ -791,13 +817,16 @@ class ChebConvFn(torch.autograd.Function):
             ent += [dict(x=xs[k], csr=csr_of(k), w=(dW, k * Fout, K * Fout, 1)) for k in range(K)]
         if W_aff is not None and need_wa and not ctx.coarse_dw:
             ent.append(dict(x=xs[0], csr=csr_of(0), w=(dWa, 0, Fout, 1), use_dz2=True))
+        # the slab reductions may wait for the end of the backward pass when every gradient block is a bucket view
+        in_bucket = lambda t, v: t is None or (v is not None and t.data_ptr() == v.data_ptr())
+        dw_defer = in_bucket(dW, ctx.gW) and in_bucket(dWa, ctx.gWa)
         if ent:
             same = (W_aff is None) or (_v(g)[1:] == _v(dz)[1:])
             if same:
-                gconv_dw(ent, dz, dz2=g if W_aff is not None else None)      # one launch, one reduction
+                gconv_dw(ent, dz, dz2=g if W_aff is not None else None, defer=dw_defer)      # one launch, one reduction
             else:
-                gconv_dw([e for e in ent if not e.get("use_dz2")], dz)
-                gconv_dw([dict(e, use_dz2=False) for e in ent if e.get("use_dz2")], g)
+                gconv_dw([e for e in ent if not e.get("use_dz2")], dz, defer=dw_defer)
+                gconv_dw([dict(e, use_dz2=False) for e in ent if e.get("use_dz2")], g, defer=dw_defer)
         if Cc and ctx.banked:
             dcoef_out = dcoef        # CondCoefFn turns it into the weight-row and condition gradients of all layers
         elif Cc:
@@ -875,7 +904,7 @@ class ChebConvFn(torch.autograd.Function):
                         if W_aff is not None and need_wa:
                             wen.append(dict(x=Ts[K], csr=None, w=(dWa, 0, 1, Fout)))
                         if wen:
-                            gconv_dw(wen, xs[0])
+                            gconv_dw(wen, xs[0], defer=dw_defer)
         if Co and need_co:
             dco = reduce_cond(gfull[:, :, Fout:])
         return dx, dW, dB, dWa, dci, dco, None, None, None, None, None, None, None, dcoef_out
@@ -1149,6 +1178,45 @@ class CondCoefFn(torch.autograd.Function):
         check(lib.cape_cond_coef_bwd(C.c_void_p(cond.data_ptr()), Cc, N, Cc, arr, len(layers), _ptr(dcond), Cc, 0, _stream()),
               "cape_cond_coef_bwd")
         return dcond, None
+
+
+class CondNetsFn(torch.autograd.Function):
+    """Both condition networks (reference lib/models.py:479-511, :284-290) in one launch per direction (csrc/condnet.hip):
+    ycat = [ leaky_relu(c1 W1 + b1) W2 + b2 | c2 Wc + bc ].  ``gbufs``: the six gradient-bucket views (W1, b1, W2, b2, Wc,
+    bc) or None -- with views the backward kernel writes the bucket directly."""
+
+    @staticmethod
+    def forward(ctx, c1, c2, W1, b1, W2, b2, Wc, bc, gbufs):
+        _lib.require_gpu()
+        c1, c2 = c1.contiguous(), c2.contiguous()
+        N, in1 = c1.shape
+        hid, out1, in2, out2 = int(W1.shape[1]), int(W2.shape[1]), int(c2.shape[1]), int(Wc.shape[1])
+        assert all(t.is_contiguous() and t.dtype == torch.float32 for t in (W1, b1, W2, b2, Wc, bc, c1, c2))
+        assert tuple(W1.shape) == (in1, hid) and tuple(W2.shape) == (hid, out1) and tuple(Wc.shape) == (in2, out2)
+        h = torch.empty((N, hid), device=c1.device, dtype=torch.float32)
+        ycat = torch.empty((N, out1 + out2), device=c1.device, dtype=torch.float32)
+        check(lib.cape_condnet_fwd(_ptr(c1), in1, _ptr(c2), in2, _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(Wc), _ptr(bc),
+                                   _ptr(h), _ptr(ycat), N, in1, hid, out1, in2, out2, _stream()), "cape_condnet_fwd")
+        ctx.gbufs, ctx.dims = gbufs, (N, in1, hid, out1, in2, out2)
+        ctx.save_for_backward(c1, c2, W2, h)
+        ctx.shapes = [tuple(t.shape) for t in (W1, b1, W2, b2, Wc, bc)]
+        return ycat
+
+    @staticmethod
+    def backward(ctx, dycat):
+        c1, c2, W2, h = ctx.saved_tensors
+        N, in1, hid, out1, in2, out2 = ctx.dims
+        dycat = dycat.contiguous()
+        outs = []
+        for i, shp in enumerate(ctx.shapes):
+            v = None if ctx.gbufs is None else ctx.gbufs[i]
+            if v is not None and v.is_contiguous() and v.numel() == int(np.prod(shp)):
+                outs.append(v.view(shp))
+            else:
+                outs.append(torch.empty(shp, device=c1.device, dtype=torch.float32))
+        check(lib.cape_condnet_bwd(_ptr(c1), in1, _ptr(c2), in2, _ptr(W2), _ptr(h), _ptr(dycat), *[_ptr(t) for t in outs],
+                                   N, in1, hid, out1, in2, out2, _stream()), "cape_condnet_bwd")
+        return (None, None) + tuple(outs) + (None,)
 
 
 def poolwT(x, fwd_csr, bwd_csr):

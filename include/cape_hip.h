@@ -195,6 +195,24 @@ int cape_gconv_dw_stage(const cape_src_t *srcs, int32_t nsrc, const float *dz,
                         int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
                         int64_t workspace_bytes, int32_t stage, void *stream);
 
+/* The reductions (stage 2) of up to CAPE_MAX_DW_REDUCE_ITEMS earlier stage-1 calls in ONE launch: each item repeats the
+ * arguments of its cape_gconv_dw_stage(..., stage = 1, ...) call (bf16 != 0: it was the _bf16 entry); the workspaces must
+ * still hold the partial slabs.  The training step defers every layer's reduction to the end of the backward pass. */
+#define CAPE_MAX_DW_REDUCE_ITEMS 12
+typedef struct cape_dw_item {
+    const cape_src_t *srcs;
+    int32_t nsrc;
+    const void *dz;
+    int64_t dz_sample_stride;
+    int32_t lddz;
+    const void *dz2;
+    uint32_t dz2_mask;
+    int32_t N, Mo, F, accumulate, bf16;
+    void *workspace;
+    int64_t workspace_bytes;
+} cape_dw_item_t;
+int cape_gconv_dw_reduce_batch(const cape_dw_item_t *items, int32_t nitems, void *stream);
+
 /* Which kernel cape_gconv_dw would run for these arguments (pure query, no launch): plan[0] = family (0: gather form
  * gconv_dw_kernel, 1: dw_plain_kernel on the exact-fp32 MFMA, 2: dw_packed_kernel, 3: dw_split_kernel on the bf16 pipe
  * with the exact three-way operand split), plan[1], plan[2] = tile channels x output columns, plan[3] = number of
@@ -414,6 +432,21 @@ int64_t cape_fc_wide_bwd_workspace_bytes(int32_t N, int32_t in, int32_t out);
 int cape_fc_wide_bwd(const float *x, int32_t ldx, const float *g, int32_t ldg, const float *y, int32_t ldy,
                      int32_t act, int32_t N, int32_t in, int32_t out, const float *W, float *dW, float *db,
                      float *dx, int32_t lddx, void *workspace, int64_t workspace_bytes, void *stream);
+
+/*
+ * The two condition networks in one launch per direction (lib/models.py:479-511 ``condition`` as called at :284-290):
+ *   h    = leaky_relu(c1 W1 + b1, 0.2)   [N, hid]     (tf.layers.dense, pose MLP layer 1)
+ *   ycat = [ h W2 + b2 | c2 Wc + bc ]    [N, out1 + out2]   (pose MLP layer 2 | clothing-type layer, concatenated the
+ *          way every consumer concatenates them, :533, :591, :663)
+ * W* row-major [in, out]; c1 / c2 rows ld1 / ld2 apart; h and ycat contiguous; N <= 64.  Backward: dycat [N, out1 + out2]
+ * contiguous -> gradients of all six variables (written, not accumulated).  One workgroup, fixed summation order.
+ */
+int cape_condnet_fwd(const float *c1, int32_t ld1, const float *c2, int32_t ld2, const float *W1, const float *b1,
+                     const float *W2, const float *b2, const float *Wc, const float *bc, float *h, float *ycat,
+                     int32_t N, int32_t in1, int32_t hid, int32_t out1, int32_t in2, int32_t out2, void *stream);
+int cape_condnet_bwd(const float *c1, int32_t ld1, const float *c2, int32_t ld2, const float *W2, const float *h,
+                     const float *dycat, float *gW1, float *gb1, float *gW2, float *gb2, float *gWc, float *gbc,
+                     int32_t N, int32_t in1, int32_t hid, int32_t out1, int32_t in2, int32_t out2, void *stream);
 
 /*
  * ---- bf16 storage variants (BASELINE configs[4]: "bf16 weights/activations", SURVEY section 8(b) "_bf16") -----------------
