@@ -3,7 +3,7 @@
 // clothing-type layer  c2 [N, in2] -> c2 Wc + bc [N, out2]; the outputs are written side by side as ycat [N, out1 + out2]
 // -- the concatenated condition every consumer wants (:533, :591, :663).  At N = 16 these are ~0.15 MFLOP: as six
 // rocBLAS / elementwise dispatches forward and eight backward they cost ~70 us of a 3.5 ms step in dispatch latency alone.
-// One workgroup, everything staged in LDS, fixed summation order (deterministic).
+// Forward: one workgroup per sample; backward: 16 workgroups over the rows of the widest gradient; fixed summation order.
 #include "common.h"
 
 namespace {
@@ -19,64 +19,78 @@ struct CondNetP {
     int N, in1, hid, out1, in2, out2;
 };
 
-__global__ __launch_bounds__(256) void condnet_fwd_kernel(CondNetP p) {
-    extern __shared__ float sm[];
-    float *s1 = sm;                          // [N][in1]
-    float *sh = sm + p.N * p.in1;            // [N][hid]
-    for (int i = threadIdx.x; i < p.N * p.in1; i += 256) s1[i] = p.c1[(long long)(i / p.in1) * p.ld1 + (i % p.in1)];
+// Forward: one workgroup per sample.  Thread = (output column, quarter of the contraction): four partial sums per
+// output, combined in a fixed order through LDS -- 32 instead of 126 dependent multiply-adds per thread, weight reads
+// coalesced over the columns.
+__device__ __forceinline__ float quad_sum(float *red, int col, int part, float v, int ncol) {
     __syncthreads();
-    for (int o = threadIdx.x; o < p.N * p.hid; o += 256) {
-        const int n = o / p.hid, j = o % p.hid;
-        float a = p.b1[j];
-        for (int i = 0; i < p.in1; ++i) a = fmaf(s1[n * p.in1 + i], p.W1[(long long)i * p.hid + j], a);
-        a = a > 0.f ? a : 0.2f * a;
-        sh[o] = a;
-        p.h[o] = a;
+    red[part * ncol + col] = v;
+    __syncthreads();
+    return (red[col] + red[ncol + col]) + (red[2 * ncol + col] + red[3 * ncol + col]);
+}
+
+__global__ __launch_bounds__(256) void condnet_fwd_kernel(CondNetP p) {
+    __shared__ float s1[512], sh[256], red[4 * 64];
+    const int n = blockIdx.x;
+    const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < p.in1; i += 256) s1[i] = p.c1[(long long)n * p.ld1 + i];
+    __syncthreads();
+    for (int j0 = 0; j0 < p.hid; j0 += 64) {               // hidden layer, 64 columns at a time
+        const int j = j0 + col;
+        float a = 0.f;
+        if (j < p.hid)
+            for (int i = part; i < p.in1; i += 4) a = fmaf(s1[i], p.W1[(long long)i * p.hid + j], a);
+        a = quad_sum(red, col, part, a, 64);
+        if (part == 0 && j < p.hid) {
+            a += p.b1[j];
+            a = a > 0.f ? a : 0.2f * a;
+            sh[j] = a;
+            p.h[(long long)n * p.hid + j] = a;
+        }
     }
     __syncthreads();
     const int oc = p.out1 + p.out2;
-    for (int o = threadIdx.x; o < p.N * oc; o += 256) {
-        const int n = o / oc, f = o % oc;
-        float a;
+    for (int f0 = 0; f0 < oc; f0 += 64) {
+        const int f = f0 + col;
+        float a = 0.f;
         if (f < p.out1) {
-            a = p.b2[f];
-            for (int j = 0; j < p.hid; ++j) a = fmaf(sh[n * p.hid + j], p.W2[(long long)j * p.out1 + f], a);
-        } else {
+            for (int j = part; j < p.hid; j += 4) a = fmaf(sh[j], p.W2[(long long)j * p.out1 + f], a);
+        } else if (f < oc) {
             const int g = f - p.out1;
-            a = p.bc[g];
-            for (int i = 0; i < p.in2; ++i) a = fmaf(p.c2[(long long)n * p.ld2 + i], p.Wc[(long long)i * p.out2 + g], a);
+            for (int i = part; i < p.in2; i += 4) a = fmaf(p.c2[(long long)n * p.ld2 + i], p.Wc[(long long)i * p.out2 + g], a);
         }
-        p.ycat[o] = a;
+        a = quad_sum(red, col, part, a, 64);
+        if (part == 0 && f < oc) p.ycat[(long long)n * oc + f] = a + (f < p.out1 ? p.b2[f] : p.bc[f - p.out1]);
     }
 }
 
+// Backward: every workgroup recomputes dh = (dy W2^T) * leaky'(h) for all samples (N * hid * out1 multiply-adds: cheap) and
+// then owns a slice of the rows of gW1 (+ its bias row); workgroup 0 also produces the small gradients of the other layers.
 __global__ __launch_bounds__(256) void condnet_bwd_kernel(CondNetP p) {
     extern __shared__ float sm[];
     const int oc = p.out1 + p.out2;
-    float *s1 = sm;                          // [N][in1]
-    float *sh = s1 + p.N * p.in1;            // [N][hid]   h, then dh in place
+    float *sh = sm;                          // [N][hid]   h, then dh in place
     float *sd = sh + p.N * p.hid;            // [N][oc]    dycat
-    for (int i = threadIdx.x; i < p.N * p.in1; i += 256) s1[i] = p.c1[(long long)(i / p.in1) * p.ld1 + (i % p.in1)];
     for (int i = threadIdx.x; i < p.N * p.hid; i += 256) sh[i] = p.h[i];
     for (int i = threadIdx.x; i < p.N * oc; i += 256) sd[i] = p.dycat[i];
     __syncthreads();
-    // second pose layer and the clothing-type layer: weight / bias gradients
-    for (int o = threadIdx.x; o < (p.hid + 1) * p.out1; o += 256) {
-        const int j = o / p.out1, f = o % p.out1;          // j == hid: bias row
-        float a = 0.f;
-        for (int n = 0; n < p.N; ++n) a = fmaf(j < p.hid ? sh[n * p.hid + j] : 1.f, sd[n * oc + f], a);
-        if (j < p.hid) p.gW2[o] = a;
-        else p.gb2[f] = a;
-    }
-    for (int o = threadIdx.x; o < (p.in2 + 1) * p.out2; o += 256) {
-        const int i = o / p.out2, g = o % p.out2;
-        float a = 0.f;
-        for (int n = 0; n < p.N; ++n) a = fmaf(i < p.in2 ? p.c2[(long long)n * p.ld2 + i] : 1.f, sd[n * oc + p.out1 + g], a);
-        if (i < p.in2) p.gWc[o] = a;
-        else p.gbc[g] = a;
+    if (blockIdx.x == 0) {
+        for (int o = threadIdx.x; o < (p.hid + 1) * p.out1; o += 256) {
+            const int j = o / p.out1, f = o % p.out1;          // j == hid: bias row
+            float a = 0.f;
+            for (int n = 0; n < p.N; ++n) a = fmaf(j < p.hid ? sh[n * p.hid + j] : 1.f, sd[n * oc + f], a);
+            if (j < p.hid) p.gW2[o] = a;
+            else p.gb2[f] = a;
+        }
+        for (int o = threadIdx.x; o < (p.in2 + 1) * p.out2; o += 256) {
+            const int i = o / p.out2, g = o % p.out2;
+            float a = 0.f;
+            for (int n = 0; n < p.N; ++n) a = fmaf(i < p.in2 ? p.c2[(long long)n * p.ld2 + i] : 1.f, sd[n * oc + p.out1 + g], a);
+            if (i < p.in2) p.gWc[o] = a;
+            else p.gbc[g] = a;
+        }
     }
     __syncthreads();
-    // dh = (dy W2^T) * leaky'(h), in place of h
     for (int o = threadIdx.x; o < p.N * p.hid; o += 256) {
         const int n = o / p.hid, j = o % p.hid;
         float a = 0.f;
@@ -85,24 +99,28 @@ __global__ __launch_bounds__(256) void condnet_bwd_kernel(CondNetP p) {
         sh[o] = hv > 0.f ? a : 0.2f * a;
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < (p.in1 + 1) * p.hid; o += 256) {
-        const int i = o / p.hid, j = o % p.hid;
+    // rows [i0, i1) of gW1 (row in1 = bias): thread = one output element, sum over the samples in order
+    const int rows = p.in1 + 1;
+    const int per = (rows + gridDim.x - 1) / gridDim.x;
+    const int i0 = blockIdx.x * per, i1 = min(rows, i0 + per);
+    for (int o = threadIdx.x; o < (i1 - i0) * p.hid; o += 256) {
+        const int i = i0 + o / p.hid, j = o % p.hid;
         float a = 0.f;
-        for (int n = 0; n < p.N; ++n) a = fmaf(i < p.in1 ? s1[n * p.in1 + i] : 1.f, sh[n * p.hid + j], a);
-        if (i < p.in1) p.gW1[o] = a;
+        for (int n = 0; n < p.N; ++n) a = fmaf(i < p.in1 ? p.c1[(long long)n * p.ld1 + i] : 1.f, sh[n * p.hid + j], a);
+        if (i < p.in1) p.gW1[(long long)i * p.hid + j] = a;
         else p.gb1[j] = a;
     }
 }
 
 inline size_t condnet_lds(const CondNetP &p, bool bwd) {
-    return sizeof(float) * ((size_t)p.N * p.in1 + (size_t)p.N * p.hid + (bwd ? (size_t)p.N * (p.out1 + p.out2) : 0));
+    return bwd ? sizeof(float) * ((size_t)p.N * p.hid + (size_t)p.N * (p.out1 + p.out2)) : 0;
 }
 
 inline int condnet_check(const CondNetP &p) {
     if (!p.c1 || !p.c2 || !p.W1 || !p.b1 || !p.W2 || !p.b2 || !p.Wc || !p.bc || !p.h) return CAPE_EINVAL;
     if (p.N < 1 || p.N > 64 || p.in1 < 1 || p.hid < 1 || p.out1 < 1 || p.in2 < 1 || p.out2 < 1 || p.ld1 < p.in1 || p.ld2 < p.in2)
         return CAPE_EINVAL;
-    if (condnet_lds(p, true) > 60 * 1024) return CAPE_EINVAL;
+    if (condnet_lds(p, true) > 60 * 1024 || p.in1 > 512 || p.hid > 256) return CAPE_EINVAL;     // static LDS rows of the forward kernel
     return CAPE_OK;
 }
 
@@ -117,7 +135,7 @@ extern "C" int cape_condnet_fwd(const float *c1, int32_t ld1, const float *c2, i
     if (!ycat) return CAPE_EINVAL;
     const int rc = condnet_check(p);
     if (rc) return rc;
-    CAPE_LAUNCH(condnet_fwd_kernel, dim3(1), dim3(256), condnet_lds(p, false), (hipStream_t)stream, p);
+    CAPE_LAUNCH(condnet_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, p);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }
@@ -133,7 +151,7 @@ extern "C" int cape_condnet_bwd(const float *c1, int32_t ld1, const float *c2, i
     if (!dycat || !gW1 || !gb1 || !gW2 || !gb2 || !gWc || !gbc) return CAPE_EINVAL;
     const int rc = condnet_check(p);
     if (rc) return rc;
-    CAPE_LAUNCH(condnet_bwd_kernel, dim3(1), dim3(256), condnet_lds(p, true), (hipStream_t)stream, p);
+    CAPE_LAUNCH(condnet_bwd_kernel, dim3(16), dim3(256), condnet_lds(p, true), (hipStream_t)stream, p);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }

@@ -439,7 +439,7 @@ int cape_fc_wide_bwd(const float *x, int32_t ldx, const float *g, int32_t ldg, c
  *   ycat = [ h W2 + b2 | c2 Wc + bc ]    [N, out1 + out2]   (pose MLP layer 2 | clothing-type layer, concatenated the
  *          way every consumer concatenates them, :533, :591, :663)
  * W* row-major [in, out]; c1 / c2 rows ld1 / ld2 apart; h and ycat contiguous; N <= 64.  Backward: dycat [N, out1 + out2]
- * contiguous -> gradients of all six variables (written, not accumulated).  One workgroup, fixed summation order.
+ * contiguous -> gradients of all six variables (written, not accumulated).  Fixed summation order (deterministic).
  */
 int cape_condnet_fwd(const float *c1, int32_t ld1, const float *c2, int32_t ld2, const float *W1, const float *b1,
                      const float *W2, const float *b2, const float *Wc, const float *bc, float *h, float *ycat,
