@@ -18,8 +18,8 @@ from .graph import ConvOperators, HostCSR
 
 # "twopass": sparse operators applied by the streaming spmm kernel, dense contraction as a plain GEMM
 # "fused":   sparse operators gathered inside the GEMM kernel's A-tile staging (one launch per layer)
-MODE = "twopass"
 import os as _os
+MODE = _os.environ.get("CAPE_MODE", "twopass")
 SPMM_BOUNDED = int(_os.environ.get("CAPE_SPMM_BOUNDED", "0"))   # unrolled bounded-row kernel: no measured gain
 
 _ACT_OF = {"b1leakyrelu": ("leaky", _lib.BIAS_CHANNEL), "b1relu": ("relu", _lib.BIAS_CHANNEL),
