@@ -1,0 +1,56 @@
+"""The data-parallel path with the REAL model on a GPU box (the CPU test tests/test_dist_cpu.py covers
+the exchange logic on a stand-in network).  One GPU is enough: two ranks share device 0 and exchange over gloo; the
+two-phase backward + early/late bucket exchange + HIP-graph replay are exactly what `bench.py --gpus N` runs over RCCL."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(**extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra)
+    return env
+
+
+@pytest.mark.parametrize("gan", [False, True], ids=["cvae", "adversarial"])
+def test_two_rank_step_equals_global_batch_step(gan, tmp_path):
+    """2 ranks x B meshes (mean of the rank gradients, clip after the reduce, replicas bit-identical) must reproduce the
+    single-process step on the 2B-mesh global batch: every loss term is a batch mean, so the averaged gradient IS the
+    global gradient.  Tolerance: fp32 summation order only (kernel tile selection differs between batch B and 2B)."""
+    B, steps = 2, 2
+    out = str(tmp_path / "dp.npz")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "tools", "dp_equiv_worker.py"), out, str(B), str(steps), "1" if gan else "0",
+           "gloo"]
+    r = subprocess.run(cmd, env=_env(CAPE_FORCE_DEVICE="0"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    dp = np.load(out)
+    assert int(dp["split"]) == 1                       # the two-phase backward was the path taken
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import dp_equiv_worker as W
+    model = W.build(2 * B, 'cuda:0')
+    init = {g: model._opt_state[g]['flat'].detach().clone() for g in ('g', 'd')}
+    W.run(model, W.global_batch(2 * B, int(model.nz)), steps, gan, None)
+    for grp in (('g', 'd') if gan else ('g',)):
+        ref = model._opt_state[grp]['flat'].detach().cpu().numpy()
+        got = dp["flat_" + grp]
+        moved = np.abs(ref - init[grp].cpu().numpy()).max()
+        err = np.abs(got - ref).max()
+        print(grp, "largest update %.3e, dp-vs-global difference %.3e" % (moved, err))
+        assert moved > 0 and err <= 2e-3 * moved + 1e-7, (grp, err, moved)
+
+
+def test_split_step_with_one_rank_rccl_group():
+    """The split runner against the real collective backend (a one-rank RCCL group, collectives forced on): graph A1 ->
+    async all-reduce -> graph A2 -> all-reduce -> wait -> graph B must replay and equal the single-graph step."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_selftest.py")], env=_env(), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    assert '"split": true' in r.stdout.decode()
