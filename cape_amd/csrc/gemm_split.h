@@ -34,6 +34,13 @@ typedef unsigned gs_u32x4 __attribute__((ext_vector_type(4)));      // native ve
 #define CAPE_DW_BF16X6_DEFAULT 1      // weight gradient on the bf16 pipe (dw_split_kernel); CAPE_DW_BF16X6=0 -> exact-fp32 MFMA
 #endif
 
+#ifndef CAPE_SPLIT_SKEW
+#define CAPE_SPLIT_SKEW 0                 // experiment knob: > 0 = initial delay (x 1024 cycles) of every second workgroup
+#endif
+#ifndef CAPE_SPLIT_SKEW_BIT
+#define CAPE_SPLIT_SKEW_BIT 8
+#endif
+
 #ifndef CAPE_SPLIT_SWZ
 #define CAPE_SPLIT_SWZ 0                  // 1: unpadded 64-byte LDS rows, 16-byte segment index XOR-ed with (row >> 2) & 3
 #endif
@@ -143,6 +150,12 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_B
     cape_map_block(blockIdx.x, p.N, p.row_tiles * p.col_tiles, n, t);
     const int r0 = (t / p.col_tiles) * BM;
     const int f0 = (t % p.col_tiles) * BN;
+#if CAPE_SPLIT_SKEW
+    // experiment: de-phase the workgroups that share a CU (they start together and run identical code, so their MFMA
+    // and staging phases coincide instead of overlapping)
+    if ((blockIdx.x >> CAPE_SPLIT_SKEW_BIT) & 1)
+        for (int i = 0; i < CAPE_SPLIT_SKEW; ++i) __builtin_amdgcn_s_sleep(16);
+#endif
 
     f32x16 acc[TM][TN];
     f32x16 acc2[DUAL ? TM : 1][DUAL ? TN : 1];

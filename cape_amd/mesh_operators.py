@@ -84,14 +84,13 @@ def _collapse_cost(Qv, r, c, v):
 
 
 def _get_sparse_transform(faces, num_original_verts):
-    verts_left = np.unique(faces.flatten())
-    IS = np.arange(len(verts_left))
-    mp = np.arange(0, np.max(faces.flatten()) + 1)
-    mp[verts_left] = IS
-    new_faces = mp[faces.copy().flatten()].reshape((-1, 3))
-    mtx = sp.csc_matrix((np.ones(len(verts_left)), np.vstack((IS, verts_left))),
-                        shape=(len(verts_left), num_original_verts))
-    return new_faces, mtx
+    """Compact the surviving vertices of a decimated face list: returns the re-indexed faces and the selection matrix
+    D [kept, original] with one unit entry per row at the kept vertex (reference :228-241).  ``np.unique`` delivers both the
+    sorted survivors and, via ``return_inverse``, every face corner's rank among them -- the new index."""
+    kept, corner_rank = np.unique(np.asarray(faces).reshape(-1), return_inverse=True)
+    rows = np.arange(kept.size)
+    select = sp.csc_matrix((np.ones(kept.size), (rows, kept)), shape=(kept.size, int(num_original_verts)))
+    return corner_rank.reshape(-1, 3), select
 
 
 def qslim_decimator_transformer(mesh, factor=None, n_verts_desired=None):
@@ -265,21 +264,18 @@ def setup_deformation_transfer(source, target, use_normals=False):
 def generate_transform_matrices(mesh, factors):
     """``M, A, D, U, E`` for a list of down-sampling factors (reference :244-263, main.py:31-39): meshes, adjacency
     matrices (len+1), down-sampling and up-sampling matrices (len) and edge lists (len+1)."""
-    factors = [1.0 / x for x in factors]
-    M, A, D, U, E = [], [], [], [], []
-    mesh = Mesh(np.asarray(mesh.v, dtype=np.float64), np.asarray(mesh.f, dtype=np.int64))
-    A.append(get_vert_connectivity(mesh))
-    M.append(mesh)
-    E.append(get_vertices_per_edge(mesh))
-    for factor in factors:
-        ds_f, ds_D = qslim_decimator_transformer(M[-1], factor=factor)
-        D.append(ds_D)
-        new_mesh = Mesh(ds_D.dot(M[-1].v), ds_f)
-        M.append(new_mesh)
-        A.append(get_vert_connectivity(new_mesh))
-        U.append(setup_deformation_transfer(M[-1], M[-2]))
-        E.append(get_vertices_per_edge(new_mesh))
-    return M, A, D, U, E
+    level = Mesh(np.asarray(mesh.v, dtype=np.float64), np.asarray(mesh.f, dtype=np.int64))
+    levels, downs, ups = [level], [], []
+    for f in factors:
+        faces_next, select = qslim_decimator_transformer(level, factor=1.0 / f)
+        coarse = Mesh(select.dot(level.v), faces_next)               # kept vertices keep their positions
+        downs.append(select)
+        ups.append(setup_deformation_transfer(coarse, level))        # fine vertices from the coarse surface
+        levels.append(coarse)
+        level = coarse
+    adjacency = [get_vert_connectivity(m) for m in levels]
+    edges = [get_vertices_per_edge(m) for m in levels]
+    return levels, adjacency, downs, ups, edges
 
 
 def load_obj(path):
