@@ -452,6 +452,182 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_v2_kernel(const float
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Third generation (round 2): double-buffered LDS (2 x 60 KB -> one workgroup per CU), ONE barrier per chunk, and the
+// operand split of chunk it+1 placed between the fragment reads and the MFMAs of chunk it in program order, so that the
+// wave's own VALU / LDS-write work can run in the shadow of its MFMAs.  SG: 0 = leave the interleaving to the compiler,
+// 1 = sched_group_barrier pattern (1 MFMA : 4 VALU, a DS write every 4th group), 2 = same with 6 VALU per MFMA.
+// ---------------------------------------------------------------------------------------------------------------
+template <int SG>
+__global__ __launch_bounds__(256, 1) void gemm_v3_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                        float *__restrict__ C, int N, int Mo, int K, int F,
+                                                        int row_tiles, int col_tiles) {
+    constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64, TM = 2, TN = 2, PA = 2, PB = 2, LP = PITCH;
+    constexpr int APLANE = BM * LP, BPLANE = BN * LP, BUF = 3 * (APLANE + BPLANE);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int q = tid & 3, r = tid >> 2;
+    int n, t;
+    map_block(blockIdx.x, N, row_tiles * col_tiles, n, t);
+    const int r0 = (t / col_tiles) * BM, f0 = (t % col_tiles) * BN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+
+    const float *ap[PA], *bp[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) ap[i] = A + ((long long)n * Mo + min(r0 + r + 64 * i, Mo - 1)) * K + 8 * q;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) bp[i] = B + (long long)min(f0 + r + 64 * i, F - 1) * K + 8 * q;
+
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v ra[PA][2], rb[PB][2];
+    auto load_regs = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            ra[i][0] = *reinterpret_cast<const f32x4v *>(ap[i] + k0);
+            ra[i][1] = *reinterpret_cast<const f32x4v *>(ap[i] + k0 + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            rb[i][0] = *reinterpret_cast<const f32x4v *>(bp[i] + k0);
+            rb[i][1] = *reinterpret_cast<const f32x4v *>(bp[i] + k0 + 4);
+        }
+    };
+    auto store8 = [&](unsigned char *base, int plane, int row, const f32x4v &u, const f32x4v &v) {
+        u32x4 hi, mid, lo;
+        unsigned h, m, l;
+        split2(u[0], u[1], h, m, l); hi[0] = h; mid[0] = m; lo[0] = l;
+        split2(u[2], u[3], h, m, l); hi[1] = h; mid[1] = m; lo[1] = l;
+        split2(v[0], v[1], h, m, l); hi[2] = h; mid[2] = m; lo[2] = l;
+        split2(v[2], v[3], h, m, l); hi[3] = h; mid[3] = m; lo[3] = l;
+        unsigned char *d = base + row * LP + 16 * q;
+        *reinterpret_cast<u32x4 *>(d) = hi;
+        *reinterpret_cast<u32x4 *>(d + plane) = mid;
+        *reinterpret_cast<u32x4 *>(d + 2 * plane) = lo;
+    };
+    // half 0: the A rows, half 1: the B rows of the chunk held in the staging registers
+    auto store_half = [&](unsigned char *buf, int half) {
+        if (half == 0) {
+#pragma unroll
+            for (int i = 0; i < PA; ++i) store8(buf, APLANE, r + 64 * i, ra[i][0], ra[i][1]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) store8(buf + 3 * APLANE, BPLANE, r + 64 * i, rb[i][0], rb[i][1]);
+        }
+    };
+    // two fragment register sets: the reads of k-step s+1 are in flight during the MFMAs of k-step s (SG >= 10: the
+    // fragment-prefetch schedule; below 10: reads issued right before their MFMAs, as in the second generation)
+    bf16x8 afr[2][TM][3], bfr[2][TN][3];
+    auto frags_to = [&](int set, const unsigned char *buf, int ks) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                afr[set][a][p] = *reinterpret_cast<const bf16x8 *>(buf + p * APLANE + (wm * WTM + a * 32 + li) * LP + 16 * (lh + 2 * ks));
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                bfr[set][b][p] = *reinterpret_cast<const bf16x8 *>(buf + 3 * APLANE + p * BPLANE + (wn * WTN + b * 32 + li) * LP + 16 * (lh + 2 * ks));
+    };
+    auto mfmas_of = [&](int set) {
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[set][a][term_pa(6, term)], bfr[set][b][term_pb(6, term)], acc[a][b], 0, 0, 0);
+    };
+    auto frags = [&](const unsigned char *buf, int ks) { frags_to(0, buf, ks); };
+    auto mfmas = [&]() { mfmas_of(0); };
+    auto pattern = [&]() {
+        if constexpr (SG > 0) {
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, SG == 1 ? 4 : 6, 0);      // VALU of the split
+                if ((i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // a DS write now and then
+            }
+        }
+    };
+
+    const int total = K / KC;
+    load_regs(0);
+    store_half(smem3, 0);
+    store_half(smem3, 1);
+    if (total > 1) load_regs(KC);
+    __syncthreads();
+    if constexpr (SG >= 10) {
+        frags_to(0, smem3, 0);
+        for (int it = 0; it + 1 < total; ++it) {
+            unsigned char *cur = smem3 + (it & 1) * BUF, *nxt = smem3 + ((it + 1) & 1) * BUF;
+            frags_to(1, cur, 1);
+            store_half(nxt, 0);
+            mfmas_of(0);
+            store_half(nxt, 1);
+            load_regs(min(it + 2, total - 1) * KC);
+            mfmas_of(1);
+            __syncthreads();
+            frags_to(0, nxt, 0);
+        }
+        {
+            unsigned char *cur = smem3 + ((total - 1) & 1) * BUF;
+            frags_to(1, cur, 1);
+            mfmas_of(0);
+            mfmas_of(1);
+        }
+    } else {
+    // branch-free steady state (stores unconditional, the look-ahead load clamped to the last chunk) so that the split, the
+    // LDS writes and the MFMAs of one iteration sit in ONE scheduling region; the last chunk is peeled
+    for (int it = 0; it + 1 < total; ++it) {
+        unsigned char *cur = smem3 + (it & 1) * BUF, *nxt = smem3 + ((it + 1) & 1) * BUF;
+        frags(cur, 0);
+        store_half(nxt, 0);
+        mfmas();
+        pattern();
+        frags(cur, 1);
+        store_half(nxt, 1);
+        load_regs(min(it + 2, total - 1) * KC);
+        mfmas();
+        pattern();
+        __syncthreads();
+    }
+    {
+        unsigned char *cur = smem3 + ((total - 1) & 1) * BUF;
+        frags(cur, 0);
+        mfmas();
+        frags(cur, 1);
+        mfmas();
+    }
+    }
+
+    float *cn = C + (long long)n * Mo * F;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = f0 + wn * WTN + b * 32 + li;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row = r0 + wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                if (row < Mo && col < F) cn[(long long)row * F + col] = acc[a][b][g];
+            }
+        }
+}
+
+struct Shape;
+template <int SG>
+static double run_v3(const Shape &s, const float *A, const float *B, float *C, int iters);
+
+// ---------------------------------------------------------------------------------------------------------------
 // bf16-STORAGE contraction (BASELINE configs[4]: activations and weights kept in bf16, fp32 accumulate): one MFMA product
 // per multiply-add, operands copied global -> LDS as they are (64 contraction indices = 128 bytes per row and chunk,
 // swizzled 16-byte segments), fp32 or bf16 output.  A projection of what the bf16 path of the library would reach.
@@ -627,6 +803,26 @@ static double run_v2(const Shape &s, const float *A, const float *B, float *C, i
     return 1e3 * ms / iters;
 }
 
+template <int SG>
+static double run_v3(const Shape &s, const float *A, const float *B, float *C, int iters) {
+    const int rt = (s.Mo + 127) / 128, ct = (s.F + 127) / 128;
+    const int lds = 2 * 3 * (128 * PITCH + 128 * PITCH);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_v3_kernel<SG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    auto launch = [&]() { gemm_v3_kernel<SG><<<s.N * rt * ct, 256, lds>>>(A, B, C, s.N, s.Mo, s.K, s.F, rt, ct); };
+    launch();
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < iters; ++i) launch();
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return 1e3 * ms / iters;
+}
+
 // error of rows [ra, rb) of sample n against a float64 reference; also the error an fp32 sequential dot makes
 static void check(const Shape &s, const std::vector<float> &hA, const std::vector<float> &hB, const float *dC, int n, int ra, int rb,
                   double &err_max, double &err_rms, double &f32_rms) {
@@ -699,6 +895,40 @@ int main(int argc, char **argv) {
             printf("%-22s %7.1fus %5.0fTF %4.1fTB/s %7.1fus %5.0fTF %4.1fTB/s %7.1fus %5.0fTF %4.1fTB/s   %.2e\n", name, u0, fl / u0 / 1e6,
                    by32 / u0 / 1e6, u1, fl / u1 / 1e6, by16 / u1 / 1e6, u2, fl / u2 / 1e6, by16 / u2 / 1e6, erms);
             hipFree(A); hipFree(B); hipFree(C); hipFree(A16); hipFree(B16);
+        }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "v3")) {
+        const char *vn[] = {"v2 128x128 trunc (ref)", "v3 dbuf 1 barrier", "v3 + sched 1:4", "v3 + frag prefetch"};
+        constexpr int NV3 = 4;
+        printf("%-22s", "shape (N Mo K F)");
+        for (int i = 0; i < NV3; ++i) printf(" %24s", vn[i]);
+        printf("\n");
+        for (const Shape &s : std::vector<Shape>{{16, 862, 1024, 512}, {16, 862, 512, 512}, {16, 862, 512, 256}, {16, 1723, 256, 256},
+                                                 {16, 3445, 128, 128}}) {
+            std::vector<float> hA((size_t)s.N * s.Mo * s.K), hB((size_t)s.F * s.K);
+            fill(hA, 7, 1.0f);
+            fill(hB, 100, 0.05f);
+            float *A, *B, *C;
+            hipMalloc(&A, hA.size() * 4); hipMalloc(&B, hB.size() * 4); hipMalloc(&C, (size_t)s.N * s.Mo * s.F * 4);
+            hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
+            hipMemcpy(B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
+            const double fl = 2.0 * s.N * s.Mo * (double)s.K * s.F;
+            double us[NV3], emax[NV3], erms[NV3], f32rms = 0;
+            auto chk = [&](int i) { check(s, hA, hB, C, s.N - 1, s.Mo - 24, s.Mo, emax[i], erms[i], f32rms); };
+            auto clr = [&]() { hipMemset(C, 0xFF, (size_t)s.N * s.Mo * s.F * 4); };
+            clr(); us[0] = run_v2<128, 128, 2, 2, 2, false, false>(s, A, B, C, iters); chk(0);
+            clr(); us[1] = run_v3<0>(s, A, B, C, iters); chk(1);
+            clr(); us[2] = run_v3<1>(s, A, B, C, iters); chk(2);
+            clr(); us[3] = run_v3<10>(s, A, B, C, iters); chk(3);
+            char name[64];
+            snprintf(name, sizeof name, "%d %d %d %d", s.N, s.Mo, s.K, s.F);
+            printf("%-22s", name);
+            for (int i = 0; i < NV3; ++i) printf(" %14.1fus %5.1fTF", us[i], fl / us[i] / 1e6);
+            printf("\n%-22s", "  rms err/rms(ref)");
+            for (int i = 0; i < NV3; ++i) printf(" %24.2e", erms[i]);
+            printf("   fp32 fma chain: %.2e\n", f32rms);
+            hipFree(A); hipFree(B); hipFree(C);
         }
         return 0;
     }
