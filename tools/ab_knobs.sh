@@ -4,12 +4,14 @@
 #      tools/ab_compare.py (the sweeps print a checksum of every output);
 #   2. the GPU parity suite with the knobs given in $KNOBS exported;
 #   3. paired bench runs, alternating default / knobs, so that box-to-box clock differences cancel.
-#   /usr/local/graft/bin/gpurun --timeout 600 -- 'KNOBS="CAPE_DW_BF16X6=1 CAPE_GEMM_BF16X6_DUAL=1" bash tools/ab_knobs.sh'
+#   /usr/local/graft/bin/gpurun --timeout 600 -- 'KNOBS="CAPE_DW_BF16X6=0 CAPE_GEMM_BF16X6_DUAL=0" bash tools/ab_knobs.sh'
+# (round 2 flipped both knobs to on by default after this script's run, profiles/r02_ab_*; the default KNOBS below now
+#  compare the shipped defaults against the exact-fp32 kernels)
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/ab
 mkdir -p $O
-KNOBS=${KNOBS:-"CAPE_DW_BF16X6=1 CAPE_GEMM_BF16X6_DUAL=1"}
+KNOBS=${KNOBS:-"CAPE_DW_BF16X6=0 CAPE_GEMM_BF16X6_DUAL=0"}
 PAIRS=${PAIRS:-3}
 cd $R/tools/ubench
 env CAPE_GEMM_BF16X6=0 ./gemm_bench > $O/gemm_fp32.txt 2>&1
