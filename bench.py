@@ -224,7 +224,7 @@ def cpu_baseline(batch=16, iters=5, budget_s=150.0):
 
 
 def exact_fp32_run(args):
-    """The same step with every contraction on the exact-fp32 MFMA (CAPE_GEMM_BF16X6=0; the library reads the knob once
+    """The same step with every contraction on the exact-fp32 MFMA (CAPE_GEMM_BF16X6=0 CAPE_DW_BF16X6=0; the library reads the knobs once
     per process, hence a child process): reported NEXT TO the headline so that both arithmetic paths are measured by the
     same bench invocation.  Never replaces ``value``; any failure is reported as a string instead of aborting the line."""
     import subprocess
@@ -233,12 +233,12 @@ def exact_fp32_run(args):
     if args.gan:
         cmd.append('--gan')
     try:
-        env = dict(os.environ, CAPE_GEMM_BF16X6='0')
+        env = dict(os.environ, CAPE_GEMM_BF16X6='0', CAPE_DW_BF16X6='0')
         out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=180, check=True)
         line = [l for l in out.stdout.decode().splitlines() if l.startswith('{')][-1]
         r = json.loads(line)
         return {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
-                "note": "same step, CAPE_GEMM_BF16X6=0: all contractions on v_mfma_f32_32x32x2_f32"}
+                "note": "same step, CAPE_GEMM_BF16X6=0 CAPE_DW_BF16X6=0: all contractions on v_mfma_f32_32x32x2_f32"}
     except Exception as e:                                  # noqa: BLE001 -- the comparison is optional
         return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
