@@ -43,6 +43,63 @@ __device__ __forceinline__ float2 cape_ld2(const cape_bf16 *p) {
     const unsigned u = *reinterpret_cast<const unsigned *>(p);
     return make_float2(__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xFFFF0000u));
 }
+// VW (1, 4 or 8) consecutive elements, widened to fp32 / rounded back.  Alignment: VW elements of fp32 up to 16 bytes
+// (VW = 8: two 16-byte accesses), VW elements of bf16 (8 -> one 16-byte access).
+typedef unsigned cape_u32x4 __attribute__((ext_vector_type(4)));
+template <int VW>
+__device__ __forceinline__ void cape_ldv(const float *p, float (&o)[VW]) {
+    if constexpr (VW == 1) {
+        o[0] = *p;
+    } else {
+#pragma unroll
+        for (int h = 0; h < VW / 4; ++h) {
+            const float4 v = *reinterpret_cast<const float4 *>(p + 4 * h);
+            o[4 * h] = v.x; o[4 * h + 1] = v.y; o[4 * h + 2] = v.z; o[4 * h + 3] = v.w;
+        }
+    }
+}
+template <int VW>
+__device__ __forceinline__ void cape_ldv(const cape_bf16 *p, float (&o)[VW]) {
+    if constexpr (VW == 1) {
+        o[0] = cape_ld(p);
+    } else if constexpr (VW == 4) {
+        const uint2 u = *reinterpret_cast<const uint2 *>(p);
+        o[0] = __builtin_bit_cast(float, u.x << 16); o[1] = __builtin_bit_cast(float, u.x & 0xFFFF0000u);
+        o[2] = __builtin_bit_cast(float, u.y << 16); o[3] = __builtin_bit_cast(float, u.y & 0xFFFF0000u);
+    } else {
+        const cape_u32x4 u = *reinterpret_cast<const cape_u32x4 *>(p);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            o[2 * h] = __builtin_bit_cast(float, u[h] << 16);
+            o[2 * h + 1] = __builtin_bit_cast(float, u[h] & 0xFFFF0000u);
+        }
+    }
+}
+template <int VW>
+__device__ __forceinline__ void cape_stv(float *p, const float (&v)[VW]) {
+    if constexpr (VW == 1) {
+        *p = v[0];
+    } else {
+#pragma unroll
+        for (int h = 0; h < VW / 4; ++h)
+            *reinterpret_cast<float4 *>(p + 4 * h) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+    }
+}
+template <int VW>
+__device__ __forceinline__ void cape_stv(cape_bf16 *p, const float (&v)[VW]) {
+    if constexpr (VW == 1) {
+        cape_st(p, v[0]);
+    } else if constexpr (VW == 4) {
+        uint2 u;
+        u.x = cape_pack_bf16(v[0], v[1]); u.y = cape_pack_bf16(v[2], v[3]);
+        *reinterpret_cast<uint2 *>(p) = u;
+    } else {
+        cape_u32x4 u;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) u[h] = cape_pack_bf16(v[2 * h], v[2 * h + 1]);
+        *reinterpret_cast<cape_u32x4 *>(p) = u;
+    }
+}
 template <typename AT> struct cape_is_bf16 { static constexpr bool value = false; };
 template <> struct cape_is_bf16<cape_bf16> { static constexpr bool value = true; };
 

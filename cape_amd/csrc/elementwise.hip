@@ -27,55 +27,119 @@ __host__ __device__ inline bool aligned4(const void *p, long long ss, int ld, in
 // blocks per sample of the sparse kernels (256 work items = (row, channel quad) pairs each)
 __host__ __device__ inline int spmm_bps(int Mo, int cq) { return (int)(((long long)Mo * cq + 255) / 256); }
 
+#ifndef CAPE_SPMM_UNROLL_DEFAULT
+#define CAPE_SPMM_UNROLL_DEFAULT 4
+#endif
+#ifndef CAPE_SPMM_WIDE_DEFAULT
+#define CAPE_SPMM_WIDE_DEFAULT 1
+#endif
+// Knobs of the vector sparse kernels (A/B switches, read once):
+//   CAPE_SPMM_UNROLL = 0 (entry loop as written), 4 or 8 (entries in unrolled groups, see cape_gather_row)
+//   CAPE_SPMM_WIDE   = 1: 8 channels per work item where the channel count and the alignment allow, 0: always 4
+inline int spmm_unroll() {
+    static const int u = getenv("CAPE_SPMM_UNROLL") ? atoi(getenv("CAPE_SPMM_UNROLL")) : CAPE_SPMM_UNROLL_DEFAULT;
+    return u >= 8 ? 8 : u >= 4 ? 4 : 0;
+}
+inline bool spmm_wide() {
+    static const int w = getenv("CAPE_SPMM_WIDE") ? atoi(getenv("CAPE_SPMM_WIDE")) : CAPE_SPMM_WIDE_DEFAULT;
+    return w != 0;
+}
+// eight consecutive elements addressable as vector accesses (fp32: two 16-byte accesses, bf16: one)
+inline bool aligned8(const void *p, long long ss, int ld, int C, int es) {
+    const int a = es == 4 ? 3 : 7;          // element alignment of the row starts
+    return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && ((ss & a) == 0) && ((ld & a) == 0) && ((C & 7) == 0);
+}
+// launch KERNEL<VW, T, U> with VW = 8 / 4 (wide) and U from the knob (hint4: rows of at most 4 entries -> groups of 4)
+#define CAPE_LAUNCH_SP(KERNEL, T, wide, hint4, ...)                                  \
+    do {                                                                             \
+        const int u_ = (hint4 && spmm_unroll()) ? 4 : spmm_unroll();                 \
+        if (wide) {                                                                  \
+            if (u_ == 8) CAPE_LAUNCH((KERNEL<8, T, 8>), __VA_ARGS__);                \
+            else if (u_ == 4) CAPE_LAUNCH((KERNEL<8, T, 4>), __VA_ARGS__);           \
+            else CAPE_LAUNCH((KERNEL<8, T, 0>), __VA_ARGS__);                        \
+        } else {                                                                     \
+            if (u_ == 8) CAPE_LAUNCH((KERNEL<4, T, 8>), __VA_ARGS__);                \
+            else if (u_ == 4) CAPE_LAUNCH((KERNEL<4, T, 4>), __VA_ARGS__);           \
+            else CAPE_LAUNCH((KERNEL<4, T, 0>), __VA_ARGS__);                        \
+        }                                                                            \
+    } while (0)
+
+// One output row of a CSR operator, VW channels: acc = sum_e va[e] * x[ci[e], c..c+VW-1].
+// U = 0: entry loop as written -- the index load, then the row load that depends on it, then the next entry: two
+// dependent memory round trips per entry.
+// U > 0: entries in groups of U, fully unrolled: all (index, value) pairs of a group are loaded first, then all row
+// gathers are in flight together, so a row of <= U entries costs three dependent round trips (row pointer, entries,
+// rows).  Slots past the end of the row re-read its first entry with weight 0 (same address as slot 0: one L1 line)
+// and add nothing; the order of the sum is unchanged.
+template <int VW, int U, typename T>
+__device__ __forceinline__ void cape_gather_row(const T *xb, long long ldx, const int *rp, const int *ci, const float *va, int r,
+                                                float (&acc)[VW]) {
+#pragma unroll
+    for (int u = 0; u < VW; ++u) acc[u] = 0.f;
+    int e = rp[r];
+    const int e1 = rp[r + 1];
+    if constexpr (U == 0) {
+        for (; e < e1; ++e) {
+            const float v = va[e];
+            float xv[VW];
+            cape_ldv<VW>(xb + (long long)ci[e] * ldx, xv);
+#pragma unroll
+            for (int u = 0; u < VW; ++u) acc[u] = fmaf(v, xv[u], acc[u]);
+        }
+    } else {
+        for (; e < e1; e += U) {
+            int cols[U];
+            float vals[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const bool ok = e + j < e1;
+                const int ee = ok ? e + j : e;
+                cols[j] = ci[ee];
+                vals[j] = ok ? va[ee] : 0.f;
+            }
+            float xv[U][VW];
+#pragma unroll
+            for (int j = 0; j < U; ++j) cape_ldv<VW>(xb + (long long)cols[j] * ldx, xv[j]);
+#pragma unroll
+            for (int j = 0; j < U; ++j)
+#pragma unroll
+                for (int u = 0; u < VW; ++u) acc[u] = fmaf(vals[j], xv[j][u], acc[u]);
+        }
+    }
+}
+
 // ---- spmm: y[n,r,:] = alpha * S x[n] + beta * z[n,r,:] ------------------------------------
-template <bool VEC, typename T = float>
+// work item = (sample, output row, VW channels); VW = 1 for unaligned / odd channel counts
+template <int VW, typename T = float, int U = 0>
 __global__ __launch_bounds__(256) void spmm_kernel(CViewT<T> x, const int *rp, const int *ci, const float *va,
                                                    float alpha, CViewT<T> z, float beta, ViewT<T> y, int N, int Mo, int C) {
-    const int W = VEC ? 4 : 1;
-    const int cq = (C + W - 1) / W;
+    const int cq = (C + VW - 1) / VW;
     // block -> (sample, 256 work items of that sample), all blocks of a sample on ONE XCD (spmm_grid / cape_map_block): the
     // ~7 neighbour rows an output row gathers are then served by the L2 that already holds that sample, instead of every
     // XCD fetching nearly the whole input (measured: 2.9x the algorithmic bytes in L2-miss traffic with linear blocks)
     int n, t;
     cape_map_block(blockIdx.x, N, spmm_bps(Mo, cq), n, t);
-    {
-        const long long i = (long long)t * 256 + threadIdx.x;
-        if (i >= (long long)Mo * cq) return;
-        const int q = (int)(i % cq);
-        const int r = (int)(i / cq);
-        const int c = q * W;
-        const T *xb = x.p + (long long)n * x.ss + c;
-        if (VEC) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int e1 = rp[r + 1];
-            for (int e = rp[r]; e < e1; ++e) {
-                const float v = va[e];
-                const float4 xv = cape_ld4(xb + (long long)ci[e] * x.ld);
-                acc.x = fmaf(v, xv.x, acc.x); acc.y = fmaf(v, xv.y, acc.y);
-                acc.z = fmaf(v, xv.z, acc.z); acc.w = fmaf(v, xv.w, acc.w);
-            }
-            acc.x *= alpha; acc.y *= alpha; acc.z *= alpha; acc.w *= alpha;
-            if (z.p) {
-                const float4 zv = cape_ld4(z.p + (long long)n * z.ss + (long long)r * z.ld + c);
-                acc.x = fmaf(beta, zv.x, acc.x); acc.y = fmaf(beta, zv.y, acc.y);
-                acc.z = fmaf(beta, zv.z, acc.z); acc.w = fmaf(beta, zv.w, acc.w);
-            }
-            cape_st4(y.p + (long long)n * y.ss + (long long)r * y.ld + c, acc);
-        } else {
-            float acc = 0.f;
-            const int e1 = rp[r + 1];
-            for (int e = rp[r]; e < e1; ++e) acc = fmaf(va[e], cape_ld(xb + (long long)ci[e] * x.ld), acc);
-            acc *= alpha;
-            if (z.p) acc = fmaf(beta, cape_ld(z.p + (long long)n * z.ss + (long long)r * z.ld + c), acc);
-            cape_st(y.p + (long long)n * y.ss + (long long)r * y.ld + c, acc);
-        }
+    const int i = t * 256 + (int)threadIdx.x;               // Mo * cq < 2^31 (checked by the host entry)
+    if (i >= Mo * cq) return;
+    const int r = i / cq;
+    const int c = (i - r * cq) * VW;
+    float acc[VW];
+    cape_gather_row<VW, U>(x.p + (long long)n * x.ss + c, x.ld, rp, ci, va, r, acc);
+#pragma unroll
+    for (int u = 0; u < VW; ++u) acc[u] *= alpha;
+    if (z.p) {
+        float zv[VW];
+        cape_ldv<VW>(z.p + (long long)n * z.ss + (long long)r * z.ld + c, zv);
+#pragma unroll
+        for (int u = 0; u < VW; ++u) acc[u] = fmaf(beta, zv[u], acc[u]);
     }
+    cape_stv<VW>(y.p + (long long)n * y.ss + (long long)r * y.ld + c, acc);
 }
 
 // ---- several operator applications in one launch -----------------------------------------------------------
 // separate mode: y_k = S_k x_k for every term (the X_k = S_k x of one Chebyshev layer, or T_k = S_k^T dz of its
 // data gradient);  sum mode: y = sum_k S_k x_k (dx = sum_k S_k^T G_k).  A term without CSR is the identity.
-// One thread = (sample, output row, 4 channels) of ALL terms: a layer pays one dispatch instead of K, and the
+// One work item = (sample, output row, VW channels) of ALL terms: a layer pays one dispatch instead of K, and the
 // terms' gathers of one neighbourhood hit the same L1/L2 lines.
 struct SpmmTerms {
     struct T {
@@ -87,53 +151,34 @@ struct SpmmTerms {
     int n;
 };
 
-template <bool VEC, typename T = float>
+template <int VW, typename T = float, int U = 0>
 __global__ __launch_bounds__(256) void spmm_multi_kernel(SpmmTerms P, int sum, ViewT<T> y, int N, int Mo, int C) {
-    const int W = VEC ? 4 : 1;
-    const int cq = (C + W - 1) / W;
+    const int cq = (C + VW - 1) / VW;
     int n, t;
     cape_map_block(blockIdx.x, N, spmm_bps(Mo, cq), n, t);      // see spmm_kernel
-    {
-        const long long i = (long long)t * 256 + threadIdx.x;
-        if (i >= (long long)Mo * cq) return;
-        const int q = (int)(i % cq);
-        const int r = (int)(i / cq);
-        const int c = q * W;
-        float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < P.n; ++k) {
-            const SpmmTerms::T &Tm = P.t[k];
-            const T *xb = reinterpret_cast<const T *>(Tm.x) + (long long)n * Tm.xs + c;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!Tm.rp) {
-                if (VEC) acc = cape_ld4(xb + (long long)r * Tm.ldx);
-                else acc.x = cape_ld(xb + (long long)r * Tm.ldx);
-            } else {
-                const int e1 = Tm.rp[r + 1];
-                for (int e = Tm.rp[r]; e < e1; ++e) {
-                    const float v = Tm.va[e];
-                    if (VEC) {
-                        const float4 xv = cape_ld4(xb + (long long)Tm.ci[e] * Tm.ldx);
-                        acc.x = fmaf(v, xv.x, acc.x); acc.y = fmaf(v, xv.y, acc.y);
-                        acc.z = fmaf(v, xv.z, acc.z); acc.w = fmaf(v, xv.w, acc.w);
-                    } else {
-                        acc.x = fmaf(v, cape_ld(xb + (long long)Tm.ci[e] * Tm.ldx), acc.x);
-                    }
-                }
-            }
-            acc.x *= Tm.scale; acc.y *= Tm.scale; acc.z *= Tm.scale; acc.w *= Tm.scale;
-            if (sum) {
-                tot.x += acc.x; tot.y += acc.y; tot.z += acc.z; tot.w += acc.w;
-            } else if (VEC) {
-                cape_st4(reinterpret_cast<T *>(Tm.y) + (long long)n * Tm.ys + (long long)r * Tm.ldy + c, acc);
-            } else {
-                cape_st(reinterpret_cast<T *>(Tm.y) + (long long)n * Tm.ys + (long long)r * Tm.ldy + c, acc.x);
-            }
-        }
+    const int i = t * 256 + (int)threadIdx.x;
+    if (i >= Mo * cq) return;
+    const int r = i / cq;
+    const int c = (i - r * cq) * VW;
+    float tot[VW];
+#pragma unroll
+    for (int u = 0; u < VW; ++u) tot[u] = 0.f;
+    for (int k = 0; k < P.n; ++k) {
+        const SpmmTerms::T &Tm = P.t[k];
+        const T *xb = reinterpret_cast<const T *>(Tm.x) + (long long)n * Tm.xs + c;
+        float acc[VW];
+        if (!Tm.rp) cape_ldv<VW>(xb + (long long)r * Tm.ldx, acc);
+        else cape_gather_row<VW, U>(xb, Tm.ldx, Tm.rp, Tm.ci, Tm.va, r, acc);
+#pragma unroll
+        for (int u = 0; u < VW; ++u) acc[u] *= Tm.scale;
         if (sum) {
-            if (VEC) cape_st4(y.p + (long long)n * y.ss + (long long)r * y.ld + c, tot);
-            else cape_st(y.p + (long long)n * y.ss + (long long)r * y.ld + c, tot.x);
+#pragma unroll
+            for (int u = 0; u < VW; ++u) tot[u] += acc[u];
+        } else {
+            cape_stv<VW>(reinterpret_cast<T *>(Tm.y) + (long long)n * Tm.ys + (long long)r * Tm.ldy + c, acc);
         }
     }
+    if (sum) cape_stv<VW>(y.p + (long long)n * y.ss + (long long)r * y.ld + c, tot);
 }
 
 // ---- operator applications AFTER the dense contraction (up-sampling layers) ----------------------------------
@@ -154,123 +199,70 @@ struct CombineParams {
     int mask_words;
 };
 
-template <bool VEC, typename T = float>
+template <int VW, typename T = float, int U = 0>
 __global__ __launch_bounds__(256) void spmm_combine_kernel(CombineParams Q, ViewT<T> y, int N, int Mo, int F) {
-    const int W = VEC ? 4 : 1;
-    const int cq = (F + W - 1) / W;
+    const int cq = (F + VW - 1) / VW;
     int n, t;
     cape_map_block(blockIdx.x, N, spmm_bps(Mo, cq), n, t);      // see spmm_kernel
-    {
-        const long long total = (long long)Mo * cq;             // work items of one sample
-        const long long i = (long long)t * 256 + threadIdx.x;
-        const bool live = i < total;                            // whole blocks stay alive: the mask shuffles need every lane
-        const long long ii = live ? i : total - 1;
-        const int q = (int)(ii % cq);
-        const int r = (int)(ii / cq);
-        const int c = q * W;
-        float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < Q.P.n; ++k) {
-            const SpmmTerms::T &Tm = Q.P.t[k];
-            const T *xb = reinterpret_cast<const T *>(Tm.x) + (long long)n * Tm.xs + c;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!Tm.rp) {
-                if (VEC) acc = cape_ld4(xb + (long long)r * Tm.ldx);
-                else acc.x = cape_ld(xb + (long long)r * Tm.ldx);
-            } else {
-                const int e1 = Tm.rp[r + 1];
-                for (int e = Tm.rp[r]; e < e1; ++e) {
-                    const float v = Tm.va[e];
-                    if (VEC) {
-                        const float4 xv = cape_ld4(xb + (long long)Tm.ci[e] * Tm.ldx);
-                        acc.x = fmaf(v, xv.x, acc.x); acc.y = fmaf(v, xv.y, acc.y);
-                        acc.z = fmaf(v, xv.z, acc.z); acc.w = fmaf(v, xv.w, acc.w);
-                    } else {
-                        acc.x = fmaf(v, cape_ld(xb + (long long)Tm.ci[e] * Tm.ldx), acc.x);
-                    }
-                }
-            }
-            float *dst = ((Q.to2 >> k) & 1u) ? a2 : a1;
-            dst[0] = fmaf(Tm.scale, acc.x, dst[0]); dst[1] = fmaf(Tm.scale, acc.y, dst[1]);
-            dst[2] = fmaf(Tm.scale, acc.z, dst[2]); dst[3] = fmaf(Tm.scale, acc.w, dst[3]);
-        }
-        for (int j = 0; j < Q.rankR; ++j) {
-            const float rs = Q.rowscale[(long long)j * Mo + r];
-            float *dst = ((Q.rank_to2 >> j) & 1u) ? a2 : a1;
+    const int total = Mo * cq;                              // work items of one sample (< 2^31, checked by the host entry)
+    const int i = t * 256 + (int)threadIdx.x;
+    const bool live = i < total;                            // whole blocks stay alive: the mask shuffles need every lane
+    const int ii = live ? i : total - 1;
+    const int r = ii / cq;
+    const int q = ii - r * cq;
+    const int c = q * VW;
+    float a1[VW], a2[VW];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (u < W && c + u < F) dst[u] = fmaf(rs, Q.coef[((long long)n * Q.rankR + j) * F + c + u], dst[u]);
-        }
-        float o[4];
-        unsigned bits = 0;
+    for (int u = 0; u < VW; ++u) a1[u] = a2[u] = 0.f;
+    for (int k = 0; k < Q.P.n; ++k) {
+        const SpmmTerms::T &Tm = Q.P.t[k];
+        const T *xb = reinterpret_cast<const T *>(Tm.x) + (long long)n * Tm.xs + c;
+        float acc[VW];
+        if (!Tm.rp) cape_ldv<VW>(xb + (long long)r * Tm.ldx, acc);
+        else cape_gather_row<VW, U>(xb, Tm.ldx, Tm.rp, Tm.ci, Tm.va, r, acc);
+        if ((Q.to2 >> k) & 1u) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float v = a1[u];
-            if (Q.dual) {
-                if (v > 0.f) bits |= 1u << u;
-                v = (v > 0.f ? v : 0.f) + a2[u];
-            } else {
-                if (u < W && c + u < F) {
-                    if (Q.bias_mode == CAPE_BIAS_CHANNEL) v += Q.bias[c + u];
-                    else if (Q.bias_mode == CAPE_BIAS_VERTEX) v += Q.bias[(long long)r * F + c + u];
-                }
-                v = cape_act(v, Q.act);
-            }
-            o[u] = v;
-        }
-        if (Q.mask) {
-            // VEC only, F % 32 == 0: the 8 lanes of one 32-channel word are consecutive and aligned
-            unsigned w = live ? (bits << (4 * (q & 7))) : 0u;
-            w |= __shfl_xor(w, 1); w |= __shfl_xor(w, 2); w |= __shfl_xor(w, 4);
-            if (live && (q & 7) == 0) Q.mask[((long long)n * Mo + r) * Q.mask_words + (q >> 3)] = w;
-        }
-        if (live) {
-            if (VEC) cape_st4(y.p + (long long)n * y.ss + (long long)r * y.ld + c, make_float4(o[0], o[1], o[2], o[3]));
-            else cape_st(y.p + (long long)n * y.ss + (long long)r * y.ld + c, o[0]);
+            for (int u = 0; u < VW; ++u) a2[u] = fmaf(Tm.scale, acc[u], a2[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < VW; ++u) a1[u] = fmaf(Tm.scale, acc[u], a1[u]);
         }
     }
-}
-
-// Rows of the mesh operators have 1..16 entries (3-11 for L~, up to ~16 for composed T_k(L~)U).  With a
-// compile-time bound the entry loop unrolls completely: every (index, value) pair is loaded first, then all
-// gathers are in flight together -- two dependent memory round trips per thread instead of one per entry.
-template <int W>
-__global__ __launch_bounds__(256) void spmm_bounded_kernel(CView x, const int *rp, const int *ci, const float *va,
-                                                           float alpha, CView z, float beta, View y, int N, int Mo, int C) {
-    const int cq = C >> 2;
-    const long long total = (long long)N * Mo * cq;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int q = (int)(i % cq);
-        const long long nr = i / cq;
-        const int r = (int)(nr % Mo);
-        const int n = (int)(nr / Mo);
-        const int c = q * 4;
-        const float *xb = x.p + (long long)n * x.ss + c;
-        const int e0 = rp[r], len = rp[r + 1] - e0;
-        int cols[W];
-        float vals[W];
+    for (int j = 0; j < Q.rankR; ++j) {
+        const float rs = Q.rowscale[(long long)j * Mo + r];
+        const float *cf = Q.coef + ((long long)n * Q.rankR + j) * F + c;
+        if ((Q.rank_to2 >> j) & 1u) {
 #pragma unroll
-        for (int j = 0; j < W; ++j) {
-            const int e = e0 + (j < len ? j : 0);      // clamped: always a valid entry of this row
-            cols[j] = ci[e];
-            vals[j] = j < len ? va[e] : 0.f;
-        }
-        float4 xv[W];
+            for (int u = 0; u < VW; ++u) a2[u] = fmaf(rs, cf[u], a2[u]);
+        } else {
 #pragma unroll
-        for (int j = 0; j < W; ++j) xv[j] = *reinterpret_cast<const float4 *>(xb + (long long)cols[j] * x.ld);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-            acc.x = fmaf(vals[j], xv[j].x, acc.x); acc.y = fmaf(vals[j], xv[j].y, acc.y);
-            acc.z = fmaf(vals[j], xv[j].z, acc.z); acc.w = fmaf(vals[j], xv[j].w, acc.w);
+            for (int u = 0; u < VW; ++u) a1[u] = fmaf(rs, cf[u], a1[u]);
         }
-        acc.x *= alpha; acc.y *= alpha; acc.z *= alpha; acc.w *= alpha;
-        if (z.p) {
-            const float4 zv = *reinterpret_cast<const float4 *>(z.p + (long long)n * z.ss + (long long)r * z.ld + c);
-            acc.x = fmaf(beta, zv.x, acc.x); acc.y = fmaf(beta, zv.y, acc.y);
-            acc.z = fmaf(beta, zv.z, acc.z); acc.w = fmaf(beta, zv.w, acc.w);
-        }
-        *reinterpret_cast<float4 *>(y.p + (long long)n * y.ss + (long long)r * y.ld + c) = acc;
     }
+    float o[VW];
+    unsigned bits = 0;
+#pragma unroll
+    for (int u = 0; u < VW; ++u) {
+        float v = a1[u];
+        if (Q.dual) {
+            if (v > 0.f) bits |= 1u << u;
+            v = (v > 0.f ? v : 0.f) + a2[u];
+        } else {
+            if (Q.bias_mode == CAPE_BIAS_CHANNEL) v += Q.bias[c + u];
+            else if (Q.bias_mode == CAPE_BIAS_VERTEX) v += Q.bias[(long long)r * F + c + u];
+            v = cape_act(v, Q.act);
+        }
+        o[u] = v;
+    }
+    if (Q.mask) {
+        // VW >= 4 only, F % 32 == 0: the 32 / VW lanes of one 32-channel word are consecutive and aligned
+        constexpr int LW = VW >= 4 ? 32 / VW : 1;
+        unsigned w = live ? (bits << (VW * (q & (LW - 1)))) : 0u;
+#pragma unroll
+        for (int s = 1; s < LW; s <<= 1) w |= __shfl_xor(w, s);
+        if (live && (q & (LW - 1)) == 0) Q.mask[((long long)n * Mo + r) * Q.mask_words + (q / LW)] = w;
+    }
+    if (live) cape_stv<VW>(y.p + (long long)n * y.ss + (long long)r * y.ld + c, o);
 }
 
 // ---- bias + activation ----------------------------------------------------------------------
@@ -547,10 +539,21 @@ __global__ __launch_bounds__(256) void rowscale_final_kernel(const float *part, 
 }
 
 // ---- fused backward preparation: dz, bias gradient and rank-1 term gradients in one pass over g ----
-constexpr int BP_RB_MAX = 128;              // rows per block (upper bound; shrunk until >= ~1024 blocks)
+constexpr int BP_RB_MAX = 128;              // rows per block (upper bound; halved until the grid has BP_BLOCKS blocks)
+#ifndef CAPE_BP_BLOCKS_DEFAULT
+#define CAPE_BP_BLOCKS_DEFAULT 448
+#endif
+#ifndef CAPE_BP_UNROLL_DEFAULT
+#define CAPE_BP_UNROLL_DEFAULT 2           // rows loaded ahead per thread in bwd_prep_vec_kernel (CAPE_BP_UNROLL = 1, 2, 4)
+#endif
+#ifndef CAPE_BP_RB_MIN_DEFAULT
+#define CAPE_BP_RB_MIN_DEFAULT 16
+#endif
 inline int bp_rows(int N, int Mo) {
+    static const int want = getenv("CAPE_BP_BLOCKS") ? atoi(getenv("CAPE_BP_BLOCKS")) : CAPE_BP_BLOCKS_DEFAULT;
+    static const int rbmin = getenv("CAPE_BP_RB_MIN") ? atoi(getenv("CAPE_BP_RB_MIN")) : CAPE_BP_RB_MIN_DEFAULT;
     int rb = BP_RB_MAX;
-    while (rb > 16 && (long long)N * ((Mo + rb - 1) / rb) < 448) rb >>= 1;
+    while (rb > rbmin && (long long)N * ((Mo + rb - 1) / rb) < want) rb >>= 1;
     return rb;
 }
 constexpr int BP_MAXT = RSR_MAXR + 2;       // reduction terms: [0]=sum dz, [1..R]=rowscale_j*dz, [R+1]=rowscale_rg*g
@@ -600,68 +603,103 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(CViewT<AT> g, CViewT<AT> 
     }
 }
 
-// float4 variant (F % 4 == 0, 16-byte aligned views, F <= 1024): thread = (float4 column, row lane)
-template <typename AT = float>
+// vector variant (F % VW == 0, aligned views): thread = (column group of VW channels, row lane).  The rows of a lane are
+// taken UR at a time: the UR gradient rows (and their sign words / outputs) are all loaded before the first is used, so a
+// thread waits for one memory round trip per UR rows instead of one per row.
+template <typename AT, int VW, int UR>
 __global__ __launch_bounds__(256) void bwd_prep_vec_kernel(CViewT<AT> g, CViewT<AT> y, int act, const unsigned *mask, ViewT<AT> dz,
                                                            const float *rowscale, int R, int rg, int want_bias, int want_g,
                                                            int N, int Mo, int F, float *part, int chunks, int RB) {
-    __shared__ float4 red[256];
+    __shared__ float red[VW][256];
     const int n = blockIdx.x / chunks, ch = blockIdx.x % chunks;
     const int ra = ch * RB, rb = min(Mo, ra + RB);
     const int words = (F + 31) / 32;
     const int T = R + 2;
+    constexpr int FB = 64 * VW;                 // channels per column pass (256 threads x VW >= FB)
     float *pp = part + ((long long)n * chunks + ch) * T * F;
-    for (int fbase = 0; fbase < F; fbase += 256) {
-        const int fw = min(256, F - fbase);
-        const int c4n = fw >> 2;
-        const int lanes = 256 / c4n;
-        const int q = threadIdx.x % c4n, rl = threadIdx.x / c4n;
-        const int f = fbase + 4 * q;
-        float4 acc[BP_MAXT];
+    const AT *gb = g.p + (long long)n * g.ss;
+    const AT *yb = y.p ? y.p + (long long)n * y.ss : nullptr;
+    AT *zb = dz.p + (long long)n * dz.ss;
+    const unsigned *mb = mask ? mask + (long long)n * Mo * words : nullptr;
+    for (int fbase = 0; fbase < F; fbase += FB) {
+        const int fw = min(FB, F - fbase);
+        const int cvn = fw / VW;                // column groups of this pass (divides 256)
+        const int lanes = 256 / cvn;
+        const int q = threadIdx.x % cvn, rl = threadIdx.x / cvn;
+        const int f = fbase + VW * q;
+        float acc[BP_MAXT][VW];
 #pragma unroll
-        for (int j = 0; j < BP_MAXT; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rl < lanes)
-            for (int r = ra + rl; r < rb; r += lanes) {
-                const float4 gv = cape_ld4(g.p + (long long)n * g.ss + (long long)r * g.ld + f);
-                float4 d = gv;
-                if (mask) {
-                    const unsigned w = mask[((long long)n * Mo + r) * words + (f >> 5)] >> (f & 31);
-                    d.x = (w & 1u) ? gv.x : 0.f; d.y = (w & 2u) ? gv.y : 0.f; d.z = (w & 4u) ? gv.z : 0.f; d.w = (w & 8u) ? gv.w : 0.f;
-                } else if (act != CAPE_ACT_NONE) {
-                    const float4 o = cape_ld4(y.p + (long long)n * y.ss + (long long)r * y.ld + f);
-                    d.x = gv.x * cape_act_grad_from_out(o.x, act); d.y = gv.y * cape_act_grad_from_out(o.y, act);
-                    d.z = gv.z * cape_act_grad_from_out(o.z, act); d.w = gv.w * cape_act_grad_from_out(o.w, act);
-                }
-                cape_st4(dz.p + (long long)n * dz.ss + (long long)r * dz.ld + f, d);
-                acc[0].x += d.x; acc[0].y += d.y; acc[0].z += d.z; acc[0].w += d.w;
+        for (int j = 0; j < BP_MAXT; ++j)
 #pragma unroll
-                for (int j = 0; j < RSR_MAXR; ++j)
-                    if (j < R) {
-                        const float sv = rowscale[(long long)j * Mo + r];
-                        acc[1 + j].x = fmaf(sv, d.x, acc[1 + j].x); acc[1 + j].y = fmaf(sv, d.y, acc[1 + j].y);
-                        acc[1 + j].z = fmaf(sv, d.z, acc[1 + j].z); acc[1 + j].w = fmaf(sv, d.w, acc[1 + j].w);
+            for (int u = 0; u < VW; ++u) acc[j][u] = 0.f;
+        for (int r0 = ra + rl; r0 < rb; r0 += UR * lanes) {
+            float gv[UR][VW], ov[UR][VW];
+            unsigned mw[UR];
+#pragma unroll
+            for (int k = 0; k < UR; ++k) {
+                const int r = r0 + k * lanes;
+                const int rr = r < rb ? r : r0;             // rows past the chunk re-read the first (result unused)
+                cape_ldv<VW>(gb + (long long)rr * g.ld + f, gv[k]);
+                if (mb) mw[k] = mb[(long long)rr * words + (f >> 5)] >> (f & 31);
+                else if (act != CAPE_ACT_NONE) cape_ldv<VW>(yb + (long long)rr * y.ld + f, ov[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < UR; ++k) {
+                const int r = r0 + k * lanes;
+                if (r < rb) {
+                    float d[VW];
+#pragma unroll
+                    for (int u = 0; u < VW; ++u) {
+                        if (mb) d[u] = ((mw[k] >> u) & 1u) ? gv[k][u] : 0.f;
+                        else if (act != CAPE_ACT_NONE) d[u] = gv[k][u] * cape_act_grad_from_out(ov[k][u], act);
+                        else d[u] = gv[k][u];
                     }
-                if (want_g) {
-                    const float sv = rowscale[(long long)rg * Mo + r];
-                    acc[BP_MAXT - 1].x = fmaf(sv, gv.x, acc[BP_MAXT - 1].x); acc[BP_MAXT - 1].y = fmaf(sv, gv.y, acc[BP_MAXT - 1].y);
-                    acc[BP_MAXT - 1].z = fmaf(sv, gv.z, acc[BP_MAXT - 1].z); acc[BP_MAXT - 1].w = fmaf(sv, gv.w, acc[BP_MAXT - 1].w);
+                    cape_stv<VW>(zb + (long long)r * dz.ld + f, d);
+#pragma unroll
+                    for (int u = 0; u < VW; ++u) acc[0][u] += d[u];
+#pragma unroll
+                    for (int j = 0; j < RSR_MAXR; ++j)
+                        if (j < R) {
+                            const float sv = rowscale[(long long)j * Mo + r];
+#pragma unroll
+                            for (int u = 0; u < VW; ++u) acc[1 + j][u] = fmaf(sv, d[u], acc[1 + j][u]);
+                        }
+                    if (want_g) {
+                        const float sv = rowscale[(long long)rg * Mo + r];
+#pragma unroll
+                        for (int u = 0; u < VW; ++u) acc[BP_MAXT - 1][u] = fmaf(sv, gv[k][u], acc[BP_MAXT - 1][u]);
+                    }
                 }
             }
-        // reduce the row lanes term by term through LDS
+        }
+        // reduce the row lanes term by term: first inside each wave (the lanes of one column group are cvn apart: xor
+        // shuffles over cvn, 2 cvn, ... 32), then the <= 4 per-wave (or per-lane, cvn >= 64) sums through LDS
+        const int le = cvn < 64 ? 4 : lanes;                   // partial sums per column group that reach LDS
+        const bool writer = cvn < 64 ? (int)(threadIdx.x & 63) < cvn : true;
+        const int slot = cvn < 64 ? (int)(threadIdx.x >> 6) * cvn + q : (int)threadIdx.x;
 #pragma unroll
         for (int j = 0; j < BP_MAXT; ++j) {
             const bool used = (j == 0 && want_bias) || (j >= 1 && j <= R) || (j == BP_MAXT - 1 && want_g);
             if (!used) continue;
-            red[threadIdx.x] = acc[j];
+            float v[VW];
+#pragma unroll
+            for (int u = 0; u < VW; ++u) v[u] = acc[j][u];
+            for (int sh = cvn; sh < 64; sh <<= 1)
+#pragma unroll
+                for (int u = 0; u < VW; ++u) v[u] += __shfl_xor(v[u], sh);
+            if (writer)
+#pragma unroll
+                for (int u = 0; u < VW; ++u) red[u][slot] = v[u];
             __syncthreads();
-            if (rl == 0) {
-                float4 t = acc[j];
-                for (int l = 1; l < lanes; ++l) {
-                    const float4 v = red[l * c4n + q];
-                    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
-                }
+            if ((int)threadIdx.x < cvn) {
+                float t[VW];
+#pragma unroll
+                for (int u = 0; u < VW; ++u) t[u] = red[u][q];
+                for (int l = 1; l < le; ++l)
+#pragma unroll
+                    for (int u = 0; u < VW; ++u) t[u] += red[u][l * cvn + q];
                 const int trow = (j == BP_MAXT - 1) ? (R + 1) : j;
-                *reinterpret_cast<float4 *>(pp + (long long)trow * F + f) = t;
+                cape_stv<VW>(pp + (long long)trow * F + f, t);
             }
             __syncthreads();
         }
@@ -761,27 +799,23 @@ int spmm_impl(const T *x, int64_t x_sample_stride, int32_t ldx, const int32_t *r
               int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
     if (!x || !rowptr || !colidx || !vals || !y || N < 1 || Mo < 1 || C < 1 || ldx < C || ldy < C) return CAPE_EINVAL;
     if (z && ldz < C) return CAPE_EINVAL;
+    if ((long long)Mo * C >= (1LL << 31)) return CAPE_EINVAL;       // 32-bit work-item index per sample
     constexpr int es = (int)sizeof(T);
     CViewT<T> xv{x, x_sample_stride, ldx}, zv{z, z_sample_stride, ldz};
     ViewT<T> yv{y, y_sample_stride, ldy};
     const bool vec = aligned4(x, x_sample_stride, ldx, C, es) && aligned4(y, y_sample_stride, ldy, C, es) &&
                      (!z || aligned4(z, z_sample_stride, ldz, C, es));
     hipStream_t st = (hipStream_t)stream;
-    if constexpr (es == 4) {
-        if (vec && max_row_nnz >= 1 && max_row_nnz <= 16) {
-            const long long total = (long long)N * Mo * (C / 4);
-            const dim3 g(grid_for(total)), b(256);
-            if (max_row_nnz <= 4) CAPE_LAUNCH(spmm_bounded_kernel<4>, g, b, 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
-            else if (max_row_nnz <= 8) CAPE_LAUNCH(spmm_bounded_kernel<8>, g, b, 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
-            else CAPE_LAUNCH(spmm_bounded_kernel<16>, g, b, 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
-            CAPE_LAUNCH_CHECK();
-            return CAPE_OK;
-        }
-    }
     if (vec) {
-        CAPE_LAUNCH((spmm_kernel<true, T>), dim3((unsigned)(N * spmm_bps(Mo, C / 4))), dim3(256), 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
+        // max_row_nnz is a hint: operators whose rows hold at most 4 entries (the up-/down-sampling matrices) take the
+        // 4-wide entry groups
+        const bool wide = spmm_wide() && aligned8(x, x_sample_stride, ldx, C, es) && aligned8(y, y_sample_stride, ldy, C, es) &&
+                          (!z || aligned8(z, z_sample_stride, ldz, C, es));
+        const bool hint4 = max_row_nnz >= 1 && max_row_nnz <= 4;
+        CAPE_LAUNCH_SP(spmm_kernel, T, wide, hint4, dim3((unsigned)(N * spmm_bps(Mo, C / (wide ? 8 : 4)))), dim3(256), 0, st, xv, rowptr,
+                       colidx, vals, alpha, zv, beta, yv, N, Mo, C);
     } else {
-        CAPE_LAUNCH((spmm_kernel<false, T>), dim3((unsigned)(N * spmm_bps(Mo, C))), dim3(256), 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
+        CAPE_LAUNCH((spmm_kernel<1, T, 0>), dim3((unsigned)(N * spmm_bps(Mo, C))), dim3(256), 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
     }
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
@@ -810,10 +844,12 @@ int spmm_multi_impl(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, 
                     int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
     if (!terms || nterms < 1 || nterms > CAPE_MAX_SPMM_TERMS || N < 1 || Mo < 1 || C < 1) return CAPE_EINVAL;
     if (sum && (!y || ldy < C)) return CAPE_EINVAL;
+    if ((long long)Mo * C >= (1LL << 31)) return CAPE_EINVAL;       // 32-bit work-item index per sample
     constexpr int es = (int)sizeof(T);
     SpmmTerms P;
     P.n = nterms;
     bool vec = !sum || aligned4(y, y_sample_stride, ldy, C, es);
+    bool wide = spmm_wide() && (!sum || aligned8(y, y_sample_stride, ldy, C, es));
     for (int k = 0; k < nterms; ++k) {
         const cape_spmm_term_t &t = terms[k];
         if (!t.x || t.ldx < C) return CAPE_EINVAL;
@@ -824,11 +860,13 @@ int spmm_multi_impl(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, 
         P.t[k].y = t.y; P.t[k].ys = t.y_sample_stride; P.t[k].ldy = t.ldy;
         P.t[k].scale = t.scale;
         vec = vec && aligned4(t.x, t.x_sample_stride, t.ldx, C, es) && (sum || aligned4(t.y, t.y_sample_stride, t.ldy, C, es));
+        wide = wide && aligned8(t.x, t.x_sample_stride, t.ldx, C, es) && (sum || aligned8(t.y, t.y_sample_stride, t.ldy, C, es));
     }
+    wide = wide && vec;
     ViewT<T> yv{y, y_sample_stride, ldy};
     hipStream_t st = (hipStream_t)stream;
-    if (vec) CAPE_LAUNCH((spmm_multi_kernel<true, T>), dim3((unsigned)(N * spmm_bps(Mo, C / 4))), dim3(256), 0, st, P, sum, yv, N, Mo, C);
-    else CAPE_LAUNCH((spmm_multi_kernel<false, T>), dim3((unsigned)(N * spmm_bps(Mo, C))), dim3(256), 0, st, P, sum, yv, N, Mo, C);
+    if (vec) CAPE_LAUNCH_SP(spmm_multi_kernel, T, wide, false, dim3((unsigned)(N * spmm_bps(Mo, C / (wide ? 8 : 4)))), dim3(256), 0, st, P, sum, yv, N, Mo, C);
+    else CAPE_LAUNCH((spmm_multi_kernel<1, T, 0>), dim3((unsigned)(N * spmm_bps(Mo, C))), dim3(256), 0, st, P, sum, yv, N, Mo, C);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }
@@ -855,9 +893,11 @@ int spmm_combine_impl(const cape_spmm_term_t *terms, int32_t nterms, uint32_t to
     if (act < CAPE_ACT_NONE || act > CAPE_ACT_TANH) return CAPE_EINVAL;
     if (dual && (bias_mode != CAPE_BIAS_NONE || act != CAPE_ACT_NONE)) return CAPE_EINVAL;
     if (!dual && (to_acc2 || mask_out)) return CAPE_EINVAL;
+    if ((long long)Mo * F >= (1LL << 31)) return CAPE_EINVAL;       // 32-bit work-item index per sample
     CombineParams Q;
     Q.P.n = nterms;
     bool vec = aligned4(y, y_sample_stride, ldy, F, es);
+    bool wide = spmm_wide() && aligned8(y, y_sample_stride, ldy, F, es);
     for (int k = 0; k < nterms; ++k) {
         const cape_spmm_term_t &t = terms[k];
         if (!t.x || t.ldx < F) return CAPE_EINVAL;
@@ -867,7 +907,9 @@ int spmm_combine_impl(const cape_spmm_term_t *terms, int32_t nterms, uint32_t to
         Q.P.t[k].y = nullptr; Q.P.t[k].ys = 0; Q.P.t[k].ldy = 0;
         Q.P.t[k].scale = t.scale;
         vec = vec && aligned4(t.x, t.x_sample_stride, t.ldx, F, es);
+        wide = wide && aligned8(t.x, t.x_sample_stride, t.ldx, F, es);
     }
+    wide = wide && vec;
     Q.to2 = to_acc2;
     Q.rankR = 0; Q.rowscale = nullptr; Q.coef = nullptr; Q.rank_to2 = 0;
     if (rank && rank->R > 0) {
@@ -879,8 +921,8 @@ int spmm_combine_impl(const cape_spmm_term_t *terms, int32_t nterms, uint32_t to
     if (mask_out && (!vec || (F & 31))) return CAPE_EINVAL;      // sign words are assembled from 8 float4 lanes
     ViewT<T> yv{y, y_sample_stride, ldy};
     hipStream_t st = (hipStream_t)stream;
-    if (vec) CAPE_LAUNCH((spmm_combine_kernel<true, T>), dim3((unsigned)(N * spmm_bps(Mo, F / 4))), dim3(256), 0, st, Q, yv, N, Mo, F);
-    else CAPE_LAUNCH((spmm_combine_kernel<false, T>), dim3((unsigned)(N * spmm_bps(Mo, F))), dim3(256), 0, st, Q, yv, N, Mo, F);
+    if (vec) CAPE_LAUNCH_SP(spmm_combine_kernel, T, wide, false, dim3((unsigned)(N * spmm_bps(Mo, F / (wide ? 8 : 4)))), dim3(256), 0, st, Q, yv, N, Mo, F);
+    else CAPE_LAUNCH((spmm_combine_kernel<1, T, 0>), dim3((unsigned)(N * spmm_bps(Mo, F))), dim3(256), 0, st, Q, yv, N, Mo, F);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }
@@ -1055,9 +1097,28 @@ int bwd_prep_impl(const T *g, int64_t g_sample_stride, int32_t ldg, const T *y, 
     const bool vec = aligned4(g, g_sample_stride, ldg, F, es) && aligned4(dz, dz_sample_stride, lddz, F, es) &&
                      (mask || act == CAPE_ACT_NONE || aligned4(y, y_sample_stride, ldy, F, es)) &&
                      (F >= 256 ? (F % 256) == 0 : (256 % (F / 4)) == 0) && ((F & 31) == 0 || !mask);
-    if (vec)
-        CAPE_LAUNCH((bwd_prep_vec_kernel<T>), dim3(N * chunks), dim3(256), 0, st, gv, yv, act, mask, zv, rowscale, R, rg, dbias ? 1 : 0,
-                    dcoef_g ? 1 : 0, N, Mo, F, (float *)workspace, chunks, RB);
+    // 8 channels per thread where the rows allow it (column passes of 512 channels; F / 8 column groups must divide 256)
+    const bool wide = vec && spmm_wide() && aligned8(g, g_sample_stride, ldg, F, es) && aligned8(dz, dz_sample_stride, lddz, F, es) &&
+                      (mask || act == CAPE_ACT_NONE || aligned8(y, y_sample_stride, ldy, F, es)) &&
+                      F >= 256 && (F >= 512 ? (F % 512) == 0 : (256 % (F / 8)) == 0);
+    // measured (tools/bench_sparse.py, profiles/r02_ubench_sparse_bwd_prep.txt): two rows ahead is the best depth for the 4-wide
+    // kernel; the 8-wide one pays only from 256 channels (fewer row lanes per column group below that), fp32 without
+    // read-ahead (167 registers at depth 4, 129 at 2)
+    static const int bp_ur_env = getenv("CAPE_BP_UNROLL") ? atoi(getenv("CAPE_BP_UNROLL")) : 0;
+    const int bp_ur = bp_ur_env ? bp_ur_env : (wide && es == 4) ? 1 : CAPE_BP_UNROLL_DEFAULT;
+#define CAPE_BP_LAUNCH(VW_, UR_)                                                                                                    \
+    CAPE_LAUNCH((bwd_prep_vec_kernel<T, VW_, UR_>), dim3(N * chunks), dim3(256), 0, st, gv, yv, act, mask, zv, rowscale, R, rg,     \
+                dbias ? 1 : 0, dcoef_g ? 1 : 0, N, Mo, F, (float *)workspace, chunks, RB)
+    if (vec && wide) {
+        if (bp_ur >= 4) CAPE_BP_LAUNCH(8, 4);
+        else if (bp_ur >= 2) CAPE_BP_LAUNCH(8, 2);
+        else CAPE_BP_LAUNCH(8, 1);
+    } else if (vec) {
+        if (bp_ur >= 4) CAPE_BP_LAUNCH(4, 4);
+        else if (bp_ur >= 2) CAPE_BP_LAUNCH(4, 2);
+        else CAPE_BP_LAUNCH(4, 1);
+    }
+#undef CAPE_BP_LAUNCH
     else
         CAPE_LAUNCH((bwd_prep_kernel<T>), dim3(N * chunks), dim3(256), 0, st, gv, yv, act, mask, zv, rowscale, R, rg, dbias ? 1 : 0,
                     dcoef_g ? 1 : 0, N, Mo, F, (float *)workspace, chunks, RB);

@@ -209,7 +209,7 @@ class base_model(object):
         Ch = int(x.shape[-1])
         self._conv_meta[wname] = (Ch, int(K), int(Fout))
         gW = self._grad_views.get(wname)
-        gB = self._grad_views.get(bname) if (bias is not None and bias.shape[1] == 1) else None
+        gB = self._grad_views.get(bname) if bias is not None else None      # channel bias [1,1,F] or vertex bias [1,M,F]
         gWa = None
         if W_affine is not None:
             self._conv_meta[waname] = (Ch, 1, int(Fout))

@@ -20,7 +20,6 @@ from .graph import ConvOperators, HostCSR
 # "fused":   sparse operators gathered inside the GEMM kernel's A-tile staging (one launch per layer)
 import os as _os
 MODE = _os.environ.get("CAPE_MODE", "twopass")
-SPMM_BOUNDED = int(_os.environ.get("CAPE_SPMM_BOUNDED", "0"))   # unrolled bounded-row kernel: no measured gain
 
 _ACT_OF = {"b1leakyrelu": ("leaky", _lib.BIAS_CHANNEL), "b1relu": ("relu", _lib.BIAS_CHANNEL),
            "b1tanh": ("tanh", _lib.BIAS_CHANNEL), "b2relu": ("relu", _lib.BIAS_VERTEX)}
@@ -350,7 +349,7 @@ def spmm(x, csr, y=None, alpha=1.0, z=None, beta=0.0):
         zp, zs, zl = None, 0, 0
     def launch():
         rc = _fn("cape_spmm", x)(xp, xs, xl, C.c_void_p(csr.rowptr_t.data_ptr()), C.c_void_p(csr.colidx_t.data_ptr()),
-                           C.c_void_p(csr.vals_t.data_ptr()), int(csr.max_row if (csr.min_row >= 1 and SPMM_BOUNDED) else 0),
+                           C.c_void_p(csr.vals_t.data_ptr()), int(csr.max_row),
                            float(alpha), zp, zs, zl, float(beta), yp, ys, yl, N, Mo, Cn, _stream())
         check(rc, "cape_spmm")
 
@@ -801,7 +800,9 @@ class ChebConvFn(torch.autograd.Function):
                                            defer=(not chan_bias or ctx.gB is not None) and (not Cc or ctx.banked))
         if need_b and ctx.has_bias:
             if ctx.bias_mode == _lib.BIAS_VERTEX:
-                dB = torch.empty((1, Mo, Fout), device=dev, dtype=torch.float32)
+                gb = ctx.gB                      # the bucket view of the [1, M, F] bias: written in place, no copy later
+                dB = gb.view(1, Mo, Fout) if (gb is not None and gb.numel() == Mo * Fout and gb.is_contiguous()) else \
+                    torch.empty((1, Mo, Fout), device=dev, dtype=torch.float32)
                 colsum(dz, dB, per_vertex=True)
             else:
                 dB = dbv.view(1, 1, Fout)

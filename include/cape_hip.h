@@ -256,8 +256,9 @@ typedef struct cape_bwd_prep_item {
 int cape_bwd_prep_finalize(const cape_bwd_prep_item_t *items, int32_t nitems, void *stream);
 
 /* y[n,r,:] = alpha * sum_e vals[e]*x[n,colidx[e],:] + beta * z[n,r,:]   (z may be NULL, may alias y).
- * max_row_nnz: upper bound on the entries of any row if the caller knows it (selects a fully unrolled
- * kernel for <= 4 / 8 / 16; every row must then be non-empty), 0 = unknown. */
+ * max_row_nnz: upper bound on the entries of any row if the caller knows it, 0 = unknown.  A hint only: it picks
+ * the width of the unrolled entry groups (4 for the up-/down-sampling matrices, 8 otherwise); any row length is
+ * handled either way. */
 int cape_spmm(const float *x, int64_t x_sample_stride, int32_t ldx, const int32_t *rowptr,
               const int32_t *colidx, const float *vals, int32_t max_row_nnz, float alpha, const float *z,
               int64_t z_sample_stride, int32_t ldz, float beta, float *y,
