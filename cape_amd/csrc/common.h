@@ -43,6 +43,22 @@ __device__ __forceinline__ float2 cape_ld2(const cape_bf16 *p) {
     const unsigned u = *reinterpret_cast<const unsigned *>(p);
     return make_float2(__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xFFFF0000u));
 }
+// v + (value of lane ^ 16) and v + (value of lane ^ 32) without the LDS crossbar: the gfx950 row / half swaps
+// (__shfl_xor compiles to ds_bpermute_b32; used by the dense-layer kernels, which reduce 64 accumulators per thread)
+// Written as inline asm: the ROCm 7.2 builtins (__builtin_amdgcn_permlane16_swap / 32_swap) return the first register
+// twice (the generated code adds vdst to itself), so the exchanged half is lost; tools/ubench/permlane_check.hip verifies
+// both helpers against __shfl_xor.  v_permlane16_swap a, b:  a' = [a0 b0 a2 b2], b' = [a1 b1 a3 b3] (rows of 16 lanes);
+// v_permlane32_swap a, b:  a' = [a.lo b.lo], b' = [a.hi b.hi].  With a = b = v the sum a' + b' is v + v(lane ^ 16 / 32).
+__device__ __forceinline__ float cape_sum_xor16(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float cape_sum_xor32(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
 // VW (1, 4 or 8) consecutive elements, widened to fp32 / rounded back.  Alignment: VW elements of fp32 up to 16 bytes
 // (VW = 8: two 16-byte accesses), VW elements of bf16 (8 -> one 16-byte access).
 typedef unsigned cape_u32x4 __attribute__((ext_vector_type(4)));

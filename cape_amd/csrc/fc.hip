@@ -321,10 +321,7 @@ __global__ __launch_bounds__(256) void fc_long_partial_v4_kernel(LongArgs A, con
         for (int k = 0; k < 16; ++k)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float v = acc[k][c];
-                v += __shfl_xor(v, 16);
-                v += __shfl_xor(v, 32);
-                acc[k][c] = v;
+                acc[k][c] = cape_sum_xor32(cape_sum_xor16(acc[k][c]));
             }
         __syncthreads();
         if (lane < 16) {
@@ -442,7 +439,7 @@ __global__ __launch_bounds__(256) void fc_wide_fwd_v4_kernel(const float *x, int
 #pragma unroll
     for (int k = 0; k < 16; ++k)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[k][c] += __shfl_xor(acc[k][c], 32);
+        for (int c = 0; c < 4; ++c) acc[k][c] = cape_sum_xor32(acc[k][c]);
     if (lane < 32) {
 #pragma unroll
         for (int k = 0; k < 16; ++k)
@@ -487,9 +484,12 @@ __global__ __launch_bounds__(256) void fc_wide_bwd_dw_v4_kernel(const float *x, 
         dz[k] = v;
         bs.x += v.x; bs.y += v.y; bs.z += v.z; bs.w += v.w;
     }
-    if (db && ig == 0) *reinterpret_cast<float4 *>(db + jc) = bs;
+    if (db && ig == 0 && blockIdx.y == 0) *reinterpret_cast<float4 *>(db + jc) = bs;
     if (!dW) return;
-    for (int i = ig; i < in; i += 4) {
+    // the weight rows are shared out over gridDim.y blocks (216 column blocks alone leave CUs idle)
+    const int per = (in + gridDim.y - 1) / gridDim.y;
+    const int ia = blockIdx.y * per, ib = min(in, ia + per);
+    for (int i = ia + ig; i < ib; i += 4) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -515,7 +515,14 @@ __global__ __launch_bounds__(256) void fc_wide_bwd_dx_partial_v4_kernel(const fl
     const int j0 = blockIdx.x * 64;
     const int jw = min(64, out - j0);
     const int jl = threadIdx.x & 63, hi = threadIdx.x >> 6;
-    for (int i = hi; i < in; i += 4) Wt[jl * ldw + i] = jl < jw ? W[(long long)i * out + j0 + jl] : 0.f;
+    for (int i0 = hi; i0 < in; i0 += 32) {          // 8 weight rows per thread in flight
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = (jl < jw && i0 + 4 * u < in) ? W[(long long)(i0 + 4 * u) * out + j0 + jl] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + 4 * u < in) Wt[jl * ldw + i0 + 4 * u] = wv[u];
+    }
     for (int n = hi; n < 16; n += 4) {
         float v = 0.f;
         if (n < N && jl < jw) {
@@ -648,7 +655,7 @@ extern "C" int cape_fc_wide_bwd(const float *x, int32_t ldx, const float *g, int
         const bool v4 = N <= 16 && (out & 3) == 0 && (ldg & 3) == 0 && fc_al16(g) && (!dW || fc_al16(dW)) && (!db || fc_al16(db)) &&
                         (act == CAPE_ACT_NONE || ((ldy & 3) == 0 && fc_al16(y)));
         if (v4)
-            CAPE_LAUNCH(fc_wide_bwd_dw_v4_kernel, dim3((out + 255) / 256), dim3(256), (size_t)16 * in * 4, st, x, ldx, g, ldg, y, ldy, act, N, in, out,
+            CAPE_LAUNCH(fc_wide_bwd_dw_v4_kernel, dim3((out + 255) / 256, dW ? 4 : 1), dim3(256), (size_t)16 * in * 4, st, x, ldx, g, ldg, y, ldy, act, N, in, out,
                         dW, db);
         else
             CAPE_LAUNCH(fc_wide_bwd_dw_kernel, dim3((out + 255) / 256), dim3(256), (size_t)N * in * 4, st, x, ldx, g, ldg, y, ldy, act, N, in, out, dW,

@@ -301,8 +301,20 @@ def gconv_dw(entries, dz, accumulate=False, dz2=None, defer=False):
             plan = (C.c_int32 * 4)()
             check(_fn("cape_gconv_dw_plan", dz)(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, plan), "cape_gconv_dw_plan")
             PLAN_LOG.add(("dw", plan[0], plan[1], plan[2]) + (("bf16",) if bf else ()))
-        check(_fn("cape_gconv_dw_stage", dz)(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, 1 if accumulate else 0,
-                                             C.c_void_p(ws.data_ptr()), need, 1, _stream()), "cape_gconv_dw_stage")
+        def contraction():
+            check(_fn("cape_gconv_dw_stage", dz)(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, 1 if accumulate else 0,
+                                                 C.c_void_p(ws.data_ptr()), need, 1, _stream()), "cape_gconv_dw_stage")
+        side = _side_stream(dz.device)
+        if side is None:
+            contraction()
+        else:
+            # the contraction only feeds the queued reduction: it runs on a second stream, next to the data-gradient chain
+            # of the layers below (sparse / backward-prep kernels that leave the matrix pipe idle); flush_deferred() joins.
+            # Every buffer it touches is held in DEFERRED_DW until then, so no block is recycled under it.
+            side.wait_stream(torch.cuda.current_stream(dz.device))
+            with torch.cuda.stream(side):
+                contraction()
+            _SIDE_PENDING[0] = True
         it = _lib.CapeDwItem()
         it.srcs, it.nsrc = C.addressof(arr), len(entries)
         it.dz, it.dz_sample_stride, it.lddz = p.value, ss, ld
@@ -533,8 +545,26 @@ DEFERRED = None
 DEFERRED_DW = []          # queued weight-gradient slab reductions (gconv_dw(defer=True)), same lifetime as DEFERRED
 
 
+DW_SIDE_STREAM = int(_os.environ.get("CAPE_DW_SIDE_STREAM", "0"))   # 1: deferred weight-gradient contractions on a second stream
+_SIDE = {}
+_SIDE_PENDING = [False]
+
+
+def _side_stream(device):
+    if not DW_SIDE_STREAM:
+        return None
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 def flush_deferred():
     global DEFERRED
+    if _SIDE_PENDING[0]:
+        for st in _SIDE.values():
+            torch.cuda.current_stream(st.device).wait_stream(st)
+        _SIDE_PENDING[0] = False
     if DEFERRED_DW:
         queued, DEFERRED_DW[:] = list(DEFERRED_DW), []
         nmax = 12                                    # CAPE_MAX_DW_REDUCE_ITEMS

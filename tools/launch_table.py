@@ -21,13 +21,13 @@ def wrapped(entries, y, **kw):
     return orig(entries, y, **kw)
 ops.gconv_fwd = wrapped
 orig_dw = ops.gconv_dw
-def wrapped_dw(entries, dz, accumulate=False, dz2=None):
+def wrapped_dw(entries, dz, accumulate=False, dz2=None, **kw):
     N, Mo, F = dz.shape
     if ops.LAUNCH_LOG is None:
-        return orig_dw(entries, dz, accumulate, dz2)
+        return orig_dw(entries, dz, accumulate, dz2, **kw)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    orig_dw(entries, dz, accumulate, dz2)
+    orig_dw(entries, dz, accumulate, dz2, **kw)
     e1.record()
     Cs = [int(e.get("C", e["x"].shape[2])) for e in entries]
     fl = sum(2.0 * N * Mo * c * F for c in Cs)
