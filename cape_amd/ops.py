@@ -1095,6 +1095,9 @@ class GroupNormFn(torch.autograd.Function):
         return dx, dgb[0], dgb[1], None, None, None
 
 
+UNIT_GRAD = None        # the 0-dim tensor holding 1.0 that the training step seeds its backward pass with (models._one_scalar)
+
+
 class ReconEdgeLossFn(torch.autograd.Function):
     """total = w_recon * mean|pred-gt| + w_edge * edge_loss  (lib/models.py:357-375,
     lib/losses.py:9-25).  Returns (total, recon, edge); only ``total`` is differentiable."""
@@ -1122,6 +1125,8 @@ class ReconEdgeLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gtotal, _gout):
         (dpred,) = ctx.saved_tensors
+        if UNIT_GRAD is not None and gtotal.data_ptr() == UNIT_GRAD.data_ptr():
+            return dpred, None, None, None, None, None, None, None      # d(loss)/d(total) is the caller's constant 1
         return dpred * gtotal, None, None, None, None, None, None, None
 
 

@@ -848,6 +848,9 @@ static void check(const Shape &s, const std::vector<float> &hA, const std::vecto
 int main(int argc, char **argv) {
     std::vector<Shape> shapes = {{16, 862, 1024, 512}, {16, 862, 768, 512}, {16, 862, 512, 512}, {16, 862, 512, 256},
                                  {16, 1723, 256, 256}};
+    if (argc > 1 && !strcmp(argv[1], "short"))       // the short-contraction launches of the step (1x1 convs, narrow levels)
+        shapes = {{16, 862, 64, 512}, {16, 862, 256, 512}, {16, 1723, 128, 256}, {16, 1723, 256, 256}, {16, 3445, 64, 128},
+                  {16, 3445, 128, 128}, {16, 862, 512, 64}};
     const int iters = 20;
     {
         float *o; hipMalloc(&o, 2048 * 256 * 4);
