@@ -20,6 +20,13 @@ import os
 import torch
 
 
+# Stream-capture error mode of every graph this module records.  "thread_local": calls made by OTHER threads while the
+# capture is open do not invalidate it -- with a process group alive, the collective backend's watchdog thread polls its
+# events concurrently, and under the default "global" mode that intermittently killed the capture of the second backward
+# graph (hipErrorStreamCaptureInvalidated from the next kernel launch).
+_CAPTURE_MODE = "thread_local"
+
+
 class GraphedTrainStep(object):
     def __init__(self, model, with_gan=False, grad_hook=None, use_graph=True, split=None):
         self.model, self.with_gan, self.grad_hook = model, with_gan, grad_hook
@@ -160,23 +167,23 @@ class GraphedTrainStep(object):
             torch.cuda.synchronize()
         self._gA = torch.cuda.CUDAGraph()
         if self.split:
-            with torch.cuda.graph(self._gA):
+            with torch.cuda.graph(self._gA, capture_error_mode=_CAPTURE_MODE):
                 self._fwd_bwd1()
             self._gA2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._gA2, pool=self._gA.pool()):
+            with torch.cuda.graph(self._gA2, pool=self._gA.pool(), capture_error_mode=_CAPTURE_MODE):
                 self._bwd2()
             self._gB = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._gB, pool=self._gA.pool()):
+            with torch.cuda.graph(self._gB, pool=self._gA.pool(), capture_error_mode=_CAPTURE_MODE):
                 self._update()
             return self
         exchange = self.grad_hook is not None
-        with torch.cuda.graph(self._gA):
+        with torch.cuda.graph(self._gA, capture_error_mode=_CAPTURE_MODE):
             self._fwd_bwd()
             if not exchange:
                 self._update()
         if exchange:
             self._gB = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._gB, pool=self._gA.pool()):
+            with torch.cuda.graph(self._gB, pool=self._gA.pool(), capture_error_mode=_CAPTURE_MODE):
                 self._update()
         return self
 

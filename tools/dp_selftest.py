@@ -15,7 +15,11 @@ import bench                                                   # noqa: E402
 from cape_amd import dist as cdist                             # noqa: E402
 from cape_amd.runtime import GraphedTrainStep                  # noqa: E402
 
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+import socket                                                  # noqa: E402
+with socket.socket() as _s:                                    # a free port: a fixed one collides with a lingering run
+    _s.bind(("127.0.0.1", 0))
+    _port = _s.getsockname()[1]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
 torch.cuda.set_device(0)
 tdist.init_process_group("nccl", rank=0, world_size=1)
 res = {}
