@@ -778,13 +778,16 @@ class CAPE(base_model):
             return base_lr * self.decay_rate ** ((step - warm) // max(ds, 1))
         return base_lr * self.decay_rate ** (step // max(ds, 1))
 
-    def set_learning_rates(self):
+    def set_learning_rates(self, groups=('g', 'd')):
         """Host side of the lr schedule (:426-442): write -lr into the device scalars read by
-        ``apply_updates`` (kept outside any captured graph)."""
+        ``apply_updates`` (kept outside any captured graph).  ``groups``: the variable groups the coming step updates
+        (a CVAE-only step skips the discriminator's scalar: one tiny launch less per step)."""
         lr_g = self._lr_at(self.lr_g, self.global_step)
         lr_d = self._lr_at(self.lr_d, self.global_step)
-        self._opt_state['g']['neg_lr'].fill_(-lr_g)
-        self._opt_state['d']['neg_lr'].fill_(-lr_d)
+        if 'g' in groups:
+            self._opt_state['g']['neg_lr'].fill_(-lr_g)
+        if 'd' in groups:
+            self._opt_state['d']['neg_lr'].fill_(-lr_d)
         return lr_g, lr_d
 
     def _reg_ranges(self):

@@ -189,7 +189,7 @@ class GraphedTrainStep(object):
 
     def step(self):
         m = self.model
-        m.set_learning_rates()
+        m.set_learning_rates(self._groups())
         if self._gA is None:
             if self.split:
                 self._split_step_eager()
