@@ -734,12 +734,22 @@ inline int choose_dw(const cape_src_t *srcs, int nsrc, const float *dz, int64_t 
     const bool dzvec = dw_dz_vec(dz, dz_sample_stride, lddz, dz2, es);
     const bool plain = dwp_on && dzvec && (((F + 3) & ~3) <= lddz) && dw_srcs_plain(srcs, nsrc, es);
     if (bf16) {
-        // bf16 storage: the split-pipe kernel with one plane (plain sources, whole float4-equivalent columns), the
-        // generic gather kernel otherwise; the fp32-MFMA plain / packed kernels read fp32 only
+        // bf16 storage: the split-pipe kernel with one plane where it applies (plain sources, whole float4-equivalent
+        // columns, even F); the 3-channel ends take the pipelined fp32-MFMA kernels like the fp32 path (packed when
+        // several narrow sources share a tile, plain otherwise); the generic gather kernel for everything else
         bool c4b = true;
-        for (int i = 0; i < nsrc; ++i) c4b = c4b && (srcs[i].C & 3) == 0;
+        int sumCb = 0;
+        for (int i = 0; i < nsrc; ++i) { c4b = c4b && (srcs[i].C & 3) == 0; sumCb += srcs[i].C; }
+        if (plain && c4b && (F & 1) == 0) {
+            plan_dw(srcs, nsrc, N, Mo, F, pl);
+            return 3;
+        }
+        if (plain && c4b && !(dz2 && dz2_mask) && nsrc > 1 && sumCb <= 128 && F <= 64) {
+            plan_dw_plain(srcs, nsrc, N, Mo, F, true, pl);
+            return 2;
+        }
         plan_dw(srcs, nsrc, N, Mo, F, pl);
-        return (plain && c4b && (F & 1) == 0) ? 3 : 0;
+        return plain ? 1 : 0;
     }
     int sumC = 0;
     for (int i = 0; i < nsrc; ++i) sumC += srcs[i].C;
@@ -1051,6 +1061,17 @@ int gconv_dw_stage_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz,
         else if (pl.ct == 64) CAPE_LAUNCH((dw_split_kernel<64, 128, cape_bf16>), grid, block, 0, st, p);
         else if (pl.ft == 64) CAPE_LAUNCH((dw_split_kernel<128, 64, cape_bf16>), grid, block, 0, st, p);
         else CAPE_LAUNCH((dw_split_kernel<128, 128, cape_bf16>), grid, block, 0, st, p);
+    } else if (bf16 && packed) {
+        if (pl.ft == 32) CAPE_LAUNCH((dw_packed_kernel<128, 32, 4, 1, cape_bf16>), grid, block, 0, st, p);
+        else if (pl.ct == 64 && pl.ft == 64) CAPE_LAUNCH((dw_packed_kernel<64, 64, 2, 2, cape_bf16>), grid, block, 0, st, p);
+        else if (pl.ct == 64) CAPE_LAUNCH((dw_packed_kernel<64, 128, 2, 2, cape_bf16>), grid, block, 0, st, p);
+        else if (pl.ft == 64) CAPE_LAUNCH((dw_packed_kernel<128, 64, 2, 2, cape_bf16>), grid, block, 0, st, p);
+        else CAPE_LAUNCH((dw_packed_kernel<128, 128, 2, 2, cape_bf16>), grid, block, 0, st, p);
+    } else if (bf16 && plain) {
+        if (pl.ct == 64 && pl.ft == 64) CAPE_LAUNCH((dw_plain_kernel<64, 64, 2, 2, cape_bf16>), grid, block, 0, st, p);
+        else if (pl.ct == 64) CAPE_LAUNCH((dw_plain_kernel<64, 128, 2, 2, cape_bf16>), grid, block, 0, st, p);
+        else if (pl.ft == 64) CAPE_LAUNCH((dw_plain_kernel<128, 64, 2, 2, cape_bf16>), grid, block, 0, st, p);
+        else CAPE_LAUNCH((dw_plain_kernel<128, 128, 2, 2, cape_bf16>), grid, block, 0, st, p);
     } else if (bf16) {
         if (pl.ct == 64 && pl.ft == 64) CAPE_LAUNCH((gconv_dw_kernel<64, 64, cape_bf16>), grid, block, 0, st, p);
         else if (pl.ct == 64) CAPE_LAUNCH((gconv_dw_kernel<64, 128, cape_bf16>), grid, block, 0, st, p);

@@ -265,7 +265,9 @@ __global__ __launch_bounds__(256, 2) void gemm_plain_kernel(GconvParams p) {
 // gradient chunk of iteration i+1 are in flight in registers while iteration i is on the MFMA pipe.
 // Requires: source plain, 16-byte aligned, C % 4 == 0; dz 16-byte aligned, F % 4 == 0.
 // =============================================================================================================
-template <int CT, int FT, int WAVES_M, int WAVES_N>
+// AT = storage type of the sources and of dz (float, or cape_bf16: rows read 8 bytes at a time and widened, the
+// multiply stays on the fp32 MFMA -- exact for bf16 values).
+template <int CT, int FT, int WAVES_M, int WAVES_N, typename AT = float>
 __global__ __launch_bounds__(256, 2) void dw_plain_kernel(DwParams p) {
     constexpr int RK = 32;
     constexpr int LDA = CT + 4, LDB = FT + 4;
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void dw_plain_kernel(DwParams p) {
         const int f = f0 + 4 * (idx % (FT / 4));
         b_col[i] = f < p.F ? f : 0;
     }
-    const float *dz0 = ((p.dz2_mask >> si) & 1u) ? p.dz2 : p.dz;
+    const AT *dz0 = reinterpret_cast<const AT *>(((p.dz2_mask >> si) & 1u) ? p.dz2 : p.dz);
 
     const int chunks = (rb - ra + RK - 1) / RK;
     const int total = (n_end - n_begin) * chunks;
@@ -331,20 +333,20 @@ __global__ __launch_bounds__(256, 2) void dw_plain_kernel(DwParams p) {
     unsigned okA = 0, okB = 0;
 
     auto load_regs = [&]() {
-        const float *xb = S.x + (long long)l_n * S.xs;
-        const float *zb = dz0 + (long long)l_n * p.dzs;
+        const AT *xb = reinterpret_cast<const AT *>(S.x) + (long long)l_n * S.xs;
+        const AT *zb = dz0 + (long long)l_n * p.dzs;
         okA = okB = 0;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int r = l_r + a_rl[i];
             okA |= (r < rb ? 1u : 0u) << i;
-            ra4[i] = *reinterpret_cast<const float4 *>(xb + (long long)min(r, rb - 1) * S.ldx + a_col[i]);
+            ra4[i] = cape_ld4(xb + (long long)min(r, rb - 1) * S.ldx + a_col[i]);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int r = l_r + b_rl[i];
             okB |= (r < rb ? 1u : 0u) << i;
-            rb4[i] = *reinterpret_cast<const float4 *>(zb + (long long)min(r, rb - 1) * p.lddz + b_col[i]);
+            rb4[i] = cape_ld4(zb + (long long)min(r, rb - 1) * p.lddz + b_col[i]);
         }
         l_r += RK;
         if (l_r >= rb) { l_r = ra; ++l_n; }
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void dw_plain_kernel(DwParams p) {
 // (virtual axis, DwParams::vstart): at 6890 vertices the layers are 3 x 32 channels wide, and three half-empty
 // tiles that each re-read dz become one.  It carries per-slot source pointers; layers wide enough to fill
 // their own tiles use dw_plain_kernel (one source per tile, scalar base addresses -- measured 14 % faster there).
-template <int CT, int FT, int WAVES_M, int WAVES_N>
+template <int CT, int FT, int WAVES_M, int WAVES_N, typename AT = float>
 __global__ __launch_bounds__(256, 2) void dw_packed_kernel(DwParams p) {
     constexpr int RK = 32;
     constexpr int LDA = CT + 4, LDB = FT + 4;
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void dw_packed_kernel(DwParams p) {
             for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
 
     // per-thread staging coordinates (fixed for the whole kernel): slot i of the A chunk reads 4 channels of ONE source
-    const float *a_ptr[NA];
+    const AT *a_ptr[NA];
     long long a_xs[NA];
     int a_ld[NA], a_rl[NA], b_rl[NB], b_col[NB];
     int first_src = 0;
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void dw_packed_kernel(DwParams p) {
         int si = 0;
         while (si + 1 < p.nsrc && vc >= p.vstart[si + 1]) ++si;
         const bool ok = vc - p.vstart[si] < p.s[si].C;      // padding columns read column 0: their outputs are never stored
-        a_ptr[i] = p.s[si].x + (ok ? vc - p.vstart[si] : 0);
+        a_ptr[i] = reinterpret_cast<const AT *>(p.s[si].x) + (ok ? vc - p.vstart[si] : 0);
         a_xs[i] = p.s[si].xs;
         a_ld[i] = p.s[si].ldx;
     }
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void dw_packed_kernel(DwParams p) {
         const int f = f0 + 4 * (idx % (FT / 4));
         b_col[i] = f < p.F ? f : 0;
     }
-    const float *dz0 = ((p.dz2_mask >> first_src) & 1u) ? p.dz2 : p.dz;
+    const AT *dz0 = reinterpret_cast<const AT *>(((p.dz2_mask >> first_src) & 1u) ? p.dz2 : p.dz);
 
     const int chunks = (rb - ra + RK - 1) / RK;
     const int total = (n_end - n_begin) * chunks;
@@ -493,19 +495,19 @@ __global__ __launch_bounds__(256, 2) void dw_packed_kernel(DwParams p) {
     unsigned okA = 0, okB = 0;
 
     auto load_regs = [&]() {
-        const float *zb = dz0 + (long long)l_n * p.dzs;
+        const AT *zb = dz0 + (long long)l_n * p.dzs;
         okA = okB = 0;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int r = l_r + a_rl[i];
             okA |= (r < rb ? 1u : 0u) << i;
-            ra4[i] = *reinterpret_cast<const float4 *>(a_ptr[i] + (long long)l_n * a_xs[i] + (long long)min(r, rb - 1) * a_ld[i]);
+            ra4[i] = cape_ld4(a_ptr[i] + (long long)l_n * a_xs[i] + (long long)min(r, rb - 1) * a_ld[i]);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int r = l_r + b_rl[i];
             okB |= (r < rb ? 1u : 0u) << i;
-            rb4[i] = *reinterpret_cast<const float4 *>(zb + (long long)min(r, rb - 1) * p.lddz + b_col[i]);
+            rb4[i] = cape_ld4(zb + (long long)min(r, rb - 1) * p.lddz + b_col[i]);
         }
         l_r += RK;
         if (l_r >= rb) { l_r = ra; ++l_n; }

@@ -222,7 +222,7 @@ def dw_kernel_name(fam, ct, ft, bf16=False):
     if fam == 3 or fam == 0:
         return "%s<%d, %d, %s>" % (_DW_FAMILY[fam], ct, ft, "unsigned short" if bf16 else "float")
     waves = "4, 1" if (fam == 2 and ft == 32) else "2, 2"
-    return "%s<%d, %d, %s>" % (_DW_FAMILY[fam], ct, ft, waves)
+    return "%s<%d, %d, %s, %s>" % (_DW_FAMILY[fam], ct, ft, waves, "unsigned short" if bf16 else "float")
 
 
 # --------------------------------------------------------------------------------------------
