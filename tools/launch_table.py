@@ -4,7 +4,9 @@ sys.path.insert(0, '.')
 import bench
 from cape_amd import ops
 from cape_amd.runtime import GraphedTrainStep
-model = bench.build_model(16, 0, 'CAPE-affineconv_nz64_pose32_clotype32_male')
+cfg = next((a.split('=', 1)[1] for a in sys.argv if a.startswith('config=')), 'CAPE-affineconv_nz64_pose32_clotype32_male')
+batch = int(next((a.split('=', 1)[1] for a in sys.argv if a.startswith('batch=')), 16))
+model = bench.build_model(batch, 0, cfg)
 r = GraphedTrainStep(model, with_gan=('gan' in sys.argv), use_graph=False)
 r.load_batch(**bench.synthetic_batch(model, 1234))
 for _ in range(2):
