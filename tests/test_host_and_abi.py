@@ -166,6 +166,46 @@ def test_forward_plan_query_is_pure_host_logic():
     assert 0 < w1 < w2 and lib.cape_gconv_dw_workspace_bytes(None, 1, 16, 862, 64) == -1
 
 
+def test_weight_gradient_split_plan_is_one_balanced_round():
+    """cape_gconv_dw_plan (pure host logic): the contraction of every weight-gradient launch of the nz64 model at batch 16
+    is cut so that (tiles x splits) fits the 512 resident 128x128 workgroups -- ONE round -- and the split count is a whole
+    number of groups of 8 (split s runs on XCD s % 8).  The rule it replaced gave 21 splits = 672 workgroups on the widest
+    layer."""
+    import ctypes as C
+    from cape_amd import _lib
+    lib = _lib.lib
+    if int(os.environ.get("CAPE_DW_SPLIT_POLICY", "1")) != 1:
+        pytest.skip("older split rule selected by the environment")
+
+    def srcs(Cs, Mo):
+        arr = (_lib.CapeSrc * len(Cs))()
+        for i, (s, Cn) in enumerate(zip(arr, Cs)):
+            s.x, s.x_sample_stride, s.ldx, s.C = 0x100000 * (i + 1), Mo * Cn, Cn, Cn
+            s.rowptr = s.colidx = s.vals = None
+            s.w, s.w_rs, s.w_cs = 0x10000000, 512, 1
+            s.w2, s.w2_rs, s.w2_cs = None, 0, 0
+        return arr
+
+    def plan(Cs, Mo, F, N=16):
+        out = (C.c_int32 * 4)()
+        assert lib.cape_gconv_dw_plan(srcs(Cs, Mo), len(Cs), C.c_void_p(0x40000000), Mo * F, F, None, 0, N, Mo, F, out) == 0
+        fam, ct, ft, nsplit = list(out)
+        ntiles = sum(-(-c // ct) for c in Cs) * -(-F // ft)
+        return fam, ct, ft, nsplit, ntiles
+
+    # (sources, vertices, output channels): encoder conv8 / conv7, decoder affine1 / affine2, mid and fine levels
+    for Cs, Mo, F in (([512, 512], 862, 512), ([256, 256], 862, 512), ([512, 512, 512], 862, 256), ([256, 256, 256], 862, 256),
+                      ([128, 128], 1723, 256), ([128, 128, 128], 1723, 128), ([64, 64], 3445, 128), ([64, 64, 64], 3445, 64)):
+        fam, ct, ft, nsplit, ntiles = plan(Cs, Mo, F)
+        assert fam in (2, 3), (Cs, Mo, F, fam)
+        if fam == 3:
+            assert ntiles * nsplit <= 512, (Cs, Mo, F, ct, ft, nsplit, ntiles)          # one round of two workgroups per CU
+            assert ntiles * nsplit >= 256, (Cs, Mo, F, ct, ft, nsplit, ntiles)          # and at least one per CU
+            assert nsplit % 8 == 0, (Cs, Mo, F, nsplit)
+    # the widest layer: 32 tiles x 16 splits (one sample each), not 21 uneven ones
+    assert plan([512, 512], 862, 512)[3:] == (16, 32)
+
+
 def test_bench_exact_fp32_comparison_is_fault_tolerant(monkeypatch):
     """bench.py's optional child run (exact-fp32 MFMA comparison) must never break the JSON line: a failing child gives
     an error record, a good child gives its numbers."""
