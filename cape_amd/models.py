@@ -203,6 +203,11 @@ class base_model(object):
         = vertex-constant input channels appended after x's channels (never materialised)."""
         Cin = x.shape[-1] + (0 if cond_in is None else cond_in.shape[1])
         W = self._weight_variable([Cin * K, Fout])
+        dops = self._conv_ops(L, K, unpool=unpool, pool=pool)
+        if cond_in is not None and not dops.fused:
+            # polynomial orders above 3 take the explicit recurrence (no precomposed operators): the condition channels
+            # are materialised for it, as the reference does (tf.concat before the filter, lib/models.py:586-613)
+            x, cond_in = ops.ConcatCondFn.apply(x, cond_in), None
         wname = '/'.join(self._scope + ['weights'])
         waname = '/'.join(self._scope[:-1] + ['affine', 'weights'])
         bname = '/'.join(self._scope + ['bias'])
@@ -222,7 +227,7 @@ class base_model(object):
                 coef, cond_in = next(self._cond_bank), None
             elif self._cond_rec is not None:
                 self._cond_rec.append(dict(wname=wname, waname=waname if W_affine is not None else None, Ch=Ch, K=int(K)))
-        return ops.chebyshev5(x, W, self._conv_ops(L, K, unpool=unpool, pool=pool), bias=bias,
+        return ops.chebyshev5(x, W, dops, bias=bias,
                               activation=activation, cond=cond, W_affine=W_affine, cond_in=cond_in,
                               grad_bufs=(gW, gWa), bias_grad_buf=gB, coef=coef)
 

@@ -103,6 +103,10 @@ CASES = [
     # BASELINE configs[2] at its stated batch (static batch 16, reference lib/models.py:272-282, config_parser.py:33):
     # the shapes for which the HIP library selects its large-tile kernels
     ("affine_nz64_b16", "affine_nz64", None, 16, 21),
+    # polynomial order 6 in every generator layer: the explicit Chebyshev recurrence of lib/models.py:88-96 (K > 2) and
+    # the [M, Fin, K] -> [M*N.., Fin*K] reshuffle of :97-102 with K = 6 (BASELINE configs[1] is one such layer)
+    ("cheb_k6", "affine_nz18", dict(use_res_block=True, use_res_block_dec=False, cond_encoder=True, K=[6] * 8,
+                                    F=[16, 16, 32, 32, 32, 32, 64, 64], reduce_dim=16), 2, 14),
 ]
 
 def main():
