@@ -105,6 +105,11 @@ CASES = [
     ("affine_nz64_b16", "affine_nz64", None, 16, 21),
     # polynomial order 6 in every generator layer: the explicit Chebyshev recurrence of lib/models.py:88-96 (K > 2) and
     # the [M, Fin, K] -> [M*N.., Fin*K] reshuffle of :97-102 with K = 6 (BASELINE configs[1] is one such layer)
+    # option switches no shipped YAML uses: two-layer clothing-type network, ReLU, discriminator order 2, condition
+    # networks excluded from the optimiser, conditioned plain encoder with the udn decoder
+    ("switches_relu", "affine_nz18", dict(n_layer_cond=2, activation='b1relu', Kd=2, optim_condnet=False, use_res_block=False,
+                                          use_res_block_dec=False, cond_encoder=True, F=[16, 16, 32, 32, 64, 64, 128, 128],
+                                          reduce_dim=16), 2, 15),
     ("cheb_k6", "affine_nz18", dict(use_res_block=True, use_res_block_dec=False, cond_encoder=True, K=[6] * 8,
                                     F=[16, 16, 32, 32, 32, 32, 64, 64], reduce_dim=16), 2, 14),
 ]
