@@ -110,6 +110,9 @@ CASES = [
     ("switches_relu", "affine_nz18", dict(n_layer_cond=2, activation='b1relu', Kd=2, optim_condnet=False, use_res_block=False,
                                           use_res_block_dec=False, cond_encoder=True, F=[16, 16, 32, 32, 64, 64, 128, 128],
                                           reduce_dim=16), 2, 15),
+    # mixed polynomial orders with the affine res-blocks: the precomposed K = 3 operators and the recurrence (K = 4, 5, 6)
+    # next to each other, the affine block in both its fused and its composed form
+    ("affine_mixed_k", "affine_nz18", dict(K=[3, 4, 3, 4, 2, 5, 3, 6], F=[16, 16, 32, 32, 64, 64, 128, 128], reduce_dim=16), 2, 16),
     ("cheb_k6", "affine_nz18", dict(use_res_block=True, use_res_block_dec=False, cond_encoder=True, K=[6] * 8,
                                     F=[16, 16, 32, 32, 32, 32, 64, 64], reduce_dim=16), 2, 14),
 ]

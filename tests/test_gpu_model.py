@@ -230,7 +230,7 @@ def test_encode_decode_api_padding(mesh_ops):
     assert model.predict(x[:3], cond[:3], clo[:3]).shape == (3, 6890, 3)
 
 
-@pytest.mark.parametrize("tag", ["affine_nz64", "cmr_nz18", "resblock_udn_tanh", "cheb_k6", "switches_relu"])
+@pytest.mark.parametrize("tag", ["affine_nz64", "cmr_nz18", "resblock_udn_tanh", "cheb_k6", "switches_relu", "affine_mixed_k"])
 def test_model_matches_reference_golden(tag, mesh_ops):
     """HIP path vs the golden vectors produced by the reference's own lib/models.py code (run on the
     numpy TF1 shim by oracle/make_golden.py): same named weights, same inputs."""
