@@ -78,10 +78,13 @@ CONFIGS = [
     # encoder res_block (:715-741) + plain udn decoder (:173-191) + conditioned encoder, tanh
     ("affine_nz18", dict(use_res_block=True, use_res_block_dec=False, cond_encoder=True, activation='b1tanh',
                          F=[16, 16, 32, 32, 64, 64, 128, 128], reduce_dim=32, loss='l2')),
+    # polynomial orders 2-6 mixed over the layers, affine res-blocks: precomposed operators (K <= 3) next to the explicit
+    # recurrence (:88-96) with materialised condition channels, the affine block fused and composed
+    ("affine_nz18", dict(K=[3, 4, 3, 4, 2, 5, 3, 6], F=[16, 16, 32, 32, 64, 64, 128, 128], reduce_dim=16)),
 ]
 
 
-@pytest.mark.parametrize("cfg,overrides", CONFIGS, ids=["affine_nz64", "cmr_nz18", "resblock_udn_tanh"])
+@pytest.mark.parametrize("cfg,overrides", CONFIGS, ids=["affine_nz64", "cmr_nz18", "resblock_udn_tanh", "affine_mixed_k"])
 def test_full_model_forward_backward(cfg, overrides, mesh_ops):
     _full_model_parity(cfg, overrides, mesh_ops, N=2)
 
