@@ -113,6 +113,9 @@ CASES = [
     # mixed polynomial orders with the affine res-blocks: the precomposed K = 3 operators and the recurrence (K = 4, 5, 6)
     # next to each other, the affine block in both its fused and its composed form
     ("affine_mixed_k", "affine_nz18", dict(K=[3, 4, 3, 4, 2, 5, 3, 6], F=[16, 16, 32, 32, 64, 64, 128, 128], reduce_dim=16), 2, 16),
+    # Huber reconstruction loss (lib/models.py:360-363) with b1relu and the res-block encoder on the affine decoder
+    ("huber_res_affine", "affine_nz18", dict(loss='huber', activation='b1relu', use_res_block=True, cond_encoder=True,
+                                             F=[16, 16, 32, 32, 64, 64, 128, 128], reduce_dim=16), 2, 17),
     ("cheb_k6", "affine_nz18", dict(use_res_block=True, use_res_block_dec=False, cond_encoder=True, K=[6] * 8,
                                     F=[16, 16, 32, 32, 32, 32, 64, 64], reduce_dim=16), 2, 14),
 ]
