@@ -33,6 +33,24 @@ def test_csr_validate_error_codes():
     assert lib.cape_csr_validate(2, 2, 3, None, None) == -1
 
 
+def test_sparse_entry_points_reject_bad_arguments_before_launching():
+    """Argument checks of the sparse entry points run on the host before any launch: NULL operands, leading dimensions
+    narrower than the channel count, and per-sample extents that would overflow the kernels' 32-bit work-item index."""
+    import ctypes as C
+    from cape_amd._lib import lib
+    P = C.c_void_p
+    x, y, rp, ci, va = P(0x100000), P(0x200000), P(0x300000), P(0x400000), P(0x500000)
+    args = lambda **kw: [kw.get("x", x), 64 * 64, kw.get("ldx", 64), rp, ci, va, 8, 1.0, None, 0, 0, 0.0, kw.get("y", y),
+                         64 * 64, kw.get("ldy", 64), kw.get("N", 2), kw.get("Mo", 64), kw.get("C", 64), None]
+    assert lib.cape_spmm(*args(x=None)) == -1
+    assert lib.cape_spmm(*args(y=None)) == -1
+    assert lib.cape_spmm(*args(ldx=32)) == -1                      # leading dimension below the channel count
+    assert lib.cape_spmm(*args(N=0)) == -1
+    big = 1 << 20                                                  # Mo * C = 2^31: beyond the 32-bit item index
+    assert lib.cape_spmm(*args(Mo=big, C=2048, ldx=2048, ldy=2048)) == -1
+    assert lib.cape_spmm_bf16(*args(Mo=big, C=2048, ldx=2048, ldy=2048)) == -1
+
+
 def test_compute_entry_points_fail_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
