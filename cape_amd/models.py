@@ -478,7 +478,12 @@ class CAPE(base_model):
             Cn = int(x.shape[-1])
             gamma = self._get_variable('gamma', (Cn,), 'gn_gamma')
             beta = self._get_variable('beta', (Cn,), 'gn_beta')
-        return ops.GroupNormFn.apply(x, gamma, beta, min(G, Cn), eps, 1 if relu else 0)
+        Ge = min(G, Cn)
+        if Cn % Ge and Cn // Ge == 1:
+            # G < C < 2G: the reference's free-dimension reshape (lib/models.py:698) then takes the rows of the [N*C, V]
+            # matrix one at a time -- a per-(sample, channel) normalisation, i.e. C groups
+            Ge = Cn
+        return ops.GroupNormFn.apply(x, gamma, beta, Ge, eps, 1 if relu else 0)
 
     def res_block_decoder(self, x_in, i, name, cond=None):
         Fi, Lm = self.out_channels[-i - 1], self.Laplacian[-i - 2]

@@ -115,11 +115,14 @@ def group_norm(x, gamma, beta, G=32, eps=1e-5):
     xt = np.transpose(x, (0, 2, 1))
     N, C, V = xt.shape
     G = min(G, C)
-    xg = xt.reshape(N, G, C // G, V)
+    # the reference reshapes with a free leading dimension (tf.reshape(x, [-1, G, C // G, V]), :698): when G does not
+    # divide C the rows of the [N*C, V] matrix are still taken C // G at a time (C = 48: one channel row per group, i.e.
+    # a per-(sample, channel) normalisation) -- restated as written
+    xg = xt.reshape(-1, G, C // G, V)
     mean = xg.mean(axis=(2, 3), keepdims=True)
     var = ((xg - mean) ** 2).mean(axis=(2, 3), keepdims=True)
     xg = (xg - mean) / np.sqrt(var + dt.type(eps))
-    out = xg.reshape(N, C, V) * gamma.astype(dt).reshape(1, C, 1) + beta.astype(dt).reshape(1, C, 1)
+    out = xg.reshape(-1, C, V) * gamma.astype(dt).reshape(1, C, 1) + beta.astype(dt).reshape(1, C, 1)
     return np.ascontiguousarray(np.transpose(out, (0, 2, 1)))
 
 

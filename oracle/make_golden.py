@@ -116,6 +116,9 @@ CASES = [
     # Huber reconstruction loss (lib/models.py:360-363) with b1relu and the res-block encoder on the affine decoder
     ("huber_res_affine", "affine_nz18", dict(loss='huber', activation='b1relu', use_res_block=True, cond_encoder=True,
                                              F=[16, 16, 32, 32, 64, 64, 128, 128], reduce_dim=16), 2, 17),
+    # GraphCMR / group-norm decoder with polynomial order 3, res-block encoder and conditioned encoder
+    ("cmr_k3_res", "cmr_nz18", dict(K=[3] * 8, use_res_block=True, cond_encoder=True,
+                                    F=[16, 16, 32, 32, 64, 64, 128, 128], reduce_dim=16), 2, 18),
     ("cheb_k6", "affine_nz18", dict(use_res_block=True, use_res_block_dec=False, cond_encoder=True, K=[6] * 8,
                                     F=[16, 16, 32, 32, 32, 32, 64, 64], reduce_dim=16), 2, 14),
 ]

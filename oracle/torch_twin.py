@@ -59,11 +59,11 @@ def group_norm(x, gamma, beta, G=32, eps=1e-5):
     xt = x.permute(0, 2, 1)
     N, C, V = xt.shape
     G = min(G, C)
-    xg = xt.reshape(N, G, C // G, V)
+    xg = xt.reshape(-1, G, C // G, V)          # free leading dimension, as the reference writes it (see cape_oracle.group_norm)
     mean = xg.mean(dim=(2, 3), keepdim=True)
     var = ((xg - mean) ** 2).mean(dim=(2, 3), keepdim=True)
     xg = (xg - mean) / torch.sqrt(var + eps)
-    out = xg.reshape(N, C, V) * gamma.reshape(1, C, 1) + beta.reshape(1, C, 1)
+    out = xg.reshape(-1, C, V) * gamma.reshape(1, C, 1) + beta.reshape(1, C, 1)
     return out.permute(0, 2, 1).contiguous()
 
 
