@@ -119,6 +119,14 @@ CASES = [
     # GraphCMR / group-norm decoder with polynomial order 3, res-block encoder and conditioned encoder
     ("cmr_k3_res", "cmr_nz18", dict(K=[3] * 8, use_res_block=True, cond_encoder=True,
                                     F=[16, 16, 32, 32, 64, 64, 128, 128], reduce_dim=16), 2, 18),
+    # no channel reduction before / after the dense layers (reduce_dim = 0 skips the 1x1 convolutions, :175-180, :590-597)
+    ("reduce0", "affine_nz18", dict(reduce_dim=0, F=[16, 16, 32, 32, 32, 32, 32, 32]), 2, 31),
+    # b2relu: one bias per vertex and channel (:148-152) in every conv layer, udn decoder
+    ("b2relu_udn", "affine_nz18", dict(activation='b2relu', use_res_block_dec=False, F=[16, 16, 32, 32, 64, 64, 128, 128],
+                                       reduce_dim=16), 2, 32),
+    # three-layer clothing-type network, other embedding sizes (:479-511)
+    ("cond3", "affine_nz18", dict(n_layer_cond=3, nz_cond=16, nz_cond2=4, F=[16, 16, 32, 32, 64, 64, 128, 128],
+                                  reduce_dim=16), 2, 33),
     ("cheb_k6", "affine_nz18", dict(use_res_block=True, use_res_block_dec=False, cond_encoder=True, K=[6] * 8,
                                     F=[16, 16, 32, 32, 32, 32, 64, 64], reduce_dim=16), 2, 14),
 ]
