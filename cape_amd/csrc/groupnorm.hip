@@ -13,6 +13,10 @@
 //   backward: the ReLU mask is re-derived as fma(a, x, b) > 0 (bit-identical to the forward decision: same operands, same
 //             fma), so y is not read; partial sums of d' and d'*xhat per (sample, chunk, channel) -> per (sample, group)
 //             sums -> dx = A_c d' - (B_g + xhat C_g).
+// Channel counts that are not a multiple of 4 (e.g. 24 + 8 + 6 condition channels): rows are still 16-byte aligned
+// (ld % 4 == 0, so ld >= Cp = round_up(C, 4)); every pass works on Cp / 4 quads, the last quad loads its pad lanes (inside
+// the row, values unused) and stores / accumulates only the lanes below C.  The per-channel tables (partials, coef, bcoef)
+// use the stride Cp so that their float4 accesses stay aligned.
 #include "common.h"
 
 namespace {
@@ -23,6 +27,17 @@ inline int gn_rows(int N, int V) {
     int rb = 128;
     while (rb > 16 && (long long)N * ((V + rb - 1) / rb) < 1024) rb >>= 1;
     return rb;
+}
+
+// store the first min(4, left) lanes of a quad (left = channels from this quad's first to the row's end)
+__device__ __forceinline__ void gn_store4(float *p, const float4 &o, int left) {
+    if (left >= 4) {
+        *reinterpret_cast<float4 *>(p) = o;
+    } else {
+        p[0] = o.x;
+        if (left > 1) p[1] = o.y;
+        if (left > 2) p[2] = o.z;
+    }
 }
 
 inline int grid_for(long long total) {
@@ -42,9 +57,10 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float *x, long lo
     const int n = blockIdx.x / chunks, ch = blockIdx.x % chunks;
     const int ra = ch * RB, rb = min(V, ra + RB);
     const float *xb = x + (long long)n * xs;
-    float *pp = part + ((long long)n * chunks + ch) * 2 * C;
-    for (int cbase = 0; cbase < C; cbase += 256) {
-        const int cw = min(256, C - cbase);
+    const int Cp = (C + 3) & ~3;
+    float *pp = part + ((long long)n * chunks + ch) * 2 * Cp;
+    for (int cbase = 0; cbase < Cp; cbase += 256) {
+        const int cw = min(256, Cp - cbase);
         const int c4n = cw >> 2;
         const int lanes = 256 / c4n;
         const int q = threadIdx.x % c4n, rl = threadIdx.x / c4n;
@@ -60,9 +76,9 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float *x, long lo
                     t1.x = fmaf(dx_, dx_, t1.x); t1.y = fmaf(dy_, dy_, t1.y); t1.z = fmaf(dz_, dz_, t1.z); t1.w = fmaf(dw_, dw_, t1.w);
                 }
             } else {
-                const float *cf = coef + (long long)n * 4 * C + c;
-                const float4 a = *reinterpret_cast<const float4 *>(cf), b = *reinterpret_cast<const float4 *>(cf + C);
-                const float4 rr = *reinterpret_cast<const float4 *>(cf + 2 * C), mr = *reinterpret_cast<const float4 *>(cf + 3 * C);
+                const float *cf = coef + (long long)n * 4 * Cp + c;
+                const float4 a = *reinterpret_cast<const float4 *>(cf), b = *reinterpret_cast<const float4 *>(cf + Cp);
+                const float4 rr = *reinterpret_cast<const float4 *>(cf + 2 * Cp), mr = *reinterpret_cast<const float4 *>(cf + 3 * Cp);
                 const float *gb = dy + (long long)n * dys;
                 for (int r = ra + rl; r < rb; r += lanes) {
                     const float4 v = *reinterpret_cast<const float4 *>(xb + (long long)r * ldx + c);
@@ -88,7 +104,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float *x, long lo
                     const float4 v = red[l * c4n + q];
                     t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
                 }
-                *reinterpret_cast<float4 *>(pp + (long long)j * C + c) = t;
+                *reinterpret_cast<float4 *>(pp + (long long)j * Cp + c) = t;      // (pad lanes of the last quad: never read)
             }
         }
         __syncthreads();
@@ -103,6 +119,7 @@ __global__ __launch_bounds__(256) void gn_final_kernel(const float *part, int ch
     __shared__ double sS[256], sQ[256];
     const int n = blockIdx.x / G, g = blockIdx.x % G;
     const int Cg = C / G;
+    const int Cp = (C + 3) & ~3;
     int cp = 1;
     while (cp < Cg) cp <<= 1;                       // channel lanes (power of two >= group width, <= 256)
     const int CL = 256 / cp;                        // chunk lanes
@@ -111,9 +128,9 @@ __global__ __launch_bounds__(256) void gn_final_kernel(const float *part, int ch
     if (cc < Cg) {
         const int c = g * Cg + cc;
         for (int k = cl; k < chunks; k += CL) {
-            const float *pp = part + ((long long)n * chunks + k) * 2 * C;
+            const float *pp = part + ((long long)n * chunks + k) * 2 * Cp;
             S += (double)pp[c];
-            Q += (double)pp[C + c];
+            Q += (double)pp[Cp + c];
         }
     }
     sS[threadIdx.x] = S; sQ[threadIdx.x] = Q;
@@ -143,33 +160,33 @@ __global__ __launch_bounds__(256) void gn_final_kernel(const float *part, int ch
     if (threadIdx.x < Cg) {
         const int c = g * Cg + threadIdx.x;
         const float mean = (float)sS[0], rstd = (float)sQ[0];
-        float *cf = coef + (long long)n * 4 * C;
+        float *cf = coef + (long long)n * 4 * Cp;
         const float a = rstd * gamma[c];
         cf[c] = a;
-        cf[C + c] = fmaf(-mean, a, beta[c]);
-        cf[2 * C + c] = rstd;
-        cf[3 * C + c] = mean * rstd;
+        cf[Cp + c] = fmaf(-mean, a, beta[c]);
+        cf[2 * Cp + c] = rstd;
+        cf[3 * Cp + c] = mean * rstd;
     }
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float *x, long long xs, int ldx, const float *coef, int relu,
                                                        float *y, long long ys, int ldy, int N, int V, int C) {
-    const int c4 = C >> 2;
+    const int Cp = (C + 3) & ~3, c4 = Cp >> 2;
     const long long total = (long long)N * V * c4;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % c4) * 4;
         const long long nv = i / c4;
         const int v = (int)(nv % V);
         const int n = (int)(nv / V);
-        const float *cf = coef + (long long)n * 4 * C + c;
-        const float4 a = *reinterpret_cast<const float4 *>(cf), b = *reinterpret_cast<const float4 *>(cf + C);
+        const float *cf = coef + (long long)n * 4 * Cp + c;
+        const float4 a = *reinterpret_cast<const float4 *>(cf), b = *reinterpret_cast<const float4 *>(cf + Cp);
         const float4 xv = *reinterpret_cast<const float4 *>(x + (long long)n * xs + (long long)v * ldx + c);
         float4 o;
         o.x = fmaf(a.x, xv.x, b.x); o.y = fmaf(a.y, xv.y, b.y); o.z = fmaf(a.z, xv.z, b.z); o.w = fmaf(a.w, xv.w, b.w);
         if (relu) {
             o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
         }
-        *reinterpret_cast<float4 *>(y + (long long)n * ys + (long long)v * ldy + c) = o;
+        gn_store4(y + (long long)n * ys + (long long)v * ldy + c, o, C - c);
     }
 }
 
@@ -181,6 +198,7 @@ __global__ __launch_bounds__(256) void gn_bwd_final_kernel(const float *part, in
     __shared__ double s1s[256], s2s[256];
     const int n = blockIdx.x / G, g = blockIdx.x % G;
     const int Cg = C / G;
+    const int Cp = (C + 3) & ~3;
     int cp = 1;
     while (cp < Cg) cp <<= 1;
     const int CL = 256 / cp;
@@ -189,9 +207,9 @@ __global__ __launch_bounds__(256) void gn_bwd_final_kernel(const float *part, in
     if (cc < Cg) {
         const int c = g * Cg + cc;
         for (int k = cl; k < chunks; k += CL) {
-            const float *pp = part + ((long long)n * chunks + k) * 2 * C;
+            const float *pp = part + ((long long)n * chunks + k) * 2 * Cp;
             a1 += (double)pp[c];
-            a2 += (double)pp[C + c];
+            a2 += (double)pp[Cp + c];
         }
     }
     s1s[threadIdx.x] = a1; s2s[threadIdx.x] = a2;
@@ -214,29 +232,29 @@ __global__ __launch_bounds__(256) void gn_bwd_final_kernel(const float *part, in
     __syncthreads();
     if (threadIdx.x < Cg) {
         const int c = g * Cg + threadIdx.x;
-        float *bc = bcoef + (long long)n * 3 * C;
+        float *bc = bcoef + (long long)n * 3 * Cp;
         bc[c] = stats[2 * blockIdx.x + 1] * gamma[c];
-        bc[C + c] = (float)s1s[0];
-        bc[2 * C + c] = (float)s2s[0];
+        bc[Cp + c] = (float)s1s[0];
+        bc[2 * Cp + c] = (float)s2s[0];
     }
 }
 
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *x, long long xs, int ldx, const float *dy, long long dys,
                                                            int lddy, const float *coef, const float *bcoef, int relu, float *dx,
                                                            long long dxs, int lddx, int N, int V, int C) {
-    const int c4 = C >> 2;
+    const int Cp = (C + 3) & ~3, c4 = Cp >> 2;
     const long long total = (long long)N * V * c4;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % c4) * 4;
         const long long nv = i / c4;
         const int v = (int)(nv % V);
         const int n = (int)(nv / V);
-        const float *cf = coef + (long long)n * 4 * C + c;
-        const float *bc = bcoef + (long long)n * 3 * C + c;
-        const float4 a = *reinterpret_cast<const float4 *>(cf), b = *reinterpret_cast<const float4 *>(cf + C);
-        const float4 rr = *reinterpret_cast<const float4 *>(cf + 2 * C), mr = *reinterpret_cast<const float4 *>(cf + 3 * C);
-        const float4 A = *reinterpret_cast<const float4 *>(bc), B = *reinterpret_cast<const float4 *>(bc + C);
-        const float4 Cc = *reinterpret_cast<const float4 *>(bc + 2 * C);
+        const float *cf = coef + (long long)n * 4 * Cp + c;
+        const float *bc = bcoef + (long long)n * 3 * Cp + c;
+        const float4 a = *reinterpret_cast<const float4 *>(cf), b = *reinterpret_cast<const float4 *>(cf + Cp);
+        const float4 rr = *reinterpret_cast<const float4 *>(cf + 2 * Cp), mr = *reinterpret_cast<const float4 *>(cf + 3 * Cp);
+        const float4 A = *reinterpret_cast<const float4 *>(bc), B = *reinterpret_cast<const float4 *>(bc + Cp);
+        const float4 Cc = *reinterpret_cast<const float4 *>(bc + 2 * Cp);
         const float4 xv = *reinterpret_cast<const float4 *>(x + (long long)n * xs + (long long)v * ldx + c);
         float4 d = *reinterpret_cast<const float4 *>(dy + (long long)n * dys + (long long)v * lddy + c);
         if (relu) {
@@ -248,7 +266,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *x, long 
         o.y = A.y * d.y - fmaf(fmaf(xv.y, rr.y, -mr.y), Cc.y, B.y);
         o.z = A.z * d.z - fmaf(fmaf(xv.z, rr.z, -mr.z), Cc.z, B.z);
         o.w = A.w * d.w - fmaf(fmaf(xv.w, rr.w, -mr.w), Cc.w, B.w);
-        *reinterpret_cast<float4 *>(dx + (long long)n * dxs + (long long)v * lddx + c) = o;
+        gn_store4(dx + (long long)n * dxs + (long long)v * lddx + c, o, C - c);
     }
 }
 
@@ -258,10 +276,7 @@ inline bool gn_aligned(const void *p, long long ss, int ld) {
 
 // the last column tile of a partial-sum pass must have a quad count that leaves at least one row lane
 inline bool gn_shape_ok(int C, int G) {
-    if (C & 3) return false;
-    if (C / G > 256) return false;
-    const int tail = C % 256;
-    return tail == 0 || (tail >> 2) <= 256;
+    return C / G <= 256;
 }
 
 }  // namespace
@@ -270,7 +285,7 @@ extern "C" int64_t cape_groupnorm_workspace_bytes(int32_t N, int32_t V, int32_t 
     if (N < 1 || V < 1 || C < 1) return CAPE_EINVAL;
     const int RB = gn_rows(N, V);
     const long long chunks = (V + RB - 1) / RB;
-    return (int64_t)N * chunks * 2 * C * (int64_t)sizeof(float);
+    return (int64_t)N * chunks * 2 * ((C + 3) & ~3) * (int64_t)sizeof(float);
 }
 
 extern "C" int cape_groupnorm_fwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *gamma,
@@ -291,7 +306,7 @@ extern "C" int cape_groupnorm_fwd(const float *x, int64_t x_sample_stride, int32
     CAPE_LAUNCH(gn_final_kernel, dim3(N * G), dim3(256), 0, st, (const float *)workspace, chunks, x, (long long)x_sample_stride,
                 gamma, beta, eps, G, V, C, stats, coef);
     CAPE_LAUNCH_CHECK();
-    CAPE_LAUNCH(gn_apply_kernel, dim3(grid_for((long long)N * V * (C / 4))), dim3(256), 0, st, x, (long long)x_sample_stride, ldx,
+    CAPE_LAUNCH(gn_apply_kernel, dim3(grid_for((long long)N * V * ((C + 3) / 4))), dim3(256), 0, st, x, (long long)x_sample_stride, ldx,
                 (const float *)coef, relu, y, (long long)y_sample_stride, ldy, N, V, C);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
@@ -318,7 +333,7 @@ extern "C" int cape_groupnorm_bwd(const float *x, int64_t x_sample_stride, int32
     CAPE_LAUNCH(gn_bwd_final_kernel, dim3(N * G), dim3(256), 0, st, (const float *)workspace, chunks, gamma, stats, G, V, C,
                 dgamma_partial, dbeta_partial, bcoef);
     CAPE_LAUNCH_CHECK();
-    CAPE_LAUNCH(gn_bwd_apply_kernel, dim3(grid_for((long long)N * V * (C / 4))), dim3(256), 0, st, x, (long long)x_sample_stride,
+    CAPE_LAUNCH(gn_bwd_apply_kernel, dim3(grid_for((long long)N * V * ((C + 3) / 4))), dim3(256), 0, st, x, (long long)x_sample_stride,
                 ldx, dy, (long long)dy_sample_stride, lddy, coef, (const float *)bcoef, relu, dx, (long long)dx_sample_stride, lddx,
                 N, V, C);
     CAPE_LAUNCH_CHECK();

@@ -426,11 +426,14 @@ class CAPE(base_model):
         both networks run as ONE launch per direction (ops.CondNetsFn) and the embeddings are the two halves of the
         concatenated condition every consumer needs (``_cat_cond``); variables are created under the reference's names."""
         self._ycat = None
-        if (self.n_layer_cond == 1 and cond.is_cuda and cond.dim() == 2 and cond.shape[0] <= 64
+        y_dim = int(cond.shape[-1])
+        nzc = int(self.nz_cond)
+        hid = y_dim // 2 if nzc < y_dim // 2 else (y_dim if nzc < y_dim * 2 else nzc // 2)       # rule of :498-503
+        # shape limits of the fused kernels (csrc/condnet.hip condnet_check); anything else takes the per-layer path below
+        fits = (y_dim <= 512 and hid <= 256 and
+                4 * int(cond.shape[0]) * (hid + nzc + int(self.nz_cond2)) <= 60 * 1024)
+        if (self.n_layer_cond == 1 and cond.is_cuda and cond.dim() == 2 and cond.shape[0] <= 64 and fits
                 and cond.dtype == torch.float32 and cond2.dtype == torch.float32):
-            y_dim = int(cond.shape[-1])
-            nzc = int(self.nz_cond)
-            hid = y_dim // 2 if nzc < y_dim // 2 else (y_dim if nzc < y_dim * 2 else nzc // 2)       # rule of :498-503
             with self.variable_scope('condition_pose'):
                 with self.variable_scope('fc1'):
                     W1, b1, g1 = self._dense_vars(y_dim, hid)
@@ -478,11 +481,7 @@ class CAPE(base_model):
             Cn = int(x.shape[-1])
             gamma = self._get_variable('gamma', (Cn,), 'gn_gamma')
             beta = self._get_variable('beta', (Cn,), 'gn_beta')
-        Ge = min(G, Cn)
-        if Cn % Ge and Cn // Ge == 1:
-            # G < C < 2G: the reference's free-dimension reshape (lib/models.py:698) then takes the rows of the [N*C, V]
-            # matrix one at a time -- a per-(sample, channel) normalisation, i.e. C groups
-            Ge = Cn
+        Ge = ops.group_count(x.shape[0], Cn, G)      # the reference's free-dimension reshape, lib/models.py:698
         return ops.GroupNormFn.apply(x, gamma, beta, Ge, eps, 1 if relu else 0)
 
     def res_block_decoder(self, x_in, i, name, cond=None):
@@ -523,6 +522,7 @@ class CAPE(base_model):
             x = self.unpool(x, U)
             with self.variable_scope('graph_conv'):
                 x_gc = torch.relu(self.filter(x, Lm, Fh, K))
+                ops._trace_sign(x_gc, "relu")
             with self.variable_scope('affine'):
                 x_aff = self.filter(x, Lm, Fh, 1)
             return x_aff + x_gc
@@ -904,10 +904,16 @@ class CAPE(base_model):
         ops.DEFERRED = []
 
     def _deferred_end(self):
+        """Finish the queued reductions of a backward sweep.  When the sweep itself raised, the queues hold items whose
+        buffers belong to an abandoned tape: they are dropped, not flushed, so that nothing stale reaches the bucket of a
+        later call."""
+        import sys
         try:
-            ops.flush_deferred()
+            if sys.exc_info()[0] is None:
+                ops.flush_deferred()
         finally:
             ops.DEFERRED = None
+            ops.DEFERRED_DW[:] = []
 
     @contextlib.contextmanager
     def _data_grad_only_through_d(self, active):
@@ -930,16 +936,18 @@ class CAPE(base_model):
         ne = st['n_early']
         one = self._one_scalar()
         self._deferred_begin()
-        heads = [t for t in (self._enc_feat_cut,) + tuple(self._y_pair) if t.requires_grad]
-        with self._data_grad_only_through_d('loss_d' in out):
-            res = torch.autograd.grad(out['loss_g'], st['params'][:ne] + heads, grad_outputs=one, retain_graph=True, allow_unused=True)
-        self.store_grads('g', res[:ne], 0, ne)
-        self._phase_heads = (heads, list(res[ne:]))
-        if 'loss_d' in out:
-            grads_d = torch.autograd.grad(out['loss_d'], self._opt_state['d']['params'], grad_outputs=one, retain_graph=True,
-                                          allow_unused=True)
-            self.store_grads('d', grads_d)
-        self._deferred_end()
+        try:
+            heads = [t for t in (self._enc_feat_cut,) + tuple(self._y_pair) if t.requires_grad]
+            with self._data_grad_only_through_d('loss_d' in out):
+                res = torch.autograd.grad(out['loss_g'], st['params'][:ne] + heads, grad_outputs=one, retain_graph=True, allow_unused=True)
+            self.store_grads('g', res[:ne], 0, ne)
+            self._phase_heads = (heads, list(res[ne:]))
+            if 'loss_d' in out:
+                grads_d = torch.autograd.grad(out['loss_d'], self._opt_state['d']['params'], grad_outputs=one, retain_graph=True,
+                                              allow_unused=True)
+                self.store_grads('d', grads_d)
+        finally:
+            self._deferred_end()
         # Adam path: the regularised dense kernels are all EARLY variables, so their regulariser gradient must be in
         # the bucket before the early range is handed to the asynchronous all-reduce (adding it in phase 2 would race
         # with the collective that reduces the same range in place)
@@ -958,11 +966,13 @@ class CAPE(base_model):
                 seeds.append(g)
         late = st['params'][ne:]
         self._deferred_begin()
-        if late:
-            res = torch.autograd.grad(roots, late, grad_outputs=seeds, allow_unused=True) if roots else [None] * len(late)
-            self.store_grads('g', res, ne, None)
-        self._deferred_end()
-        self._phase_heads = self._enc_feat = self._enc_feat_cut = None
+        try:
+            if late:
+                res = torch.autograd.grad(roots, late, grad_outputs=seeds, allow_unused=True) if roots else [None] * len(late)
+                self.store_grads('g', res, ne, None)
+        finally:
+            self._deferred_end()
+            self._phase_heads = self._enc_feat = self._enc_feat_cut = None
 
     def backward_to_flat(self, out):
         """Gradients of loss_g w.r.t. the G group and loss_d w.r.t. the D group -> flat gradient buffers."""

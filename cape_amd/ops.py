@@ -146,6 +146,23 @@ def _mk_srcs(entries):
 # --------------------------------------------------------------------------------------------
 LAUNCH_LOG = None
 PLAN_LOG = None
+# ACT_TRACE: a list -> every (leaky-)ReLU site of a forward pass appends the branch each unit took (bool tensor, True =
+# positive side), in execution order.  The gradient-parity tests replay that pattern in the fp64 twin, so that a unit whose
+# pre-activation lies within fp32 rounding of zero takes the SAME branch on both sides (tests/test_gpu_model.py).
+ACT_TRACE = None
+
+
+def _trace_sign(y, act):
+    if ACT_TRACE is not None and act in ("leaky", "relu"):
+        ACT_TRACE.append((y.detach() > 0).cpu())
+
+
+def _trace_mask_bits(mask, F):
+    """Unpack the 1-bit ReLU mask [N, Mo, ceil(F/32)] the DUAL kernels write."""
+    if ACT_TRACE is not None:
+        sh = torch.arange(32, device=mask.device, dtype=torch.int32)
+        bits = ((mask.unsqueeze(-1) >> sh) & 1).reshape(mask.shape[0], mask.shape[1], -1)[:, :, :F]
+        ACT_TRACE.append((bits != 0).cpu())
 
 
 def _gconv_work(entries, N, Mo, F):
@@ -740,8 +757,10 @@ class ChebConvFn(torch.autograd.Function):
         if W_aff is not None:
             mask = torch.empty((N, ops.Mo, (Fout + 31) // 32), device=x.device, dtype=torch.int32)
             gconv_fwd(entries, y, mask=mask, rank=rank)
+            _trace_mask_bits(mask, Fout)
         else:
             gconv_fwd(entries, y, bias=bias, bias_mode=bias_mode, act=act, rank=rank)
+            _trace_sign(y, act)
         if Co:
             fill_cond(cond_out.contiguous(), yfull[:, :, Fout:])
         ctx.ops, ctx.act, ctx.bias_mode, ctx.Fout, ctx.Co, ctx.Cc = ops, act, bias_mode, Fout, Co, Cc
@@ -789,8 +808,10 @@ class ChebConvFn(torch.autograd.Function):
         if W_aff is not None:
             mask = torch.empty((N, ops.Mo, (Fout + 31) // 32), device=x.device, dtype=torch.int32)
             spmm_combine(zs, csrs, y, to_acc2=to2, rank=rank, dual=True, mask=mask)
+            _trace_mask_bits(mask, Fout)
         else:
             spmm_combine(zs, csrs, y, rank=rank, bias=bias, bias_mode=bias_mode, act=act)
+            _trace_sign(y, act)
         Co = 0 if cond_out is None else cond_out.shape[1]
         if Co:
             fill_cond(cond_out.contiguous(), yfull[:, :, Fout:])
@@ -966,6 +987,7 @@ class ChebConvRecurrenceFn(torch.autograd.Function):
         y = alloc_act(N, M, Fout, x.device)
         gconv_fwd([dict(x=xs[k], csr=None, w=(W, k * Fout, K * Fout, 1)) for k in range(K)], y,
                   bias=bias, bias_mode=bias_mode, act=act)
+        _trace_sign(y, act)
         ctx.ops, ctx.act, ctx.bias_mode, ctx.has_bias = ops, act, bias_mode, bias is not None
         ctx.save_for_backward(W, y, *xs)
         return y
@@ -1050,6 +1072,23 @@ class ConcatCondFn(torch.autograd.Function):
         return dx, dc
 
 
+def group_count(N, Cn, G=32):
+    """Number of normalisation groups the reference's ``gn`` forms for ``Cn`` channels (lib/models.py:693-699): it
+    reshapes [N, C, V] to [-1, G, C // G, V] with G = min(32, C) and a FREE leading dimension.  When G divides C that is G
+    groups per sample; otherwise the rows of the [N*C, V] matrix are taken w = C // G at a time irrespective of the sample
+    boundaries -- C / w groups of w consecutive channels per sample when w divides C (w = 1, i.e. G < C < 2G: a
+    per-(sample, channel) normalisation).  Groups that would straddle samples are refused (TensorFlow itself rejects the
+    reshape unless N*C is a multiple of G*w)."""
+    Ge = min(int(G), int(Cn))
+    if Cn % Ge == 0:
+        return Ge
+    w = Cn // Ge
+    if Cn % w or (int(N) * Cn) % (Ge * w):
+        raise ValueError("group norm: %d channels cannot be split into groups of %d inside each sample "
+                         "(reference lib/models.py:698 reshape)" % (Cn, w))
+    return Cn // w
+
+
 class GroupNormFn(torch.autograd.Function):
     """gn(norm_type='group') optionally fused with the following tf.nn.relu
     (lib/models.py:681-712, 751-760).  Saved for backward: the input, the per-(sample, group) statistics and the
@@ -1067,7 +1106,7 @@ class GroupNormFn(torch.autograd.Function):
             x = xa
         y = alloc_act(N, V, Cn, x.device)
         stats = torch.empty((N, G, 2), device=x.device, dtype=torch.float32)
-        coef = torch.empty((N, 4, Cn), device=x.device, dtype=torch.float32)
+        coef = torch.empty((N, 4, _pad4(Cn)), device=x.device, dtype=torch.float32)      # per-channel tables: stride round_up(C, 4)
         need = int(lib.cape_groupnorm_workspace_bytes(N, V, Cn))
         ws = torch.empty((need + 3) // 4, device=x.device, dtype=torch.float32)
         xp, xs, xl = _v(x)
@@ -1076,6 +1115,8 @@ class GroupNormFn(torch.autograd.Function):
                     lambda: check(lib.cape_groupnorm_fwd(xp, xs, xl, _ptr(gamma), _ptr(beta), float(eps), int(G), int(relu), yp, ys, yl,
                                                          _ptr(stats), _ptr(coef), N, V, Cn, _ptr(ws), need, _stream()),
                                   "cape_groupnorm_fwd"))
+        if relu:
+            _trace_sign(y, "relu")             # y = relu(fma(a, x, b)): positive exactly where the kernel's fma was
         ctx.G, ctx.relu = G, relu
         ctx.save_for_backward(x, gamma, stats, coef)
         return y
@@ -1091,7 +1132,7 @@ class GroupNormFn(torch.autograd.Function):
             g = ga
         dx = alloc_act(N, V, Cn, x.device)
         dgb = torch.empty((2, N, Cn), device=x.device, dtype=torch.float32)        # per-sample dgamma / dbeta partials
-        bcoef = torch.empty((N, 3, Cn), device=x.device, dtype=torch.float32)
+        bcoef = torch.empty((N, 3, _pad4(Cn)), device=x.device, dtype=torch.float32)
         need = int(lib.cape_groupnorm_workspace_bytes(N, V, Cn))
         ws = torch.empty((need + 3) // 4, device=x.device, dtype=torch.float32)
         xp, xs, xl = _v(x)
@@ -1243,6 +1284,7 @@ class CondNetsFn(torch.autograd.Function):
         ycat = torch.empty((N, out1 + out2), device=c1.device, dtype=torch.float32)
         check(lib.cape_condnet_fwd(_ptr(c1), in1, _ptr(c2), in2, _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(Wc), _ptr(bc),
                                    _ptr(h), _ptr(ycat), N, in1, hid, out1, in2, out2, _stream()), "cape_condnet_fwd")
+        _trace_sign(h, "leaky")
         ctx.gbufs, ctx.dims = gbufs, (N, in1, hid, out1, in2, out2)
         ctx.save_for_backward(c1, c2, W2, h)
         ctx.shapes = [tuple(t.shape) for t in (W1, b1, W2, b2, Wc, bc)]
@@ -1277,6 +1319,7 @@ class BiasActFn(torch.autograd.Function):
     def forward(ctx, x, bias, act, bias_mode):
         x = as_act(x)
         y = bias_act_fwd(x, bias, bias_mode, act)
+        _trace_sign(y, act)
         ctx.act, ctx.bias_mode = act, bias_mode
         ctx.save_for_backward(y)
         ctx.bshape = None if bias is None else tuple(bias.shape)
@@ -1370,6 +1413,7 @@ class FcWideFn(torch.autograd.Function):
         _log_launch("fc_wide_fwd", 2 * N * kin * out, 4 * (kin * out + N * kin + N * out),
                     lambda: check(lib.cape_fc_wide_fwd(C.c_void_p(x.data_ptr()), kin, N, kin, out, C.c_void_p(W.data_ptr()), _ptr(b),
                                                        _lib.ACT[act], C.c_void_p(y.data_ptr()), out, _stream()), "cape_fc_wide_fwd"))
+        _trace_sign(y, act)
         ctx.act, ctx.gW, ctx.gb, ctx.has_b = act, gW, gb, b is not None
         ctx.save_for_backward(x, W, y)
         return y
@@ -1417,6 +1461,7 @@ def dense(x, kernel, bias, activation=None, grad_bufs=(None, None)):
         y = torch.addmm(bias, x, kernel)
     if activation == 'leaky_relu':
         y = torch.nn.functional.leaky_relu(y, 0.2)
+        _trace_sign(y, "leaky")
     return y
 
 

@@ -127,6 +127,8 @@ CASES = [
     # three-layer clothing-type network, other embedding sizes (:479-511)
     ("cond3", "affine_nz18", dict(n_layer_cond=3, nz_cond=16, nz_cond2=4, F=[16, 16, 32, 32, 64, 64, 128, 128],
                                   reduce_dim=16), 2, 33),
+    # BASELINE configs[3] at its stated batch: the GraphCMR / group-norm generator + discriminator at static batch 32
+    ("cmr_nz18_b32", "cmr_nz18", None, 32, 41),
     ("cheb_k6", "affine_nz18", dict(use_res_block=True, use_res_block_dec=False, cond_encoder=True, K=[6] * 8,
                                     F=[16, 16, 32, 32, 32, 32, 64, 64], reduce_dim=16), 2, 14),
 ]

@@ -54,6 +54,22 @@ def bias_act(x, b, kind):
     return torch.relu(z)
 
 
+def forced_act(z, slope, sign, rows=None):
+    """(leaky-)ReLU whose branch per unit is GIVEN (``sign``: bool, True = positive side) instead of decided by z > 0.
+    Used by the gradient-parity tests: the device's fp32 forward and this fp64 graph disagree about the branch of the few
+    units whose pre-activation lies within fp32 rounding of zero; with the device's pattern imposed both graphs are the same
+    piecewise-linear function and the gradients compare at arithmetic accuracy.  ``rows``: the pattern covers only these
+    vertex rows of z (a layer evaluated on the kept vertices of the following row-selection pool); the other rows, whose
+    gradient the pool discards, keep their own sign."""
+    sign = torch.as_tensor(sign, dtype=torch.bool)
+    if rows is not None:
+        full = (z.detach() > 0)
+        full[:, torch.as_tensor(np.asarray(rows), dtype=torch.long)] = sign
+        sign = full
+    assert tuple(sign.shape) == tuple(z.shape), (tuple(sign.shape), tuple(z.shape))
+    return torch.where(sign, z, slope * z)
+
+
 def group_norm(x, gamma, beta, G=32, eps=1e-5):
     """lib/models.py:693-709."""
     xt = x.permute(0, 2, 1)
@@ -86,6 +102,25 @@ class TwinCAPE(co.OracleCAPE):
         super(TwinCAPE, self).__init__(*a, **kw)
         self.td = tdtype
         self.params = {}
+        self.forced_signs = None      # collections.deque of recorded branch patterns, consumed in execution order
+        self.flip_log = []            # per site: number of units whose own sign differs from the imposed one
+        self.sign_log = None          # a list -> plain evaluation records (own pattern, pool matrix or None) per site
+
+    def _site(self, z, slope, plain, pool=None):
+        """One (leaky-)ReLU site: ``plain(z)`` unless a recorded branch pattern is being replayed."""
+        if self.forced_signs is None:
+            if self.sign_log is not None:
+                self.sign_log.append(((z.detach() > 0), pool))
+            return plain(z) if plain is not None else torch.where(z > 0, z, slope * z)
+        sign = torch.as_tensor(self.forced_signs.popleft(), dtype=torch.bool)
+        rows = None
+        if sign.dim() == 3 and z.dim() == 3 and sign.shape[1] != z.shape[1]:
+            P = sp.csr_matrix(pool)                      # row selection: output row r = input row indices[r]
+            assert P.shape[0] == sign.shape[1] and P.nnz == P.shape[0], "pattern rows do not match the pool"
+            rows = P.indices
+        own = (z.detach() > 0) if rows is None else (z.detach()[:, torch.as_tensor(rows, dtype=torch.long)] > 0)
+        self.flip_log.append(int((own != sign).sum()))
+        return forced_act(z, slope, sign, rows)
 
     def _p(self, name_arr):
         full, arr = name_arr
@@ -109,18 +144,20 @@ class TwinCAPE(co.OracleCAPE):
             b = self._get('bias', (units,), 'zeros', 'fc_bias')
         y = x @ k + b
         if activation == 'leaky_relu':
-            y = torch.nn.functional.leaky_relu(y, 0.2)
+            y = self._site(y, 0.2, lambda z: torch.nn.functional.leaky_relu(z, 0.2))
         return y
 
     def filter(self, x, L, Fout, K):
         return chebyshev5(x, L, self._weight((x.shape[-1] * K, Fout)), K)
 
-    def brelu(self, x):
+    def brelu(self, x, pool=None):
         if self.activation == 'b2relu':
             b = self._bias((1, x.shape[1], x.shape[2]))
         else:
             b = self._bias((1, 1, x.shape[2]))
-        return bias_act(x, b, self.activation)
+        if (self.forced_signs is None and self.sign_log is None) or self.activation == 'b1tanh':
+            return bias_act(x, b, self.activation)
+        return self._site(x + b, 0.2 if self.activation == 'b1leakyrelu' else 0.0, None, pool=pool)
 
     def _t(self, a):
         return a if torch.is_tensor(a) else torch.as_tensor(np.asarray(a), dtype=self.td)
@@ -128,7 +165,7 @@ class TwinCAPE(co.OracleCAPE):
     def cnp(self, x, i, name):
         with self.vs.scope(name):
             x = self.filter(x, self.Laplacian[i], self.out_channels[i], self.poly_order[i])
-            return poolwT(self.brelu(x), self.Downsample_mtx[i])
+            return poolwT(self.brelu(x, pool=self.Downsample_mtx[i]), self.Downsample_mtx[i])
 
     def udn(self, x, out_channels, i, name):
         with self.vs.scope(name):
@@ -139,7 +176,7 @@ class TwinCAPE(co.OracleCAPE):
     def cnp_d(self, x, i, name):
         with self.vs.scope(name):
             x = self.filter(x, self.Laplacian_d[i], self.out_channels[i], self.poly_order_d[i])
-            return poolwT(self.brelu(x), self.Downsample_mtx_d[i])
+            return poolwT(self.brelu(x, pool=self.Downsample_mtx_d[i]), self.Downsample_mtx_d[i])
 
     def gn(self, x, name):
         with self.vs.scope(name):
@@ -168,13 +205,13 @@ class TwinCAPE(co.OracleCAPE):
         Fi, Lm = self.out_channels[-i - 1], self.Laplacian[-i - 2]
         with self.vs.scope(name):
             xu = poolwT(x_in, self.Upsample_mtx[-i - 1])
-            x = torch.relu(self.gn(xu, 'group_norm'))
+            x = self._site(self.gn(xu, 'group_norm'), 0.0, torch.relu)
             with self.vs.scope('graph_linear_1'):
                 x = self.filter(x, Lm, Fi // 2, 1)
-            x = torch.relu(self.gn(x, 'group_norm_1'))
+            x = self._site(self.gn(x, 'group_norm_1'), 0.0, torch.relu)
             with self.vs.scope('graph_conv'):
                 x = self.filter(x, Lm, Fi // 2, self.poly_order[-i - 1])
-            x = torch.relu(self.gn(x, 'group_norm_2'))
+            x = self._site(self.gn(x, 'group_norm_2'), 0.0, torch.relu)
             with self.vs.scope('graph_linear_2'):
                 x = self.filter(x, Lm, Fi, 1)
             if xu.shape[-1] != x.shape[-1]:
@@ -187,7 +224,7 @@ class TwinCAPE(co.OracleCAPE):
         with self.vs.scope(name):
             x = poolwT(x, self.Upsample_mtx[-i - 1])
             with self.vs.scope('graph_conv'):
-                x_gc = torch.relu(self.filter(x, Lm, self.out_channels[-i - 1] // 2, self.poly_order[-i - 1]))
+                x_gc = self._site(self.filter(x, Lm, self.out_channels[-i - 1] // 2, self.poly_order[-i - 1]), 0.0, torch.relu)
             with self.vs.scope('affine'):
                 x_aff = self.filter(x, Lm, x_gc.shape[-1], 1)
             return x_aff + x_gc

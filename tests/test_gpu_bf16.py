@@ -14,6 +14,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 TOL = 2e-2
+BF16_GRAD_TOL = 5e-2      # gradients of the bf16 network against fp64 on the same activation pattern (relative L2)
 
 
 def vertex_err(a, ref):
@@ -238,6 +239,83 @@ def test_full_model_bf16_storage(mesh_ops):
     # the gradient of the bf16 network for ITS activation pattern; against the fp64 pattern every (leaky-)ReLU layer adds
     # a few per cent (see test_cheb_conv_bf16) -- bounded, reported, not a parity figure
     assert gl < 0.25, gl
+
+
+def _grad_errors(model, twin, out, ls):
+    g_names, d_names = model._g_names, model._d_names
+    tg = torch.autograd.grad(ls['loss_g'], [twin.params[n] for n in g_names], retain_graph=True, allow_unused=True)
+    td = torch.autograd.grad(ls['loss_d'], [twin.params[n] for n in d_names], allow_unused=True)
+    hg = torch.autograd.grad(out['loss_g'], [model._vars[n] for n in g_names], retain_graph=True, allow_unused=True)
+    hd = torch.autograd.grad(out['loss_d'], [model._vars[n] for n in d_names], allow_unused=True)
+    num = den = 0.0
+    rows = []
+    for names, tgr, hgr in ((g_names, tg, hg), (d_names, td, hd)):
+        for n, a, b in zip(names, tgr, hgr):
+            if a is None:
+                continue
+            a64, b64 = a.numpy(), b.cpu().numpy().astype(np.float64)
+            e2, r2 = ((b64 - a64) ** 2).sum(), (a64 ** 2).sum()
+            rows.append((n, float(np.sqrt(e2 / max(r2, 1e-300))), r2))
+            num += e2
+            den += r2
+    return float(np.sqrt(num / den)), rows, den
+
+
+def test_bf16_batch16_parity_covers_every_bench_kernel(mesh_ops):
+    """BASELINE configs[4]'s per-GPU shard AT its size (16 meshes, bf16 activation storage): the library selects its
+    128 x 128 one-product tiles (gemm_split_kernel<128,128,*,unsigned short>, dw_split_kernel<128,128,unsigned short>) only
+    there.  (1) forward against the golden vectors the reference's own lib/models.py produced at batch 16 and against the
+    fp64 twin: <= 2e-2, per-vertex and in relative L2, latent heads and every loss; (2) gradients against the
+    fp64 twin evaluated on the activation pattern the bf16 forward took (no branch ambiguity, see tests/test_gpu_model.py):
+    every variable and the whole bucket in relative L2; (3) every kernel instantiation of the step ``bench.py --dtype bf16``
+    times must have been launched by (1) and (2)."""
+    import test_gpu_model as T
+    from cape_amd import ops
+    g, meta, N, inputs = T._golden_batch_inputs("affine_nz64_b16", mesh_ops)
+    assert N == 16
+    P, twin, model = T._build("affine_nz64", mesh_ops, N, dict(act_dtype='bf16'))
+    x, gt, xd, cond, cond_d, clo, clo_d, eps = inputs
+    xh, zm, zl, d_real, d_fake, ls = T._run_twin(twin, *inputs)
+    model.load_variables(twin.vs.vars)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=model.device)
+    ops.PLAN_LOG, ops.ACT_TRACE = set(), []
+    try:
+        out = model.forward_losses(t(x), t(cond), t(clo), t(gt), t(xd), t(cond_d), t(clo_d), eps=t(eps))
+        signs = list(ops.ACT_TRACE)
+        ops.ACT_TRACE = None
+        _, _, _, _, _, lsm = T._run_twin(twin, *inputs, signs=signs)
+        gl, rows, den = _grad_errors(model, twin, out, lsm)
+        torch.cuda.synchronize()
+        parity_plans = set(ops.PLAN_LOG)
+    finally:
+        ops.PLAN_LOG = ops.ACT_TRACE = None
+    assert parity_plans and all(p[-1] == "bf16" for p in parity_plans), parity_plans
+    pred = out['prediction'].detach().cpu().numpy().astype(np.float64)
+    for name, ref in (("reference golden (batch 16)", g["out_op_prediction"].astype(np.float64)), ("fp64 twin", xh.detach().numpy())):
+        e_v = T.vertex_err(pred, ref)
+        e_l2 = float(np.sqrt(((pred - ref) ** 2).sum() / (ref ** 2).sum()))
+        print("bf16 storage, batch 16, prediction vs %s: worst vertex %.2e, relative L2 %.2e" % (name, e_v, e_l2))
+        assert e_v < TOL and e_l2 < TOL, (name, e_v, e_l2)
+    assert T.rel_err(out['z_mean'].detach().cpu().numpy(), g["out_z_mean"]) < TOL
+    assert T.rel_err(out['z_logvar'].detach().cpu().numpy(), g["out_z_logvar"]) < TOL
+    for key, name in (("recon", "recon_loss"), ("latent", "latent_loss"), ("edge", "edge_loss"),
+                      ("gan_g", "loss_g"), ("gan_d", "loss_d"), ("loss_g", "op_loss_g"), ("loss_d", "op_loss_d")):
+        assert abs(float(out[key]) - float(g["out_" + name])) < TOL * max(abs(float(g["out_" + name])), 1e-3), key
+    worst = sorted(rows, key=lambda r: -r[1])[:6]
+    print("bf16 storage, batch 16, gradients on the device's activation pattern (%d of %d units differ from fp64): global "
+          "relative L2 %.2e; worst variables %s" % (sum(twin.flip_log), sum(int(s_.numel()) for s_ in signs), gl,
+                                                     ", ".join("%s %.2e" % (n.split('/', 1)[-1], e) for n, e, _ in worst)))
+    assert gl < BF16_GRAD_TOL, gl
+    for n, e, r2 in rows:
+        if r2 > 1e-8 * den:
+            assert e < 2 * BF16_GRAD_TOL, (n, e)
+    del out
+    bench_plans = T._bench_step_plans(model, inputs, (False,))
+    missing = bench_plans - parity_plans
+    assert not missing, "kernels launched by the benchmarked bf16 step without a parity case: %s" % T._plan_names(missing)
+    for need in (("fwd", 2, 128, 128, 0, 0, "bf16"), ("fwd", 2, 128, 128, 1, 0, "bf16"), ("dw", 3, 128, 128, "bf16")):
+        assert need in bench_plans, (need, sorted(bench_plans))
+    print("kernel instantiations of the benchmarked bf16 step, all covered at batch 16:", T._plan_names(bench_plans))
 
 
 def test_bf16_train_steps_reduce_the_loss(mesh_ops):

@@ -158,7 +158,10 @@ def test_spmm_and_sparse_op(mesh_ops, dev):
         assert vertex_err(hx.grad.cpu().numpy(), refg) < TOL
 
 
-@pytest.mark.parametrize("shape", [(2, 862, 544, 1), (2, 6890, 96, 1), (3, 1723, 64, 0)])
+@pytest.mark.parametrize("shape", [(2, 862, 544, 1), (2, 6890, 96, 1), (3, 1723, 64, 0),
+                                   # channel counts outside the shipped YAMLs: G < C < 2G (one channel per group, 48 as in the
+                                   # cmr_k3_res golden), C % 4 != 0 (24 + 8 + 6 condition channels), C // G = 2 with C % G != 0
+                                   (2, 862, 48, 1), (16, 431, 38, 1), (32, 431, 70, 0), (32, 200, 264, 1)])
 def test_groupnorm(shape, dev):
     from cape_amd import ops
     from oracle import torch_twin as tt
@@ -173,7 +176,7 @@ def test_groupnorm(shape, dev):
         ty = torch.relu(ty)
     ty.backward(torch.tensor(gy))
     hx, hg, hb = (torch.tensor(a, dtype=torch.float32, device=dev, requires_grad=True) for a in (x, gamma, beta))
-    hy = ops.GroupNormFn.apply(hx, hg, hb, min(32, C), 1e-5, relu)
+    hy = ops.GroupNormFn.apply(hx, hg, hb, ops.group_count(N, C), 1e-5, relu)
     hy.backward(torch.tensor(gy, dtype=torch.float32, device=dev))
     assert vertex_err(hy.detach().cpu().numpy(), ty.detach().numpy()) < TOL
     assert vertex_err(hx.grad.cpu().numpy(), tx.grad.numpy()) < 5 * TOL
