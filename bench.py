@@ -229,7 +229,7 @@ def exact_fp32_run(args):
     same bench invocation.  Never replaces ``value``; any failure is reported as a string instead of aborting the line."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(min(args.steps, 30)), '--warmup', str(min(args.warmup, 5)),
-           '--batch', str(args.batch), '--config', args.config, '--no-cpu-baseline', '--no-roofline', '--no-ab']
+           '--batch', str(args.batch), '--config', args.config, '--no-cpu-baseline', '--no-roofline', '--no-ab', '--no-extras']
     if args.gan:
         cmd.append('--gan')
     try:
@@ -241,6 +241,175 @@ def exact_fp32_run(args):
                 "note": "same step, CAPE_GEMM_BF16X6=0 CAPE_DW_BF16X6=0: all contractions on v_mfma_f32_32x32x2_f32"}
     except Exception as e:                                  # noqa: BLE001 -- the comparison is optional
         return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
+
+def _timed_replays(runner, steps, warmup):
+    for _ in range(warmup):
+        runner.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        runner.step()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / steps
+
+
+def measure_extra_step(config, batch, gan, dtype, steps=20, warmup=3, want_roofline=True):
+    """One of BASELINE.json's other configs on THIS GPU, measured like the headline (captured step, inputs resident):
+    ms per step, step-level roofline fraction and the dominant kernel with its own roofline fraction."""
+    from cape_amd.runtime import GraphedTrainStep
+    model = build_model(batch, torch.cuda.current_device(), config, act_dtype=dtype)
+    runner = GraphedTrainStep(model, with_gan=gan)
+    runner.load_batch(**synthetic_batch(model, seed=4321))
+    torch.cuda.synchronize()
+    runner.capture()
+    ms = _timed_replays(runner, steps, warmup)
+    out = dict(ms_per_step=round(ms, 4), meshes_per_s=round(1e3 * batch / ms, 1), batch=batch, steps=steps)
+    sr = step_roofline(ms, batch, gan, dtype == 'bf16', cmr=config.startswith("CAPE_nz18"))
+    out["step_roofline_frac"], out["step_roofline_bound"], out["t_roof_ms"] = sr["frac"], sr["bound"], sr["t_roof_ms"]
+    if want_roofline:
+        roof, _ = kernel_roofline(runner)
+        if roof is not None:
+            out["dominant_kernel"] = dict(kernel=roof["kernel"], bound=roof["bound"], frac=roof["frac"], achieved=roof["achieved"],
+                                          unit=roof["unit"], avg_launch_us=roof["avg_launch_us"], launches_per_step=roof["launches_per_step"])
+    del runner, model
+    torch.cuda.empty_cache()
+    return out
+
+
+def measure_config1(iters=50):
+    """BASELINE.json configs[1]: single Chebyshev K = 6 graph-conv layer fwd+bwd, 64 x 6890 x 16 -> 32 (reference
+    lib/models.py:69-103 with the explicit recurrence of :88-96), HIP-graph replay, against SURVEY 8(d)'s roofline
+    (9.6 GFLOP / 198 MB algorithmic: 60.8 us at the fp32-MFMA peak, 24.8 us at 8 TB/s)."""
+    from cape_amd import ops
+    from cape_amd.graph import ConvOperators
+    from cape_amd.load_data import load_graph_mtx
+    L = load_graph_mtx(None, load_for_demo=True)[0]
+    dev = torch.device('cuda', torch.cuda.current_device())
+    N, Cin, Fout, K = 64, 16, 32, 6
+    dops = ops.DeviceConvOps(ConvOperators(L[0], K), dev)
+    g = torch.Generator(device='cpu').manual_seed(0)
+    x = torch.randn(N, 6890, Cin, generator=g).to(dev).requires_grad_(True)
+    W = (0.1 * torch.randn(Cin * K, Fout, generator=g)).clamp_(-0.2, 0.2).to(dev).requires_grad_(True)
+    dy = torch.randn(N, 6890, Fout, generator=g).to(dev)
+
+    def step():
+        y = ops.chebyshev5(x, W, dops)
+        torch.autograd.grad(y, [x, W], dy)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        graph.replay()
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / iters
+    ops.LAUNCH_LOG = []
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    log, ops.LAUNCH_LOG = ops.LAUNCH_LOG, None
+    agg = {}
+    for name, _, _, e0, e1 in log:
+        a = agg.setdefault(name, [0, 0.0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1) * 1e-3
+    nnz = int(L[0].nnz)
+    X, Y, Wt = N * 6890 * Cin, N * 6890 * Fout, Cin * K * Fout
+    flops = 3 * (2 * N * 6890 * Cin * K * Fout + (K - 1) * 2 * nnz * Cin * N + (K - 2) * 2 * 6890 * Cin * N)
+    byts = 4 * (3 * X + 2 * Y + 3 * Wt) + 2 * (8 * nnz + 4 * 6891)
+    t_roof = max(flops / (FP32_MFMA_PEAK_TFLOPS * 1e12), byts / (HBM_PEAK_GBS * 1e9))
+    return dict(workload="single Chebyshev K=6 layer fwd+bwd, 64x6890x16->32", ms_per_step=round(1e3 * t, 4),
+                meshes_per_s=round(N / t, 1), alg_gflop=round(flops / 1e9, 2), alg_mb=round(byts / 1e6, 1),
+                tflops=round(flops / t / 1e12, 2), alg_gbs=round(byts / t / 1e9, 1), t_roof_ms=round(1e3 * t_roof, 4),
+                step_roofline_frac=round(t_roof / t, 4), step_roofline_bound="mfma (fp32)" if flops / (FP32_MFMA_PEAK_TFLOPS * 1e12) >= byts / (HBM_PEAK_GBS * 1e9) else "hbm",
+                kernels={k: dict(launches=v[0] // 3, avg_us=round(1e6 * v[1] / v[0], 2)) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])})
+
+
+# xGMI message model of SURVEY 8(e): every GPU has 7 point-to-point links of ~153 GB/s; with direct reduce-scatter +
+# all-gather every peer pair uses its own link, so an all-reduce of S bytes over N GPUs moves 2 * S / N per link
+XGMI_LINK_GBS = 153.0
+COLLECTIVE_LATENCY_MS = 0.03          # per all-reduce launch (RCCL launch + first/last hop); one-rank RCCL measures 0.01
+SPLIT_STEP_OVERHEAD_MS = 0.10         # two-graph step + collective launches, measured with a one-rank RCCL group (dp_selftest)
+
+
+def modelled_scaling(ms_by_batch, grad_bytes, late_fraction, phase2_share=0.35):
+    """MODELLED (not measured) 1/2/4/8-GPU table, as SURVEY 8(e) asks for when one GPU is reachable: per-GPU step times are
+    the ones measured on THIS GPU at the per-GPU batch of each row; the exchange is the message model above, with the
+    overlap cape_amd/runtime.py implements: the early (1 - late_fraction) of the gradient bucket is reduced while backward
+    phase 2 (encoder convolutions: ~phase2_share of the step) runs, the late part after it."""
+    def comm_ms(nbytes, n):
+        return 0.0 if n == 1 else 1e3 * 2.0 * nbytes / n / (XGMI_LINK_GBS * 1e9) + COLLECTIVE_LATENCY_MS
+
+    def row(n, b):
+        t = ms_by_batch[b]
+        if n == 1:
+            return t, 0.0, 0.0
+        early = comm_ms((1.0 - late_fraction) * grad_bytes, n)
+        late = comm_ms(late_fraction * grad_bytes, n)
+        exposed = max(0.0, early - phase2_share * t) + late
+        return t + SPLIT_STEP_OVERHEAD_MS + exposed, early + late, exposed
+
+    out = dict(label="MODELLED, not measured: single-GPU step times measured in this run + xGMI message model (SURVEY 8e)",
+               assumptions=dict(grad_bucket_mb=round(grad_bytes / 1e6, 1), late_fraction=round(late_fraction, 4),
+                                xgmi_link_gbs=XGMI_LINK_GBS, all_reduce="direct reduce-scatter + all-gather, 2*S/N bytes per link",
+                                collective_latency_ms=COLLECTIVE_LATENCY_MS, split_step_overhead_ms=SPLIT_STEP_OVERHEAD_MS,
+                                overlap="early part hidden behind backward phase 2 (%.0f %% of the step)" % (100 * phase2_share)),
+               weak=[], strong=[])
+    b0 = max(ms_by_batch)
+    t1 = ms_by_batch[b0]
+    for n in (1, 2, 4, 8):
+        t, comm, exposed = row(n, b0)
+        out["weak"].append(dict(n_gpus=n, per_gpu_batch=b0, ms_per_step=round(t, 4), meshes_per_s=round(1e3 * n * b0 / t, 1),
+                                comm_ms=round(comm, 4), exposed_comm_ms=round(exposed, 4), efficiency=round(t1 / t, 4)))
+        b = b0 // n
+        if b in ms_by_batch:
+            t, comm, exposed = row(n, b)
+            out["strong"].append(dict(n_gpus=n, per_gpu_batch=b, ms_per_step=round(t, 4), meshes_per_s=round(1e3 * b0 / t, 1),
+                                      comm_ms=round(comm, 4), exposed_comm_ms=round(exposed, 4), efficiency=round(t1 / (n * t), 4)))
+    return out
+
+
+def extra_measurements(args, headline_ms, model):
+    """Time-boxed: the other BASELINE configs on this GPU and the inputs of the modelled scaling table."""
+    t_begin = time.time()
+    extras, budget = {}, float(os.environ.get("CAPE_BENCH_EXTRAS_BUDGET_S", "150"))
+    st = model._opt_state['g']
+    grad_bytes = 4 * int(st['flat_grad'].numel())
+    late_fraction = 1.0 - float(st['split_off']) / float(st['flat_grad'].numel())
+
+    def guarded(name, fn):
+        if time.time() - t_begin > budget:
+            extras[name] = {"skipped": "time box of %.0f s spent" % budget}
+            return None
+        try:
+            extras[name] = fn()
+            return extras[name]
+        except Exception as e:                                  # noqa: BLE001 -- never lose the headline line
+            extras[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+            return None
+
+    guarded("config4_bf16_shard16", lambda: measure_extra_step(args.config, 16, False, 'bf16'))
+    guarded("config3_nz18_gan_b32", lambda: measure_extra_step("CAPE_nz18_pose24_clotype8_male", 32, True, 'fp32', steps=10, warmup=2))
+    guarded("config1_k6_layer", measure_config1)
+    ms_by_batch = {args.batch: headline_ms}
+    for b in (args.batch // 2, args.batch // 4, args.batch // 8):
+        if b >= 1:
+            r = guarded("strong_scaling_input_batch%d" % b, lambda b=b: measure_extra_step(args.config, b, args.gan, 'fp32', want_roofline=False))
+            if r is not None and "ms_per_step" in r:
+                ms_by_batch[b] = r["ms_per_step"]
+    return extras, modelled_scaling(ms_by_batch, grad_bytes, late_fraction)
 
 
 def main():
@@ -260,6 +429,9 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the time-boxed extra measurements (BASELINE configs[1], [3], [4] on this GPU and the modelled '
+                         '1/2/4/8 scaling table); they run only at N = 1 for the default fp32 headline')
     ap.add_argument('--no-ab', action='store_true',
                     help='skip the short exact-fp32-MFMA comparison run (a child process with CAPE_GEMM_BF16X6=0)')
     ap.add_argument('--host-inputs', action='store_true',
@@ -357,6 +529,9 @@ def main():
         result["cpu_baseline"] = None
     if world == 1 and not args.no_ab and not args.host_inputs and args.dtype == 'fp32' and os.environ.get("CAPE_GEMM_BF16X6", "1") != "0":
         result["exact_fp32_mfma"] = exact_fp32_run(args)
+    if (world == 1 and not args.no_extras and not args.host_inputs and args.dtype == 'fp32' and not args.global_batch
+            and args.config.startswith("CAPE-affineconv_nz64") and not args.no_graph):
+        result["extra_configs"], result["scaling_model"] = extra_measurements(args, ms, model)
     print(json.dumps(result))
 
 

@@ -620,47 +620,26 @@ struct DwPlan {
     long long slab;
 };
 
-#ifndef CAPE_DW_SPLIT_POLICY_DEFAULT
-#define CAPE_DW_SPLIT_POLICY_DEFAULT 1
-#endif
 inline void plan_dw_splits(int N, int Mo, DwPlan &pl) {
-    static const int policy = getenv("CAPE_DW_SPLIT_POLICY") ? atoi(getenv("CAPE_DW_SPLIT_POLICY")) : CAPE_DW_SPLIT_POLICY_DEFAULT;
-    if (policy == 1) {
-        // ONE round of workgroups (two per CU = 512 slots) with equal contraction lengths: split over the samples first
-        // (the largest divisor of N that fits: every group gets the same number of samples), then the vertex range into
-        // equal row blocks.  The older rule below rounded the split count UP, so the widest layers ran 672 workgroups of
-        // 24 chunks on 512 slots (one and a third rounds, groups of 6 / 6 / 4 samples) where 512 of 27 chunks do.
-        int S = 512 / pl.ntiles;              // (768 / 1024 slots for the smaller tiles measured slower)
-        if (S < 1) S = 1;
-        int ngroups = 1;
-        for (int d = 1; d <= N && d <= S; ++d)
-            if (N % d == 0) ngroups = d;
-        const int maxr = (Mo + 127) / 128;
-        int rsplit = S / ngroups;
-        if (rsplit > maxr) rsplit = maxr;
-        if (rsplit < 1) rsplit = 1;
-        int rows = (Mo + rsplit - 1) / rsplit;
-        rows = ((rows + 31) / 32) * 32;
-        pl.rows_per_split = rows;
-        pl.rsplit = (Mo + rows - 1) / rows;
-        pl.samples_per_group = N / ngroups;
-        pl.ngroups = ngroups;
-        return;
-    }
-    // aim for ~512 workgroups: split the vertex dimension down to 128 rows, then the batch into groups
-    int S = (512 + pl.ntiles - 1) / pl.ntiles;
+    // ONE round of workgroups (two per CU = 512 slots) with equal contraction lengths: split over the samples first
+    // (the largest divisor of N that fits: every group gets the same number of samples), then the vertex range into
+    // equal row blocks.  (An older rule rounded the split count UP, so the widest layers ran 672 workgroups of 24 chunks
+    // on 512 slots -- one and a third rounds, groups of 6 / 6 / 4 samples -- where 512 of 27 chunks do: 50.7 -> 43.8 us.)
+    int S = 512 / pl.ntiles;              // (768 / 1024 slots for the smaller tiles measured slower)
     if (S < 1) S = 1;
-    int maxr = (Mo + 127) / 128;
-    int rsplit = S < maxr ? S : maxr;
+    int ngroups = 1;
+    for (int d = 1; d <= N && d <= S; ++d)
+        if (N % d == 0) ngroups = d;
+    const int maxr = (Mo + 127) / 128;
+    int rsplit = S / ngroups;
+    if (rsplit > maxr) rsplit = maxr;
+    if (rsplit < 1) rsplit = 1;
     int rows = (Mo + rsplit - 1) / rsplit;
     rows = ((rows + 31) / 32) * 32;
     pl.rows_per_split = rows;
     pl.rsplit = (Mo + rows - 1) / rows;
-    int ngroups = (S + pl.rsplit - 1) / pl.rsplit;
-    if (ngroups > N) ngroups = N;
-    if (ngroups < 1) ngroups = 1;
-    pl.samples_per_group = (N + ngroups - 1) / ngroups;
-    pl.ngroups = (N + pl.samples_per_group - 1) / pl.samples_per_group;
+    pl.samples_per_group = N / ngroups;
+    pl.ngroups = ngroups;
 }
 
 // gather kernel: one [ct x ft] tile grid per source

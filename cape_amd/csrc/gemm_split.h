@@ -17,6 +17,8 @@
 // epilogue (rank-1 terms, bias, activation, de-interleave) and software pipeline as gemm_plain_kernel.
 // Not bit-identical to the fp32-MFMA kernels (different summation tree); inf inputs give NaN (inf - inf in the split).
 #pragma once
+#include <type_traits>
+
 #include "gconv_shared.h"
 
 namespace {
@@ -27,58 +29,23 @@ typedef unsigned gs_u32x4 __attribute__((ext_vector_type(4)));      // native ve
 #ifndef CAPE_GEMM_BF16X6_DEFAULT
 #define CAPE_GEMM_BF16X6_DEFAULT 1
 #endif
-#ifndef CAPE_SPLIT_RN
-#define CAPE_SPLIT_RN 0                   // 1: round-to-nearest operand split (see gs_split2)
-#endif
 #ifndef CAPE_DW_BF16X6_DEFAULT
 #define CAPE_DW_BF16X6_DEFAULT 1      // weight gradient on the bf16 pipe (dw_split_kernel); CAPE_DW_BF16X6=0 -> exact-fp32 MFMA
 #endif
 
-#ifndef CAPE_SPLIT_SKEW
-#define CAPE_SPLIT_SKEW 0                 // experiment knob: > 0 = initial delay (x 1024 cycles) of every second workgroup
-#endif
-#ifndef CAPE_SPLIT_SKEW_BIT
-#define CAPE_SPLIT_SKEW_BIT 8
-#endif
-
-#ifndef CAPE_SPLIT_SWZ
-#define CAPE_SPLIT_SWZ 0                  // 1: unpadded 64-byte LDS rows, 16-byte segment index XOR-ed with (row >> 2) & 3
-#endif
-
 constexpr int GS_KC = 32;       // contraction indices per staged chunk = two k16 MFMA steps
-#if CAPE_SPLIT_SWZ
-// Conflict-free for the ds_read_b128 lane groups and for the k-contiguous staging stores (tools/lds_bank_check.py); 48 KB
-// instead of 60 KB per 128 x 128 tile, i.e. three workgroups per CU when the registers fit (launch bounds below).
-// Compiled and modelled only -- not yet run on the GPU.
-constexpr int GS_PITCH = 64;
-__device__ __forceinline__ int gs_seg(int row, int seg) { return seg ^ ((row >> 2) & 3); }
-constexpr int GS_BIG_MINB = 3;
-#else
 constexpr int GS_PITCH = 80;    // bytes per LDS row of one piece plane: 32 bf16 + 16 B pad (conflict-free ds_read_b128)
 __device__ __forceinline__ int gs_seg(int, int seg) { return seg; }
 constexpr int GS_BIG_MINB = 2;
-#endif
+// (Measured and dropped, kept under tools/ubench: unpadded 64-byte rows with XOR-swizzled segments at three workgroups per
+// CU, a round-to-nearest split, de-phased workgroups, pre-split operands, a double-buffered single-barrier K-loop, an
+// explicit two-group ping-pong -- all within +-5 % of this kernel; profiles/r02_ubench_split_variants.txt,
+// profiles/r03_ubench_v4_*.txt.)
 
 __device__ __forceinline__ unsigned gs_bits(float v) { return __builtin_bit_cast(unsigned, v); }
 __device__ __forceinline__ float gs_float(unsigned v) { return __builtin_bit_cast(float, v); }
 
 // two fp32 -> their three bf16 pieces, packed pairwise (first element in the low half)
-#if CAPE_SPLIT_RN
-// Round-to-nearest pieces (v_cvt_pk_bf16_f32): x = hi + mid + lo still exactly, |mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|, so the
-// dropped products are bounded by 2^-23 |ab| instead of 2^-21; 9 VALU ops per pair (cvt_pk, shift, and, packed subtract)
-// against 11 for the truncation form.  Written and checked on the host (tests/test_bf16_split_numerics.py) and for
-// code generation only: not yet run on the GPU, hence not the default.
-typedef __bf16 gs_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float gs_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void gs_split2(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
-    const gs_f32x2 x = {x0, x1};
-    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, gs_bf16x2));
-    const gs_f32x2 r = {x0 - gs_float(hi << 16), x1 - gs_float(hi & 0xFFFF0000u)};                 // exact
-    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r, gs_bf16x2));
-    const gs_f32x2 s = {r[0] - gs_float(mid << 16), r[1] - gs_float(mid & 0xFFFF0000u)};           // exact, <= 7 significant bits
-    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(s, gs_bf16x2));
-}
-#else
 __device__ __forceinline__ void gs_split2(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
     const unsigned h0 = gs_bits(x0) & 0xFFFF0000u, h1 = gs_bits(x1) & 0xFFFF0000u;
     const float r0 = x0 - gs_float(h0), r1 = x1 - gs_float(h1);                 // exact
@@ -88,7 +55,6 @@ __device__ __forceinline__ void gs_split2(float x0, float x1, unsigned &hi, unsi
     mid = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
     lo = __builtin_amdgcn_perm(gs_bits(s1), gs_bits(s0), 0x07060302u);
 }
-#endif
 
 // eight consecutive contraction indices -> one 16-byte row segment per piece plane
 __device__ __forceinline__ void gs_store8(unsigned char *dst, int plane, const float (&v)[8]) {
@@ -122,6 +88,19 @@ __device__ __forceinline__ void gs_store8_np(unsigned char *dst, int plane, cons
     }
 }
 
+// Scheduling pipeline of one k16 step: NR fragment reads (of the NEXT step) spread over the NM MFMAs of this one, one read
+// after every NM / NR MFMAs (IGroupLP: 0x008 = MFMA, 0x100 = DS read).  Applies to the instructions of the enclosing
+// scheduling region, i.e. the straight-line code since the last sched_barrier.
+template <int NM, int NR>
+__device__ __forceinline__ void gs_interleave() {
+    constexpr int PER = NM / NR > 0 ? NM / NR : 1;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+}
+
 // Workgroup tile BM x BN, 4 waves as 2 x 2, wave tile (BM/2) x (BN/2).  DUAL: sources may carry a second weight set
 // (w2) accumulated into a second tile, combined as relu(acc) + acc2 by the shared epilogue (res_block_affine,
 // reference lib/models.py:776-793); its LDS holds a third group of planes, so the DUAL tile is 128 x 64.
@@ -150,12 +129,6 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_B
     cape_map_block(blockIdx.x, p.N, p.row_tiles * p.col_tiles, n, t);
     const int r0 = (t / p.col_tiles) * BM;
     const int f0 = (t % p.col_tiles) * BN;
-#if CAPE_SPLIT_SKEW
-    // experiment: de-phase the workgroups that share a CU (they start together and run identical code, so their MFMA
-    // and staging phases coincide instead of overlapping)
-    if ((blockIdx.x >> CAPE_SPLIT_SKEW_BIT) & 1)
-        for (int i = 0; i < CAPE_SPLIT_SKEW; ++i) __builtin_amdgcn_s_sleep(16);
-#endif
 
     f32x16 acc[TM][TN];
     f32x16 acc2[DUAL ? TM : 1][DUAL ? TN : 1];
@@ -303,50 +276,72 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_B
 
     // ---- multiply one staged chunk.  Lane (li, lh) of v_mfma_f32_32x32x16_bf16 supplies row/column li and the
     // contraction indices 8*lh .. 8*lh+7 of the k16 step: one 16-byte LDS read per operand piece.
+    // The fragment reads of k16 step 1 are issued one per MFMA group INSIDE step 0 (gs_interleave): a ds_read_b128 holds its
+    // wave's issue port for ~29 cycles, so the twelve reads of a step in a row stall that wave's MFMA stream for ~350
+    // cycles -- measured on the producer/consumer prototype (profiles/r03_ubench_v5_*.txt: 2448 -> 1780 cycles per chunk
+    // for a multiply-only wave) and on this kernel's structure (profiles/r03_ubench_ilv.txt: +6..11 % on the 128 x 128
+    // tiles, +2..4 % on the 64 x 64 ones).  hipcc by itself sinks every read next to its first use.
     auto compute = [&](bool has2) {
         // rows wm*WTM + a*32 + li: all tile offsets are multiples of 32, so the swizzle term (row >> 2) & 3 is that of li
         const unsigned char *pa = sA + (wm * WTM + li) * GS_PITCH;
         const unsigned char *pb = sB + (wn * WTN + li) * GS_PITCH;
-#pragma unroll
-        for (int ks = 0; ks < GS_KC / 16; ++ks) {
+        constexpr int NT = NP == 3 ? 6 : 1;
+        static_assert(GS_KC == 32, "two k16 steps per chunk");
+        bf16x8 af[2][TM][NP], bf[2][TN][NP], bf2[2][DUAL ? TN : 1][DUAL ? NP : 1];
+        auto rd = [&](int ks, auto W2) {
             const int so = 16 * gs_seg(li, lh + 2 * ks);             // byte offset of this lane's 16-byte segment
-            bf16x8 af[TM][NP], bf[TN][NP];
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int pc = 0; pc < NP; ++pc)
-                    af[a][pc] = *reinterpret_cast<const bf16x8 *>(pa + pc * APLANE + a * 32 * GS_PITCH + so);
+                    af[ks][a][pc] = *reinterpret_cast<const bf16x8 *>(pa + pc * APLANE + a * 32 * GS_PITCH + so);
 #pragma unroll
             for (int b = 0; b < TN; ++b)
 #pragma unroll
                 for (int pc = 0; pc < NP; ++pc)
-                    bf[b][pc] = *reinterpret_cast<const bf16x8 *>(pb + pc * BPLANE + b * 32 * GS_PITCH + so);
-            // piece indices (0 = hi, 1 = mid, 2 = lo) of the six products, smallest first (bf16 storage: the one product)
-            constexpr int NT = NP == 3 ? 6 : 1;
+                    bf[ks][b][pc] = *reinterpret_cast<const bf16x8 *>(pb + pc * BPLANE + b * 32 * GS_PITCH + so);
+            if constexpr (decltype(W2)::value) {
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int pc = 0; pc < NP; ++pc)
+                        bf2[ks][b][pc] = *reinterpret_cast<const bf16x8 *>(pb + NP * BPLANE + pc * BPLANE + b * 32 * GS_PITCH + so);
+            }
+        };
+        // piece indices (0 = hi, 1 = mid, 2 = lo) of the six products, smallest first (bf16 storage: the one product)
+        auto mm = [&](int ks, auto W2) {
 #pragma unroll
             for (int term = 0; term < NT; ++term)
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][gs_ta(NP, term)], bf[b][gs_tb(NP, term)], acc[a][b], 0, 0, 0);
-            if constexpr (DUAL) {
-                if (has2) {
-                    bf16x8 bf2[TN][NP];
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][a][gs_ta(NP, term)], bf[ks][b][gs_tb(NP, term)], acc[a][b], 0, 0, 0);
+            if constexpr (decltype(W2)::value) {
 #pragma unroll
-                    for (int b = 0; b < TN; ++b)
+                for (int term = 0; term < NT; ++term)
 #pragma unroll
-                        for (int pc = 0; pc < NP; ++pc)
-                            bf2[b][pc] = *reinterpret_cast<const bf16x8 *>(pb + NP * BPLANE + pc * BPLANE + b * 32 * GS_PITCH + so);
+                    for (int a = 0; a < TM; ++a)
 #pragma unroll
-                    for (int term = 0; term < NT; ++term)
-#pragma unroll
-                        for (int a = 0; a < TM; ++a)
-#pragma unroll
-                            for (int b = 0; b < TN; ++b)
-                                acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][gs_ta(NP, term)], bf2[b][gs_tb(NP, term)], acc2[a][b], 0, 0, 0);
-                }
+                        for (int b = 0; b < TN; ++b)
+                            acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][a][gs_ta(NP, term)], bf2[ks][b][gs_tb(NP, term)], acc2[a][b], 0, 0, 0);
             }
+        };
+        auto chunk = [&](auto W2) {
+            constexpr bool w2 = decltype(W2)::value;
+            rd(0, W2);
+            __builtin_amdgcn_sched_barrier(0);
+            rd(1, W2);
+            mm(0, W2);
+            gs_interleave<NT * TM * TN * (w2 ? 2 : 1), NP * (TM + TN * (w2 ? 2 : 1))>();
+            __builtin_amdgcn_sched_barrier(0);
+            mm(1, W2);
+        };
+        if constexpr (DUAL) {
+            if (has2) chunk(std::true_type{});
+            else chunk(std::false_type{});
+        } else {
+            chunk(std::false_type{});
         }
     };
 
@@ -494,32 +489,41 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? GS_BIG_MINB : 3) void
             gs_store8_np<NP>(sB + (fb + ch) * GS_PITCH + 16 * gs_seg(fb + ch, rg), BPLANE, v);
         }
     };
-    auto compute = [&]() {
+    auto compute = [&]() {                              // (fragment reads interleaved as in gemm_split_kernel)
         const unsigned char *pa = sA + (wm * WTM + li) * GS_PITCH;
         const unsigned char *pb = sB + (wn * WTN + li) * GS_PITCH;
-#pragma unroll
-        for (int ks = 0; ks < RK / 16; ++ks) {
+        constexpr int NT = NP == 3 ? 6 : 1;
+        static_assert(RK == 32, "two k16 steps per chunk");
+        bf16x8 af[2][TM][NP], bf[2][TN][NP];
+        auto rd = [&](int ks) {
             const int so = 16 * gs_seg(li, lh + 2 * ks);
-            bf16x8 af[TM][NP], bf[TN][NP];
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int pc = 0; pc < NP; ++pc)
-                    af[a][pc] = *reinterpret_cast<const bf16x8 *>(pa + pc * APLANE + a * 32 * GS_PITCH + so);
+                    af[ks][a][pc] = *reinterpret_cast<const bf16x8 *>(pa + pc * APLANE + a * 32 * GS_PITCH + so);
 #pragma unroll
             for (int b = 0; b < TN; ++b)
 #pragma unroll
                 for (int pc = 0; pc < NP; ++pc)
-                    bf[b][pc] = *reinterpret_cast<const bf16x8 *>(pb + pc * BPLANE + b * 32 * GS_PITCH + so);
-            constexpr int NT = NP == 3 ? 6 : 1;
+                    bf[ks][b][pc] = *reinterpret_cast<const bf16x8 *>(pb + pc * BPLANE + b * 32 * GS_PITCH + so);
+        };
+        auto mm = [&](int ks) {
 #pragma unroll
             for (int term = 0; term < NT; ++term)
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][gs_ta(NP, term)], bf[b][gs_tb(NP, term)], acc[a][b], 0, 0, 0);
-        }
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][a][gs_ta(NP, term)], bf[ks][b][gs_tb(NP, term)], acc[a][b], 0, 0, 0);
+        };
+        rd(0);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(1);
+        mm(0);
+        gs_interleave<NT * TM * TN, NP * (TM + TN)>();
+        __builtin_amdgcn_sched_barrier(0);
+        mm(1);
     };
 
     if (total > 0) {

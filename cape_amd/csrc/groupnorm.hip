@@ -21,7 +21,6 @@
 
 namespace {
 
-constexpr int GN_MAXT = 4;       // reduction terms per thread
 
 inline int gn_rows(int N, int V) {
     int rb = 128;

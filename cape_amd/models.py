@@ -666,6 +666,8 @@ class CAPE(base_model):
             diff = g_outputs - g_gt
             if self.which_loss == 'l1':
                 out['recon'] = diff.abs().mean()
+                if ops.L1_SIGN_TRACE is not None:
+                    ops.L1_SIGN_TRACE.append(torch.sign(diff.detach()).cpu())
             elif self.which_loss == 'huber':
                 a = diff.abs()
                 out['recon'] = torch.where(a <= 0.1, 0.5 * a * a, 0.1 * a - 0.005).mean()

@@ -150,6 +150,7 @@ PLAN_LOG = None
 # positive side), in execution order.  The gradient-parity tests replay that pattern in the fp64 twin, so that a unit whose
 # pre-activation lies within fp32 rounding of zero takes the SAME branch on both sides (tests/test_gpu_model.py).
 ACT_TRACE = None
+L1_SIGN_TRACE = None      # a list -> the L1 reconstruction loss appends sign(pred - gt) (the one other branch point of the graph)
 
 
 def _trace_sign(y, act):
@@ -318,20 +319,8 @@ def gconv_dw(entries, dz, accumulate=False, dz2=None, defer=False):
             plan = (C.c_int32 * 4)()
             check(_fn("cape_gconv_dw_plan", dz)(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, plan), "cape_gconv_dw_plan")
             PLAN_LOG.add(("dw", plan[0], plan[1], plan[2]) + (("bf16",) if bf else ()))
-        def contraction():
-            check(_fn("cape_gconv_dw_stage", dz)(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, 1 if accumulate else 0,
-                                                 C.c_void_p(ws.data_ptr()), need, 1, _stream()), "cape_gconv_dw_stage")
-        side = _side_stream(dz.device)
-        if side is None:
-            contraction()
-        else:
-            # the contraction only feeds the queued reduction: it runs on a second stream, next to the data-gradient chain
-            # of the layers below (sparse / backward-prep kernels that leave the matrix pipe idle); flush_deferred() joins.
-            # Every buffer it touches is held in DEFERRED_DW until then, so no block is recycled under it.
-            side.wait_stream(torch.cuda.current_stream(dz.device))
-            with torch.cuda.stream(side):
-                contraction()
-            _SIDE_PENDING[0] = True
+        check(_fn("cape_gconv_dw_stage", dz)(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, 1 if accumulate else 0,
+                                             C.c_void_p(ws.data_ptr()), need, 1, _stream()), "cape_gconv_dw_stage")
         it = _lib.CapeDwItem()
         it.srcs, it.nsrc = C.addressof(arr), len(entries)
         it.dz, it.dz_sample_stride, it.lddz = p.value, ss, ld
@@ -562,26 +551,8 @@ DEFERRED = None
 DEFERRED_DW = []          # queued weight-gradient slab reductions (gconv_dw(defer=True)), same lifetime as DEFERRED
 
 
-DW_SIDE_STREAM = int(_os.environ.get("CAPE_DW_SIDE_STREAM", "0"))   # 1: deferred weight-gradient contractions on a second stream
-_SIDE = {}
-_SIDE_PENDING = [False]
-
-
-def _side_stream(device):
-    if not DW_SIDE_STREAM:
-        return None
-    key = (device.type, device.index)
-    if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=device)
-    return _SIDE[key]
-
-
 def flush_deferred():
     global DEFERRED
-    if _SIDE_PENDING[0]:
-        for st in _SIDE.values():
-            torch.cuda.current_stream(st.device).wait_stream(st)
-        _SIDE_PENDING[0] = False
     if DEFERRED_DW:
         queued, DEFERRED_DW[:] = list(DEFERRED_DW), []
         nmax = 12                                    # CAPE_MAX_DW_REDUCE_ITEMS
@@ -1159,6 +1130,8 @@ class ReconEdgeLossFn(torch.autograd.Function):
         pred, gt = pred.contiguous(), gt.contiguous()
         N, M, _ = pred.shape
         E = edges.shape[0]
+        if L1_SIGN_TRACE is not None and w_recon != 0.0:
+            L1_SIGN_TRACE.append(torch.sign(pred.detach() - gt).cpu())       # the kernel takes the sign of the same fp32 difference
         need = lib.cape_recon_edge_workspace_bytes(N, M, E)
         ws = torch.empty((need + 3) // 4, device=pred.device, dtype=torch.float32)
         out = torch.empty(2, device=pred.device, dtype=torch.float32)

@@ -105,6 +105,7 @@ class TwinCAPE(co.OracleCAPE):
         self.forced_signs = None      # collections.deque of recorded branch patterns, consumed in execution order
         self.flip_log = []            # per site: number of units whose own sign differs from the imposed one
         self.sign_log = None          # a list -> plain evaluation records (own pattern, pool matrix or None) per site
+        self.forced_l1_sign = None    # sign(pred - gt) recorded by the device: |d| is then evaluated as sign * d
 
     def _site(self, z, slope, plain, pool=None):
         """One (leaky-)ReLU site: ``plain(z)`` unless a recorded branch pattern is being replayed."""
@@ -319,7 +320,12 @@ class TwinCAPE(co.OracleCAPE):
         out = {}
         diff = g_out - g_gt
         if self.which_loss == 'l1':
-            out['recon'] = diff.abs().mean()
+            if self.forced_l1_sign is not None:
+                sg = torch.as_tensor(np.asarray(self.forced_l1_sign), dtype=diff.dtype)
+                self.flip_log.append(int((sg != torch.sign(diff.detach())).sum()))
+                out['recon'] = (sg * diff).mean()
+            else:
+                out['recon'] = diff.abs().mean()
         elif self.which_loss == 'huber':
             a = diff.abs()
             out['recon'] = torch.where(a <= 0.1, 0.5 * a * a, 0.1 * a - 0.005).mean()

@@ -98,7 +98,8 @@ def test_contraction_error_matches_fp32():
     assert e32 < 2e-6 and e6 < 4 * e32, (e6, e32)
 
 
-# ---- round-to-nearest variant (gemm_split.h, CAPE_SPLIT_RN=1; v_cvt_pk_bf16_f32 rounds to nearest even) -------------
+# ---- round-to-nearest variant (prototype in tools/ubench/gemm_bf16x3.hip, split2v<true>; v_cvt_pk_bf16_f32 rounds to
+# nearest even): measured within +-5 % of the truncation split (profiles/r02_ubench_split_variants.txt), not in the library
 def bf16_rne(x):
     u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
     u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000

@@ -278,17 +278,17 @@ def test_bf16_batch16_parity_covers_every_bench_kernel(mesh_ops):
     xh, zm, zl, d_real, d_fake, ls = T._run_twin(twin, *inputs)
     model.load_variables(twin.vs.vars)
     t = lambda a: torch.tensor(a, dtype=torch.float32, device=model.device)
-    ops.PLAN_LOG, ops.ACT_TRACE = set(), []
+    ops.PLAN_LOG, ops.ACT_TRACE, ops.L1_SIGN_TRACE = set(), [], []
     try:
         out = model.forward_losses(t(x), t(cond), t(clo), t(gt), t(xd), t(cond_d), t(clo_d), eps=t(eps))
-        signs = list(ops.ACT_TRACE)
-        ops.ACT_TRACE = None
-        _, _, _, _, _, lsm = T._run_twin(twin, *inputs, signs=signs)
+        signs, l1 = list(ops.ACT_TRACE), list(ops.L1_SIGN_TRACE)
+        ops.ACT_TRACE = ops.L1_SIGN_TRACE = None
+        _, _, _, _, _, lsm = T._run_twin(twin, *inputs, signs=signs, l1_sign=l1[0].numpy() if l1 else None)
         gl, rows, den = _grad_errors(model, twin, out, lsm)
         torch.cuda.synchronize()
         parity_plans = set(ops.PLAN_LOG)
     finally:
-        ops.PLAN_LOG = ops.ACT_TRACE = None
+        ops.PLAN_LOG = ops.ACT_TRACE = ops.L1_SIGN_TRACE = None
     assert parity_plans and all(p[-1] == "bf16" for p in parity_plans), parity_plans
     pred = out['prediction'].detach().cpu().numpy().astype(np.float64)
     for name, ref in (("reference golden (batch 16)", g["out_op_prediction"].astype(np.float64)), ("fp64 twin", xh.detach().numpy())):

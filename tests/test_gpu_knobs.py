@@ -18,7 +18,6 @@ KNOBS = [
     dict(CAPE_GEMM_BF16X6_DUAL="0"),                           # affine DUAL forward on the exact-fp32 kernel only
     dict(CAPE_DW_BF16X6="0"),                                  # weight gradient on the exact-fp32 kernels only
     dict(CAPE_GEMM_PLAIN="0", CAPE_DW_PLAIN="0"),              # generic gather kernels for every launch
-    dict(CAPE_DW_SPLIT_POLICY="0"),                            # weight gradient: the older split rule (more, uneven workgroups)
     dict(CAPE_SPMM_UNROLL="0"),                                # sparse kernels: plain entry loop
     dict(CAPE_SPMM_UNROLL="8"),                                # sparse kernels: entries in unrolled groups of 8
 ]

@@ -63,7 +63,7 @@ def _build(cfg, mesh_ops, N, overrides=None):
     return P, twin, model
 
 
-def _run_twin(twin, x, gt, xd, cond, cond_d, clo, clo_d, eps, signs=None):
+def _run_twin(twin, x, gt, xd, cond, cond_d, clo, clo_d, eps, signs=None, l1_sign=None):
     """``signs``: branch patterns recorded by the device forward (ops.ACT_TRACE), replayed site by site -- the sub-networks
     run in the order cape_amd.models.CAPE.forward_losses evaluates them."""
     import collections
@@ -78,7 +78,11 @@ def _run_twin(twin, x, gt, xd, cond, cond_d, clo, clo_d, eps, signs=None):
         assert not twin.forced_signs, "%d recorded activation sites were not consumed" % len(twin.forced_signs)
     finally:
         twin.forced_signs = None
-    ls = twin.losses(xh, gt, zm, zl, d_real, d_fake)
+    twin.forced_l1_sign = l1_sign              # the L1 loss' sign(pred - gt), the graph's one other branch point
+    try:
+        ls = twin.losses(xh, gt, zm, zl, d_real, d_fake)
+    finally:
+        twin.forced_l1_sign = None
     return xh, zm, zl, d_real, d_fake, ls
 
 
@@ -115,12 +119,13 @@ def _full_model_parity(cfg, overrides, mesh_ops, N, inputs=None):
 
     dev = model.device
     t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
-    ops.ACT_TRACE = []
+    ops.ACT_TRACE, ops.L1_SIGN_TRACE = [], []
     try:
         out = model.forward_losses(t(x), t(cond), t(clo), t(gt), t(xd), t(cond_d), t(clo_d), eps=t(eps))
-        signs = list(ops.ACT_TRACE)
+        signs, l1 = list(ops.ACT_TRACE), list(ops.L1_SIGN_TRACE)
     finally:
-        ops.ACT_TRACE = None
+        ops.ACT_TRACE = ops.L1_SIGN_TRACE = None
+    l1_sign = l1[0].numpy() if l1 else None
     assert vertex_err(out['prediction'].detach().cpu().numpy(), xh.detach().numpy()) < 1e-4
     assert rel_err(out['z_mean'].detach().cpu().numpy(), zm.detach().numpy()) < 1e-4
     assert rel_err(out['z_logvar'].detach().cpu().numpy(), zl.detach().numpy()) < 1e-4
@@ -129,7 +134,7 @@ def _full_model_parity(cfg, overrides, mesh_ops, N, inputs=None):
 
     # gradients: loss_g w.r.t. generator+condition variables, loss_d w.r.t. discriminator variables -- the twin on the
     # activation pattern the device forward took (see the module docstring)
-    _, _, _, _, _, lsm = _run_twin(twin, x, gt, xd, cond, cond_d, clo, clo_d, eps, signs=signs)
+    _, _, _, _, _, lsm = _run_twin(twin, x, gt, xd, cond, cond_d, clo, clo_d, eps, signs=signs, l1_sign=l1_sign)
     nflip, nunits = sum(twin.flip_log), sum(int(s_.numel()) for s_ in signs)
     for k in ('loss_g', 'loss_d'):          # a flipped unit has |z| ~ 1e-7: the forward value does not move
         assert abs(float(lsm[k]) - float(ls[k])) < 1e-6 * max(abs(float(ls[k])), 1e-3), k

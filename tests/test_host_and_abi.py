@@ -192,8 +192,6 @@ def test_weight_gradient_split_plan_is_one_balanced_round():
     import ctypes as C
     from cape_amd import _lib
     lib = _lib.lib
-    if int(os.environ.get("CAPE_DW_SPLIT_POLICY", "1")) != 1:
-        pytest.skip("older split rule selected by the environment")
 
     def srcs(Cs, Mo):
         arr = (_lib.CapeSrc * len(Cs))()

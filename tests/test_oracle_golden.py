@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["affine_nz64", "cmr_nz18", "resblock_udn_tanh", "affine_nz64_b16", "cheb_k6", "switches_relu", "affine_mixed_k", "huber_res_affine", "cmr_k3_res", "reduce0", "b2relu_udn", "cond3"]
+CASES = ["affine_nz64", "cmr_nz18", "resblock_udn_tanh", "affine_nz64_b16", "cmr_nz18_b32", "cheb_k6", "switches_relu", "affine_mixed_k", "huber_res_affine", "cmr_k3_res", "reduce0", "b2relu_udn", "cond3"]
 
 
 def load_case(tag):

@@ -29,8 +29,8 @@ if [ "${SKIP_TESTS:-0}" != "1" ]; then
   env $KNOBS python -m pytest tests -x -q -m gpu 2>&1 | tail -3 | tee $O/pytest_knobs.txt
 fi
 for i in $(seq 1 $PAIRS); do
-  python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-roofline --no-ab 2>/dev/null | tail -1 >> $O/bench_default.jsonl
-  env $KNOBS python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-roofline --no-ab 2>/dev/null | tail -1 >> $O/bench_knobs.jsonl
+  python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-roofline --no-ab --no-extras 2>/dev/null | tail -1 >> $O/bench_default.jsonl
+  env $KNOBS python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-roofline --no-ab --no-extras 2>/dev/null | tail -1 >> $O/bench_knobs.jsonl
 done
 tail -n +1 $O/ubench_split_v2.txt $O/ubench_bf16_storage.txt | cut -c1-230
 python - <<PY

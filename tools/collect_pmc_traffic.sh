@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
   name=${pass%%:*}; ctrs=${pass#*:}
   rm -rf /tmp/prof_$name
-  rocprofv3 --pmc $ctrs -d /tmp/prof_$name -o r -- python $R/bench.py --no-cpu-baseline --no-roofline --no-ab --no-graph --steps 2 --warmup 1 > /dev/null 2>&1
+  rocprofv3 --pmc $ctrs -d /tmp/prof_$name -o r -- python $R/bench.py --no-cpu-baseline --no-roofline --no-ab --no-extras --no-graph --steps 2 --warmup 1 > /dev/null 2>&1
   DBP=$(ls /tmp/prof_$name/*.db /tmp/prof_$name/*/*.db 2>/dev/null | head -1)
   python $R/tools/pmc_summary.py $DBP $O/pmc_$name.json
 done

@@ -9,20 +9,20 @@ O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
-python $R/bench.py --gan --no-cpu-baseline --no-ab > $O/${TAG}_bench_gan.json 2>> $O/${TAG}_bench.err
+python $R/bench.py --gan --no-cpu-baseline --no-ab --no-extras > $O/${TAG}_bench_gan.json 2>> $O/${TAG}_bench.err
 # BASELINE configs[4] (bf16 storage, one GPU's shard of 16), configs[3] (nz18 group-norm generator + discriminator, batch 32)
 python $R/bench.py --dtype bf16 --no-cpu-baseline > $O/${TAG}_bench_bf16.json 2>> $O/${TAG}_bench.err
-python $R/bench.py --config CAPE_nz18_pose24_clotype8_male --gan --batch 32 --no-cpu-baseline --no-ab > $O/${TAG}_bench_nz18_gan_b32.json 2>> $O/${TAG}_bench.err
-python $R/bench.py --config CAPE_nz18_pose24_clotype8_male --batch 16 --no-cpu-baseline --no-ab > $O/${TAG}_bench_nz18_cvae_b16.json 2>> $O/${TAG}_bench.err
+python $R/bench.py --config CAPE_nz18_pose24_clotype8_male --gan --batch 32 --no-cpu-baseline --no-ab --no-extras > $O/${TAG}_bench_nz18_gan_b32.json 2>> $O/${TAG}_bench.err
+python $R/bench.py --config CAPE_nz18_pose24_clotype8_male --batch 16 --no-cpu-baseline --no-ab --no-extras > $O/${TAG}_bench_nz18_cvae_b16.json 2>> $O/${TAG}_bench.err
 python $R/bench.py --host-inputs --no-cpu-baseline --no-roofline > $O/${TAG}_bench_host_inputs.json 2>> $O/${TAG}_bench.err
-rm -rf /tmp/prof_ks && rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -o r -- python $R/bench.py --no-cpu-baseline --no-roofline --no-ab --steps 20 --warmup 3 > $O/${TAG}_bench_under_rocprof.json 2>/dev/null
+rm -rf /tmp/prof_ks && rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -o r -- python $R/bench.py --no-cpu-baseline --no-roofline --no-ab --no-extras --steps 20 --warmup 3 > $O/${TAG}_bench_under_rocprof.json 2>/dev/null
 DB=$(ls /tmp/prof_ks/*.db /tmp/prof_ks/*/*.db 2>/dev/null | head -1)
 python $R/tools/rocpd_summary.py $DB $O/${TAG}_bench_kernel_stats.txt
 python $R/tools/rocpd_step_seq.py $DB $O/${TAG}_step_sequence.txt
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   name=${pass%%:*}; ctrs=${pass#*:}
   rm -rf /tmp/prof_$name
-  rocprofv3 --pmc $ctrs -d /tmp/prof_$name -o r -- python $R/bench.py --no-cpu-baseline --no-roofline --no-ab --no-graph --steps 2 --warmup 1 > /dev/null 2>&1
+  rocprofv3 --pmc $ctrs -d /tmp/prof_$name -o r -- python $R/bench.py --no-cpu-baseline --no-roofline --no-ab --no-extras --no-graph --steps 2 --warmup 1 > /dev/null 2>&1
   DBP=$(ls /tmp/prof_$name/*.db /tmp/prof_$name/*/*.db 2>/dev/null | head -1)
   python $R/tools/pmc_summary.py $DBP $O/pmc_$name.json
 done

@@ -228,13 +228,25 @@ __global__ __launch_bounds__(256, MINB) void gemm_bf16x3_kernel(const float *__r
 }
 
 // sustained v_mfma_f32_32x32x16_bf16 rate, no memory traffic (NACC independent accumulators per wave)
-template <int NACC>
-__global__ __launch_bounds__(256) void mfma_bf16_loop(float *out, int iters) {
+// RND: 1 = operands with full random mantissas and mixed exponents, different in every lane (switching activity of real
+// data: the chip clocks to its power budget); ticks: s_memtime before / after the loop of block 0, wave 0
+template <int NACC, int RND = 0>
+__global__ __launch_bounds__(256) void mfma_bf16_loop(float *out, int iters, unsigned long long *ticks = nullptr) {
     f32x16 acc[NACC];
     for (int a = 0; a < NACC; ++a)
         for (int g = 0; g < 16; ++g) acc[a][g] = 0.f;
     bf16x8 av, bv;
     for (int j = 0; j < 8; ++j) { av[j] = (__bf16)(1e-3f * (1 + (threadIdx.x + j) % 7)); bv[j] = (__bf16)(1e-3f * (2 + (threadIdx.x + j) % 5)); }
+    if (RND) {
+        unsigned s = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+        for (int j = 0; j < 8; ++j) {
+            s = s * 1664525u + 1013904223u;
+            av[j] = (__bf16)(((int)(s >> 8) % 65536 - 32768) * (1.0f / 32768) * 1e-3f * (1 << ((s >> 28) & 3)));
+            s = s * 1664525u + 1013904223u;
+            bv[j] = (__bf16)(((int)(s >> 8) % 65536 - 32768) * (1.0f / 32768) * 1e-3f * (1 << ((s >> 28) & 3)));
+        }
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
         for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[a], 0, 0, 0);
@@ -242,7 +254,30 @@ __global__ __launch_bounds__(256) void mfma_bf16_loop(float *out, int iters) {
     float sum = 0.f;
     for (int a = 0; a < NACC; ++a)
         for (int g = 0; g < 16; ++g) sum += acc[a][g];
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (ticks && blockIdx.x == 0 && threadIdx.x == 0) ticks[0] = t1 - t0;
     out[blockIdx.x * 256 + threadIdx.x] = sum;
+}
+
+template <int RND>
+static void peak_ticks(int blocks, int iters, float *out) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    unsigned long long *tk, h = 0;
+    hipMalloc(&tk, 8);
+    mfma_bf16_loop<4, RND><<<blocks, 256>>>(out, iters, tk);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    mfma_bf16_loop<4, RND><<<blocks, 256>>>(out, iters, tk);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipMemcpy(&h, tk, 8, hipMemcpyDeviceToHost);
+    const double fl = (double)blocks * 4 * iters * 4 * 32768.0;
+    printf("bf16 MFMA loop, %s operands: %d blocks x %d iters: %.3f ms  %.0f TFLOP/s;  %.1f s_memtime ticks per MFMA per SIMD, tick rate %.2f GHz\n",
+           RND ? "random" : "constant", blocks, iters, ms, fl / ms / 1e9, (double)h / (4.0 * iters * (blocks / 256.0)), (double)h / ms / 1e6);
+    hipFree(tk);
 }
 
 static void peak(int blocks, int iters, float *out) {
@@ -299,7 +334,7 @@ __global__ void presplit_kernel(const float *__restrict__ x, unsigned *__restric
 }
 
 // PRE_A / PRE_B: that operand is read as pre-split planes (A3 / B3) instead of fp32
-template <int BM, int BN, int WM, int WN, int MINB, bool RN, bool SWZ, bool PRE_A = false, bool PRE_B = false>
+template <int BM, int BN, int WM, int WN, int MINB, bool RN, bool SWZ, bool PRE_A = false, bool PRE_B = false, int ILV = 0>
 __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_v2_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                                       float *__restrict__ C, int N, int Mo, int K, int F,
                                                                       int row_tiles, int col_tiles,
@@ -396,6 +431,79 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void gemm_v2_kernel(const float
         }
     };
     auto compute = [&]() {
+        if constexpr (ILV != 0) {
+            // ILV: the fragment reads of k16 step 1 sit one per two MFMAs inside step 0 (a ds_read_b128 blocks its wave's
+            // issue for ~29 cycles; twelve in a row stall the wave's MFMA stream for ~350 cycles, r03_ubench_v5c.txt)
+            bf16x8 fa[2][TM][3], fb[2][TN][3];
+            auto rd = [&](int ks) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const int row = wm * WTM + a * 32 + li;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        fa[ks][a][p] = *reinterpret_cast<const bf16x8 *>(sA + p * APLANE + row * LP + 16 * seg(row, lh + 2 * ks));
+                }
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const int row = wn * WTN + b * 32 + li;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        fb[ks][b][p] = *reinterpret_cast<const bf16x8 *>(sB + p * BPLANE + row * LP + 16 * seg(row, lh + 2 * ks));
+                }
+            };
+            auto mm = [&](int ks) {
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][a][term_pa(6, term)], fb[ks][b][term_pb(6, term)],
+                                                                                acc[a][b], 0, 0, 0);
+            };
+            if constexpr (ILV == 2 && TM == 2 && TN == 2) {
+                // ILV 2: only the four fragments of the first product are read up front; the other eight of step 0 ride one
+                // per MFMA inside products 0 and 1, the twelve of step 1 inside products 2 .. 4
+                constexpr int oa[3] = {0, 2, 1}, ob[3] = {2, 0, 1};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int st = 0; st < 3; ++st) {
+#pragma unroll
+                        for (int a = 0; a < TM; ++a) {
+                            const int row = wm * WTM + a * 32 + li;
+                            fa[ks][a][oa[st]] = *reinterpret_cast<const bf16x8 *>(sA + oa[st] * APLANE + row * LP + 16 * seg(row, lh + 2 * ks));
+                        }
+#pragma unroll
+                        for (int b = 0; b < TN; ++b) {
+                            const int row = wn * WTN + b * 32 + li;
+                            fb[ks][b][ob[st]] = *reinterpret_cast<const bf16x8 *>(sB + ob[st] * BPLANE + row * LP + 16 * seg(row, lh + 2 * ks));
+                        }
+                    }
+                mm(0);
+                mm(1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                for (int i = 0; i < 20; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 28, 0);
+                return;
+            }
+            rd(0);
+            __builtin_amdgcn_sched_barrier(0);
+            rd(1);
+            mm(0);
+#pragma unroll
+            for (int i = 0; i < 3 * (TM + TN); ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mm(1);
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < KC / 16; ++ks) {
             bf16x8 af[TM][3], bf[TN][3];
@@ -628,6 +736,411 @@ template <int SG>
 static double run_v3(const Shape &s, const float *A, const float *B, float *C, int iters);
 
 // ---------------------------------------------------------------------------------------------------------------
+// Fourth generation (round 3): explicit PING-PONG.  512 threads = two groups of four waves; each group owns one 128 x 128
+// output tile and its own single-buffered piece planes (2 x 60 KB of LDS -> one workgroup per CU, two waves per SIMD, one
+// of each group).  The groups run in anti-phase, locked by workgroup barriers: while one group multiplies its staged chunk
+// (MFMA + LDS fragment reads), the other splits and stores its next chunk (VALU + LDS writes); the global loads of a
+// chunk are issued at the start of the multiply phase before the one that stages them.  Rationale: two independent
+// 256-thread workgroups per CU (v2) fall into lockstep -- when both multiply they share the matrix pipe and finish
+// together, then both stage while the pipe idles -- so the stage time is never hidden (MI355X_MICROARCH.md, "Two waves per
+// SIMD": the matrix pipe is per SIMD and fully paced; a partner's VALU costs the multiplying wave little).
+// PRIO: 1 = s_setprio 1 during the multiply phase.
+// ---------------------------------------------------------------------------------------------------------------
+template <int PRIO>
+__global__ __launch_bounds__(512, 1) void gemm_v4_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                         float *__restrict__ C, int N, int Mo, int K, int F, int row_tiles,
+                                                         int col_tiles, unsigned long long *ts = nullptr) {
+    constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64, TM = 2, TN = 2, PA = 2, PB = 2;
+    constexpr int APLANE = BM * PITCH, BPLANE = BN * PITCH, GROUP = 3 * (APLANE + BPLANE);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem4[];
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    unsigned char *sA = smem4 + grp * GROUP, *sB = sA + 3 * APLANE;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int q = tid & 3, r = tid >> 2;
+
+    // the two tiles of a workgroup are consecutive tiles of one sample's list on this block's XCD
+    const int T = row_tiles * col_tiles;
+    int n, t;
+    bool valid;
+    if ((N & 7) == 0) {
+        const int per = N >> 3, l = (blockIdx.x >> 3) * 2 + grp;
+        valid = l < per * T && !((PRIO & 4) && grp == 1);      // PRIO & 4: solo, the second group idles (timing only)
+        n = (blockIdx.x & 7) * per + (valid ? l / T : 0);
+        t = valid ? l % T : 0;
+    } else {
+        const int l = blockIdx.x * 2 + grp;
+        valid = l < N * T;
+        n = valid ? l / T : 0;
+        t = valid ? l % T : 0;
+    }
+    // row tile fastest: the two groups of a workgroup read the same weight columns
+    const int r0 = (t % row_tiles) * BM, f0 = (t / row_tiles) * BN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+
+    const float *ap[PA], *bp[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) ap[i] = A + ((long long)n * Mo + min(r0 + r + 64 * i, Mo - 1)) * K + 8 * q;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) bp[i] = B + (long long)min(f0 + r + 64 * i, F - 1) * K + 8 * q;
+
+    float4 ra[PA][2], rb[PB][2];
+    auto load_regs = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            ra[i][0] = *reinterpret_cast<const float4 *>(ap[i] + k0);
+            ra[i][1] = *reinterpret_cast<const float4 *>(ap[i] + k0 + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            rb[i][0] = *reinterpret_cast<const float4 *>(bp[i] + k0);
+            rb[i][1] = *reinterpret_cast<const float4 *>(bp[i] + k0 + 4);
+        }
+    };
+    auto store8 = [&](unsigned char *base, int plane, int row, const float4 &u, const float4 &v) {
+        uint4 hi, mid, lo;
+        split8(u, v, hi, mid, lo);
+        unsigned char *d = base + row * PITCH + 16 * q;
+        *reinterpret_cast<uint4 *>(d) = hi;
+        *reinterpret_cast<uint4 *>(d + plane) = mid;
+        *reinterpret_cast<uint4 *>(d + 2 * plane) = lo;
+    };
+    auto store_regs = [&]() {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) store8(sA, APLANE, r + 64 * i, ra[i][0], ra[i][1]);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) store8(sB, BPLANE, r + 64 * i, rb[i][0], rb[i][1]);
+    };
+    auto compute = [&]() {
+        if constexpr (PRIO & 8) {
+            // PRIO & 8: fragment reads issued a whole k16 step ahead, in the order the products consume them (LDS returns in
+            // order: the first product starts after four reads, the rest of the stream lands behind the MFMAs); scheduling
+            // barriers keep the compiler from sinking each read next to its first use (its default: read 4, wait, 4 MFMAs ...)
+            bf16x8 af[2][TM][3], bf[2][TN][3];
+            constexpr int oa[3] = {0, 2, 1}, ob[3] = {2, 0, 1};          // piece of A / B first needed by product 0, 1, 2
+            auto issue = [&](int ks) {
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+                        af[ks][a][oa[s]] = *reinterpret_cast<const bf16x8 *>(sA + oa[s] * APLANE + (wm * WTM + a * 32 + li) * PITCH + 16 * (lh + 2 * ks));
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        bf[ks][b][ob[s]] = *reinterpret_cast<const bf16x8 *>(sB + ob[s] * BPLANE + (wn * WTN + b * 32 + li) * PITCH + 16 * (lh + 2 * ks));
+                    __builtin_amdgcn_sched_barrier(0);        // keep the sets in consumption order
+                }
+            };
+            auto terms = [&](int ks, int t0, int t1) {
+#pragma unroll
+                for (int term = t0; term < t1; ++term)
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][a][term_pa(6, term)], bf[ks][b][term_pb(6, term)],
+                                                                                acc[a][b], 0, 0, 0);
+            };
+            issue(0);
+            __builtin_amdgcn_sched_barrier(0);
+            terms(0, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(1);
+            __builtin_amdgcn_sched_barrier(0);
+            terms(0, 1, 6);
+            terms(1, 0, 6);
+            return;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int row = wm * WTM + a * 32 + li;
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    af[a][p] = *reinterpret_cast<const bf16x8 *>(sA + p * APLANE + row * PITCH + 16 * (lh + 2 * ks));
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int row = wn * WTN + b * 32 + li;
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    bf[b][p] = *reinterpret_cast<const bf16x8 *>(sB + p * BPLANE + row * PITCH + 16 * (lh + 2 * ks));
+            }
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][term_pa(6, term)], bf[b][term_pb(6, term)],
+                                                                            acc[a][b], 0, 0, 0);
+        }
+    };
+
+    // local step j of a group: even = stage chunk j/2, odd = multiply chunk j/2; group g performs step j in phase j + g
+    const int total = K / KC;
+    if (valid) load_regs(0);
+    // PRIO & 2: phase timestamps of wave 0 of each group of block 8 (s_memtime): [group][phase][start, work done, barrier passed]
+    const bool stamp = (PRIO & 2) && ts != nullptr && blockIdx.x == 8 && tid == 0;
+    for (int ph = 0; ph <= 2 * total; ++ph) {
+        const int j = ph - grp;
+        unsigned long long t0 = 0, t1 = 0;
+        if (PRIO & 2) t0 = __builtin_amdgcn_s_memtime();
+        if (valid && j >= 0 && j < 2 * total) {
+            const int it = j >> 1;
+            if (j & 1) {
+                if (it + 1 < total) load_regs((it + 1) * KC);
+                if (PRIO & 1) __builtin_amdgcn_s_setprio(1);
+                compute();
+                if (PRIO & 1) __builtin_amdgcn_s_setprio(0);
+            } else {
+                store_regs();
+            }
+        }
+        if (PRIO & 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            t1 = __builtin_amdgcn_s_memtime();
+        }
+        __syncthreads();
+        if (stamp && ph < 64) {
+            unsigned long long *o = ts + ((long long)grp * 64 + ph) * 3;
+            o[0] = t0; o[1] = t1; o[2] = __builtin_amdgcn_s_memtime();
+        }
+    }
+
+    if (!valid) return;
+    float *cn = C + (long long)n * Mo * F;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = f0 + wn * WTN + b * 32 + li;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row = r0 + wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                if (row < Mo && col < F) cn[(long long)row * F + col] = acc[a][b][g];
+            }
+        }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fifth generation (round 3): PRODUCER / CONSUMER specialisation.  512 threads, one 128 x 128 tile per workgroup, one
+// workgroup per CU.  Waves 0-3 (one per SIMD) only multiply: fragment reads + MFMAs, the fragments of the next k16 step
+// (also across the chunk boundary) always in flight behind the MFMAs of the current one.  Waves 4-7 (their SIMD partners)
+// only stage: global loads two chunks ahead, operand split, LDS stores.  Three chunk buffers in LDS (unpadded 64-byte rows,
+// 16-byte segments XOR-swizzled: 3 x 48 KB) so that the chunk the consumers prefetch from is always complete; ONE
+// workgroup barrier per chunk.  Measured background (r03_ubench_v4_*.txt): a wave that multiplies AND stages spends 2170
+// cycles on a 1536-cycle MFMA stream even alone on its SIMD (exposed first fragment reads, loop overhead), and 2400-2600
+// next to a staging partner; the matrix pipe issues one 32x32x16 MFMA per 32 cycles at 1.75-1.87 GHz under load.
+// VAR & 1: weights pre-split into bf16 planes in HBM (B3);  VAR & 2: phase timestamps.
+// ---------------------------------------------------------------------------------------------------------------
+template <int VAR>
+__global__ __launch_bounds__((VAR & 8) ? 768 : 512, 1) void gemm_v5_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                         float *__restrict__ C, int N, int Mo, int K, int F, int row_tiles,
+                                                         int col_tiles, const unsigned short *__restrict__ B3 = nullptr,
+                                                         unsigned long long *ts = nullptr) {
+    constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64, TM = 2, TN = 2;
+    constexpr int NPT = (VAR & 8) ? 512 : 256, RPP = NPT / 4, PA = BM / RPP, PB = BN / RPP;      // producer threads, rows per staging pass
+    constexpr int LP = 64, APLANE = BM * LP, BPLANE = BN * LP, BUF = 3 * (APLANE + BPLANE);
+    constexpr bool PRE_B = (VAR & 1) != 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem5[];
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) ? 1 : 0;      // 0: consumer (waves 0-3), 1: producer (waves 4-7 [-11])
+    const int tid = role ? (int)threadIdx.x - 256 : (int)threadIdx.x;
+    auto seg = [](int row, int sg) { return sg ^ ((row >> 2) & 3); };
+
+    int n, t;
+    map_block(blockIdx.x, N, row_tiles * col_tiles, n, t);
+    const int r0 = (t / col_tiles) * BM, f0 = (t % col_tiles) * BN;
+    const int total = K / KC;
+    const bool stamp = (VAR & 2) && ts != nullptr && blockIdx.x == 8 && tid == 0;
+
+    if (role == 1) {
+        if (VAR & 4) __builtin_amdgcn_s_setprio(3);
+        // ---------------- producer: chunk c -> buffer c % 3, global loads two chunks ahead ----------------
+        const int q = tid & 3, r = tid >> 2;
+        const float *ap[PA], *bp[PB];
+#pragma unroll
+        for (int i = 0; i < PA; ++i) ap[i] = A + ((long long)n * Mo + min(r0 + r + RPP * i, Mo - 1)) * K + 8 * q;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) bp[i] = B + (long long)min(f0 + r + RPP * i, F - 1) * K + 8 * q;
+        const long long b_plane = (long long)F * K;
+        float4 ra[2][PA][2], rb[2][PB][2];
+        uint4 pb3[2][PRE_B ? PB : 1][3];
+        auto load_regs = [&](int set, int k0) {
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                ra[set][i][0] = *reinterpret_cast<const float4 *>(ap[i] + k0);
+                ra[set][i][1] = *reinterpret_cast<const float4 *>(ap[i] + k0 + 4);
+            }
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                if constexpr (PRE_B) {
+                    const long long e = (bp[i] - B) + k0;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) pb3[set][i][pl] = *reinterpret_cast<const uint4 *>(B3 + pl * b_plane + e);
+                } else {
+                    rb[set][i][0] = *reinterpret_cast<const float4 *>(bp[i] + k0);
+                    rb[set][i][1] = *reinterpret_cast<const float4 *>(bp[i] + k0 + 4);
+                }
+            }
+        };
+        auto store_regs = [&](int set, unsigned char *buf) {
+            unsigned char *sA = buf, *sB = buf + 3 * APLANE;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                uint4 hi, mid, lo;
+                split8(ra[set][i][0], ra[set][i][1], hi, mid, lo);
+                const int row = r + RPP * i;
+                unsigned char *d = sA + row * LP + 16 * seg(row, q);
+                *reinterpret_cast<uint4 *>(d) = hi;
+                *reinterpret_cast<uint4 *>(d + APLANE) = mid;
+                *reinterpret_cast<uint4 *>(d + 2 * APLANE) = lo;
+            }
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                uint4 hi, mid, lo;
+                if constexpr (PRE_B) { hi = pb3[set][i][0]; mid = pb3[set][i][1]; lo = pb3[set][i][2]; }
+                else split8(rb[set][i][0], rb[set][i][1], hi, mid, lo);
+                const int row = r + RPP * i;
+                unsigned char *d = sB + row * LP + 16 * seg(row, q);
+                *reinterpret_cast<uint4 *>(d) = hi;
+                *reinterpret_cast<uint4 *>(d + BPLANE) = mid;
+                *reinterpret_cast<uint4 *>(d + 2 * BPLANE) = lo;
+            }
+        };
+        if (!(VAR & 16)) load_regs(0, 0);
+        if (total > 1 && !(VAR & 16)) load_regs(1, KC);
+        int bo = 0;
+        for (int c = 0; c < total; c += 2) {
+            unsigned long long t0 = 0, t1 = 0;
+            if (VAR & 2) t0 = __builtin_amdgcn_s_memtime();
+            if (!(VAR & 16)) store_regs(0, smem5 + bo);
+            if (c + 2 < total && !(VAR & 16)) load_regs(0, (c + 2) * KC);
+            if (VAR & 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t1 = __builtin_amdgcn_s_memtime(); }
+            __syncthreads();
+            if (stamp && c < 64) { ts[(64 + c) * 3] = t0; ts[(64 + c) * 3 + 1] = t1; ts[(64 + c) * 3 + 2] = __builtin_amdgcn_s_memtime(); }
+            bo = (bo == 2 * BUF) ? 0 : bo + BUF;
+            if (c + 1 < total) {
+                if (VAR & 2) t0 = __builtin_amdgcn_s_memtime();
+                if (!(VAR & 16)) store_regs(1, smem5 + bo);
+                if (c + 3 < total && !(VAR & 16)) load_regs(1, (c + 3) * KC);
+                if (VAR & 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t1 = __builtin_amdgcn_s_memtime(); }
+                __syncthreads();
+                if (stamp && c + 1 < 64) { ts[(64 + c + 1) * 3] = t0; ts[(64 + c + 1) * 3 + 1] = t1; ts[(64 + c + 1) * 3 + 2] = __builtin_amdgcn_s_memtime(); }
+                bo = (bo == 2 * BUF) ? 0 : bo + BUF;
+            }
+        }
+        __syncthreads();          // barriers #total, #total + 1: the consumers lag one chunk behind
+        __syncthreads();
+        return;
+    }
+
+    // ---------------- consumer ----------------
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+    // byte offsets of this lane's row segments inside a buffer (rows wm*64 + a*32 + li: the swizzle term is that of li)
+    const int sw = (li >> 2) & 3;
+    const int offA = (wm * WTM + li) * LP, offB = 3 * APLANE + (wn * WTN + li) * LP;
+    constexpr int oa[3] = {0, 2, 1}, ob[3] = {2, 0, 1};          // piece of A / B first needed by product 0, 1, 2
+    bf16x8 f0a[TM][3], f0b[TN][3], f1a[TM][3], f1b[TN][3];
+    auto issue = [&](bf16x8 (&fa)[TM][3], bf16x8 (&fb)[TN][3], const unsigned char *buf, int ks) {
+        const int so = 16 * ((lh + 2 * ks) ^ sw);
+#pragma unroll
+        for (int st = 0; st < 3; ++st) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+                fa[a][oa[st]] = *reinterpret_cast<const bf16x8 *>(buf + offA + oa[st] * APLANE + a * 32 * LP + so);
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+                fb[b][ob[st]] = *reinterpret_cast<const bf16x8 *>(buf + offB + ob[st] * BPLANE + b * 32 * LP + so);
+            if (!(VAR & 64)) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto terms = [&](bf16x8 (&fa)[TM][3], bf16x8 (&fb)[TN][3], int t0, int t1) {
+#pragma unroll
+        for (int term = t0; term < t1; ++term)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][term_pa(6, term)], fb[b][term_pb(6, term)], acc[a][b], 0, 0, 0);
+    };
+    // VAR & 64: one fragment read in the shadow of every second MFMA (a ds_read_b128 blocks its wave's issue for ~29 cycles:
+    // twelve in a row leave the matrix pipe idle for ~350 cycles, measured r03_ubench_v5c.txt)
+    auto interleave = [&]() {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // 2 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+        }
+    };
+    __syncthreads();              // #0: chunk 0 staged
+    __syncthreads();              // #1: chunk 1 staged
+    int bo = 0;
+    issue(f0a, f0b, smem5, 0);
+    if (VAR & 32) issue(f1a, f1b, smem5, 1);
+    for (int c = 0; c < total; ++c) {
+        unsigned long long t0 = 0, t1 = 0;
+        if (VAR & 2) t0 = __builtin_amdgcn_s_memtime();
+        const unsigned char *buf = smem5 + bo;
+        bo = (bo == 2 * BUF) ? 0 : bo + BUF;
+        if constexpr ((VAR & 64) != 0) {
+            issue(f1a, f1b, buf, 1);
+            terms(f0a, f0b, 0, 6);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            issue(f0a, f0b, smem5 + bo, 0);          // (the last chunk prefetches from a buffer nobody uses)
+            terms(f1a, f1b, 0, 6);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            if (!(VAR & 32)) issue(f1a, f1b, buf, 1);     // k16 step 1 of this chunk, behind the MFMAs of step 0
+            __builtin_amdgcn_sched_barrier(0);
+            terms(f0a, f0b, 0, 6);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < total && !(VAR & 32)) issue(f0a, f0b, smem5 + bo, 0);      // step 0 of the NEXT chunk (complete since the last barrier)
+            __builtin_amdgcn_sched_barrier(0);
+            terms(f1a, f1b, 0, 6);
+        }
+        if (VAR & 2) t1 = __builtin_amdgcn_s_memtime();
+        __syncthreads();          // #(c + 2)
+        if (stamp && c < 64) { ts[c * 3] = t0; ts[c * 3 + 1] = t1; ts[c * 3 + 2] = __builtin_amdgcn_s_memtime(); }
+    }
+
+    float *cn = C + (long long)n * Mo * F;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = f0 + wn * WTN + b * 32 + li;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row = r0 + wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                if (row < Mo && col < F) cn[(long long)row * F + col] = acc[a][b][g];
+            }
+        }
+}
+
+template <int PRIO>
+static double run_v4(const Shape &s, const float *A, const float *B, float *C, int iters);
+
+// ---------------------------------------------------------------------------------------------------------------
 // bf16-STORAGE contraction (BASELINE configs[4]: activations and weights kept in bf16, fp32 accumulate): one MFMA product
 // per multiply-add, operands copied global -> LDS as they are (64 contraction indices = 128 bytes per row and chunk,
 // swizzled 16-byte segments), fp32 or bf16 output.  A projection of what the bf16 path of the library would reach.
@@ -737,7 +1250,7 @@ __global__ void to_bf16_kernel(const float *__restrict__ x, __bf16 *__restrict__
     if (i < n) y[i] = (__bf16)x[i];
 }
 
-template <int BM, int BN, int WM, int WN, int MINB, bool RN, bool SWZ, bool PRE_A = false, bool PRE_B = false>
+template <int BM, int BN, int WM, int WN, int MINB, bool RN, bool SWZ, bool PRE_A = false, bool PRE_B = false, int ILV = 0>
 static double run_v2(const struct Shape &s, const float *A, const float *B, float *C, int iters);
 
 struct Shape { int N, Mo, K, F; };
@@ -771,7 +1284,7 @@ static double run(const Shape &s, const float *A, const float *B, float *C, int 
     return 1e3 * ms / iters;
 }
 
-template <int BM, int BN, int WM, int WN, int MINB, bool RN, bool SWZ, bool PRE_A, bool PRE_B>
+template <int BM, int BN, int WM, int WN, int MINB, bool RN, bool SWZ, bool PRE_A, bool PRE_B, int ILV>
 static double run_v2(const Shape &s, const float *A, const float *B, float *C, int iters) {
     const int rt = (s.Mo + BM - 1) / BM, ct = (s.F + BN - 1) / BN;
     hipEvent_t e0, e1;
@@ -787,7 +1300,7 @@ static double run_v2(const Shape &s, const float *A, const float *B, float *C, i
         presplit_kernel<RN><<<(unsigned)((nb / 2 + 255) / 256), 256>>>(B, (unsigned *)B3, nb / 2);
     }
     auto launch = [&]() {
-        gemm_v2_kernel<BM, BN, WM, WN, MINB, RN, SWZ, PRE_A, PRE_B><<<s.N * rt * ct, 64 * WM * WN>>>(A, B, C, s.N, s.Mo, s.K, s.F, rt, ct, A3, B3);
+        gemm_v2_kernel<BM, BN, WM, WN, MINB, RN, SWZ, PRE_A, PRE_B, ILV><<<s.N * rt * ct, 64 * WM * WN>>>(A, B, C, s.N, s.Mo, s.K, s.F, rt, ct, A3, B3);
     };
     launch();
     hipDeviceSynchronize();
@@ -823,6 +1336,101 @@ static double run_v3(const Shape &s, const float *A, const float *B, float *C, i
     return 1e3 * ms / iters;
 }
 
+template <int PRIO>
+static double run_v4(const Shape &s, const float *A, const float *B, float *C, int iters) {
+    const int rt = (s.Mo + 127) / 128, ct = (s.F + 127) / 128, T = rt * ct;
+    const int lds = 2 * 3 * (128 * PITCH + 128 * PITCH);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_v4_kernel<PRIO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int grid = (s.N & 7) == 0 ? 8 * (((s.N >> 3) * T + 1) / 2) : (s.N * T + 1) / 2;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    auto launch = [&]() { gemm_v4_kernel<PRIO><<<grid, 512, lds>>>(A, B, C, s.N, s.Mo, s.K, s.F, rt, ct); };
+    launch();
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < iters; ++i) launch();
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return 1e3 * ms / iters;
+}
+
+template <int VAR>
+static double run_v5(const Shape &s, const float *A, const float *B, float *C, int iters, bool timing = false) {
+    const int rt = (s.Mo + 127) / 128, ct = (s.F + 127) / 128;
+    const int lds = 3 * 3 * (128 * 64 + 128 * 64);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_v5_kernel<VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    unsigned short *B3 = nullptr;
+    const long long nb = (long long)s.F * s.K;
+    if (VAR & 1) {
+        hipMalloc(&B3, nb * 6);
+        presplit_kernel<false><<<(unsigned)((nb / 2 + 255) / 256), 256>>>(B, (unsigned *)B3, nb / 2);
+    }
+    unsigned long long *ts = nullptr;
+    if (VAR & 2) { hipMalloc(&ts, 2 * 64 * 3 * 8); hipMemset(ts, 0, 2 * 64 * 3 * 8); }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    auto launch = [&]() { gemm_v5_kernel<VAR><<<s.N * rt * ct, (VAR & 8) ? 768 : 512, lds>>>(A, B, C, s.N, s.Mo, s.K, s.F, rt, ct, B3, ts); };
+    launch();
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < iters; ++i) launch();
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (VAR & 2) {
+        std::vector<unsigned long long> h(2 * 64 * 3);
+        hipMemcpy(h.data(), ts, h.size() * 8, hipMemcpyDeviceToHost);
+        double cw = 0, cb = 0, pw = 0, pb = 0;
+        for (int c = 6; c < 26; ++c) {
+            cw += (double)(h[c * 3 + 1] - h[c * 3]); cb += (double)(h[c * 3 + 2] - h[c * 3 + 1]);
+            pw += (double)(h[(64 + c) * 3 + 1] - h[(64 + c) * 3]); pb += (double)(h[(64 + c) * 3 + 2] - h[(64 + c) * 3 + 1]);
+        }
+        printf("  v5 timing (cycles per chunk, chunks 6..25): consumer multiply %.0f + barrier %.0f;  producer stage %.0f + barrier %.0f;  chunk period %.0f\n",
+               cw / 20, cb / 20, pw / 20, pb / 20, (double)(h[26 * 3] - h[6 * 3]) / 20.0);
+        hipFree(ts);
+    }
+    if (B3) hipFree(B3);
+    return 1e3 * ms / iters;
+}
+
+// phase timing of the ping-pong kernel: durations of the multiply / stage phases of one wave per group
+template <int PRIO>
+static void time_v4(const Shape &s, const float *A, const float *B, float *C, const char *label) {
+    const int rt = (s.Mo + 127) / 128, ct = (s.F + 127) / 128, T = rt * ct;
+    const int lds = 2 * 3 * (128 * PITCH + 128 * PITCH);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_v4_kernel<PRIO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int grid = (s.N & 7) == 0 ? 8 * (((s.N >> 3) * T + 1) / 2) : (s.N * T + 1) / 2;
+    unsigned long long *ts;
+    hipMalloc(&ts, 2 * 64 * 3 * 8);
+    hipMemset(ts, 0, 2 * 64 * 3 * 8);
+    for (int i = 0; i < 3; ++i) gemm_v4_kernel<PRIO><<<grid, 512, lds>>>(A, B, C, s.N, s.Mo, s.K, s.F, rt, ct, ts);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(2 * 64 * 3);
+    hipMemcpy(h.data(), ts, h.size() * 8, hipMemcpyDeviceToHost);
+    printf("%s: phase timing (s_memtime ticks), wave 0 of each group of one workgroup; phases 8..27\n", label);
+    for (int g = 0; g < 2; ++g) {
+        double w[2] = {0, 0}, b[2] = {0, 0};
+        int cnt[2] = {0, 0};
+        for (int ph = 8; ph < 28; ++ph) {
+            const unsigned long long *o = &h[((size_t)g * 64 + ph) * 3];
+            const int kind = ((ph - g) & 1);                 // 1 = multiply, 0 = stage
+            w[kind] += (double)(o[1] - o[0]);
+            b[kind] += (double)(o[2] - o[1]);
+            ++cnt[kind];
+        }
+        printf("  group %d: multiply phase work %.0f + barrier wait %.0f ticks; stage phase work %.0f + barrier wait %.0f ticks\n", g,
+               w[1] / cnt[1], b[1] / cnt[1], w[0] / cnt[0], b[0] / cnt[0]);
+    }
+    const unsigned long long *o0 = &h[(0 * 64 + 8) * 3], *o1 = &h[(0 * 64 + 28) * 3];
+    printf("  20 phases of group 0: %.0f ticks per phase\n", (double)(o1[0] - o0[0]) / 20.0);
+    hipFree(ts);
+}
+
 // error of rows [ra, rb) of sample n against a float64 reference; also the error an fp32 sequential dot makes
 static void check(const Shape &s, const std::vector<float> &hA, const std::vector<float> &hB, const float *dC, int n, int ra, int rb,
                   double &err_max, double &err_rms, double &f32_rms) {
@@ -855,6 +1463,7 @@ int main(int argc, char **argv) {
     {
         float *o; hipMalloc(&o, 2048 * 256 * 4);
         peak(256, 20000, o); peak(512, 10000, o); peak(512, 50, o); peak(1024, 5000, o);
+        peak_ticks<0>(256, 20000, o); peak_ticks<1>(256, 20000, o); peak_ticks<0>(512, 10000, o); peak_ticks<1>(512, 10000, o);
         hipFree(o);
     }
     if (argc > 1 && !strcmp(argv[1], "bf16")) {
@@ -898,6 +1507,145 @@ int main(int argc, char **argv) {
             printf("%-22s %7.1fus %5.0fTF %4.1fTB/s %7.1fus %5.0fTF %4.1fTB/s %7.1fus %5.0fTF %4.1fTB/s   %.2e\n", name, u0, fl / u0 / 1e6,
                    by32 / u0 / 1e6, u1, fl / u1 / 1e6, by16 / u1 / 1e6, u2, fl / u2 / 1e6, by16 / u2 / 1e6, erms);
             hipFree(A); hipFree(B); hipFree(C); hipFree(A16); hipFree(B16);
+        }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "ilv")) {
+        const char *vn[] = {"v2 128x128 (ref)", "v2 128x128 interleaved", "v2 64x64 occ5 (ref)", "v2 64x64 interleaved", "128x128 ilv 2 (4 up front)"};
+        constexpr int NVI = 5;
+        printf("%-22s", "shape (N Mo K F)");
+        for (int i = 0; i < NVI; ++i) printf(" %24s", vn[i]);
+        printf("\n");
+        for (const Shape &s : std::vector<Shape>{{16, 862, 1024, 512}, {16, 862, 768, 512}, {16, 862, 512, 512}, {16, 862, 512, 256},
+                                                 {16, 1723, 256, 256}, {16, 1723, 512, 128}, {16, 3445, 128, 128}, {16, 3445, 256, 128},
+                                                 {16, 3445, 192, 64}, {16, 6890, 64, 64}}) {
+            std::vector<float> hA((size_t)s.N * s.Mo * s.K), hB((size_t)s.F * s.K);
+            fill(hA, 7, 1.0f);
+            fill(hB, 100, 0.05f);
+            float *A, *B, *C;
+            hipMalloc(&A, hA.size() * 4); hipMalloc(&B, hB.size() * 4); hipMalloc(&C, (size_t)s.N * s.Mo * s.F * 4);
+            hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
+            hipMemcpy(B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
+            const double fl = 2.0 * s.N * s.Mo * (double)s.K * s.F;
+            double us[NVI], emax[NVI], erms[NVI], f32rms = 0;
+            auto chk = [&](int i) { check(s, hA, hB, C, s.N - 1, s.Mo - 24, s.Mo, emax[i], erms[i], f32rms); };
+            auto clr = [&]() { hipMemset(C, 0xFF, (size_t)s.N * s.Mo * s.F * 4); };
+            clr(); us[0] = run_v2<128, 128, 2, 2, 2, false, false>(s, A, B, C, iters); chk(0);
+            clr(); us[1] = run_v2<128, 128, 2, 2, 2, false, false, false, false, 1>(s, A, B, C, iters); chk(1);
+            clr(); us[2] = run_v2<64, 64, 2, 2, 5, false, false>(s, A, B, C, iters); chk(2);
+            clr(); us[3] = run_v2<64, 64, 2, 2, 5, false, false, false, false, 1>(s, A, B, C, iters); chk(3);
+            clr(); us[4] = run_v2<128, 128, 2, 2, 2, false, false, false, false, 2>(s, A, B, C, iters); chk(4);
+            char name[64];
+            snprintf(name, sizeof name, "%d %d %d %d", s.N, s.Mo, s.K, s.F);
+            printf("%-22s", name);
+            for (int i = 0; i < NVI; ++i) printf(" %14.1fus %5.1fTF", us[i], fl / us[i] / 1e6);
+            printf("\n%-22s", "  rms err/rms(ref)");
+            for (int i = 0; i < NVI; ++i) printf(" %24.2e", erms[i]);
+            printf("   fp32 fma chain: %.2e\n", f32rms);
+            hipFree(A); hipFree(B); hipFree(C);
+        }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "v5")) {
+        const char *vn[] = {"v2 128x128 trunc (ref)", "v5 producer/consumer", "v5 + presplit weights", "v5i interleaved reads", "v5i + presplit", "v5i 8 prod + presplit"};
+        constexpr int NV5 = 6;
+        printf("%-22s", "shape (N Mo K F)");
+        for (int i = 0; i < NV5; ++i) printf(" %24s", vn[i]);
+        printf("\n");
+        for (const Shape &s : std::vector<Shape>{{16, 862, 1024, 512}, {16, 862, 768, 512}, {16, 862, 512, 512}, {16, 862, 512, 256},
+                                                 {16, 1723, 256, 256}, {16, 1723, 512, 128}, {16, 3445, 128, 128}, {16, 3445, 256, 128}}) {
+            std::vector<float> hA((size_t)s.N * s.Mo * s.K), hB((size_t)s.F * s.K);
+            fill(hA, 7, 1.0f);
+            fill(hB, 100, 0.05f);
+            float *A, *B, *C;
+            hipMalloc(&A, hA.size() * 4); hipMalloc(&B, hB.size() * 4); hipMalloc(&C, (size_t)s.N * s.Mo * s.F * 4);
+            hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
+            hipMemcpy(B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
+            const double fl = 2.0 * s.N * s.Mo * (double)s.K * s.F;
+            double us[NV5], emax[NV5], erms[NV5], f32rms = 0;
+            auto chk = [&](int i) {
+                check(s, hA, hB, C, s.N - 1, s.Mo - 24, s.Mo, emax[i], erms[i], f32rms);
+                double em2, er2, f2;
+                check(s, hA, hB, C, 0, 120, 136, em2, er2, f2);          // rows across the first tile boundary of sample 0
+                if (er2 > erms[i]) erms[i] = er2;
+            };
+            auto clr = [&]() { hipMemset(C, 0xFF, (size_t)s.N * s.Mo * s.F * 4); };
+            clr(); us[0] = run_v2<128, 128, 2, 2, 2, false, false>(s, A, B, C, iters); chk(0);
+            clr(); us[1] = run_v5<0>(s, A, B, C, iters); chk(1);
+            clr(); us[2] = run_v5<1>(s, A, B, C, iters); chk(2);
+            clr(); us[3] = run_v5<64>(s, A, B, C, iters); chk(3);
+            clr(); us[4] = run_v5<65>(s, A, B, C, iters); chk(4);
+            clr(); us[5] = run_v5<73>(s, A, B, C, iters); chk(5);
+            if (s.K == 1024) {
+                run_v5<2>(s, A, B, C, 2);
+                run_v5<3>(s, A, B, C, 2);
+                run_v5<6>(s, A, B, C, 2);
+                run_v5<10>(s, A, B, C, 2);
+                run_v5<11>(s, A, B, C, 2);
+                printf("  interleaved reads (1 per 2 MFMAs): base / presplit / 8 producers + presplit / producers idle:\n");
+                run_v5<2 | 64>(s, A, B, C, 2);
+                run_v5<3 | 64>(s, A, B, C, 2);
+                run_v5<11 | 64>(s, A, B, C, 2);
+                run_v5<2 | 16 | 64>(s, A, B, C, 2);
+                printf("  floors: producers idle (consumer reads stale LDS) / consumer without fragment reads / both:\n");
+                run_v5<2 | 16>(s, A, B, C, 2);
+                run_v5<2 | 32>(s, A, B, C, 2);
+                run_v5<2 | 16 | 32>(s, A, B, C, 2);
+            }
+            char name[64];
+            snprintf(name, sizeof name, "%d %d %d %d", s.N, s.Mo, s.K, s.F);
+            printf("%-22s", name);
+            for (int i = 0; i < NV5; ++i) printf(" %14.1fus %5.1fTF", us[i], fl / us[i] / 1e6);
+            printf("\n%-22s", "  rms err/rms(ref)");
+            for (int i = 0; i < NV5; ++i) printf(" %24.2e", erms[i]);
+            printf("   fp32 fma chain: %.2e\n", f32rms);
+            hipFree(A); hipFree(B); hipFree(C);
+        }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "v4")) {
+        const char *vn[] = {"v2 128x128 trunc (ref)", "v4 ping-pong", "v4 ping-pong + setprio", "v4 pp + ordered reads", "v4 pp + ordered + prio"};
+        constexpr int NV4 = 5;
+        printf("%-22s", "shape (N Mo K F)");
+        for (int i = 0; i < NV4; ++i) printf(" %24s", vn[i]);
+        printf("\n");
+        for (const Shape &s : std::vector<Shape>{{16, 862, 1024, 512}, {16, 862, 768, 512}, {16, 862, 512, 512}, {16, 862, 512, 256},
+                                                 {16, 1723, 256, 256}, {16, 1723, 512, 128}, {16, 3445, 128, 128}, {16, 3445, 256, 128}}) {
+            std::vector<float> hA((size_t)s.N * s.Mo * s.K), hB((size_t)s.F * s.K);
+            fill(hA, 7, 1.0f);
+            fill(hB, 100, 0.05f);
+            float *A, *B, *C;
+            hipMalloc(&A, hA.size() * 4); hipMalloc(&B, hB.size() * 4); hipMalloc(&C, (size_t)s.N * s.Mo * s.F * 4);
+            hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
+            hipMemcpy(B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
+            const double fl = 2.0 * s.N * s.Mo * (double)s.K * s.F;
+            double us[NV4], emax[NV4], erms[NV4], f32rms = 0;
+            auto chk = [&](int i) {
+                check(s, hA, hB, C, s.N - 1, s.Mo - 24, s.Mo, emax[i], erms[i], f32rms);
+                double em2, er2, f2;
+                check(s, hA, hB, C, 0, 120, 136, em2, er2, f2);          // rows across the first tile boundary of sample 0
+                if (er2 > erms[i]) erms[i] = er2;
+            };
+            auto clr = [&]() { hipMemset(C, 0xFF, (size_t)s.N * s.Mo * s.F * 4); };
+            clr(); us[0] = run_v2<128, 128, 2, 2, 2, false, false>(s, A, B, C, iters); chk(0);
+            clr(); us[1] = run_v4<0>(s, A, B, C, iters); chk(1);
+            clr(); us[2] = run_v4<1>(s, A, B, C, iters); chk(2);
+            clr(); us[3] = run_v4<8>(s, A, B, C, iters); chk(3);
+            clr(); us[4] = run_v4<9>(s, A, B, C, iters); chk(4);
+            if (s.K == 1024) {
+                time_v4<2>(s, A, B, C, "ping-pong");
+                time_v4<6>(s, A, B, C, "solo (second group idle)");
+                time_v4<10>(s, A, B, C, "ping-pong + ordered reads");
+                time_v4<14>(s, A, B, C, "solo + ordered reads");
+            }
+            char name[64];
+            snprintf(name, sizeof name, "%d %d %d %d", s.N, s.Mo, s.K, s.F);
+            printf("%-22s", name);
+            for (int i = 0; i < NV4; ++i) printf(" %14.1fus %5.1fTF", us[i], fl / us[i] / 1e6);
+            printf("\n%-22s", "  rms err/rms(ref)");
+            for (int i = 0; i < NV4; ++i) printf(" %24.2e", erms[i]);
+            printf("   fp32 fma chain: %.2e\n", f32rms);
+            hipFree(A); hipFree(B); hipFree(C);
         }
         return 0;
     }
