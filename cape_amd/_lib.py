@@ -122,6 +122,12 @@ SIGNATURES = {
     "cape_fc_wide_fwd": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p, _i32, _p, _i32, _p]),
     "cape_fc_wide_bwd_workspace_bytes": (_i64, [_i32, _i32, _i32]),
     "cape_fc_wide_bwd": (C.c_int, [_p, _i32, _p, _i32, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _p, _i64, _p]),
+    "cape_cheb_fused_supported": (C.c_int, [_i32, _i32, _i32]),
+    "cape_cheb_fused_debug_timestamps": (C.c_int, [_p]),
+    "cape_cheb_fused_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _p]),
+    "cape_cheb_fused_bwd_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
+    "cape_cheb_fused_bwd": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _p, _p, _i64, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                      _p, _p, _p, _p, _i32, _p, _i64, _p]),
     "cape_recon_edge_workspace_bytes": (_i64, [_i32, _i32, _i32]),
     "cape_recon_edge_loss_fwd_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _f32,
                                                _p, _p, _p, _p, _i64, _p]),

@@ -1,0 +1,634 @@
+// General-K Chebyshev graph convolution with the recurrence ON CHIP (reference lib/models.py:69-103, the explicit
+// recurrence of :88-96 for polynomial orders above the precomposed-operator limit; BASELINE configs[1]: one K = 6 layer,
+// 64 x 6890 x 16 -> 32).  The materialised form (ops.ChebConvRecurrenceFn) writes every T_k(L~) x to HBM and reads the
+// K-stack back three times (forward / data-gradient / weight-gradient contractions): 0.51 ms against a 61 us roofline.
+//
+// Here one workgroup owns (sample n, vertex patch p) -- cape_amd.graph.ChebPatchPlan: compact equal-sized patches from a
+// recursive spectral bisection, each with its (K-1)-ring halo, local indices sorted by ring, local CSR rows of L~ -- and keeps
+// the running pair T_{k-1}, T_{k-2} of patch + halo in LDS (two buffers, row pitch Cin + 4 floats: conflict-free
+// ds_read_b128 MFMA operand reads):
+//   forward :  T_0 = x[patch + halo];  step k computes T_k = 2 L~ T_{k-1} - T_{k-2} IN PLACE over T_{k-2} on the
+//              (K-1-k)-ring (the halo is recomputed redundantly, the valid region shrinks by one ring per step) while the
+//              matrix pipe accumulates  y[patch] += T_{k-1}[patch] W_{k-1}  straight from LDS (exact-fp32 MFMA
+//              v_mfma_f32_32x32x2_f32, contraction index permuted so that one 16-byte LDS read feeds four MFMA steps).
+//              HBM traffic: x once (+ halo re-reads, L2 hits), y once.  The K-stack never leaves the chip.
+//   backward:  (1) the same recurrence again, accumulating  dW_k += T_k[patch]^T dy[patch]  (v_mfma_f32_16x16x4_f32, the
+//              dy fragments of the wave's row slice held in registers for all k); per-workgroup partials, reduced in a
+//              fixed order by cheb_fused_dw_reduce_kernel;  (2) Clenshaw for the adjoint,
+//              b_k = G_k + 2 L~ b_{k+1} - b_{k+2} with G_k = dy W_k^T evaluated on the k-ring (L~ is symmetric:
+//              lib/mesh_sampling.py:10-38 builds I - D^-1/2 A D^-1/2), dx[patch] = G_0 + L~ b_1 - b_2.
+// One barrier per recurrence step.  Deterministic (no atomics).  fp32 storage; Cin in {8, 16, 24, 32}, Fout in {32, 64}.
+#include "common.h"
+
+namespace {
+
+unsigned long long *g_cf_ts = nullptr;      // set by cape_cheb_fused_debug_timestamps (diagnostic only)
+#define CF_STAMP(idx) do { if (p.ts && blockIdx.x == 9 && threadIdx.x == 0) p.ts[idx] = __builtin_amdgcn_s_memtime(); } while (0)
+
+constexpr int CF_THREADS = 1024;      // one thread per local row in the recurrence steps; waves 0-7 also own one 32-row MFMA tile
+constexpr int CF_RPT = 1;             // local rows per thread (entries in registers)
+constexpr int CF_TILE_WAVES = 8;
+constexpr int CF_W = 12;              // entries of a row of L~ held in registers (the plan refuses longer rows)
+constexpr int CF_MAXK = 8;
+constexpr int CF_RED_GROUPS = 32;       // first stage of the weight-gradient reduction: slabs -> 32 groups -> 1
+
+struct ChebFusedP {
+    const float *x; long long xs; int ldx;
+    const float *W;                       // [Cin*K, Fout], row c*K + k (reference layout)
+    float *y; long long ys; int ldy;
+    const float *dy; long long dys; int lddy;
+    float *dx; long long dxs; int lddx;
+    float *dwpart;                        // [N*P][K*Cin*Fout] (row c*K + k)
+    int N, M, K, P;
+    const int *pinfo; const int *vid; const int *ell_col; const float *ell_val;      // ELL rows at offset pinfo[1] * CF_W
+    int rmax;
+    unsigned long long *ts;               // phase timestamps of one workgroup (diagnostic, tools/cheb_fused_phases.py) or NULL
+};
+
+// The rows of L~ do not change between the recurrence steps: thread i keeps the entries of local row i in registers for
+// the whole kernel (column = local index, padded with (i, 0)), so a step is nothing but LDS gathers and FMAs -- the first
+// version re-read rowptr / column / value from global memory per (row, channel quad) and step: three dependent memory
+// round trips per item, 181 us forward where the LDS traffic allows ~40.
+struct CfRow {
+    int col[CF_W];
+    float val[CF_W];
+    int deg;
+};
+
+// ELL form of the patch's rows (plan arrays ell_col / ell_val, CF_W entries per row, padded with (own row, 0)): no row
+// pointer to wait for, three 16-byte loads per array
+__device__ __forceinline__ void cf_load_row(CfRow &r, int i, int nrows, const int *ec, const float *ev) {
+    r.deg = 0;
+#pragma unroll
+    for (int j = 0; j < CF_W; ++j) { r.col[j] = 0; r.val[j] = 0.f; }
+    if (i < nrows) {
+        const int4 *c4 = reinterpret_cast<const int4 *>(ec + (long long)i * CF_W);
+        const float4 *v4 = reinterpret_cast<const float4 *>(ev + (long long)i * CF_W);
+#pragma unroll
+        for (int h = 0; h < CF_W / 4; ++h) {
+            const int4 c = c4[h];
+            const float4 v = v4[h];
+            r.col[4 * h] = c.x; r.col[4 * h + 1] = c.y; r.col[4 * h + 2] = c.z; r.col[4 * h + 3] = c.w;
+            r.val[4 * h] = v.x; r.val[4 * h + 1] = v.y; r.val[4 * h + 2] = v.z; r.val[4 * h + 3] = v.w;
+        }
+        // entries are packed to the front, padding = (i, 0): deg = index of the last real entry + 1
+        int d = 0;
+#pragma unroll
+        for (int j = 0; j < CF_W; ++j) d = (r.val[j] != 0.f || r.col[j] != i) ? j + 1 : d;
+        r.deg = d;
+    }
+}
+
+// s[q] = sum_e val[e] * src[col[e]][quad (q + i % CQ) % CQ]  for local row i (entries in order: fixed summation order)
+template <int CIN>
+__device__ __forceinline__ void cf_gather(const float *src, const CfRow &row, int i, float4 (&a)[CIN / 4]) {
+    constexpr int PITCH = CIN + 4, CQ = CIN / 4;
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // every lane gathers a different row; all lanes reading the SAME channel quad would spread over only 16 of the 64 LDS
+    // banks (pitch 80 bytes).  Lane i starts at quad (i + q) % CQ instead: a[] is indexed by the logical quad through a
+    // compile-time rotation (CQ small), the per-channel summation order over the entries is unchanged.
+    const int rot = i % CQ;
+    // entries in groups of CF_G: all gathers of a group are issued before the first FMA waits for them (one LDS round trip
+    // per group instead of one per entry); a padded entry inside a started group re-reads the own row with weight 0.
+    // (Measured: groups of 4 need 64 registers for the gathered rows and make the 1024-thread kernel spill (-30 %); a
+    // 512-thread form with two rows per thread and groups of 4 fits but is 8 % slower -- the steps are bound by LDS bank
+    // conflicts of the 64 different rows a wave gathers (3.3 cycles per conflict-free cycle), not by latency.)
+    constexpr int CF_G = 1;
+#pragma unroll
+    for (int g = 0; g < CF_W / CF_G; ++g) {
+        if (CF_G * g < row.deg) {
+            float4 sv[CF_G][CQ];
+#pragma unroll
+            for (int e = 0; e < CF_G; ++e) {
+                const float *sp_ = src + row.col[CF_G * g + e] * PITCH;
+#pragma unroll
+                for (int q = 0; q < CQ; ++q) sv[e][q] = *reinterpret_cast<const float4 *>(sp_ + 4 * ((q + rot) % CQ));
+            }
+#pragma unroll
+            for (int e = 0; e < CF_G; ++e) {
+                const float v = row.val[CF_G * g + e];
+#pragma unroll
+                for (int q = 0; q < CQ; ++q) {
+                    a[q].x = fmaf(v, sv[e][q].x, a[q].x); a[q].y = fmaf(v, sv[e][q].y, a[q].y);
+                    a[q].z = fmaf(v, sv[e][q].z, a[q].z); a[q].w = fmaf(v, sv[e][q].w, a[q].w);
+                }
+            }
+        }
+    }
+}
+
+// one step on local rows [0, R), thread i = row i:  s = sum_e val[e] * src[col[e]];
+// MODE 0: dst = alpha s;  1: dst = alpha s - dst  (T_k = 2 L~ T_{k-1} - T_{k-2});  2: dst = dst + alpha s  (Clenshaw)
+template <int CIN, int MODE>
+__device__ __forceinline__ void cf_sparse_step(const float *src, float *dst, int R, float alpha, const CfRow &row, int i) {
+    constexpr int PITCH = CIN + 4, CQ = CIN / 4;
+    if (i >= R) return;
+    float4 a[CQ];
+    cf_gather<CIN>(src, row, i, a);
+    const int rot = i % CQ;
+    // a[q] holds channel quad (q + rot) % CQ
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) {
+        float4 *d = reinterpret_cast<float4 *>(dst + i * PITCH + 4 * ((q + rot) % CQ));
+        float4 o;
+        if (MODE == 0) {
+            o.x = alpha * a[q].x; o.y = alpha * a[q].y; o.z = alpha * a[q].z; o.w = alpha * a[q].w;
+        } else if (MODE == 1) {
+            const float4 z = *d;
+            o.x = fmaf(alpha, a[q].x, -z.x); o.y = fmaf(alpha, a[q].y, -z.y); o.z = fmaf(alpha, a[q].z, -z.z); o.w = fmaf(alpha, a[q].w, -z.w);
+        } else {
+            const float4 z = *d;
+            o.x = fmaf(alpha, a[q].x, z.x); o.y = fmaf(alpha, a[q].y, z.y); o.z = fmaf(alpha, a[q].z, z.z); o.w = fmaf(alpha, a[q].w, z.w);
+        }
+        *d = o;
+    }
+}
+
+// W_k fragments of the forward contraction: lane (li, lh) holds W_k[c = 8 j + 4 lh + t][32 ft + li].  Loaded BEFORE the
+// recurrence step that precedes their use, so the L2 latency hides behind the LDS gathers.
+template <int CIN, int FOUT>
+struct CfWFrag { float v[CIN / 8][FOUT / 32][4]; };
+
+template <int CIN, int FOUT>
+__device__ __forceinline__ void cf_load_w(CfWFrag<CIN, FOUT> &w, const float *W, int K, int k, int li, int lh) {
+#pragma unroll
+    for (int j = 0; j < CIN / 8; ++j)
+#pragma unroll
+        for (int ft = 0; ft < FOUT / 32; ++ft)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w.v[j][ft][t] = W[(long long)((8 * j + 4 * lh + t) * K + k) * FOUT + 32 * ft + li];
+}
+
+// acc[ft] += T[rows 32*tile .. +31][0 .. CIN) * W_k[:, 32*ft .. +31]   (wave-level; exact fp32 MFMA 32x32x2)
+// contraction index permuted: MFMA step (j, t) of lane half lh uses c = 8 j + 4 lh + t on BOTH operands
+template <int CIN, int FOUT>
+__device__ __forceinline__ void cf_contract(const float *T, int tile, int Rown, const CfWFrag<CIN, FOUT> &w, int li, int lh,
+                                            f32x16 (&acc)[FOUT / 32]) {
+    constexpr int PITCH = CIN + 4;
+    const int row = min(32 * tile + li, Rown - 1);
+#pragma unroll
+    for (int j = 0; j < CIN / 8; ++j) {
+        const float4 a = *reinterpret_cast<const float4 *>(T + row * PITCH + 8 * j + 4 * lh);
+        const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int ft = 0; ft < FOUT / 32; ++ft) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], w.v[j][ft][t], acc[ft], 0, 0, 0);
+        }
+    }
+}
+
+// (A single-buffer form of the forward kernel -- T_{k-2} of the own rows in registers, two workgroups per CU so that the
+// global-memory phases of one overlap with the LDS phases of the other -- does not fit: two 512-thread workgroups per CU
+// leave 128 registers per thread and the row entries + gathered rows need ~200.)
+template <int CIN, int FOUT>
+__global__ __launch_bounds__(CF_THREADS) void cheb_fused_fwd_kernel(ChebFusedP p) {
+    extern __shared__ float4 cf_smem[];
+    constexpr int PITCH = CIN + 4, CQ = CIN / 4;
+    float *buf0 = reinterpret_cast<float *>(cf_smem);
+    float *buf1 = buf0 + (long long)p.rmax * PITCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    int n, pt;
+    cape_map_block(blockIdx.x, p.N, p.P, n, pt);
+    const int *pi = p.pinfo + pt * 16;
+    const int *vid = p.vid + pi[0];
+    const int *ec = p.ell_col + (long long)pi[1] * CF_W;
+    const float *ev = p.ell_val + (long long)pi[1] * CF_W;
+    const int K = p.K, Rown = pi[3], Rtot = pi[3 + K - 1];
+    const float *xb = p.x + (long long)n * p.xs;
+
+    CF_STAMP(0);
+#pragma unroll
+    for (int u = 0; u < CF_RPT; ++u) {             // thread = local row(s): one index load, then the whole row
+        const int i = tid + CF_THREADS * u;
+        if (i < Rtot) {
+            const float *xr = xb + (long long)vid[i] * p.ldx;
+#pragma unroll
+            for (int q = 0; q < CQ; ++q)
+                *reinterpret_cast<float4 *>(buf0 + i * PITCH + 4 * q) = *reinterpret_cast<const float4 *>(xr + 4 * q);
+        }
+    }
+    f32x16 acc[FOUT / 32];
+#pragma unroll
+    for (int ft = 0; ft < FOUT / 32; ++ft)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[ft][g] = 0.f;
+    const bool has_tile = wave < CF_TILE_WAVES && 32 * wave < Rown;
+    CfRow row[CF_RPT];
+#pragma unroll
+    for (int u = 0; u < CF_RPT; ++u) cf_load_row(row[u], tid + CF_THREADS * u, pi[3 + (K >= 2 ? K - 2 : 0)], ec, ev);
+    __syncthreads();
+    CF_STAMP(1);
+
+    float *prev = buf0, *other = buf1;          // prev = T_{k-1}; other = T_{k-2} (overwritten by T_k)
+    CfWFrag<CIN, FOUT> wf;
+    for (int k = 1; k < K; ++k) {
+        // T_k on the (K-1-k)-ring, in place over T_{k-2}; the matrix pipe takes T_{k-1}[patch] meanwhile
+        if (has_tile) cf_load_w<CIN, FOUT>(wf, p.W, K, k - 1, li, lh);
+        if (k == 1) {
+#pragma unroll
+            for (int u = 0; u < CF_RPT; ++u) cf_sparse_step<CIN, 0>(prev, other, pi[3 + K - 1 - k], 1.f, row[u], tid + CF_THREADS * u);
+        } else {
+#pragma unroll
+            for (int u = 0; u < CF_RPT; ++u) cf_sparse_step<CIN, 1>(prev, other, pi[3 + K - 1 - k], 2.f, row[u], tid + CF_THREADS * u);
+        }
+        CF_STAMP(2 + 3 * k);
+        if (has_tile) cf_contract<CIN, FOUT>(prev, wave, Rown, wf, li, lh, acc);
+        CF_STAMP(3 + 3 * k);
+        __syncthreads();
+        CF_STAMP(4 + 3 * k);
+        float *t = prev; prev = other; other = t;
+    }
+    if (has_tile) {
+        cf_load_w<CIN, FOUT>(wf, p.W, K, K - 1, li, lh);
+        cf_contract<CIN, FOUT>(prev, wave, Rown, wf, li, lh, acc);
+    }
+    CF_STAMP(30);
+
+    if (!has_tile) return;
+    float *yb = p.y + (long long)n * p.ys;
+#pragma unroll
+    for (int ft = 0; ft < FOUT / 32; ++ft)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int r = 32 * wave + (g & 3) + 8 * (g >> 2) + 4 * lh;
+            if (r < Rown) yb[(long long)vid[r] * p.ldy + 32 * ft + li] = acc[ft][g];
+        }
+    CF_STAMP(31);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int CIN, int FOUT>
+__global__ __launch_bounds__(CF_THREADS) void cheb_fused_bwd_kernel(ChebFusedP p) {
+    extern __shared__ float4 cf_smem[];
+    constexpr int PITCH = CIN + 4, CQ = CIN / 4;
+    constexpr int CT = CIN / 16 > 0 ? (CIN + 15) / 16 : 1;      // 16-channel tiles of the 16x16x4 MFMA (Cin 8 / 24: padded rows)
+    constexpr int FT = FOUT / 16;
+    float *buf0 = reinterpret_cast<float *>(cf_smem);
+    float *buf1 = buf0 + (long long)p.rmax * PITCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, l4 = lane >> 4;
+    int n, pt;
+    cape_map_block(blockIdx.x, p.N, p.P, n, pt);
+    const int *pi = p.pinfo + pt * 16;
+    const int *vid = p.vid + pi[0];
+    const int *ec = p.ell_col + (long long)pi[1] * CF_W;
+    const float *ev = p.ell_val + (long long)pi[1] * CF_W;
+    const int K = p.K, Rown = pi[3], Rtot = pi[3 + K - 1];
+    const float *xb = p.x + (long long)n * p.xs;
+    const float *gb = p.dy + (long long)n * p.dys;
+
+    // ================= part 1: dW_k[c, f] += sum_{r in patch} T_k[r, c] dy[r, f] =================
+    // wave w contracts the patch rows [32 w, 32 w + 32) (eight k4 steps); the MFMA's A operand is T_k^T (lane (l16, l4):
+    // channel 16 ct + l16, row 4 s + l4), its B operand dy (row 4 s + l4, column 16 ft + l16) -- held in registers for all k
+#pragma unroll
+    for (int u = 0; u < CF_RPT; ++u) {             // thread = local rows tid, tid + 512: one index load, then the whole row
+        const int i = tid + CF_THREADS * u;
+        if (i < Rtot) {
+            const float *xr = xb + (long long)vid[i] * p.ldx;
+#pragma unroll
+            for (int q = 0; q < CQ; ++q)
+                *reinterpret_cast<float4 *>(buf0 + i * PITCH + 4 * q) = *reinterpret_cast<const float4 *>(xr + 4 * q);
+        }
+    }
+    float dyf[8][FT];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int r = 32 * wave + 4 * s + l4;
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) dyf[s][ft] = (wave < CF_TILE_WAVES && r < Rown) ? gb[(long long)vid[r] * p.lddy + 16 * ft + l16] : 0.f;
+    }
+    __syncthreads();
+    float *dwp = p.dwpart + ((long long)n * p.P + pt) * (long long)(K * CIN * FOUT);
+    float *red = buf1 + (long long)p.rmax * PITCH;         // [8 tile waves][CIN][FOUT]: the waves' partial tiles of one k
+    const bool has_tile = wave < CF_TILE_WAVES;
+    CfRow row[CF_RPT];
+#pragma unroll
+    for (int u = 0; u < CF_RPT; ++u) cf_load_row(row[u], tid + CF_THREADS * u, pi[3 + (K >= 2 ? K - 2 : 0)], ec, ev);
+    // per-wave partial of dW_k from T (= T_k on the patch rows) into red[wave]; then, after a barrier, the eight partials
+    // are summed in wave order into the workgroup's slab of the partial workspace (fixed order: deterministic)
+    auto dw_tile = [&](const float *T) {
+        f32x4 dacc[CT][FT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft) dacc[ct][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!has_tile) return;
+        if (32 * wave < Rown) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int r = min(32 * wave + 4 * s + l4, Rown - 1);       // (rows beyond the patch meet dy = 0)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int c = 16 * ct + l16;
+                    const float a = c < CIN ? T[r * PITCH + c] : 0.f;
+#pragma unroll
+                    for (int ft = 0; ft < FT; ++ft)
+                        dacc[ct][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, dyf[s][ft], dacc[ct][ft], 0, 0, 0);
+                }
+            }
+        }
+        float *o = red + wave * (CIN * FOUT);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = 16 * ct + 4 * l4 + g;            // 16x16 accumulator: row 4 * (lane >> 4) + g, column lane & 15
+                    if (c < CIN) o[c * FOUT + 16 * ft + l16] = dacc[ct][ft][g];
+                }
+    };
+    auto dw_flush = [&](int k) {
+        for (int e = tid; e < CIN * FOUT; e += CF_THREADS) {
+            float t = red[e];
+#pragma unroll
+            for (int w = 1; w < CF_TILE_WAVES; ++w) t += red[w * (CIN * FOUT) + e];
+            const int c = e / FOUT, f = e - c * FOUT;
+            dwp[(long long)(c * K + k) * FOUT + f] = t;
+        }
+    };
+    float *prev = buf0, *other = buf1;
+    for (int k = 1; k < K; ++k) {
+        if (k == 1) {
+#pragma unroll
+            for (int u = 0; u < CF_RPT; ++u) cf_sparse_step<CIN, 0>(prev, other, pi[3 + K - 1 - k], 1.f, row[u], tid + CF_THREADS * u);
+        }
+        else {
+#pragma unroll
+            for (int u = 0; u < CF_RPT; ++u) cf_sparse_step<CIN, 1>(prev, other, pi[3 + K - 1 - k], 2.f, row[u], tid + CF_THREADS * u);
+        }
+        dw_tile(prev);
+        __syncthreads();
+        dw_flush(k - 1);
+        __syncthreads();
+        float *t = prev; prev = other; other = t;
+    }
+    dw_tile(prev);
+    __syncthreads();
+    dw_flush(K - 1);
+    __syncthreads();
+
+    // ================= part 2: dx = sum_k T_k(L~) G_k,  G_k = dy W_k^T, by Clenshaw =================
+    // G_k tile (16 rows x 16 channels) = dy[16 rows, FOUT] * W_k^T on the 16x16x4 MFMA, contraction index permuted: step s of
+    // lane quarter l4 uses f = NF l4 + s on both operands (NF = FOUT / 4 consecutive floats per lane: wide loads).  The dy
+    // fragments do not depend on k: each wave keeps those of its (at most four) row tiles in registers for the whole
+    // Clenshaw recurrence; the W_k^T fragments are loaded once per k.
+    constexpr int NF = FOUT / 4;
+    constexpr int MAXT = (CF_THREADS * CF_RPT / 16) / (CF_THREADS / 64);      // row tiles per wave: rmax <= CF_THREADS * CF_RPT rows
+    float gfr[MAXT][NF];
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+        const int r = min(16 * (wave + (CF_THREADS / 64) * j) + l16, Rtot - 1);
+        const float *grow = gb + (long long)vid[r] * p.lddy + NF * l4;
+#pragma unroll
+        for (int h = 0; h < NF / 4; ++h) {
+            const float4 v = *reinterpret_cast<const float4 *>(grow + 4 * h);
+            gfr[j][4 * h] = v.x; gfr[j][4 * h + 1] = v.y; gfr[j][4 * h + 2] = v.z; gfr[j][4 * h + 3] = v.w;
+        }
+    }
+    float *bA = buf0, *bB = buf1;                // bA = b_{k+1}, bB = b_{k+2}
+    // b_{K-1} = G_{K-1} on the (K-1)-ring -> bA;  then for k = K-2 .. 1:  bB <- G_k - bB (bB = b_{k+2}; absent for
+    // k = K-2), barrier, bB += 2 L~ bA on the k-ring, swap;  finally dx = G_0 + L~ b_1 - b_2 on the patch.
+    auto put_g = [&](float *dst, int R, int k, bool sub) {
+        float wfr[CT][NF];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = 16 * ct + l16;
+            const float *wrow = p.W + (long long)(min(c, CIN - 1) * K + k) * FOUT + NF * l4;
+#pragma unroll
+            for (int h = 0; h < NF / 4; ++h) {
+                const float4 v = *reinterpret_cast<const float4 *>(wrow + 4 * h);
+                const bool ok = c < CIN;
+                wfr[ct][4 * h] = ok ? v.x : 0.f; wfr[ct][4 * h + 1] = ok ? v.y : 0.f;
+                wfr[ct][4 * h + 2] = ok ? v.z : 0.f; wfr[ct][4 * h + 3] = ok ? v.w : 0.f;
+            }
+        }
+        const int ntile = (R + 15) / 16;
+#pragma unroll
+        for (int j = 0; j < MAXT; ++j) {
+            const int tile = wave + (CF_THREADS / 64) * j;
+            if (tile < ntile) {
+                f32x4 gacc[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) gacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sidx = 0; sidx < NF; ++sidx)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        gacc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfr[j][sidx], wfr[ct][sidx], gacc[ct], 0, 0, 0);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int r = 16 * tile + 4 * l4 + g, c = 16 * ct + l16;
+                        if (r < R && c < CIN) {
+                            float *d = dst + r * PITCH + c;
+                            *d = sub ? gacc[ct][g] - *d : gacc[ct][g];
+                        }
+                    }
+            }
+        }
+    };
+    if (K == 1) {
+        put_g(bA, Rown, 0, false);
+        __syncthreads();
+    } else {
+        put_g(bA, pi[3 + K - 1], K - 1, false);              // b_{K-1}
+        __syncthreads();
+        for (int k = K - 2; k >= 1; --k) {
+            const int R = pi[3 + k];
+            put_g(bB, R, k, k < K - 2);                       // G_k - b_{k+2}
+            __syncthreads();
+            {
+#pragma unroll
+            for (int u = 0; u < CF_RPT; ++u) cf_sparse_step<CIN, 2>(bA, bB, R, 2.f, row[u], tid + CF_THREADS * u);
+        }          // bB[i] += 2 (L~ bA)[i]
+            __syncthreads();
+            float *t = bA; bA = bB; bB = t;
+        }
+        // dx = G_0 + L~ b_1 - b_2  (b_2 absent for K = 2)
+        put_g(bB, Rown, 0, K > 2);
+        __syncthreads();
+    }
+    float *dxb = p.dx + (long long)n * p.dxs;
+    if (K > 1) {
+        {
+#pragma unroll
+            for (int u = 0; u < CF_RPT; ++u) cf_sparse_step<CIN, 2>(bA, bB, Rown, 1.f, row[u], tid + CF_THREADS * u);
+        }           // bB = (G_0 - b_2) + L~ b_1
+        __syncthreads();
+    }
+    const float *res = K > 1 ? bB : bA;
+    for (int it = tid; it < Rown * CQ; it += CF_THREADS) {
+        const int i = it / CQ, q = it - i * CQ;
+        *reinterpret_cast<float4 *>(dxb + (long long)vid[i] * p.lddx + 4 * q) = *reinterpret_cast<const float4 *>(res + i * PITCH + 4 * q);
+    }
+}
+
+// out[j][i] = sum of the input slabs [j * per, min((j + 1) * per, nslab)) in order; thread = one float4 of one output slab
+__global__ __launch_bounds__(256) void cheb_fused_dw_reduce_kernel(const float *part, long long nslab, long long per, long long elems,
+                                                                   float *out, int accumulate) {
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q * 4 >= elems) return;
+    const long long step = elems >> 2;
+    const long long s0 = (long long)blockIdx.y * per, s1 = min(nslab, s0 + per);
+    const float4 *src = reinterpret_cast<const float4 *>(part) + q;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    long long s = s0;
+    for (; s + 3 < s1; s += 4) {
+        const float4 v0 = src[s * step], v1 = src[(s + 1) * step], v2 = src[(s + 2) * step], v3 = src[(s + 3) * step];
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+        a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+        a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+    }
+    for (; s < s1; ++s) {
+        const float4 v0 = src[s * step];
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    }
+    float4 t;
+    t.x = (a0.x + a1.x) + (a2.x + a3.x); t.y = (a0.y + a1.y) + (a2.y + a3.y);
+    t.z = (a0.z + a1.z) + (a2.z + a3.z); t.w = (a0.w + a1.w) + (a2.w + a3.w);
+    float4 *d = reinterpret_cast<float4 *>(out) + (long long)blockIdx.y * step + q;
+    if (accumulate) {
+        const float4 o = *d;
+        t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+    }
+    *d = t;
+}
+
+// (the kernels are templates over Cin in {8, 16, 24, 32} x Fout in {32, 64}; the wider instantiations of the backward
+// kernel spill registers -- up to 130 -- so only the shapes that fit are offered: everything else keeps the materialised form)
+inline bool cf_shape_ok(int Cin, int Fout, int K) {
+    return (Cin == 8 || Cin == 16) && Fout == 32 && K >= 2 && K <= CF_MAXK;
+}
+
+inline bool cf_aligned(const void *ptr, long long ss, int ld) {
+    return ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0) && ((ss & 3) == 0) && ((ld & 3) == 0);
+}
+
+template <template <int, int> class Launcher>
+inline int cf_dispatch(int Cin, int Fout, const ChebFusedP &p, size_t lds, hipStream_t st) {
+    switch (Cin * 100 + Fout) {
+        case 832: return Launcher<8, 32>::go(p, lds, st);
+        case 1632: return Launcher<16, 32>::go(p, lds, st);
+        case 2432: return Launcher<24, 32>::go(p, lds, st);
+        case 3232: return Launcher<32, 32>::go(p, lds, st);
+        case 864: return Launcher<8, 64>::go(p, lds, st);
+        case 1664: return Launcher<16, 64>::go(p, lds, st);
+        case 2464: return Launcher<24, 64>::go(p, lds, st);
+        case 3264: return Launcher<32, 64>::go(p, lds, st);
+    }
+    return CAPE_EINVAL;
+}
+
+template <int CIN, int FOUT>
+struct CfFwd {
+    static int go(const ChebFusedP &p, size_t lds, hipStream_t st) {
+        static bool set = false;
+        if (!set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&cheb_fused_fwd_kernel<CIN, FOUT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return CAPE_EINVAL;
+            set = true;
+        }
+        CAPE_LAUNCH((cheb_fused_fwd_kernel<CIN, FOUT>), dim3(p.N * p.P), dim3(CF_THREADS), lds, st, p);
+        CAPE_LAUNCH_CHECK();
+        return CAPE_OK;
+    }
+};
+
+template <int CIN, int FOUT>
+struct CfBwd {
+    static int go(const ChebFusedP &p, size_t lds, hipStream_t st) {
+        static bool set = false;
+        if (!set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&cheb_fused_bwd_kernel<CIN, FOUT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return CAPE_EINVAL;
+            set = true;
+        }
+        CAPE_LAUNCH((cheb_fused_bwd_kernel<CIN, FOUT>), dim3(p.N * p.P), dim3(CF_THREADS), lds, st, p);
+        CAPE_LAUNCH_CHECK();
+        return CAPE_OK;
+    }
+};
+
+inline int cf_fill(ChebFusedP &p, int N, int M, int Cin, int Fout, int K, int P, const int *pinfo, const int *vid, const int *ell_col,
+                   const float *ell_val, int rmax, bool bwd, size_t &lds) {
+    if (N < 1 || M < 1 || P < 1 || rmax < 1 || !pinfo || !vid || !ell_col || !ell_val || !cf_shape_ok(Cin, Fout, K))
+        return CAPE_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(ell_col) & 15) || (reinterpret_cast<uintptr_t>(ell_val) & 15)) return CAPE_EINVAL;
+    lds = (size_t)2 * rmax * (Cin + 4) * sizeof(float) + (bwd ? (size_t)CF_TILE_WAVES * Cin * Fout * sizeof(float) : 0);
+    if (lds > 160 * 1024 || rmax > CF_THREADS * CF_RPT) return CAPE_EINVAL;        // CF_RPT local rows per thread
+    p.N = N; p.M = M; p.K = K; p.P = P;
+    p.pinfo = pinfo; p.vid = vid; p.ell_col = ell_col; p.ell_val = ell_val; p.rmax = rmax;
+    p.ts = g_cf_ts;
+    return CAPE_OK;
+}
+
+}  // namespace
+
+// diagnostic: device buffer of >= 64 uint64 that the next launches stamp with s_memtime at their phase boundaries (NULL = off)
+extern "C" int cape_cheb_fused_debug_timestamps(void *ts) { g_cf_ts = (unsigned long long *)ts; return CAPE_OK; }
+
+extern "C" int cape_cheb_fused_supported(int32_t Cin, int32_t Fout, int32_t K) { return cf_shape_ok(Cin, Fout, K) ? 1 : 0; }
+
+extern "C" int cape_cheb_fused_fwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *W, float *y,
+                                   int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t M, int32_t Cin, int32_t Fout, int32_t K,
+                                   int32_t P, const int32_t *pinfo, const int32_t *vid, const int32_t *ell_col, const float *ell_val,
+                                   int32_t rmax, void *stream) {
+    ChebFusedP p{};
+    size_t lds = 0;
+    const int rc = cf_fill(p, N, M, Cin, Fout, K, P, pinfo, vid, ell_col, ell_val, rmax, false, lds);
+    if (rc != CAPE_OK) return rc;
+    if (!x || !W || !y || ldx < Cin || ldy < Fout || !cf_aligned(x, x_sample_stride, ldx)) return CAPE_EINVAL;
+    p.x = x; p.xs = x_sample_stride; p.ldx = ldx; p.W = W; p.y = y; p.ys = y_sample_stride; p.ldy = ldy;
+    return cf_dispatch<CfFwd>(Cin, Fout, p, lds, (hipStream_t)stream);
+}
+
+extern "C" int64_t cape_cheb_fused_bwd_workspace_bytes(int32_t N, int32_t Cin, int32_t Fout, int32_t K, int32_t P) {
+    if (N < 1 || P < 1 || !cf_shape_ok(Cin, Fout, K)) return CAPE_EINVAL;
+    // one slab per workgroup + the slabs of the first reduction stage
+    return ((int64_t)N * P + CF_RED_GROUPS) * (int64_t)K * Cin * Fout * (int64_t)sizeof(float);
+}
+
+extern "C" int cape_cheb_fused_bwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *dy, int64_t dy_sample_stride,
+                                   int32_t lddy, const float *W, float *dx, int64_t dx_sample_stride, int32_t lddx, float *dW,
+                                   int32_t accumulate, int32_t N, int32_t M, int32_t Cin, int32_t Fout, int32_t K, int32_t P,
+                                   const int32_t *pinfo, const int32_t *vid, const int32_t *ell_col, const float *ell_val,
+                                   int32_t rmax, void *workspace, int64_t workspace_bytes, void *stream) {
+    ChebFusedP p{};
+    size_t lds = 0;
+    const int rc = cf_fill(p, N, M, Cin, Fout, K, P, pinfo, vid, ell_col, ell_val, rmax, true, lds);
+    if (rc != CAPE_OK) return rc;
+    if (!x || !dy || !W || !dx || !dW || !workspace || ldx < Cin || lddy < Fout || lddx < Cin ||
+        !cf_aligned(x, x_sample_stride, ldx) || !cf_aligned(dx, dx_sample_stride, lddx) || (reinterpret_cast<uintptr_t>(dW) & 15))
+        return CAPE_EINVAL;
+    if (workspace_bytes < cape_cheb_fused_bwd_workspace_bytes(N, Cin, Fout, K, P)) return CAPE_EWORKSPACE;
+    p.x = x; p.xs = x_sample_stride; p.ldx = ldx; p.W = W;
+    p.dy = dy; p.dys = dy_sample_stride; p.lddy = lddy;
+    p.dx = dx; p.dxs = dx_sample_stride; p.lddx = lddx;
+    p.dwpart = (float *)workspace;
+    const int rc2 = cf_dispatch<CfBwd>(Cin, Fout, p, lds, (hipStream_t)stream);
+    if (rc2 != CAPE_OK) return rc2;
+    const long long elems = (long long)K * Cin * Fout;
+    const long long nslab = (long long)N * P;
+    const long long per = (nslab + CF_RED_GROUPS - 1) / CF_RED_GROUPS;
+    const int groups = (int)((nslab + per - 1) / per);
+    float *stage = (float *)workspace + nslab * elems;
+    const unsigned bx = (unsigned)((elems / 4 + 255) / 256);
+    CAPE_LAUNCH(cheb_fused_dw_reduce_kernel, dim3(bx, groups), dim3(256), 0, (hipStream_t)stream, (const float *)workspace, nslab, per,
+                elems, stage, 0);
+    CAPE_LAUNCH_CHECK();
+    CAPE_LAUNCH(cheb_fused_dw_reduce_kernel, dim3(bx, 1), dim3(256), 0, (hipStream_t)stream, (const float *)stage, (long long)groups,
+                (long long)groups, elems, dW, accumulate);
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}

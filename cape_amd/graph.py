@@ -155,3 +155,163 @@ def vertex_edge_table(edges, num_verts):
     np.add.at(ptr, verts + 1, 1)
     ptr = np.cumsum(ptr)
     return ptr.astype(np.int32), codes.astype(np.int32)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Vertex patches for the on-chip Chebyshev recurrence (csrc/cheb_fused.hip; polynomial orders above FUSE_MAX_K, e.g.
+# BASELINE configs[1]: K = 6).  The recurrence T_k = 2 L~ T_{k-1} - T_{k-2} (reference lib/models.py:88-96) couples a
+# vertex with its (K-1)-ring, so a workgroup that keeps T_{k-1} / T_{k-2} of a vertex patch in LDS needs the patch plus a
+# (K-1)-ring halo and recomputes the halo redundantly; step k is valid on the (K-1-k)-ring, the trailing contraction only
+# runs on the patch itself.  Compact, equal-sized patches keep that halo small: recursive spectral bisection (Fiedler
+# vector of the induced sub-graph, split at the median) -- balanced to +-1 vertex and, on the SMPL mesh, a 5-ring halo of
+# 1.5x the patch (BFS-level cuts: 3x).
+# ------------------------------------------------------------------------------------------------------------------
+def _adjacency(Lt):
+    A = sp.csr_matrix(Lt).copy()
+    A.setdiag(0)
+    A.eliminate_zeros()
+    A = (A + A.T).tocsr()
+    A.data[:] = 1.0
+    return A
+
+
+def spectral_patches(A, nparts):
+    """owner[v] in [0, nparts): recursive spectral bisection of the graph with (symmetric 0/1) adjacency ``A``."""
+    from scipy.sparse.csgraph import breadth_first_order, connected_components
+    from scipy.sparse.linalg import eigsh
+    M = A.shape[0]
+    owner = np.zeros(M, dtype=np.int32)
+
+    def ordering(sub):
+        n = sub.shape[0]
+        nc, lab = connected_components(sub, directed=False)
+        if nc > 1:                                       # components one after another
+            return np.argsort(lab, kind="stable")
+        try:
+            deg = np.asarray(sub.sum(1)).ravel()
+            vals, vecs = eigsh((sp.diags(deg) - sub).tocsc(), k=2, sigma=-1e-3, which="LM", tol=1e-6,
+                               v0=np.linspace(-1.0, 1.0, n))
+            f = vecs[:, np.argsort(vals)[1]]
+            if f[np.argmax(np.abs(f))] < 0:              # fixed sign: the plan must not depend on the solver's mood
+                f = -f
+            return np.argsort(f, kind="stable")
+        except Exception:                                # noqa: BLE001 -- any ordering is correct, only the halo grows
+            o = breadth_first_order(sub, 0, directed=False, return_predecessors=False)
+            return np.concatenate([o, np.setdiff1d(np.arange(n), o)])
+
+    def rec(idx, k, base):
+        if k == 1:
+            owner[idx] = base
+            return
+        o = ordering(A[idx][:, idx].astype(np.float64))
+        k1 = k // 2
+        cut = int(round(len(idx) * k1 / k))
+        rec(idx[o[:cut]], k1, base)
+        rec(idx[o[cut:]], k - k1, base + k1)
+
+    rec(np.arange(M), int(nparts), 0)
+    return owner
+
+
+class ChebPatchPlan(object):
+    """Patches + halos + local CSR of L~ for one (Laplacian, K, Cin) layer, flattened for csrc/cheb_fused.hip.
+
+    Per patch p (``pinfo[p]``, 16 int32): [0] offset into ``vid``; [1] first row of the patch in ``ell_col`` / ``ell_val``
+    (the kernel's form; ``csr_rowptr_off[p]`` is the offset into ``rowptr`` of the CSR form kept for checks); [2] offset into
+    ``lcol`` / ``val``; [3 + j] R_j = number of local vertices within ring <= j (j = 0 .. K-1; R_0 = the patch itself,
+    local indices are sorted by ring); rows i < R_{K-2} have CSR rows (their neighbours all lie within ring K-1).
+    """
+    LDS_BUDGET = 158 * 1024            # of the CU's 160 KB
+    MAX_OWN = 256                      # 8 waves x one 32-row MFMA tile
+    MAX_ROWS = 1024                    # one thread per local row
+    MAX_ROW_NNZ = 12                   # entries of a row the kernel keeps in registers (CF_W)
+
+    def __init__(self, Lt, K, Cin, reserve_bytes=0):
+        """``reserve_bytes``: LDS the kernel needs besides the two recurrence buffers (the backward kernel's cross-wave
+        reduction area, 8 * Cin * Fout floats)."""
+        Lt = as_csr64(Lt)
+        M, K = Lt.shape[0], int(K)
+        assert 2 <= K <= 8
+        A = _adjacency(Lt)
+        pitch = int(Cin) + 4
+        rmax_allowed = min((self.LDS_BUDGET - int(reserve_bytes)) // (2 * pitch * 4), self.MAX_ROWS)
+        if int(np.diff(Lt.indptr).max()) > self.MAX_ROW_NNZ:
+            raise ValueError("rows of the operator are longer than the %d entries the kernel holds in registers" % self.MAX_ROW_NNZ)
+        plan = None
+        for nparts in (4, 6, 8, 12, 16, 20, 24, 32, 40, 48, 64, 96, 128):
+            if -(-M // nparts) > self.MAX_OWN:
+                continue
+            cand = self._build(Lt, A, K, nparts)
+            if cand["rmax"] <= rmax_allowed:
+                plan = cand
+                break
+        if plan is None:
+            raise ValueError("no patch plan fits the LDS for K = %d, Cin = %d on a %d-vertex graph" % (K, Cin, M))
+        self.__dict__.update(plan)
+        self.K, self.M, self.Cin, self.pitch = K, M, int(Cin), pitch
+
+    @staticmethod
+    def _build(Lt, A, K, nparts):
+        M = Lt.shape[0]
+        owner = spectral_patches(A, nparts)
+        indptr, indices, data = Lt.indptr, Lt.indices, Lt.data
+        pinfo = np.zeros((nparts, 16), dtype=np.int32)
+        vids, rowptrs, lcols, vals = [], [], [], []
+        voff = roff = eoff = 0
+        rmax = 0
+        for p in range(nparts):
+            ring = np.full(M, -1, dtype=np.int32)
+            cur = owner == p
+            ring[cur] = 0
+            order = [np.flatnonzero(cur)]
+            R = [int(cur.sum())]
+            for j in range(1, K):
+                nxt = np.asarray((A @ cur.astype(np.float64)) > 0).ravel() & (ring < 0)
+                ring[nxt] = j
+                order.append(np.flatnonzero(nxt))
+                R.append(R[-1] + int(nxt.sum()))
+                cur = nxt
+            loc = np.concatenate(order).astype(np.int32)          # local index -> global vertex, sorted by ring
+            g2l = np.full(M, -1, dtype=np.int64)
+            g2l[loc] = np.arange(len(loc))
+            nrows = R[K - 2]
+            rp = [0]
+            for i in range(nrows):
+                v = loc[i]
+                cols = g2l[indices[indptr[v]:indptr[v + 1]]]
+                assert (cols >= 0).all()
+                o = np.argsort(cols, kind="stable")
+                lcols.append(cols[o].astype(np.int32))
+                vals.append(data[indptr[v]:indptr[v + 1]][o].astype(np.float32))
+                rp.append(rp[-1] + len(cols))
+            pinfo[p, 0], pinfo[p, 1], pinfo[p, 2] = voff, roff, eoff
+            pinfo[p, 3:3 + K] = R
+            vids.append(loc)
+            rowptrs.append(np.asarray(rp, dtype=np.int32))
+            voff += len(loc)
+            roff += nrows + 1
+            eoff += rp[-1]
+            rmax = max(rmax, len(loc))
+        # ELL form of the same rows (what the kernel reads): MAX_ROW_NNZ entries per row, real entries first, padding =
+        # (own local index, 0); pinfo[p][1] is re-pointed at the patch's first ELL row
+        W_ = ChebPatchPlan.MAX_ROW_NNZ
+        nrow_total = sum(len(r) - 1 for r in rowptrs)
+        ell_col = np.zeros((nrow_total, W_), dtype=np.int32)
+        ell_val = np.zeros((nrow_total, W_), dtype=np.float32)
+        csr_rowptr_off = pinfo[:, 1].copy()
+        row0 = e = 0
+        for p in range(nparts):
+            rp = rowptrs[p]
+            for i in range(len(rp) - 1):
+                d = int(rp[i + 1] - rp[i])
+                ell_col[row0 + i, :] = i
+                ell_col[row0 + i, :d] = lcols[e]
+                ell_val[row0 + i, :d] = vals[e]
+                e += 1
+            pinfo[p, 1] = row0
+            row0 += len(rp) - 1
+        return dict(P=nparts, pinfo=pinfo, vid=np.concatenate(vids), rowptr=np.concatenate(rowptrs), csr_rowptr_off=csr_rowptr_off,
+                    ell_col=ell_col, ell_val=ell_val,
+                    lcol=np.concatenate(lcols) if lcols else np.zeros(0, np.int32),
+                    val=np.concatenate(vals) if vals else np.zeros(0, np.float32), rmax=int((rmax + 3) // 4 * 4),
+                    own_max=int(pinfo[:, 3].max()), halo_factor=float(pinfo[:, 3 + K - 1].sum()) / M)

@@ -20,6 +20,9 @@ from .graph import ConvOperators, HostCSR
 # "fused":   sparse operators gathered inside the GEMM kernel's A-tile staging (one launch per layer)
 import os as _os
 MODE = _os.environ.get("CAPE_MODE", "twopass")
+# polynomial orders above the precomposed-operator limit: 1 = recurrence on chip where the layer qualifies
+# (csrc/cheb_fused.hip), 0 = always the materialised K-stack (ChebConvRecurrenceFn; the A/B reference)
+FUSED_RECURRENCE = int(_os.environ.get("CAPE_FUSED_RECURRENCE", "1"))
 
 _ACT_OF = {"b1leakyrelu": ("leaky", _lib.BIAS_CHANNEL), "b1relu": ("relu", _lib.BIAS_CHANNEL),
            "b1tanh": ("tanh", _lib.BIAS_CHANNEL), "b2relu": ("relu", _lib.BIAS_VERTEX)}
@@ -112,6 +115,37 @@ class DeviceConvOps(object):
             self.Lt = DeviceCSR(host.Lt, device)
             self.LtT = DeviceCSR(host.LtT, device)
         self.host = host
+        self.device = device
+        self._patch_plans = {}
+
+    def patch_plan(self, Cin, Fout):
+        """Device copy of graph.ChebPatchPlan for the on-chip recurrence (csrc/cheb_fused.hip), or None when the layer
+        does not qualify: precomposed operators (K <= 3), pool / unpool around the layer, an asymmetric operator,
+        channel counts outside the kernel's set, or no patch plan that fits the LDS."""
+        key = (int(Cin), int(Fout))
+        if key not in self._patch_plans:
+            plan = None
+            host = self.host
+            ok = (not self.fused and host.unfused_unpool is None and host.unfused_pool is None
+                  and lib.cape_cheb_fused_supported(int(Cin), int(Fout), int(self.K)) == 1)
+            if ok:
+                from .graph import ChebPatchPlan
+                Lt = host.Lt.to_scipy()
+                if abs(Lt - Lt.T).max() <= 1e-6 * max(abs(Lt).max(), 1e-30):       # the adjoint kernel applies L~ itself
+                    try:
+                        plan = DevicePatchPlan(ChebPatchPlan(Lt, self.K, Cin, reserve_bytes=8 * 4 * int(Cin) * int(Fout)), self.device)
+                    except ValueError:
+                        plan = None
+            self._patch_plans[key] = plan
+        return self._patch_plans[key]
+
+
+class DevicePatchPlan(object):
+    def __init__(self, host, device):
+        self.host = host
+        self.P, self.rmax, self.K, self.M = host.P, host.rmax, host.K, host.M
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.pinfo, self.vid, self.ell_col, self.ell_val = t(host.pinfo), t(host.vid), t(host.ell_col), t(host.ell_val)
 
 
 def _mk_srcs(entries):
@@ -1009,6 +1043,62 @@ class ChebConvRecurrenceFn(torch.autograd.Function):
         return dx, dW, dB, None, None, None
 
 
+class ChebConvFusedFn(torch.autograd.Function):
+    """General-K chebyshev5 (lib/models.py:69-103) with the recurrence of :88-96 kept on chip (csrc/cheb_fused.hip): one
+    launch forward, one (+ the fixed-order weight-gradient reduction) backward; the K-stack never reaches HBM."""
+
+    @staticmethod
+    def forward(ctx, x, W, ops, plan):
+        _lib.require_gpu()
+        x = as_act(x)
+        N, M, Cin = x.shape
+        K, Fout = ops.K, W.shape[1]
+        if (x.stride(1) & 3) or (N > 1 and (x.stride(0) & 3)) or (x.data_ptr() & 15):
+            xa = alloc_act(N, M, Cin, x.device)
+            xa.copy_(x)
+            x = xa
+        W = W.contiguous()
+        y = alloc_act(N, M, Fout, x.device)
+        xp, xs, xl = _v(x)
+        yp, ys, yl = _v(y)
+        nnz = int(ops.host.Lt.nnz)
+        flops = 2 * N * M * Cin * K * Fout + (K - 1) * 2 * nnz * Cin * N + max(K - 2, 0) * 2 * M * Cin * N
+        _log_launch("cheb_fused_fwd_kernel", flops, 4 * (N * M * (Cin + Fout) + Cin * K * Fout) + 8 * nnz + 4 * (M + 1),
+                    lambda: check(lib.cape_cheb_fused_fwd(xp, xs, xl, _ptr(W), yp, ys, yl, N, M, Cin, Fout, K, plan.P, _ptr(plan.pinfo),
+                                                          _ptr(plan.vid), _ptr(plan.ell_col), _ptr(plan.ell_val), plan.rmax, _stream()), "cape_cheb_fused_fwd"))
+        ctx.ops, ctx.plan = ops, plan
+        ctx.save_for_backward(x, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        ops, plan = ctx.ops, ctx.plan
+        N, M, Cin = x.shape
+        K, Fout = ops.K, W.shape[1]
+        g = as_act(g)
+        if (g.stride(1) & 3) or (N > 1 and (g.stride(0) & 3)) or (g.data_ptr() & 15):
+            ga = alloc_act(N, M, Fout, g.device)
+            ga.copy_(g)
+            g = ga
+        dx = alloc_act(N, M, Cin, x.device)
+        dW = torch.empty_like(W)
+        need = int(lib.cape_cheb_fused_bwd_workspace_bytes(N, Cin, Fout, K, plan.P))
+        if need < 0:
+            check(need, "cape_cheb_fused_bwd_workspace_bytes")
+        ws = torch.empty((need + 3) // 4, device=x.device, dtype=torch.float32)
+        xp, xs, xl = _v(x)
+        gp, gs, gl = _v(g)
+        dp, ds, dl = _v(dx)
+        nnz = int(ops.host.Lt.nnz)
+        flops = 2 * (2 * N * M * Cin * K * Fout + (K - 1) * 2 * nnz * Cin * N + max(K - 2, 0) * 2 * M * Cin * N)
+        _log_launch("cheb_fused_bwd_kernel", flops, 4 * (2 * N * M * Cin + N * M * Fout + 2 * Cin * K * Fout) + 8 * nnz + 4 * (M + 1),
+                    lambda: check(lib.cape_cheb_fused_bwd(xp, xs, xl, gp, gs, gl, _ptr(W), dp, ds, dl, _ptr(dW), 0, N, M, Cin, Fout, K,
+                                                          plan.P, _ptr(plan.pinfo), _ptr(plan.vid), _ptr(plan.ell_col), _ptr(plan.ell_val),
+                                                          plan.rmax, _ptr(ws), need, _stream()), "cape_cheb_fused_bwd"))
+        return dx, dW, None, None
+
+
 class SparseOpFn(torch.autograd.Function):
     """y[n] = P x[n]  -- poolwT (lib/models.py:129-152) as a standalone operator."""
 
@@ -1174,7 +1264,16 @@ def chebyshev5(x, W, ops, bias=None, activation=None, cond=None, W_affine=None, 
     assert W_affine is None and coef is None
     if cond_in is not None:
         x = ConcatCondFn.apply(x, cond_in)
-    y = ChebConvRecurrenceFn.apply(x, W, bias, ops, act, bmode)
+    plan = None
+    if FUSED_RECURRENCE and x.is_cuda and x.dtype == torch.float32 and W.shape[0] == x.shape[2] * ops.K:
+        plan = ops.patch_plan(x.shape[2], W.shape[1])
+    if plan is not None:
+        # recurrence on chip; a bias / activation of the layer runs as the standalone element-wise operator
+        y = ChebConvFusedFn.apply(x, W, ops, plan)
+        if bias is not None or act != "none":
+            y = BiasActFn.apply(y, bias, act, bmode)
+    else:
+        y = ChebConvRecurrenceFn.apply(x, W, bias, ops, act, bmode)
     if cond is not None:
         y = ConcatCondFn.apply(y, cond)
     return y

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CAPE_ABI_VERSION 8
+#define CAPE_ABI_VERSION 9
 #define CAPE_MAX_SRC 8
 
 /* error codes (negative = argument error; positive values are hipError_t) */
@@ -496,6 +496,40 @@ int cape_bwd_prep_bf16(const void *g, int64_t g_sample_stride, int32_t ldg, cons
 /* out[m, c] (+)= sum_n x[n, m, c]: gradient of the per-vertex output bias [1, M, F] (lib/models.py:615) from a bf16 dz */
 int cape_colsum_vertex_bf16(const void *x, int64_t x_sample_stride, int32_t ldx, int32_t N, int32_t M, int32_t C,
                             int32_t accumulate, float *out, void *stream);
+
+/*
+ * General-K Chebyshev graph convolution with the recurrence ON CHIP -- reference lib/models.py:69-103 in the form of its
+ * explicit recurrence (:88-96: x_k = 2 L~ x_{k-1} - x_{k-2}), for plain layers (no pool / unpool, no bias) of polynomial
+ * order 2..8; BASELINE configs[1] is one such layer (K = 6, 64 x 6890 x 16 -> 32).  One workgroup per (sample, vertex
+ * patch) keeps the running pair of the recurrence for the patch and its (K-1)-ring halo in LDS and contracts
+ * y[patch] += T_k[patch] W_k from there; the K-stack [M, Fin*K] the reference concatenates (:85-99) never exists in HBM.
+ *   y[n] = sum_k T_k(L~) x[n] W_k,   W in the reference layout [Cin*K, Fout], row c*K + k  (:99-102)
+ * The patch plan (cape_amd.graph.ChebPatchPlan) is host data uploaded once per (Laplacian, K, Cin):
+ *   pinfo [P][16] int32: [0] offset into vid, [1] first ELL row of the patch, [2] unused,
+ *                        [3 + j] number of local vertices within ring <= j of the patch (j = 0 .. K-1; local indices are
+ *                        sorted by ring, [3] = the patch itself, at most 256)
+ *   vid    global vertex of every local index;  ell_col / ell_val [rows][12] (16-byte aligned): the rows of L~ of the
+ *          local vertices within ring <= K-2 in ELL form, column = LOCAL index (all their neighbours lie within ring
+ *          <= K-1), real entries first, padded with (own local index, 0); rows longer than 12 entries are not supported
+ *   rmax   largest patch + halo (multiple of 4): 2 * rmax * (Cin + 4) floats of LDS (+ 8 * Cin * Fout backward)
+ * Supported: fp32, Cin in {8, 16, 24, 32}, Fout in {32, 64}, rows 16-byte aligned (cape_cheb_fused_supported).
+ * The backward entry needs L~ symmetric (it is: lib/mesh_sampling.py:10-38 builds I - D^-1/2 A D^-1/2); it recomputes the
+ * recurrence for dW = sum_n sum_k T_k(L~) x[n]^T dy[n] (per-workgroup partials in ``workspace``, reduced in a fixed order)
+ * and evaluates dx[n] = sum_k T_k(L~) dy[n] W_k^T by Clenshaw's recurrence.  Deterministic, no atomics.
+ */
+int cape_cheb_fused_supported(int32_t Cin, int32_t Fout, int32_t K);
+int cape_cheb_fused_fwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *W, float *y,
+                        int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t M, int32_t Cin, int32_t Fout, int32_t K,
+                        int32_t P, const int32_t *pinfo, const int32_t *vid, const int32_t *ell_col, const float *ell_val,
+                        int32_t rmax, void *stream);
+int64_t cape_cheb_fused_bwd_workspace_bytes(int32_t N, int32_t Cin, int32_t Fout, int32_t K, int32_t P);
+int cape_cheb_fused_bwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *dy, int64_t dy_sample_stride,
+                        int32_t lddy, const float *W, float *dx, int64_t dx_sample_stride, int32_t lddx, float *dW,
+                        int32_t accumulate, int32_t N, int32_t M, int32_t Cin, int32_t Fout, int32_t K, int32_t P,
+                        const int32_t *pinfo, const int32_t *vid, const int32_t *ell_col, const float *ell_val,
+                        int32_t rmax, void *workspace, int64_t workspace_bytes, void *stream);
+/* diagnostic: device buffer of >= 64 uint64 stamped with s_memtime at the forward kernel's phase boundaries (NULL = off) */
+int cape_cheb_fused_debug_timestamps(void *ts);
 
 #ifdef __cplusplus
 }

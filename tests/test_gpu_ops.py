@@ -230,3 +230,120 @@ def test_baseline_config2_full_size(mesh_ops, dev):
     assert vertex_err(hy.detach().cpu().numpy(), ty.detach().numpy()) < TOL
     assert vertex_err(hx.grad.cpu().numpy(), tx.grad.numpy()) < TOL
     assert mat_err(hW.grad.cpu().numpy(), tW.grad.numpy()) < TOL
+
+
+FUSED_CASES = [
+    # level, N, Cin, Fout, K
+    (0, 3, 16, 32, 6),        # BASELINE configs[1]'s layer shape (small batch)
+    (0, 2, 8, 32, 4),
+    (2, 5, 16, 32, 5),        # 3445 vertices, N not a multiple of 8 (plain block -> (sample, patch) map)
+    (4, 8, 8, 32, 7),         # 1723 vertices
+    (6, 2, 16, 32, 8),        # 862 vertices, the largest order
+    (0, 2, 16, 32, 2),        # order 2 through the same kernel (forced: the library's default for K <= 3 is the precomposed form)
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES, ids=["L%d_N%d_%dto%d_K%d" % c for c in FUSED_CASES])
+def test_cheb_fused_recurrence(case, mesh_ops, dev):
+    """csrc/cheb_fused.hip (recurrence of lib/models.py:88-96 kept in LDS per vertex patch) against the float64 twin:
+    forward, data gradient and weight gradient; the kernel must actually have been the one that ran, and it must agree
+    with the materialised K-stack form of the same layer."""
+    import scipy.sparse as sp
+    from cape_amd import ops
+    from cape_amd.graph import ConvOperators
+    from cape_amd.mesh_sampling import rescale_L
+    from oracle import torch_twin as tt
+    level, N, Cin, Fout, K = case
+    L = mesh_ops["L"][level]
+    M = L.shape[0]
+    rng = np.random.default_rng(1000 * level + 10 * K + Cin)
+    x = rng.standard_normal((N, M, Cin))
+    W = 0.1 * rng.standard_normal((Cin * K, Fout))
+    dy = rng.standard_normal((N, M, Fout))
+    tx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    tW = torch.tensor(W, dtype=torch.float64, requires_grad=True)
+    ty = tt.chebyshev5(tx, L, tW, K)
+    ty.backward(torch.tensor(dy))
+
+    host = ConvOperators(L, K)
+    if host.fused:                                   # K <= 3: build the recurrence form explicitly for this test
+        import cape_amd.graph as G
+        old = G.FUSE_MAX_K
+        G.FUSE_MAX_K = 1
+        try:
+            host = ConvOperators(L, K)
+        finally:
+            G.FUSE_MAX_K = old
+    dops = ops.DeviceConvOps(host, dev)
+    plan = dops.patch_plan(Cin, Fout)
+    assert plan is not None and plan.host.own_max <= 256
+    # every vertex belongs to exactly one patch; ring sizes grow; local CSR rows reproduce L~
+    ph = plan.host
+    own = np.concatenate([ph.vid[ph.pinfo[p, 0]:ph.pinfo[p, 0] + ph.pinfo[p, 3]] for p in range(ph.P)])
+    assert np.array_equal(np.sort(own), np.arange(M))
+    Lt = sp.csr_matrix(rescale_L(sp.csr_matrix(L), lmax=2))
+    Lt.sort_indices()
+    for p in (0, ph.P - 1):
+        v0, e0 = int(ph.pinfo[p, 0]), int(ph.pinfo[p, 2])
+        r0 = int(ph.csr_rowptr_off[p])
+        R = ph.pinfo[p, 3:3 + K]
+        assert np.all(np.diff(R) >= 0)
+        vid = ph.vid[v0:v0 + R[-1]]
+        nrow = int(R[max(K - 2, 0)])
+        rp = ph.rowptr[r0:r0 + nrow + 1]
+        i = nrow - 1
+        cols, vals = vid[ph.lcol[e0 + rp[i]:e0 + rp[i + 1]]], ph.val[e0 + rp[i]:e0 + rp[i + 1]]
+        ref = Lt[int(vid[i])]
+        o = np.argsort(cols)
+        assert np.array_equal(cols[o], ref.indices) and np.allclose(vals[o], ref.data.astype(np.float32))
+
+    hx = torch.tensor(x, dtype=torch.float32, device=dev, requires_grad=True)
+    hW = torch.tensor(W, dtype=torch.float32, device=dev, requires_grad=True)
+    ops.LAUNCH_LOG = []
+    try:
+        hy = ops.chebyshev5(hx, hW, dops)
+        hy.backward(torch.tensor(dy, dtype=torch.float32, device=dev))
+        torch.cuda.synchronize()
+        names = [e[0] for e in ops.LAUNCH_LOG]
+    finally:
+        ops.LAUNCH_LOG = None
+    assert names == ["cheb_fused_fwd_kernel", "cheb_fused_bwd_kernel"], names
+    assert vertex_err(hy.detach().cpu().numpy(), ty.detach().numpy()) < TOL
+    assert vertex_err(hx.grad.cpu().numpy(), tx.grad.numpy()) < TOL
+    assert mat_err(hW.grad.cpu().numpy(), tW.grad.numpy()) < TOL
+    # the materialised form of the same layer (the A/B reference): same numbers to fp32 accuracy
+    gx, gW = hx.grad.clone(), hW.grad.clone()
+    hx.grad = hW.grad = None
+    ops.FUSED_RECURRENCE = 0
+    try:
+        hy2 = ops.chebyshev5(hx, hW, dops)
+        hy2.backward(torch.tensor(dy, dtype=torch.float32, device=dev))
+    finally:
+        ops.FUSED_RECURRENCE = 1
+    assert vertex_err(hy.detach().cpu().numpy(), hy2.detach().cpu().numpy().astype(np.float64)) < TOL
+    assert vertex_err(gx.cpu().numpy(), hx.grad.cpu().numpy().astype(np.float64)) < TOL
+    assert mat_err(gW.cpu().numpy(), hW.grad.cpu().numpy().astype(np.float64)) < TOL
+
+
+def test_cheb_fused_with_bias_and_activation(mesh_ops, dev):
+    """A K = 5 layer with channel bias + leaky ReLU: recurrence on chip, bias / activation as the standalone operator."""
+    from cape_amd import ops
+    from cape_amd.graph import ConvOperators
+    from oracle import torch_twin as tt
+    N, Cin, Fout, K = 2, 16, 32, 5
+    L = mesh_ops["L"][2]
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((N, L.shape[0], Cin))
+    W = 0.1 * rng.standard_normal((Cin * K, Fout))
+    b = 0.1 * rng.standard_normal((1, 1, Fout))
+    dy = rng.standard_normal((N, L.shape[0], Fout))
+    tx, tW, tb = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (x, W, b))
+    ty = tt.bias_act(tt.chebyshev5(tx, L, tW, K), tb, "b1leakyrelu")
+    ty.backward(torch.tensor(dy))
+    hx, hW, hb = (torch.tensor(a, dtype=torch.float32, device=dev, requires_grad=True) for a in (x, W, b))
+    hy = ops.chebyshev5(hx, hW, ops.DeviceConvOps(ConvOperators(L, K), dev), bias=hb, activation="b1leakyrelu")
+    hy.backward(torch.tensor(dy, dtype=torch.float32, device=dev))
+    assert vertex_err(hy.detach().cpu().numpy(), ty.detach().numpy()) < TOL
+    assert vertex_err(hx.grad.cpu().numpy(), tx.grad.numpy()) < TOL
+    assert mat_err(hW.grad.cpu().numpy(), tW.grad.numpy()) < TOL
+    assert mat_err(hb.grad.cpu().numpy(), tb.grad.numpy()) < TOL
