@@ -76,6 +76,33 @@ __device__ __forceinline__ void gs_store8(unsigned char *dst, int plane, const f
 __device__ __forceinline__ constexpr int gs_ta(int np, int t) { return np == 1 ? 0 : (t == 1 ? 2 : ((t == 2 || t == 4) ? 1 : 0)); }
 __device__ __forceinline__ constexpr int gs_tb(int np, int t) { return np == 1 ? 0 : (t == 0 ? 2 : ((t == 2 || t == 3) ? 1 : 0)); }
 
+// Weights of the bf16-storage launches keep TWO bf16 planes, w = hi + mid (hi = the top 16 bits, mid = the remainder
+// rounded to nearest: 16 significant bits), multiplied as two MFMA products against the one-plane activations.  The
+// fp32 master weights rounded to a single bf16 were the dominant error of the bf16 model: the same rounded weight meets
+// every vertex and sample, so its error does not average out -- prediction error 2.0e-2 with one plane against 6.3e-3
+// when only the activations are bf16 (tools/diag_bf16_error.py, profiles/r03_diag_bf16_error.txt).  The launches are
+// HBM-bound, the second product costs matrix-pipe time that was idle.
+__device__ __forceinline__ void gs_store8_w2(unsigned char *dst, int plane, const float (&v)[8]) {
+    uint4 hi, mid;
+    unsigned *ph = &hi.x, *pm = &mid.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned h0 = gs_bits(v[2 * j]) & 0xFFFF0000u, h1 = gs_bits(v[2 * j + 1]) & 0xFFFF0000u;
+        const float r0 = v[2 * j] - gs_float(h0), r1 = v[2 * j + 1] - gs_float(h1);        // exact
+        ph[j] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+        pm[j] = cape_pack_bf16(r0, r1);
+    }
+    *reinterpret_cast<uint4 *>(dst) = hi;
+    *reinterpret_cast<uint4 *>(dst + plane) = mid;
+}
+
+// planes of the A (activation) and B (weight) operand and the MFMA products per multiply-add:
+//   fp32 storage: 3 / 3 planes, 6 products;  bf16 storage: 1 / NPB planes (NPB = 2 for weights, 1 when B is an activation
+//   too -- the weight gradient), NPB products
+__device__ __forceinline__ constexpr int gs_nt(int npa, int npb) { return npa == 3 ? 6 : npb; }
+__device__ __forceinline__ constexpr int gs_pa(int npa, int t) { return npa == 3 ? gs_ta(3, t) : 0; }
+__device__ __forceinline__ constexpr int gs_pb(int npa, int npb, int t) { return npa == 3 ? gs_tb(3, t) : (npb == 2 ? 1 - t : 0); }   // mid first
+
 template <int NP>
 __device__ __forceinline__ void gs_store8_np(unsigned char *dst, int plane, const float (&v)[8]) {
     if constexpr (NP == 3) {
@@ -101,24 +128,32 @@ __device__ __forceinline__ void gs_interleave() {
     }
 }
 
+template <int NPB>
+__device__ __forceinline__ void gs_store_w(unsigned char *dst, int plane, const float (&v)[8]) {
+    if constexpr (NPB == 3) gs_store8(dst, plane, v);
+    else gs_store8_w2(dst, plane, v);
+}
+
 // Workgroup tile BM x BN, 4 waves as 2 x 2, wave tile (BM/2) x (BN/2).  DUAL: sources may carry a second weight set
 // (w2) accumulated into a second tile, combined as relu(acc) + acc2 by the shared epilogue (res_block_affine,
 // reference lib/models.py:776-793); its LDS holds a third group of planes, so the DUAL tile is 128 x 64.
 // AT = float: fp32 activations, three bf16 planes per operand, six products.  AT = cape_bf16: activations (sources and
-// output) stored as bf16, weights still fp32 in HBM (rounded to bf16 while staged), one plane, one product, fp32 accumulate.
+// output) stored as bf16: one activation plane; weights still fp32 in HBM, staged as two bf16 planes hi + mid (gs_store8_w2),
+// two products per multiply-add, fp32 accumulate.
 template <int BM, int BN, bool BKC, bool DUAL = false, typename AT = float>
 __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_BIG_MINB : 4) void gemm_split_kernel(GconvParams p) {
     constexpr bool BF = cape_is_bf16<AT>::value;
-    constexpr int NP = BF ? 1 : 3;
+    constexpr int NP = BF ? 1 : 3;              // planes of the activation operand
+    constexpr int NPB = BF ? 2 : 3;             // planes of the weight operand (bf16 storage: hi + mid, see gs_store8_w2)
     constexpr int WTM = BM / 2, WTN = BN / 2;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int PA = BM / 64, PB = BN / 64;      // staging passes of the k-contiguous form: 64 rows x 4 eight-float groups
     constexpr int KPT = BN / 8;                     // [k][n] weight staging: one output column, KPT consecutive k per thread
     constexpr int APLANE = BM * GS_PITCH, BPLANE = BN * GS_PITCH;
     static_assert(TM >= 1 && TN >= 1 && (BN == 64 || BN == 128), "tile");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NP * (APLANE + (DUAL ? 2 : 1) * BPLANE)];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NP * APLANE + NPB * (DUAL ? 2 : 1) * BPLANE];
     unsigned char *sA = smem, *sB = smem + NP * APLANE;
-    unsigned char *sB2 = sB + NP * BPLANE;          // DUAL only
+    unsigned char *sB2 = sB + NPB * BPLANE;         // DUAL only
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
@@ -248,26 +283,26 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_B
         }
         if constexpr (BKC) {
 #pragma unroll
-            for (int i = 0; i < PB; ++i) gs_store8_np<NP>(sB + (r + 64 * i) * GS_PITCH + 16 * gs_seg(r + 64 * i, q), BPLANE, rbv[i]);
+            for (int i = 0; i < PB; ++i) gs_store_w<NPB>(sB + (r + 64 * i) * GS_PITCH + 16 * gs_seg(r + 64 * i, q), BPLANE, rbv[i]);
         } else {
 #pragma unroll
             for (int g = 0; g < KPT / 8; ++g) {
                 const float v[8] = {rbv[0][8 * g + 0], rbv[0][8 * g + 1], rbv[0][8 * g + 2], rbv[0][8 * g + 3],
                                     rbv[0][8 * g + 4], rbv[0][8 * g + 5], rbv[0][8 * g + 6], rbv[0][8 * g + 7]};
-                gs_store8_np<NP>(sB + bcol * GS_PITCH + 16 * gs_seg(bcol, kg * (KPT / 8) + g), BPLANE, v);
+                gs_store_w<NPB>(sB + bcol * GS_PITCH + 16 * gs_seg(bcol, kg * (KPT / 8) + g), BPLANE, v);
             }
         }
         if constexpr (DUAL) {
             if (s_has2) {
                 if constexpr (BKC) {
 #pragma unroll
-                    for (int i = 0; i < PB; ++i) gs_store8_np<NP>(sB2 + (r + 64 * i) * GS_PITCH + 16 * gs_seg(r + 64 * i, q), BPLANE, rbv2[i]);
+                    for (int i = 0; i < PB; ++i) gs_store_w<NPB>(sB2 + (r + 64 * i) * GS_PITCH + 16 * gs_seg(r + 64 * i, q), BPLANE, rbv2[i]);
                 } else {
 #pragma unroll
                     for (int g = 0; g < KPT / 8; ++g) {
                         const float v[8] = {rbv2[0][8 * g + 0], rbv2[0][8 * g + 1], rbv2[0][8 * g + 2], rbv2[0][8 * g + 3],
                                             rbv2[0][8 * g + 4], rbv2[0][8 * g + 5], rbv2[0][8 * g + 6], rbv2[0][8 * g + 7]};
-                        gs_store8_np<NP>(sB2 + bcol * GS_PITCH + 16 * gs_seg(bcol, kg * (KPT / 8) + g), BPLANE, v);
+                        gs_store_w<NPB>(sB2 + bcol * GS_PITCH + 16 * gs_seg(bcol, kg * (KPT / 8) + g), BPLANE, v);
                     }
                 }
             }
@@ -285,9 +320,9 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_B
         // rows wm*WTM + a*32 + li: all tile offsets are multiples of 32, so the swizzle term (row >> 2) & 3 is that of li
         const unsigned char *pa = sA + (wm * WTM + li) * GS_PITCH;
         const unsigned char *pb = sB + (wn * WTN + li) * GS_PITCH;
-        constexpr int NT = NP == 3 ? 6 : 1;
+        constexpr int NT = gs_nt(NP, NPB);
         static_assert(GS_KC == 32, "two k16 steps per chunk");
-        bf16x8 af[2][TM][NP], bf[2][TN][NP], bf2[2][DUAL ? TN : 1][DUAL ? NP : 1];
+        bf16x8 af[2][TM][NP], bf[2][TN][NPB], bf2[2][DUAL ? TN : 1][DUAL ? NPB : 1];
         auto rd = [&](int ks, auto W2) {
             const int so = 16 * gs_seg(li, lh + 2 * ks);             // byte offset of this lane's 16-byte segment
 #pragma unroll
@@ -298,17 +333,17 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_B
 #pragma unroll
             for (int b = 0; b < TN; ++b)
 #pragma unroll
-                for (int pc = 0; pc < NP; ++pc)
+                for (int pc = 0; pc < NPB; ++pc)
                     bf[ks][b][pc] = *reinterpret_cast<const bf16x8 *>(pb + pc * BPLANE + b * 32 * GS_PITCH + so);
             if constexpr (decltype(W2)::value) {
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
 #pragma unroll
-                    for (int pc = 0; pc < NP; ++pc)
-                        bf2[ks][b][pc] = *reinterpret_cast<const bf16x8 *>(pb + NP * BPLANE + pc * BPLANE + b * 32 * GS_PITCH + so);
+                    for (int pc = 0; pc < NPB; ++pc)
+                        bf2[ks][b][pc] = *reinterpret_cast<const bf16x8 *>(pb + NPB * BPLANE + pc * BPLANE + b * 32 * GS_PITCH + so);
             }
         };
-        // piece indices (0 = hi, 1 = mid, 2 = lo) of the six products, smallest first (bf16 storage: the one product)
+        // piece indices (0 = hi, 1 = mid, 2 = lo) of the six products, smallest first (bf16 storage: activation x weight-mid, then activation x weight-hi)
         auto mm = [&](int ks, auto W2) {
 #pragma unroll
             for (int term = 0; term < NT; ++term)
@@ -316,7 +351,7 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_B
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][a][gs_ta(NP, term)], bf[ks][b][gs_tb(NP, term)], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][a][gs_pa(NP, term)], bf[ks][b][gs_pb(NP, NPB, term)], acc[a][b], 0, 0, 0);
             if constexpr (decltype(W2)::value) {
 #pragma unroll
                 for (int term = 0; term < NT; ++term)
@@ -324,7 +359,7 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_B
                     for (int a = 0; a < TM; ++a)
 #pragma unroll
                         for (int b = 0; b < TN; ++b)
-                            acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][a][gs_ta(NP, term)], bf2[ks][b][gs_tb(NP, term)], acc2[a][b], 0, 0, 0);
+                            acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][a][gs_pa(NP, term)], bf2[ks][b][gs_pb(NP, NPB, term)], acc2[a][b], 0, 0, 0);
             }
         };
         auto chunk = [&](auto W2) {
@@ -333,7 +368,7 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_B
             __builtin_amdgcn_sched_barrier(0);
             rd(1, W2);
             mm(0, W2);
-            gs_interleave<NT * TM * TN * (w2 ? 2 : 1), NP * (TM + TN * (w2 ? 2 : 1))>();
+            gs_interleave<NT * TM * TN * (w2 ? 2 : 1), NP * TM + NPB * TN * (w2 ? 2 : 1)>();
             __builtin_amdgcn_sched_barrier(0);
             mm(1, W2);
         };

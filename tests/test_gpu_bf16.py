@@ -14,7 +14,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 TOL = 2e-2
-BF16_GRAD_TOL = 5e-2      # gradients of the bf16 network against fp64 on the same activation pattern (relative L2)
+BF16_GRAD_TOL = 1e-2      # gradients of the bf16 network against fp64 on the same activation pattern (relative L2; measured 2.5e-3 global, 8.8e-3 worst variable)
 
 
 def vertex_err(a, ref):
@@ -139,7 +139,7 @@ def test_bf16_backward_kernels_on_identical_inputs(mesh_ops):
         ChP = (Ch + 3) // 4 * 4
         Gall = ops.alloc_act(N, Mo, K * ChP, dev, dtype=bf)
         ops.gconv_fwd([dict(x=dz, csr=None, w=(W, 0, 1, Fout))], Gall, deinterleave=K, F=K * Ch)
-        Gref = dz.float() @ W.to(bf).float().t()           # the kernel rounds the weights to bf16 while staging them
+        Gref = dz.float() @ W.t()                          # (weights enter as two bf16 planes hi + mid: 16 significant bits)
         Gs = [Gall[:, :, k * ChP:k * ChP + Ch] for k in range(K)]
         for k in range(K):
             assert rel(Gs[k], Gref[:, :, k::K]) < 1e-2, k
@@ -212,12 +212,11 @@ def test_full_model_bf16_storage(mesh_ops):
     e_zm = T.rel_err(out['z_mean'].detach().cpu().numpy(), zm.detach().numpy())
     e_zl = T.rel_err(out['z_logvar'].detach().cpu().numpy(), zl.detach().numpy())
     print("bf16 storage forward: prediction relative L2 %.2e, worst vertex %.2e;  z_mean %.2e  z_logvar %.2e" % (e_pred_l2, e_pred, e_zm, e_zl))
-    # SURVEY 8c asks <= 2e-2 relative vs the fp32 path.  Single operators sit at 3e-3 and the encoder (9 layers + dense heads)
-    # at 5e-3; the reconstruction after the WHOLE chain -- 35 stacked layers, each rounding its output (and, on up-sampling
-    # layers, one intermediate) to bf16, random-initialised weights -- measures 2.06e-2 relative L2 (2.1e-2 at the worst vertex)
-    # on these inputs: the bar is met per operator and at the latent heads, and missed by 3 % of itself at the end of the
-    # decoder; the assertion below is the measured level with headroom, stated here rather than hidden in a looser metric.
-    assert out['prediction'].dtype == torch.float32 and e_pred_l2 < 3e-2 and e_pred < 5e-2 and e_zm < TOL and e_zl < TOL
+    # SURVEY 8c asks <= 2e-2 relative vs the fp32 path.  With the fp32 master weights rounded to ONE bf16 plane the
+    # reconstruction after the whole chain (35 stacked layers) measured 2.0e-2 relative L2 / 2.35e-2 at the worst vertex on
+    # these inputs -- the weight rounding, identical for every vertex and sample, was the dominant and coherent part
+    # (tools/diag_bf16_error.py: 6.3e-3 with exact weights).  The contractions now take the weights as two bf16 planes.
+    assert out['prediction'].dtype == torch.float32 and e_pred_l2 < TOL and e_pred < TOL and e_zm < TOL and e_zl < TOL
     for k in ('recon', 'latent', 'edge', 'gan_g', 'gan_d', 'loss_g', 'loss_d'):
         assert abs(float(out[k]) - float(ls[k])) < TOL * max(abs(float(ls[k])), 1e-3), (k, float(out[k]), float(ls[k]))
     tg = torch.autograd.grad(ls['loss_g'], [twin.params[n] for n in g_names], retain_graph=True, allow_unused=True)
