@@ -235,9 +235,10 @@ def test_full_model_bf16_storage(mesh_ops):
                 worst = (n, e)
     gl = np.sqrt(num / den)
     print("bf16 storage gradients: global relative L2 error %.2e; worst variable (max-norm) %s %.2e" % (gl, worst[0], worst[1]))
-    # the gradient of the bf16 network for ITS activation pattern; against the fp64 pattern every (leaky-)ReLU layer adds
-    # a few per cent (see test_cheb_conv_bf16) -- bounded, reported, not a parity figure
-    assert gl < 0.25, gl
+    # the gradient of the bf16 network for ITS activation pattern, compared here with the fp64 pattern (units within the bf16
+    # forward error of zero take the other branch); measured 7.4e-3 with the two-plane weights (0.2 when the weights were
+    # rounded to one bf16 plane).  The pattern-pinned comparison is test_bf16_batch16_parity_covers_every_bench_kernel.
+    assert gl < 3e-2, gl
 
 
 def _grad_errors(model, twin, out, ls):
