@@ -12,7 +12,7 @@
 //              matrix pipe accumulates  y[patch] += T_{k-1}[patch] W_{k-1}  straight from LDS (exact-fp32 MFMA
 //              v_mfma_f32_32x32x2_f32, contraction index permuted so that one 16-byte LDS read feeds four MFMA steps).
 //              HBM traffic: x once (+ halo re-reads, L2 hits), y once.  The K-stack never leaves the chip.
-//   backward:  (1) the same recurrence again, accumulating  dW_k += T_k[patch]^T dy[patch]  (v_mfma_f32_16x16x4_f32, the
+//   backward (two kernels, dW and dx):  (1) the same recurrence again, accumulating  dW_k += T_k[patch]^T dy[patch]  (v_mfma_f32_16x16x4_f32, the
 //              dy fragments of the wave's row slice held in registers for all k); per-workgroup partials, reduced in a
 //              fixed order by cheb_fused_dw_reduce_kernel;  (2) Clenshaw for the adjoint,
 //              b_k = G_k + 2 L~ b_{k+1} - b_{k+2} with G_k = dy W_k^T evaluated on the k-ring (L~ is symmetric:
@@ -50,9 +50,10 @@ struct ChebFusedP {
 // version re-read rowptr / column / value from global memory per (row, channel quad) and step: three dependent memory
 // round trips per item, 181 us forward where the LDS traffic allows ~40.
 struct CfRow {
-    int col[CF_W];
+    unsigned colp[CF_W / 2];            // local column indices, two 16-bit values per register (patch + halo <= 1024 rows)
     float val[CF_W];
     int deg;
+    __device__ __forceinline__ int col(int j) const { return (int)((colp[j >> 1] >> (16 * (j & 1))) & 0xFFFFu); }
 };
 
 // ELL form of the patch's rows (plan arrays ell_col / ell_val, CF_W entries per row, padded with (own row, 0)): no row
@@ -60,7 +61,9 @@ struct CfRow {
 __device__ __forceinline__ void cf_load_row(CfRow &r, int i, int nrows, const int *ec, const float *ev) {
     r.deg = 0;
 #pragma unroll
-    for (int j = 0; j < CF_W; ++j) { r.col[j] = 0; r.val[j] = 0.f; }
+    for (int j = 0; j < CF_W; ++j) r.val[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < CF_W / 2; ++j) r.colp[j] = 0u;
     if (i < nrows) {
         const int4 *c4 = reinterpret_cast<const int4 *>(ec + (long long)i * CF_W);
         const float4 *v4 = reinterpret_cast<const float4 *>(ev + (long long)i * CF_W);
@@ -68,13 +71,14 @@ __device__ __forceinline__ void cf_load_row(CfRow &r, int i, int nrows, const in
         for (int h = 0; h < CF_W / 4; ++h) {
             const int4 c = c4[h];
             const float4 v = v4[h];
-            r.col[4 * h] = c.x; r.col[4 * h + 1] = c.y; r.col[4 * h + 2] = c.z; r.col[4 * h + 3] = c.w;
+            r.colp[2 * h] = (unsigned)c.x | ((unsigned)c.y << 16);
+            r.colp[2 * h + 1] = (unsigned)c.z | ((unsigned)c.w << 16);
             r.val[4 * h] = v.x; r.val[4 * h + 1] = v.y; r.val[4 * h + 2] = v.z; r.val[4 * h + 3] = v.w;
         }
         // entries are packed to the front, padding = (i, 0): deg = index of the last real entry + 1
         int d = 0;
 #pragma unroll
-        for (int j = 0; j < CF_W; ++j) d = (r.val[j] != 0.f || r.col[j] != i) ? j + 1 : d;
+        for (int j = 0; j < CF_W; ++j) d = (r.val[j] != 0.f || r.col(j) != i) ? j + 1 : d;
         r.deg = d;
     }
 }
@@ -101,7 +105,7 @@ __device__ __forceinline__ void cf_gather(const float *src, const CfRow &row, in
             float4 sv[CF_G][CQ];
 #pragma unroll
             for (int e = 0; e < CF_G; ++e) {
-                const float *sp_ = src + row.col[CF_G * g + e] * PITCH;
+                const float *sp_ = src + row.col(CF_G * g + e) * PITCH;
 #pragma unroll
                 for (int q = 0; q < CQ; ++q) sv[e][q] = *reinterpret_cast<const float4 *>(sp_ + 4 * ((q + rot) % CQ));
             }
@@ -263,8 +267,11 @@ __global__ __launch_bounds__(CF_THREADS) void cheb_fused_fwd_kernel(ChebFusedP p
 // ------------------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Backward, weight gradient: the forward recurrence again, every T_k[patch] contracted with dy[patch].  (One backward kernel
+// doing this AND the Clenshaw part needed more than the 128 registers a 1024-thread workgroup has: it spilled 8-19 of them,
+// 146 MB of scratch writes per launch by the HBM counters; the two halves share nothing but the LDS buffers.)
 template <int CIN, int FOUT>
-__global__ __launch_bounds__(CF_THREADS) void cheb_fused_bwd_kernel(ChebFusedP p) {
+__global__ __launch_bounds__(CF_THREADS) void cheb_fused_dw_kernel(ChebFusedP p) {
     extern __shared__ float4 cf_smem[];
     constexpr int PITCH = CIN + 4, CQ = CIN / 4;
     constexpr int CT = CIN / 16 > 0 ? (CIN + 15) / 16 : 1;      // 16-channel tiles of the 16x16x4 MFMA (Cin 8 / 24: padded rows)
@@ -373,25 +380,47 @@ __global__ __launch_bounds__(CF_THREADS) void cheb_fused_bwd_kernel(ChebFusedP p
     __syncthreads();
     dw_flush(K - 1);
     __syncthreads();
+}
 
+// Backward, data gradient: dx = sum_k T_k(L~) G_k with G_k = dy W_k^T, by Clenshaw's recurrence.
+template <int CIN, int FOUT>
+__global__ __launch_bounds__(CF_THREADS) void cheb_fused_dx_kernel(ChebFusedP p) {
+    extern __shared__ float4 cf_smem[];
+    constexpr int PITCH = CIN + 4, CQ = CIN / 4;
+    constexpr int CT = CIN / 16 > 0 ? (CIN + 15) / 16 : 1;      // 16-channel tiles of the 16x16x4 MFMA (Cin 8 / 24: padded rows)
+    float *buf0 = reinterpret_cast<float *>(cf_smem);
+    float *buf1 = buf0 + (long long)p.rmax * PITCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, l4 = lane >> 4;
+    int n, pt;
+    cape_map_block(blockIdx.x, p.N, p.P, n, pt);
+    const int *pi = p.pinfo + pt * 16;
+    const int *vid = p.vid + pi[0];
+    const int *ec = p.ell_col + (long long)pi[1] * CF_W;
+    const float *ev = p.ell_val + (long long)pi[1] * CF_W;
+    const int K = p.K, Rown = pi[3], Rtot = pi[3 + K - 1];
+    const float *gb = p.dy + (long long)n * p.dys;
+
+    CfRow row[CF_RPT];
+#pragma unroll
+    for (int u = 0; u < CF_RPT; ++u) cf_load_row(row[u], tid + CF_THREADS * u, pi[3 + (K >= 2 ? K - 2 : 0)], ec, ev);
     // ================= part 2: dx = sum_k T_k(L~) G_k,  G_k = dy W_k^T, by Clenshaw =================
     // G_k tile (16 rows x 16 channels) = dy[16 rows, FOUT] * W_k^T on the 16x16x4 MFMA, contraction index permuted: step s of
     // lane quarter l4 uses f = NF l4 + s on both operands (NF = FOUT / 4 consecutive floats per lane: wide loads).  The dy
     // fragments do not depend on k: each wave keeps those of its (at most four) row tiles in registers for the whole
     // Clenshaw recurrence; the W_k^T fragments are loaded once per k.
     constexpr int NF = FOUT / 4;
-    constexpr int MAXT = (CF_THREADS * CF_RPT / 16) / (CF_THREADS / 64);      // row tiles per wave: rmax <= CF_THREADS * CF_RPT rows
-    float gfr[MAXT][NF];
-#pragma unroll
-    for (int j = 0; j < MAXT; ++j) {
-        const int r = min(16 * (wave + (CF_THREADS / 64) * j) + l16, Rtot - 1);
+    // (the dy fragments of a tile do not depend on k, but keeping them resident -- 8 floats per tile, up to four tiles per
+    // wave -- pushed the kernel over its 128 registers; they are re-read per k: two 16-byte loads per tile, L2 hits)
+    auto load_g = [&](int tile, float (&g)[NF]) {
+        const int r = min(16 * tile + l16, Rtot - 1);
         const float *grow = gb + (long long)vid[r] * p.lddy + NF * l4;
 #pragma unroll
         for (int h = 0; h < NF / 4; ++h) {
             const float4 v = *reinterpret_cast<const float4 *>(grow + 4 * h);
-            gfr[j][4 * h] = v.x; gfr[j][4 * h + 1] = v.y; gfr[j][4 * h + 2] = v.z; gfr[j][4 * h + 3] = v.w;
+            g[4 * h] = v.x; g[4 * h + 1] = v.y; g[4 * h + 2] = v.z; g[4 * h + 3] = v.w;
         }
-    }
+    };
     float *bA = buf0, *bB = buf1;                // bA = b_{k+1}, bB = b_{k+2}
     // b_{K-1} = G_{K-1} on the (K-1)-ring -> bA;  then for k = K-2 .. 1:  bB <- G_k - bB (bB = b_{k+2}; absent for
     // k = K-2), barrier, bB += 2 L~ bA on the k-ring, swap;  finally dx = G_0 + L~ b_1 - b_2 on the patch.
@@ -410,29 +439,28 @@ __global__ __launch_bounds__(CF_THREADS) void cheb_fused_bwd_kernel(ChebFusedP p
             }
         }
         const int ntile = (R + 15) / 16;
+#pragma unroll 1
+        for (int tile = wave; tile < ntile; tile += CF_THREADS / 64) {
+            f32x4 gacc[CT];
 #pragma unroll
-        for (int j = 0; j < MAXT; ++j) {
-            const int tile = wave + (CF_THREADS / 64) * j;
-            if (tile < ntile) {
-                f32x4 gacc[CT];
+            for (int ct = 0; ct < CT; ++ct) gacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float gl[NF];
+            load_g(tile, gl);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) gacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int sidx = 0; sidx < NF; ++sidx)
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-                        gacc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfr[j][sidx], wfr[ct][sidx], gacc[ct], 0, 0, 0);
+            for (int sidx = 0; sidx < NF; ++sidx)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
+                    gacc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(gl[sidx], wfr[ct][sidx], gacc[ct], 0, 0, 0);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int r = 16 * tile + 4 * l4 + g, c = 16 * ct + l16;
-                        if (r < R && c < CIN) {
-                            float *d = dst + r * PITCH + c;
-                            *d = sub ? gacc[ct][g] - *d : gacc[ct][g];
-                        }
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int r = 16 * tile + 4 * l4 + g, c = 16 * ct + l16;
+                    if (r < R && c < CIN) {
+                        float *d = dst + r * PITCH + c;
+                        *d = sub ? gacc[ct][g] - *d : gacc[ct][g];
                     }
-            }
+                }
         }
     };
     if (K == 1) {
@@ -545,16 +573,32 @@ struct CfFwd {
 };
 
 template <int CIN, int FOUT>
-struct CfBwd {
+struct CfDw {
     static int go(const ChebFusedP &p, size_t lds, hipStream_t st) {
         static bool set = false;
         if (!set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&cheb_fused_bwd_kernel<CIN, FOUT>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&cheb_fused_dw_kernel<CIN, FOUT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return CAPE_EINVAL;
             set = true;
         }
-        CAPE_LAUNCH((cheb_fused_bwd_kernel<CIN, FOUT>), dim3(p.N * p.P), dim3(CF_THREADS), lds, st, p);
+        CAPE_LAUNCH((cheb_fused_dw_kernel<CIN, FOUT>), dim3(p.N * p.P), dim3(CF_THREADS), lds, st, p);
+        CAPE_LAUNCH_CHECK();
+        return CAPE_OK;
+    }
+};
+
+template <int CIN, int FOUT>
+struct CfDx {
+    static int go(const ChebFusedP &p, size_t lds, hipStream_t st) {
+        static bool set = false;
+        if (!set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&cheb_fused_dx_kernel<CIN, FOUT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return CAPE_EINVAL;
+            set = true;
+        }
+        CAPE_LAUNCH((cheb_fused_dx_kernel<CIN, FOUT>), dim3(p.N * p.P), dim3(CF_THREADS), lds, st, p);
         CAPE_LAUNCH_CHECK();
         return CAPE_OK;
     }
@@ -616,8 +660,10 @@ extern "C" int cape_cheb_fused_bwd(const float *x, int64_t x_sample_stride, int3
     p.dy = dy; p.dys = dy_sample_stride; p.lddy = lddy;
     p.dx = dx; p.dxs = dx_sample_stride; p.lddx = lddx;
     p.dwpart = (float *)workspace;
-    const int rc2 = cf_dispatch<CfBwd>(Cin, Fout, p, lds, (hipStream_t)stream);
+    const int rc2 = cf_dispatch<CfDw>(Cin, Fout, p, lds, (hipStream_t)stream);
     if (rc2 != CAPE_OK) return rc2;
+    const int rc3 = cf_dispatch<CfDx>(Cin, Fout, p, (size_t)2 * rmax * (Cin + 4) * sizeof(float), (hipStream_t)stream);
+    if (rc3 != CAPE_OK) return rc3;
     const long long elems = (long long)K * Cin * Fout;
     const long long nslab = (long long)N * P;
     const long long per = (nslab + CF_RED_GROUPS - 1) / CF_RED_GROUPS;

@@ -1045,7 +1045,7 @@ class ChebConvRecurrenceFn(torch.autograd.Function):
 
 class ChebConvFusedFn(torch.autograd.Function):
     """General-K chebyshev5 (lib/models.py:69-103) with the recurrence of :88-96 kept on chip (csrc/cheb_fused.hip): one
-    launch forward, one (+ the fixed-order weight-gradient reduction) backward; the K-stack never reaches HBM."""
+    launch forward, two (+ the fixed-order weight-gradient reduction) backward; the K-stack never reaches HBM."""
 
     @staticmethod
     def forward(ctx, x, W, ops, plan):
@@ -1092,7 +1092,7 @@ class ChebConvFusedFn(torch.autograd.Function):
         dp, ds, dl = _v(dx)
         nnz = int(ops.host.Lt.nnz)
         flops = 2 * (2 * N * M * Cin * K * Fout + (K - 1) * 2 * nnz * Cin * N + max(K - 2, 0) * 2 * M * Cin * N)
-        _log_launch("cheb_fused_bwd_kernel", flops, 4 * (2 * N * M * Cin + N * M * Fout + 2 * Cin * K * Fout) + 8 * nnz + 4 * (M + 1),
+        _log_launch("cheb_fused_dw_kernel + cheb_fused_dx_kernel", flops, 4 * (2 * N * M * Cin + N * M * Fout + 2 * Cin * K * Fout) + 8 * nnz + 4 * (M + 1),
                     lambda: check(lib.cape_cheb_fused_bwd(xp, xs, xl, gp, gs, gl, _ptr(W), dp, ds, dl, _ptr(dW), 0, N, M, Cin, Fout, K,
                                                           plan.P, _ptr(plan.pinfo), _ptr(plan.vid), _ptr(plan.ell_col), _ptr(plan.ell_val),
                                                           plan.rmax, _ptr(ws), need, _stream()), "cape_cheb_fused_bwd"))

@@ -22,6 +22,9 @@
  *                       and, with transposed operators/weights, the data gradient that
  *                       tf.gradients (lib/models.py:460,465) derives for those ops.
  *   cape_gconv_dw       the weight gradient of the same ops (tf.gradients, :460).
+ *   cape_cheb_fused_fwd / cape_cheb_fused_bwd
+ *                       lib/models.py:69-103 for polynomial orders above the precomposed-operator limit: the explicit
+ *                       recurrence of :88-96 kept on chip (one launch per direction; BASELINE configs[1]).
  *   cape_spmm           lib/models.py:91,94,149 SparseTensorDenseMatMul as a standalone op
  *                       (general-K Chebyshev recurrence, non-selection pool matrices).
  *   cape_bias_act_fwd / cape_act_bwd / cape_colsum

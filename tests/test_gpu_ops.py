@@ -307,7 +307,7 @@ def test_cheb_fused_recurrence(case, mesh_ops, dev):
         names = [e[0] for e in ops.LAUNCH_LOG]
     finally:
         ops.LAUNCH_LOG = None
-    assert names == ["cheb_fused_fwd_kernel", "cheb_fused_bwd_kernel"], names
+    assert names == ["cheb_fused_fwd_kernel", "cheb_fused_dw_kernel + cheb_fused_dx_kernel"], names
     assert vertex_err(hy.detach().cpu().numpy(), ty.detach().numpy()) < TOL
     assert vertex_err(hx.grad.cpu().numpy(), tx.grad.numpy()) < TOL
     assert mat_err(hW.grad.cpu().numpy(), tW.grad.numpy()) < TOL

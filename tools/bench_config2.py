@@ -2,7 +2,7 @@
 HIP-graph replay timing; prints algorithmic GB/s and TFLOP/s against the rooflines of SURVEY section 8d."""
 import json, os, sys
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cape_amd import ops
 from cape_amd.graph import ConvOperators
 from cape_amd.load_data import load_graph_mtx

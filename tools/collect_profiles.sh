@@ -30,23 +30,7 @@ python $R/tools/pmc_merge.py $O/pmc_fetch.json $O/pmc_write.json $O/pmc_sq.json 
 cp $O/${TAG}_pmc_summary.json $O/pmc_summary.json      # the copy bench.py reads (stamped with the kernel-source fingerprint)
 python $R/tools/hbm_bw_table.py $O/${TAG}_pmc_summary.json $O/${TAG}_bench_kernel_stats.txt > $O/${TAG}_hbm_bandwidth_by_kernel.txt
 ls -la $O | tail -15
-# single Chebyshev K=6 layer (BASELINE configs[1]): on-chip recurrence (default) and the materialised K-stack form, each with
-# a rocprofv3 kernel summary and the HBM traffic counters (separate --pmc passes)
-cd $R && python tools/bench_config2.py > $O/${TAG}_config1_fused.json 2>> $O/${TAG}_bench.err
-cd $R && CAPE_FUSED_RECURRENCE=0 python tools/bench_config2.py > $O/${TAG}_config1_materialised.json 2>> $O/${TAG}_bench.err
-cd /tmp
-for mode in 1 0; do
-  name=$([ $mode = 1 ] && echo fused || echo materialised)
-  rm -rf /tmp/prof_c1 && CAPE_FUSED_RECURRENCE=$mode rocprofv3 --kernel-trace --stats -d /tmp/prof_c1 -o r -- python $R/tools/bench_config2.py > /dev/null 2>&1
-  DBC=$(ls /tmp/prof_c1/*.db /tmp/prof_c1/*/*.db 2>/dev/null | head -1)
-  python $R/tools/rocpd_summary.py $DBC $O/${TAG}_config1_${name}_kernel_stats.txt
-  for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
-    pn=${pass%%:*}; ctrs=${pass#*:}
-    rm -rf /tmp/prof_c1p && CAPE_FUSED_RECURRENCE=$mode CAPE_CONFIG2_EAGER=1 rocprofv3 --pmc $ctrs -d /tmp/prof_c1p -o r -- python $R/tools/bench_config2.py > /dev/null 2>&1
-    DBP=$(ls /tmp/prof_c1p/*.db /tmp/prof_c1p/*/*.db 2>/dev/null | head -1)
-    python $R/tools/pmc_summary.py $DBP $O/${TAG}_config1_${name}_pmc_$pn.json
-  done
-done
+bash $R/tools/collect_config1.sh $TAG
 cd $R
 CAPE_DIST_BACKEND=gloo CAPE_FORCE_DEVICE=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 4 --warmup 1 --no-roofline > $O/${TAG}_bench_2rank_1gpu.json 2>> $O/${TAG}_bench.err
 tail -c 400 $O/${TAG}_bench_2rank_1gpu.json
