@@ -404,6 +404,7 @@ __global__ __launch_bounds__(CF_THREADS) void cheb_fused_dx_kernel(ChebFusedP p)
     CfRow row[CF_RPT];
 #pragma unroll
     for (int u = 0; u < CF_RPT; ++u) cf_load_row(row[u], tid + CF_THREADS * u, pi[3 + (K >= 2 ? K - 2 : 0)], ec, ev);
+    CF_STAMP(31);
     // ================= part 2: dx = sum_k T_k(L~) G_k,  G_k = dy W_k^T, by Clenshaw =================
     // G_k tile (16 rows x 16 channels) = dy[16 rows, FOUT] * W_k^T on the 16x16x4 MFMA, contraction index permuted: step s of
     // lane quarter l4 uses f = NF l4 + s on both operands (NF = FOUT / 4 consecutive floats per lane: wide loads).  The dy
@@ -411,16 +412,30 @@ __global__ __launch_bounds__(CF_THREADS) void cheb_fused_dx_kernel(ChebFusedP p)
     // Clenshaw recurrence; the W_k^T fragments are loaded once per k.
     constexpr int NF = FOUT / 4;
     // (the dy fragments of a tile do not depend on k, but keeping them resident -- 8 floats per tile, up to four tiles per
-    // wave -- pushed the kernel over its 128 registers; they are re-read per k: two 16-byte loads per tile, L2 hits)
-    auto load_g = [&](int tile, float (&g)[NF]) {
-        const int r = min(16 * tile + l16, Rtot - 1);
-        const float *grow = gb + (long long)vid[r] * p.lddy + NF * l4;
+    // wave -- pushed the kernel over its 128 registers; they are re-read per k: two 16-byte loads per tile, L2 hits.  The
+    // global vertex of the lane's row in each of the wave's tiles IS kept, so that a fragment load is one memory round trip,
+    // and the next tile's fragment is in flight while the current one multiplies.)
+    constexpr int MAXT = (CF_THREADS * CF_RPT / 16 + CF_THREADS / 64 - 1) / (CF_THREADS / 64);      // row tiles per wave
+    int tvid[MAXT];
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) tvid[j] = vid[min(16 * (wave + (CF_THREADS / 64) * j) + l16, Rtot - 1)];
+    auto load_g = [&](int gv, float (&g)[NF]) {
+        const float *grow = gb + (long long)gv * p.lddy + NF * l4;
 #pragma unroll
         for (int h = 0; h < NF / 4; ++h) {
             const float4 v = *reinterpret_cast<const float4 *>(grow + 4 * h);
             g[4 * h] = v.x; g[4 * h + 1] = v.y; g[4 * h + 2] = v.z; g[4 * h + 3] = v.w;
         }
     };
+    // Phase stamps of the first version: ~6 k cycles per G_k phase, i.e. three serial L2 round trips (W_k^T fragments, then
+    // the first tile's dy fragment) before the first MFMA.  The weights (K Cin Fout floats: 12 KB) now sit in LDS behind the
+    // two buffers, and the dy fragment of the wave's FIRST tile stays in registers for all k.
+    float *wl = buf1 + (long long)p.rmax * PITCH;
+    for (int e = tid; e < K * CIN * FOUT / 4; e += CF_THREADS)
+        reinterpret_cast<float4 *>(wl)[e] = reinterpret_cast<const float4 *>(p.W)[e];
+    float g0[NF];
+    load_g(tvid[0], g0);
+    __syncthreads();
     float *bA = buf0, *bB = buf1;                // bA = b_{k+1}, bB = b_{k+2}
     // b_{K-1} = G_{K-1} on the (K-1)-ring -> bA;  then for k = K-2 .. 1:  bB <- G_k - bB (bB = b_{k+2}; absent for
     // k = K-2), barrier, bB += 2 L~ bA on the k-ring, swap;  finally dx = G_0 + L~ b_1 - b_2 on the patch.
@@ -429,7 +444,7 @@ __global__ __launch_bounds__(CF_THREADS) void cheb_fused_dx_kernel(ChebFusedP p)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int c = 16 * ct + l16;
-            const float *wrow = p.W + (long long)(min(c, CIN - 1) * K + k) * FOUT + NF * l4;
+            const float *wrow = wl + (min(c, CIN - 1) * K + k) * FOUT + NF * l4;
 #pragma unroll
             for (int h = 0; h < NF / 4; ++h) {
                 const float4 v = *reinterpret_cast<const float4 *>(wrow + 4 * h);
@@ -439,45 +454,57 @@ __global__ __launch_bounds__(CF_THREADS) void cheb_fused_dx_kernel(ChebFusedP p)
             }
         }
         const int ntile = (R + 15) / 16;
-#pragma unroll 1
-        for (int tile = wave; tile < ntile; tile += CF_THREADS / 64) {
-            f32x4 gacc[CT];
+        float gl[2][NF];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) gacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-            float gl[NF];
-            load_g(tile, gl);
+        for (int sidx = 0; sidx < NF; ++sidx) gl[0][sidx] = g0[sidx];
 #pragma unroll
-            for (int sidx = 0; sidx < NF; ++sidx)
+        for (int j = 0; j < MAXT; ++j) {
+            const int tile = wave + (CF_THREADS / 64) * j;
+            if (tile < ntile) {
+                if (j + 1 < MAXT && tile + CF_THREADS / 64 < ntile) load_g(tvid[j + 1 < MAXT ? j + 1 : j], gl[(j + 1) & 1]);
+                f32x4 gacc[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) gacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sidx = 0; sidx < NF; ++sidx)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        gacc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(gl[j & 1][sidx], wfr[ct][sidx], gacc[ct], 0, 0, 0);
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
-                    gacc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(gl[sidx], wfr[ct][sidx], gacc[ct], 0, 0, 0);
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int r = 16 * tile + 4 * l4 + g, c = 16 * ct + l16;
-                    if (r < R && c < CIN) {
-                        float *d = dst + r * PITCH + c;
-                        *d = sub ? gacc[ct][g] - *d : gacc[ct][g];
+                    for (int g = 0; g < 4; ++g) {
+                        const int r = 16 * tile + 4 * l4 + g, c = 16 * ct + l16;
+                        if (r < R && c < CIN) {
+                            float *d = dst + r * PITCH + c;
+                            *d = sub ? gacc[ct][g] - *d : gacc[ct][g];
+                        }
                     }
-                }
+            }
         }
     };
     if (K == 1) {
         put_g(bA, Rown, 0, false);
         __syncthreads();
     } else {
+        CF_STAMP(32);
         put_g(bA, pi[3 + K - 1], K - 1, false);              // b_{K-1}
+        CF_STAMP(33);
         __syncthreads();
+        CF_STAMP(34);
         for (int k = K - 2; k >= 1; --k) {
             const int R = pi[3 + k];
             put_g(bB, R, k, k < K - 2);                       // G_k - b_{k+2}
+            CF_STAMP(35 + 4 * k);
             __syncthreads();
+            CF_STAMP(36 + 4 * k);
             {
 #pragma unroll
             for (int u = 0; u < CF_RPT; ++u) cf_sparse_step<CIN, 2>(bA, bB, R, 2.f, row[u], tid + CF_THREADS * u);
         }          // bB[i] += 2 (L~ bA)[i]
+            CF_STAMP(37 + 4 * k);
             __syncthreads();
+            CF_STAMP(38 + 4 * k);
             float *t = bA; bA = bB; bB = t;
         }
         // dx = G_0 + L~ b_1 - b_2  (b_2 absent for K = 2)
@@ -497,6 +524,7 @@ __global__ __launch_bounds__(CF_THREADS) void cheb_fused_dx_kernel(ChebFusedP p)
         const int i = it / CQ, q = it - i * CQ;
         *reinterpret_cast<float4 *>(dxb + (long long)vid[i] * p.lddx + 4 * q) = *reinterpret_cast<const float4 *>(res + i * PITCH + 4 * q);
     }
+    CF_STAMP(62);
 }
 
 // out[j][i] = sum of the input slabs [j * per, min((j + 1) * per, nslab)) in order; thread = one float4 of one output slab
@@ -662,7 +690,8 @@ extern "C" int cape_cheb_fused_bwd(const float *x, int64_t x_sample_stride, int3
     p.dwpart = (float *)workspace;
     const int rc2 = cf_dispatch<CfDw>(Cin, Fout, p, lds, (hipStream_t)stream);
     if (rc2 != CAPE_OK) return rc2;
-    const int rc3 = cf_dispatch<CfDx>(Cin, Fout, p, (size_t)2 * rmax * (Cin + 4) * sizeof(float), (hipStream_t)stream);
+    const int rc3 = cf_dispatch<CfDx>(Cin, Fout, p, (size_t)2 * rmax * (Cin + 4) * sizeof(float) + (size_t)K * Cin * Fout * sizeof(float),
+                                      (hipStream_t)stream);
     if (rc3 != CAPE_OK) return rc3;
     const long long elems = (long long)K * Cin * Fout;
     const long long nslab = (long long)N * P;

@@ -35,5 +35,24 @@ for k in range(1, K):
     print("step %d: sparse %6d   contraction %6d   barrier %6d" % (k, t[2 + 3 * k] - prev, t[3 + 3 * k] - t[2 + 3 * k], t[4 + 3 * k] - t[3 + 3 * k]))
     prev = t[4 + 3 * k]
 print("last contraction %d, epilogue stores %d, total %d cycles" % (t[30] - prev, t[31] - t[30], t[31] - t[0]))
+# backward: the dx kernel (Clenshaw) stamps 31 .. 62
+xg = x.clone().requires_grad_(True)
+Wg = W.clone().requires_grad_(True)
+dy = torch.randn(N, 6890, Fout, device=dev)
+for _ in range(2):
+    y = ops.chebyshev5(xg, Wg, dops)
+    torch.autograd.grad(y, [xg, Wg], dy)
+ts.zero_()
+fn(C.c_void_p(ts.data_ptr()))
+y = ops.chebyshev5(xg, Wg, dops)
+torch.autograd.grad(y, [xg, Wg], dy)
+torch.cuda.synchronize()
+fn(None)
+t = ts.cpu().tolist()
+print("dx kernel: G_%d tiles %d cycles, barrier %d" % (K - 1, t[33] - t[32], t[34] - t[33]))
+for k in range(K - 2, 0, -1):
+    print("  k = %d: G tiles %6d   barrier %6d   sparse %6d   barrier %6d" % (k, t[35 + 4 * k] - (t[38 + 4 * (k + 1)] if k < K - 2 else t[34]),
+                                                                          t[36 + 4 * k] - t[35 + 4 * k], t[37 + 4 * k] - t[36 + 4 * k], t[38 + 4 * k] - t[37 + 4 * k]))
+print("  tail (G_0, last sparse, dx stores) %d cycles; kernel total from row load %d" % (t[62] - t[38 + 4], t[62] - t[31]))
 plan = dops.patch_plan(Cin, Fout).host
 print("patches %d, rmax %d, ring sizes of patch 9: %s" % (plan.P, plan.rmax, plan.pinfo[9 % plan.P, 3:3 + K].tolist()))
