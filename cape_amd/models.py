@@ -476,25 +476,44 @@ class CAPE(base_model):
                 x2 = self.brelu(x2)
             return self.pool(x2, self.Downsample_mtx[i])
 
-    def gn(self, x, name, relu=False, G=32, eps=1e-5):
+    def gn(self, x, name, relu=False, G=32, eps=1e-5, passthrough=False):
         with self.variable_scope(name):
             Cn = int(x.shape[-1])
             gamma = self._get_variable('gamma', (Cn,), 'gn_gamma')
             beta = self._get_variable('beta', (Cn,), 'gn_beta')
         Ge = ops.group_count(x.shape[0], Cn, G)      # the reference's free-dimension reshape, lib/models.py:698
-        return ops.GroupNormFn.apply(x, gamma, beta, Ge, eps, 1 if relu else 0)
+        return ops.GroupNormFn.apply(x, gamma, beta, Ge, eps, 1 if relu else 0, passthrough)
+
+    def _plain_weight(self, scope, shape):
+        """A 1x1 filter's weight in ``scope`` with its gradient-bucket view (what chebyshev5 does for K = 1)."""
+        with self.variable_scope(scope):
+            W = self._weight_variable(shape)
+            wname = '/'.join(self._scope + ['weights'])
+        self._conv_meta[wname] = (int(shape[0]), 1, int(shape[1]))
+        return W, self._grad_views.get(wname)
 
     def res_block_decoder(self, x_in, i, name, cond=None):
         Fi, Lm = self.out_channels[-i - 1], self.Laplacian[-i - 2]
         with self.variable_scope(name):
             xu = self.unpool(x_in, self.Upsample_mtx[-i - 1])
-            x = self.gn(xu, 'group_norm', relu=True)
+            # the fused tail: graph_linear_2 + graph_linear_input + addition + concat as one contraction (same variables,
+            # same creation order as the reference's :763-774); needs the 1x1 input filter, i.e. differing channel counts
+            fuse_tail = bool(ops.CMR_FUSED_TAIL and self._fusable() and xu.shape[-1] != Fi and xu.is_cuda
+                             and xu.dtype == torch.float32)
+            if fuse_tail:
+                x, xu = self.gn(xu, 'group_norm', relu=True, passthrough=True)
+            else:
+                x = self.gn(xu, 'group_norm', relu=True)
             with self.variable_scope('graph_linear_1'):
                 x = self.filter(x, Lm, Fi // 2, 1)
             x = self.gn(x, 'group_norm_1', relu=True)
             with self.variable_scope('graph_conv'):
                 x = self.filter(x, Lm, Fi // 2, self.poly_order[-i - 1])
             x = self.gn(x, 'group_norm_2', relu=True)
+            if fuse_tail:
+                W2, gW2 = self._plain_weight('graph_linear_2', [int(x.shape[-1]), Fi])
+                Wi, gWi = self._plain_weight('graph_linear_input', [int(xu.shape[-1]), Fi])
+                return ops.ResidualLinearFn.apply(x, xu, W2, Wi, cond, gW2, gWi)
             with self.variable_scope('graph_linear_2'):
                 x = self.filter(x, Lm, Fi, 1)
             if xu.shape[-1] != x.shape[-1]:

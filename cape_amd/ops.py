@@ -23,6 +23,9 @@ MODE = _os.environ.get("CAPE_MODE", "twopass")
 # polynomial orders above the precomposed-operator limit: 1 = recurrence on chip where the layer qualifies
 # (csrc/cheb_fused.hip), 0 = always the materialised K-stack (ChebConvRecurrenceFn; the A/B reference)
 FUSED_RECURRENCE = int(_os.environ.get("CAPE_FUSED_RECURRENCE", "1"))
+# GraphCMR decoder block: 1 = its two closing 1x1 filters, the addition and the condition concat as one two-source
+# contraction (ResidualLinearFn), 0 = the reference's op-by-op formulation (the A/B reference)
+CMR_FUSED_TAIL = int(_os.environ.get("CAPE_CMR_FUSED_TAIL", "1"))
 
 _ACT_OF = {"b1leakyrelu": ("leaky", _lib.BIAS_CHANNEL), "b1relu": ("relu", _lib.BIAS_CHANNEL),
            "b1tanh": ("tanh", _lib.BIAS_CHANNEL), "b2relu": ("relu", _lib.BIAS_VERTEX)}
@@ -60,6 +63,17 @@ def as_act(t):
     if t.shape[1] > 1 and t.stride(1) < t.shape[2]:
         t = t.contiguous()
     return t
+
+
+def _row_aligned(x):
+    """``x`` itself when its rows start on 16-byte boundaries, else a copy in a row-padded buffer (the kernels use aligned
+    16-byte accesses; e.g. a contiguous [N, M, 3] or [N, M, 262] tensor handed in from outside the layer stack)."""
+    q = 4 if x.dtype == torch.float32 else 8
+    if (x.stride(1) % q) or (x.shape[0] > 1 and (x.stride(0) % q)) or (x.data_ptr() & 15):
+        xp = alloc_act(x.shape[0], x.shape[1], x.shape[2], x.device, zero=True, dtype=x.dtype)
+        xp.copy_(x)
+        return xp
+    return x
 
 
 def _v(t):
@@ -1133,6 +1147,61 @@ class ConcatCondFn(torch.autograd.Function):
         return dx, dc
 
 
+class ResidualLinearFn(torch.autograd.Function):
+    """[ x W + r Wr | cond tiled over vertices ] -- the tail of res_block_decoder (lib/models.py:763-774): graph_linear_2
+    on the block's features, graph_linear_input on the block's (unpooled) input, their sum and the tf.concat with the
+    condition, as ONE two-source contraction that writes straight into the concatenated buffer (the reference's
+    formulation is two products, an element-wise add and a concat copy).  Backward: one weight-gradient launch for both
+    blocks, one data-gradient contraction per input."""
+
+    @staticmethod
+    def forward(ctx, x, r, W, Wr, cond, gW=None, gWr=None):
+        x, r = _row_aligned(as_act(x)), _row_aligned(as_act(r))
+        N, M, Cx = x.shape
+        Cr, F = r.shape[2], W.shape[1]
+        assert W.shape == (Cx, F) and Wr.shape == (Cr, F) and W.is_contiguous() and Wr.is_contiguous() and r.shape[:2] == (N, M)
+        Cc = 0 if cond is None else cond.shape[1]
+        yfull = alloc_act(N, M, F + Cc, x.device, dtype=x.dtype)
+        gconv_fwd([dict(x=x, csr=None, w=(W, 0, F, 1)), dict(x=r, csr=None, w=(Wr, 0, F, 1))], yfull[:, :, :F])
+        if Cc:
+            fill_cond(cond.contiguous(), yfull[:, :, F:])
+        ctx.F, ctx.Cc, ctx.gW, ctx.gWr = F, Cc, gW, gWr
+        ctx.save_for_backward(x, r, W, Wr)
+        return yfull
+
+    @staticmethod
+    def backward(ctx, gfull):
+        x, r, W, Wr = ctx.saved_tensors
+        F = ctx.F
+        gfull = _row_aligned(as_act(gfull))
+        g = gfull[:, :, :F]
+        N, M, Cx = x.shape
+        Cr = r.shape[2]
+        need_x, need_r, need_w, need_wr, need_c = (ctx.needs_input_grad[i] for i in range(5))
+        if NO_WEIGHT_GRAD and W.data_ptr() in NO_WEIGHT_GRAD:
+            need_w = need_wr = False
+        dx = dr = dW = dWr = dc = None
+        ent = []
+        if need_w:
+            dW = _grad_buffer(W, ctx.gW)
+            ent.append(dict(x=x, csr=None, w=(dW, 0, F, 1)))
+        if need_wr:
+            dWr = _grad_buffer(Wr, ctx.gWr)
+            ent.append(dict(x=r, csr=None, w=(dWr, 0, F, 1)))
+        if ent:
+            in_bucket = lambda t, v: t is None or (v is not None and t.data_ptr() == v.data_ptr())
+            gconv_dw(ent, g, defer=in_bucket(dW, ctx.gW) and in_bucket(dWr, ctx.gWr))
+        if need_x:
+            dx = alloc_act(N, M, Cx, x.device, dtype=g.dtype)
+            gconv_fwd([dict(x=g, csr=None, w=(W, 0, 1, F))], dx)              # W^T read in place (contraction index contiguous)
+        if need_r:
+            dr = alloc_act(N, M, Cr, x.device, dtype=g.dtype)
+            gconv_fwd([dict(x=g, csr=None, w=(Wr, 0, 1, F))], dr)
+        if ctx.Cc and need_c:
+            dc = reduce_cond(gfull[:, :, F:])
+        return dx, dr, dW, dWr, dc, None, None
+
+
 def group_count(N, Cn, G=32):
     """Number of normalisation groups the reference's ``gn`` forms for ``Cn`` channels (lib/models.py:693-699): it
     reshapes [N, C, V] to [-1, G, C // G, V] with G = min(32, C) and a FREE leading dimension.  When G divides C that is G
@@ -1153,10 +1222,15 @@ def group_count(N, Cn, G=32):
 class GroupNormFn(torch.autograd.Function):
     """gn(norm_type='group') optionally fused with the following tf.nn.relu
     (lib/models.py:681-712, 751-760).  Saved for backward: the input, the per-(sample, group) statistics and the
-    per-(sample, channel) scale / shift -- not the output (the ReLU mask is re-derived from the same fma)."""
+    per-(sample, channel) scale / shift -- not the output (the ReLU mask is re-derived from the same fma).
+
+    ``passthrough``: also return the input as a second output (a view).  A block that reads the same tensor on a
+    residual branch (res_block_decoder, lib/models.py:744-774: ``x + xu``) takes that output instead of the input itself:
+    both gradients of the input then arrive HERE and the apply kernel sums them in its own pass (``dx_add``) -- without
+    it autograd adds them with a separate element-wise launch per block."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, G, eps, relu):
+    def forward(ctx, x, gamma, beta, G, eps, relu, passthrough=False):
         _lib.require_gpu()
         x = as_act(x)
         assert x.dtype == torch.float32, "group norm reads fp32 activations"
@@ -1178,19 +1252,28 @@ class GroupNormFn(torch.autograd.Function):
                                   "cape_groupnorm_fwd"))
         if relu:
             _trace_sign(y, "relu")             # y = relu(fma(a, x, b)): positive exactly where the kernel's fma was
-        ctx.G, ctx.relu = G, relu
+        ctx.G, ctx.relu, ctx.passthrough = G, relu, bool(passthrough)
         ctx.save_for_backward(x, gamma, stats, coef)
+        if passthrough:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_pass=None):
         x, gamma, stats, coef = ctx.saved_tensors
-        g = as_act(g)
         N, V, Cn = x.shape
-        if (g.stride(1) & 3) or (N > 1 and (g.stride(0) & 3)) or (g.data_ptr() & 15):
-            ga = alloc_act(N, V, Cn, g.device)
-            ga.copy_(g)
-            g = ga
+
+        def aligned(t):
+            t = as_act(t)
+            if (t.stride(1) & 3) or (N > 1 and (t.stride(0) & 3)) or (t.data_ptr() & 15):
+                ta = alloc_act(N, V, Cn, t.device)
+                ta.copy_(t)
+                t = ta
+            return t
+
+        if g is None:                              # only the pass-through output was used
+            return g_pass, None, None, None, None, None, None
+        g = aligned(g)
         dx = alloc_act(N, V, Cn, x.device)
         dgb = torch.empty((2, N, Cn), device=x.device, dtype=torch.float32)        # per-sample dgamma / dbeta partials
         bcoef = torch.empty((N, 3, _pad4(Cn)), device=x.device, dtype=torch.float32)
@@ -1199,12 +1282,17 @@ class GroupNormFn(torch.autograd.Function):
         xp, xs, xl = _v(x)
         gp, gs, gl = _v(g)
         dp, ds, dl = _v(dx)
-        _log_launch("groupnorm_bwd", 0, 5 * 4 * N * V * Cn,
+        if g_pass is not None:
+            g_pass = aligned(g_pass)
+            ap, as_, al = _v(g_pass)
+        else:
+            ap, as_, al = None, 0, 0
+        _log_launch("groupnorm_bwd", 0, (5 + (1 if g_pass is not None else 0)) * 4 * N * V * Cn,
                     lambda: check(lib.cape_groupnorm_bwd(xp, xs, xl, gp, gs, gl, _ptr(gamma), _ptr(stats), _ptr(coef), int(ctx.G),
-                                                         int(ctx.relu), dp, ds, dl, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(bcoef), N, V, Cn,
-                                                         _ptr(ws), need, _stream()), "cape_groupnorm_bwd"))
+                                                         int(ctx.relu), dp, ds, dl, ap, as_, al, _ptr(dgb[0]), _ptr(dgb[1]),
+                                                         _ptr(bcoef), N, V, Cn, _ptr(ws), need, _stream()), "cape_groupnorm_bwd"))
         dgb = dgb.sum(1)                                                           # one launch for both parameter gradients
-        return dx, dgb[0], dgb[1], None, None, None
+        return dx, dgb[0], dgb[1], None, None, None, None
 
 
 UNIT_GRAD = None        # the 0-dim tensor holding 1.0 that the training step seeds its backward pass with (models._one_scalar)

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define CAPE_ABI_VERSION 9
+#define CAPE_ABI_VERSION 10
 #define CAPE_MAX_SRC 8
 
 /* error codes (negative = argument error; positive values are hipError_t) */
@@ -348,14 +348,16 @@ int cape_groupnorm_fwd(const float *x, int64_t x_sample_stride, int32_t ldx, con
                        const float *beta, float eps, int32_t G, int32_t relu, float *y,
                        int64_t y_sample_stride, int32_t ldy, float *stats, float *coef, int32_t N, int32_t V,
                        int32_t C, void *workspace, int64_t workspace_bytes, void *stream);
-/* dx plus per-sample partial parameter gradients dgamma_partial / dbeta_partial [N, C] (the caller sums them over N);
- * stats / coef are the forward outputs; bcoef is a [N, 3, C] scratch buffer. */
+/* dx (+ dx_add when not NULL: a second gradient of the same input -- the residual branch of res_block_decoder,
+ * lib/models.py:744-774 -- summed in the apply pass instead of by a separate element-wise launch) plus per-sample partial
+ * parameter gradients dgamma_partial / dbeta_partial [N, C] (the caller sums them over N); stats / coef are the forward
+ * outputs; bcoef is a [N, 3, round_up(C, 4)] scratch buffer. */
 int cape_groupnorm_bwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *dy,
                        int64_t dy_sample_stride, int32_t lddy, const float *gamma,
                        const float *stats, const float *coef, int32_t G, int32_t relu, float *dx,
-                       int64_t dx_sample_stride, int32_t lddx, float *dgamma_partial,
-                       float *dbeta_partial, float *bcoef, int32_t N, int32_t V, int32_t C,
-                       void *workspace, int64_t workspace_bytes, void *stream);
+                       int64_t dx_sample_stride, int32_t lddx, const float *dx_add, int64_t add_sample_stride,
+                       int32_t ldadd, float *dgamma_partial, float *dbeta_partial, float *bcoef, int32_t N,
+                       int32_t V, int32_t C, void *workspace, int64_t workspace_bytes, void *stream);
 
 /*
  * L1 reconstruction + edge loss (lib/models.py:357-375, lib/losses.py:9-25) and gradient:

@@ -184,6 +184,66 @@ def test_groupnorm(shape, dev):
     assert mat_err(hb.grad.cpu().numpy(), tb.grad.numpy()) < 5 * TOL
 
 
+@pytest.mark.parametrize("shape", [(4, 862, 96, 1), (32, 431, 38, 1), (3, 6890, 64, 0)])
+def test_groupnorm_passthrough_sums_the_residual_gradient(shape, dev):
+    """GroupNormFn(passthrough=True) hands the input on as a second output; the gradient that comes back through it is
+    added inside the apply kernel (dx_add)."""
+    from cape_amd import ops
+    from oracle import torch_twin as tt
+    N, V, C, relu = shape
+    rng = np.random.default_rng(7 * C)
+    x = rng.standard_normal((N, V, C)) * 1.5 - 0.3
+    gamma, beta = 1 + 0.1 * rng.standard_normal(C), 0.1 * rng.standard_normal(C)
+    gy, gr = rng.standard_normal((N, V, C)), rng.standard_normal((N, V, C))
+    tx, tg, tb = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (x, gamma, beta))
+    ty = tt.group_norm(tx, tg, tb)
+    if relu:
+        ty = torch.relu(ty)
+    ((ty * torch.tensor(gy)).sum() + (tx * torch.tensor(gr)).sum()).backward()
+    for rep in range(2):
+        hx, hg, hb = (torch.tensor(a, dtype=torch.float32, device=dev, requires_grad=True) for a in (x, gamma, beta))
+        hy, hx2 = ops.GroupNormFn.apply(hx, hg, hb, ops.group_count(N, C), 1e-5, relu, True)
+        assert hx2.data_ptr() == hx.data_ptr() or hx2.shape == hx.shape
+        d = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+        ((hy * d(gy)).sum() + (hx2 * d(gr)).sum()).backward()
+        assert vertex_err(hy.detach().cpu().numpy(), ty.detach().numpy()) < TOL
+        assert vertex_err(hx.grad.cpu().numpy(), tx.grad.numpy()) < 5 * TOL
+        assert mat_err(hg.grad.cpu().numpy(), tg.grad.numpy()) < 5 * TOL
+        assert mat_err(hb.grad.cpu().numpy(), tb.grad.numpy()) < 5 * TOL
+
+
+@pytest.mark.parametrize("shape", [(3, 862, 64, 160, 128, 32), (2, 6890, 32, 96, 64, 32), (2, 431, 128, 262, 256, 0), (16, 862, 64, 70, 32, 6)])
+def test_residual_linear(shape, dev):
+    """ResidualLinearFn: [x W + r Wr | cond] and all five gradients against float64."""
+    from cape_amd import ops
+    N, M, Cx, Cr, F, Cc = shape
+    rng = np.random.default_rng(F + Cr)
+    x, r = rng.standard_normal((N, M, Cx)), rng.standard_normal((N, M, Cr))
+    W, Wr = rng.standard_normal((Cx, F)) / np.sqrt(Cx), rng.standard_normal((Cr, F)) / np.sqrt(Cr)
+    cond = rng.standard_normal((N, Cc)) if Cc else None
+    gy = rng.standard_normal((N, M, F + Cc))
+    t = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    tx, tr, tW, tWr = t(x), t(r), t(W), t(Wr)
+    ty = tx @ tW + tr @ tWr
+    tc = None
+    if Cc:
+        tc = t(cond)
+        ty = torch.cat([ty, tc[:, None, :].expand(N, M, Cc)], dim=2)
+    ty.backward(torch.tensor(gy))
+    h = lambda a: torch.tensor(a, dtype=torch.float32, device=dev, requires_grad=True)
+    hx, hr, hW, hWr = h(x), h(r), h(W), h(Wr)
+    hc = h(cond) if Cc else None
+    hy = ops.ResidualLinearFn.apply(hx, hr, hW, hWr, hc)
+    hy.backward(torch.tensor(gy, dtype=torch.float32, device=dev))
+    assert vertex_err(hy.detach().cpu().numpy(), ty.detach().numpy()) < TOL
+    assert vertex_err(hx.grad.cpu().numpy(), tx.grad.numpy()) < TOL
+    assert vertex_err(hr.grad.cpu().numpy(), tr.grad.numpy()) < TOL
+    assert mat_err(hW.grad.cpu().numpy(), tW.grad.numpy()) < TOL
+    assert mat_err(hWr.grad.cpu().numpy(), tWr.grad.numpy()) < TOL
+    if Cc:
+        assert mat_err(hc.grad.cpu().numpy(), tc.grad.numpy()) < TOL
+
+
 def test_recon_edge_loss(mesh_ops, dev):
     from cape_amd import ops
     from cape_amd.graph import vertex_edge_table

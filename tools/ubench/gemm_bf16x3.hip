@@ -1137,6 +1137,130 @@ __global__ __launch_bounds__((VAR & 8) ? 768 : 512, 1) void gemm_v5_kernel(const
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Sixth generation (round 3): k16 chunks in two LDS half-buffers, EVERYTHING of the next chunks interleaved into the MFMA
+// stream of the current one -- the fragment reads of chunk i+1 (from half (i+1)&1), the operand split of chunk i+2 (from
+// registers) and its LDS stores (into half i&1, whose fragments were read an iteration ago), the global loads of chunk
+// i+3.  One barrier per k16.  Same 128 x 128 tile / 2 x 2 waves / two workgroups per CU as the library kernel; 32-byte LDS
+// rows with the segment XOR-ed by (row >> 3) & 1 (conflict-free for the ds_read_b128 lane groups): 48 KB per workgroup.
+// SG: 0 = leave the order to the compiler, 1 = IGroupLP pipeline (per MFMA: 4 VALU, a read every second, a store every fourth)
+// ---------------------------------------------------------------------------------------------------------------
+template <int SG>
+__global__ __launch_bounds__(256, 2) void gemm_v6_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                         float *__restrict__ C, int N, int Mo, int K, int F, int row_tiles,
+                                                         int col_tiles) {
+    constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64, TM = 2, TN = 2;
+    constexpr int LP = 32, APL = BM * LP, BPL = BN * LP, HALF = 3 * (APL + BPL);          // one k16 chunk: 24 KB
+    __shared__ __attribute__((aligned(16))) unsigned char smem6[2 * HALF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int q = tid & 1, r = tid >> 1;                       // staging: row r, eight consecutive k = segment q
+    auto seg = [](int row, int sg) { return sg ^ ((row >> 3) & 1); };
+
+    int n, t;
+    map_block(blockIdx.x, N, row_tiles * col_tiles, n, t);
+    const int r0 = (t / col_tiles) * BM, f0 = (t % col_tiles) * BN;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+
+    const float *ap = A + ((long long)n * Mo + min(r0 + r, Mo - 1)) * K + 8 * q;
+    const float *bp = B + (long long)min(f0 + r, F - 1) * K + 8 * q;
+    const int total = K / 16;
+    struct Regs { float4 a0, a1, b0, b1; };
+    auto load_regs = [&](Regs &R, int c) {
+        const int k0 = 16 * min(c, total - 1);                  // chunks beyond the end re-read the last one (never used)
+        R.a0 = *reinterpret_cast<const float4 *>(ap + k0); R.a1 = *reinterpret_cast<const float4 *>(ap + k0 + 4);
+        R.b0 = *reinterpret_cast<const float4 *>(bp + k0); R.b1 = *reinterpret_cast<const float4 *>(bp + k0 + 4);
+    };
+    auto store_regs = [&](const Regs &R, unsigned char *h) {
+        uint4 hi, mid, lo;
+        unsigned char *da = h + r * LP + 16 * seg(r, q);
+        split8(R.a0, R.a1, hi, mid, lo);
+        *reinterpret_cast<uint4 *>(da) = hi; *reinterpret_cast<uint4 *>(da + APL) = mid; *reinterpret_cast<uint4 *>(da + 2 * APL) = lo;
+        unsigned char *db = h + 3 * APL + r * LP + 16 * seg(r, q);
+        split8(R.b0, R.b1, hi, mid, lo);
+        *reinterpret_cast<uint4 *>(db) = hi; *reinterpret_cast<uint4 *>(db + BPL) = mid; *reinterpret_cast<uint4 *>(db + 2 * BPL) = lo;
+    };
+    struct Frag { bf16x8 a[TM][3], b[TN][3]; };
+    auto read_frag = [&](Frag &f, const unsigned char *h) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int row = wm * WTM + a * 32 + li;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) f.a[a][p] = *reinterpret_cast<const bf16x8 *>(h + p * APL + row * LP + 16 * seg(row, lh));
+        }
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int row = wn * WTN + b * 32 + li;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) f.b[b][p] = *reinterpret_cast<const bf16x8 *>(h + 3 * APL + p * BPL + row * LP + 16 * seg(row, lh));
+        }
+    };
+    auto mm = [&](const Frag &f) {
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[a][term_pa(6, term)], f.b[b][term_pb(6, term)], acc[a][b], 0, 0, 0);
+    };
+
+    Regs R0, R1;
+    Frag F0, F1;
+    load_regs(R0, 0);
+    load_regs(R1, 1);
+    store_regs(R0, smem6);
+    store_regs(R1, smem6 + HALF);
+    load_regs(R0, 2);                                           // chunk i + 2 of iteration i = 0
+    __syncthreads();
+    read_frag(F0, smem6);
+    // iteration i: F_cur = chunk i, R_cur = chunk i + 2 (to be staged into half i & 1), loads of chunk i + 3 go out first
+    auto iter = [&](Frag &Fc, Frag &Fn, Regs &Rc, Regs &Rn, int i) {
+        load_regs(Rn, i + 3);
+        read_frag(Fn, smem6 + ((i + 1) & 1) * HALF);
+        store_regs(Rc, smem6 + (i & 1) * HALF);
+        mm(Fc);
+        if (SG == 1) {
+#pragma unroll
+            for (int m = 0; m < 24; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // MFMA
+                if (m < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           // the four global loads first
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                        // VALU (operand split)
+                if ((m & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // fragment read
+                if ((m & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // LDS store
+            }
+        }
+        __syncthreads();
+    };
+    for (int i = 0; i < total; i += 2) {
+        iter(F0, F1, R0, R1, i);
+        if (i + 1 < total) iter(F1, F0, R1, R0, i + 1);
+    }
+
+    float *cn = C + (long long)n * Mo * F;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = f0 + wn * WTN + b * 32 + li;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row = r0 + wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                if (row < Mo && col < F) cn[(long long)row * F + col] = acc[a][b][g];
+            }
+        }
+}
+
+template <int SG>
+static double run_v6(const Shape &s, const float *A, const float *B, float *C, int iters);
+
 template <int PRIO>
 static double run_v4(const Shape &s, const float *A, const float *B, float *C, int iters);
 
@@ -1398,6 +1522,24 @@ static double run_v5(const Shape &s, const float *A, const float *B, float *C, i
     return 1e3 * ms / iters;
 }
 
+template <int SG>
+static double run_v6(const Shape &s, const float *A, const float *B, float *C, int iters) {
+    const int rt = (s.Mo + 127) / 128, ct = (s.F + 127) / 128;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    auto launch = [&]() { gemm_v6_kernel<SG><<<s.N * rt * ct, 256>>>(A, B, C, s.N, s.Mo, s.K, s.F, rt, ct); };
+    launch();
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < iters; ++i) launch();
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return 1e3 * ms / iters;
+}
+
 // phase timing of the ping-pong kernel: durations of the multiply / stage phases of one wave per group
 template <int PRIO>
 static void time_v4(const Shape &s, const float *A, const float *B, float *C, const char *label) {
@@ -1507,6 +1649,45 @@ int main(int argc, char **argv) {
             printf("%-22s %7.1fus %5.0fTF %4.1fTB/s %7.1fus %5.0fTF %4.1fTB/s %7.1fus %5.0fTF %4.1fTB/s   %.2e\n", name, u0, fl / u0 / 1e6,
                    by32 / u0 / 1e6, u1, fl / u1 / 1e6, by16 / u1 / 1e6, u2, fl / u2 / 1e6, by16 / u2 / 1e6, erms);
             hipFree(A); hipFree(B); hipFree(C); hipFree(A16); hipFree(B16);
+        }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "v6")) {
+        const char *vn[] = {"v2 128x128 (ref)", "v2 128x128 interleaved", "v6 k16 pipeline", "v6 + IGroupLP pipeline"};
+        constexpr int NV6 = 4;
+        printf("%-22s", "shape (N Mo K F)");
+        for (int i = 0; i < NV6; ++i) printf(" %24s", vn[i]);
+        printf("\n");
+        for (const Shape &s : std::vector<Shape>{{16, 862, 1024, 512}, {16, 862, 768, 512}, {16, 862, 512, 512}, {16, 862, 512, 256},
+                                                 {16, 1723, 256, 256}, {16, 1723, 512, 128}, {16, 3445, 128, 128}, {16, 3445, 256, 128}}) {
+            std::vector<float> hA((size_t)s.N * s.Mo * s.K), hB((size_t)s.F * s.K);
+            fill(hA, 7, 1.0f);
+            fill(hB, 100, 0.05f);
+            float *A, *B, *C;
+            hipMalloc(&A, hA.size() * 4); hipMalloc(&B, hB.size() * 4); hipMalloc(&C, (size_t)s.N * s.Mo * s.F * 4);
+            hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
+            hipMemcpy(B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
+            const double fl = 2.0 * s.N * s.Mo * (double)s.K * s.F;
+            double us[NV6], emax[NV6], erms[NV6], f32rms = 0;
+            auto chk = [&](int i) {
+                check(s, hA, hB, C, s.N - 1, s.Mo - 24, s.Mo, emax[i], erms[i], f32rms);
+                double em2, er2, f2;
+                check(s, hA, hB, C, 0, 120, 136, em2, er2, f2);
+                if (er2 > erms[i]) erms[i] = er2;
+            };
+            auto clr = [&]() { hipMemset(C, 0xFF, (size_t)s.N * s.Mo * s.F * 4); };
+            clr(); us[0] = run_v2<128, 128, 2, 2, 2, false, false>(s, A, B, C, iters); chk(0);
+            clr(); us[1] = run_v2<128, 128, 2, 2, 2, false, false, false, false, 1>(s, A, B, C, iters); chk(1);
+            clr(); us[2] = run_v6<0>(s, A, B, C, iters); chk(2);
+            clr(); us[3] = run_v6<1>(s, A, B, C, iters); chk(3);
+            char name[64];
+            snprintf(name, sizeof name, "%d %d %d %d", s.N, s.Mo, s.K, s.F);
+            printf("%-22s", name);
+            for (int i = 0; i < NV6; ++i) printf(" %14.1fus %5.1fTF", us[i], fl / us[i] / 1e6);
+            printf("\n%-22s", "  rms err/rms(ref)");
+            for (int i = 0; i < NV6; ++i) printf(" %24.2e", erms[i]);
+            printf("   fp32 fma chain: %.2e\n", f32rms);
+            hipFree(A); hipFree(B); hipFree(C);
         }
         return 0;
     }
