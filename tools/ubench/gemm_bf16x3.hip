@@ -1258,6 +1258,160 @@ __global__ __launch_bounds__(256, 2) void gemm_v6_kernel(const float *__restrict
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Seventh generation (round 3): TWO fp16 pieces per operand and THREE products per multiply-add instead of three bf16
+// pieces and six products.  x*s = hi + lo with hi = fp16(x*s), lo = fp16(x*s - hi) (both round-to-nearest): 22 significant
+// bits + the sign trick of RN leave a representation error of 2^-24 |x|, and the dropped lo*lo product is 2^-24 relative --
+// the same class as the bf16 form (numpy emulation: rms 8.3e-8 vs 6.8e-8, an fp32 FMA chain 5.7e-7).  fp16's 5-bit exponent
+// needs the operands in range: every A row is scaled by a power of two chosen from the row's absolute maximum (a pre-pass of
+// the workgroup over its 128 rows: the tile is read twice, the second time from L2), the weights by one power of two per
+// launch (SB, from the tensor's maximum); the epilogue multiplies row r by 1 / (s_r SB) -- all exact.
+// Pipeline of v6 (k16 chunks, two LDS half-buffers of 16 KB, one barrier per chunk); PRE 0 = no pre-pass (unit row scales:
+// what the contraction alone costs), 1 = with it.
+// ---------------------------------------------------------------------------------------------------------------
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split2h(float x0, float x1, unsigned &hi, unsigned &lo) {
+    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+    const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
+    half2v H = {h0, h1}, L = {l0, l1};
+    hi = __builtin_bit_cast(unsigned, H);
+    lo = __builtin_bit_cast(unsigned, L);
+}
+__device__ __forceinline__ void split8h(const float4 &u, const float4 &v, float sc, uint4 &hi, uint4 &lo) {
+    split2h(u.x * sc, u.y * sc, hi.x, lo.x);
+    split2h(u.z * sc, u.w * sc, hi.y, lo.y);
+    split2h(v.x * sc, v.y * sc, hi.z, lo.z);
+    split2h(v.z * sc, v.w * sc, hi.w, lo.w);
+}
+
+template <int PRE, int MINB>
+__global__ __launch_bounds__(256, MINB) void gemm_v7_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                            float *__restrict__ C, int N, int Mo, int K, int F, int row_tiles,
+                                                            int col_tiles, float SB) {
+    constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64, TM = 2, TN = 2;
+    constexpr int LP = 32, APL = BM * LP, BPL = BN * LP, HALF = 2 * (APL + BPL);          // one k16 chunk: 16 KB
+    __shared__ __attribute__((aligned(16))) unsigned char smem7[2 * HALF];
+    __shared__ float inv_scale[BM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int q = tid & 1, r = tid >> 1;                       // staging: row r, eight consecutive k = segment q
+    auto seg = [](int row, int sg) { return sg ^ ((row >> 3) & 1); };
+
+    int n, t;
+    map_block(blockIdx.x, N, row_tiles * col_tiles, n, t);
+    const int r0 = (t / col_tiles) * BM, f0 = (t % col_tiles) * BN;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+
+    const float *ap = A + ((long long)n * Mo + min(r0 + r, Mo - 1)) * K + 8 * q;
+    const float *bp = B + (long long)min(f0 + r, F - 1) * K + 8 * q;
+    const int total = K / 16;
+    float sa = 1.f;
+    if (PRE) {
+        // absolute maximum of row r (this thread: its half of every k16 chunk), then the power of two that puts it in [2^13, 2^14)
+        float m0 = 0.f, m1 = 0.f;
+#pragma unroll 4
+        for (int c = 0; c < total; ++c) {
+            const float4 u = *reinterpret_cast<const float4 *>(ap + 16 * c), v = *reinterpret_cast<const float4 *>(ap + 16 * c + 4);
+            m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(u.x), fabsf(u.y)), fmaxf(fabsf(u.z), fabsf(u.w))));
+            m1 = fmaxf(m1, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+        float m = fmaxf(m0, m1);
+        m = fmaxf(m, __shfl_xor(m, 1));
+        int e = (int)((fbits(m) >> 23) & 255);                  // biased exponent (0 for a zero / denormal row)
+        e = max(e, 14);
+        sa = bitsf((unsigned)(267 - e) << 23);                  // 2^(13 - (e - 127))
+        if (q == 0) inv_scale[r] = bitsf((unsigned)(e - 13) << 23) / SB;
+    } else if (q == 0) {
+        inv_scale[r] = 1.f / SB;
+    }
+    struct Regs { float4 a0, a1, b0, b1; };
+    auto load_regs = [&](Regs &R, int c) {
+        const int k0 = 16 * min(c, total - 1);                  // chunks beyond the end re-read the last one (never used)
+        R.a0 = *reinterpret_cast<const float4 *>(ap + k0); R.a1 = *reinterpret_cast<const float4 *>(ap + k0 + 4);
+        R.b0 = *reinterpret_cast<const float4 *>(bp + k0); R.b1 = *reinterpret_cast<const float4 *>(bp + k0 + 4);
+    };
+    auto store_regs = [&](const Regs &R, unsigned char *h) {
+        uint4 hi, lo;
+        unsigned char *da = h + r * LP + 16 * seg(r, q);
+        split8h(R.a0, R.a1, sa, hi, lo);
+        *reinterpret_cast<uint4 *>(da) = hi; *reinterpret_cast<uint4 *>(da + APL) = lo;
+        unsigned char *db = h + 2 * APL + r * LP + 16 * seg(r, q);
+        split8h(R.b0, R.b1, SB, hi, lo);
+        *reinterpret_cast<uint4 *>(db) = hi; *reinterpret_cast<uint4 *>(db + BPL) = lo;
+    };
+    struct Frag { half8 a[TM][2], b[TN][2]; };
+    auto read_frag = [&](Frag &f, const unsigned char *h) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int row = wm * WTM + a * 32 + li;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) f.a[a][p] = *reinterpret_cast<const half8 *>(h + p * APL + row * LP + 16 * seg(row, lh));
+        }
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int row = wn * WTN + b * 32 + li;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) f.b[b][p] = *reinterpret_cast<const half8 *>(h + 2 * APL + p * BPL + row * LP + 16 * seg(row, lh));
+        }
+    };
+    auto mm = [&](const Frag &f) {
+#pragma unroll
+        for (int term = 0; term < 3; ++term)                     // lo*hi, hi*lo, hi*hi: small products first
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[a][term == 0 ? 1 : 0], f.b[b][term == 1 ? 1 : 0], acc[a][b], 0, 0, 0);
+    };
+
+    Regs R0, R1;
+    Frag F0, F1;
+    load_regs(R0, 0);
+    load_regs(R1, 1);
+    store_regs(R0, smem7);
+    store_regs(R1, smem7 + HALF);
+    load_regs(R0, 2);
+    __syncthreads();
+    read_frag(F0, smem7);
+    auto iter = [&](Frag &Fc, Frag &Fn, Regs &Rc, Regs &Rn, int i) {
+        load_regs(Rn, i + 3);
+        read_frag(Fn, smem7 + ((i + 1) & 1) * HALF);
+        store_regs(Rc, smem7 + (i & 1) * HALF);
+        mm(Fc);
+        __syncthreads();
+    };
+    for (int i = 0; i < total; i += 2) {
+        iter(F0, F1, R0, R1, i);
+        if (i + 1 < total) iter(F1, F0, R1, R0, i + 1);
+    }
+
+    float *cn = C + (long long)n * Mo * F;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int col = f0 + wn * WTN + b * 32 + li;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int rl = wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                const int row = r0 + rl;
+                if (row < Mo && col < F) cn[(long long)row * F + col] = acc[a][b][g] * inv_scale[rl];
+            }
+        }
+}
+
+template <int PRE, int MINB>
+static double run_v7(const Shape &s, const float *A, const float *B, float *C, int iters, float SB);
+
 template <int SG>
 static double run_v6(const Shape &s, const float *A, const float *B, float *C, int iters);
 
@@ -1540,6 +1694,24 @@ static double run_v6(const Shape &s, const float *A, const float *B, float *C, i
     return 1e3 * ms / iters;
 }
 
+template <int PRE, int MINB>
+static double run_v7(const Shape &s, const float *A, const float *B, float *C, int iters, float SB) {
+    const int rt = (s.Mo + 127) / 128, ct = (s.F + 127) / 128;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    auto launch = [&]() { gemm_v7_kernel<PRE, MINB><<<s.N * rt * ct, 256>>>(A, B, C, s.N, s.Mo, s.K, s.F, rt, ct, SB); };
+    launch();
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < iters; ++i) launch();
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return 1e3 * ms / iters;
+}
+
 // phase timing of the ping-pong kernel: durations of the multiply / stage phases of one wave per group
 template <int PRIO>
 static void time_v4(const Shape &s, const float *A, const float *B, float *C, const char *label) {
@@ -1649,6 +1821,56 @@ int main(int argc, char **argv) {
             printf("%-22s %7.1fus %5.0fTF %4.1fTB/s %7.1fus %5.0fTF %4.1fTB/s %7.1fus %5.0fTF %4.1fTB/s   %.2e\n", name, u0, fl / u0 / 1e6,
                    by32 / u0 / 1e6, u1, fl / u1 / 1e6, by16 / u1 / 1e6, u2, fl / u2 / 1e6, by16 / u2 / 1e6, erms);
             hipFree(A); hipFree(B); hipFree(C); hipFree(A16); hipFree(B16);
+        }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "v7")) {
+        const char *vn[] = {"v2 128x128 interleaved", "v7 f16x3 no pre-pass", "v7 f16x3 + row scales", "v7 + row scales, 3 WG/CU"};
+        constexpr int NV7 = 4;
+        printf("%-22s", "shape (N Mo K F)");
+        for (int i = 0; i < NV7; ++i) printf(" %24s", vn[i]);
+        printf("\n");
+        for (const Shape &s : std::vector<Shape>{{16, 862, 1024, 512}, {16, 862, 768, 512}, {16, 862, 512, 512}, {16, 862, 512, 256},
+                                                 {16, 1723, 256, 256}, {16, 1723, 512, 128}, {16, 3445, 128, 128}, {16, 3445, 256, 128},
+                                                 {16, 6890, 128, 128}}) {
+            std::vector<float> hA((size_t)s.N * s.Mo * s.K), hB((size_t)s.F * s.K);
+            fill(hA, 7, 1.0f);
+            fill(hB, 100, 0.05f);
+            // rows of very different magnitude (the per-row scales must absorb them)
+            for (int rr = 0; rr < s.N * s.Mo; ++rr) {
+                const float sc = ldexpf(1.f, -((rr * 7) % 23));
+                for (int k = 0; k < s.K; ++k) hA[(size_t)rr * s.K + k] *= sc;
+            }
+            float bmax = 0.f;
+            for (float v : hB) bmax = fmaxf(bmax, fabsf(v));
+            int be;
+            frexpf(bmax, &be);                                  // bmax in [2^(be-1), 2^be)
+            const float SB = ldexpf(1.f, 14 - be);              // -> [2^13, 2^14)
+            float *A, *B, *C;
+            hipMalloc(&A, hA.size() * 4); hipMalloc(&B, hB.size() * 4); hipMalloc(&C, (size_t)s.N * s.Mo * s.F * 4);
+            hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
+            hipMemcpy(B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
+            const double fl = 2.0 * s.N * s.Mo * (double)s.K * s.F;
+            double us[NV7], emax[NV7], erms[NV7], f32rms = 0;
+            auto chk = [&](int i) {
+                check(s, hA, hB, C, s.N - 1, s.Mo - 24, s.Mo, emax[i], erms[i], f32rms);
+                double em2, er2, f2;
+                check(s, hA, hB, C, 0, 120, 136, em2, er2, f2);
+                if (er2 > erms[i]) erms[i] = er2;
+            };
+            auto clr = [&]() { hipMemset(C, 0xFF, (size_t)s.N * s.Mo * s.F * 4); };
+            clr(); us[0] = run_v2<128, 128, 2, 2, 2, false, false, false, false, 1>(s, A, B, C, iters); chk(0);
+            clr(); us[1] = run_v7<0, 2>(s, A, B, C, iters, SB); chk(1);
+            clr(); us[2] = run_v7<1, 2>(s, A, B, C, iters, SB); chk(2);
+            clr(); us[3] = run_v7<1, 3>(s, A, B, C, iters, SB); chk(3);
+            char name[64];
+            snprintf(name, sizeof name, "%d %d %d %d", s.N, s.Mo, s.K, s.F);
+            printf("%-22s", name);
+            for (int i = 0; i < NV7; ++i) printf(" %14.1fus %5.1fTF", us[i], fl / us[i] / 1e6);
+            printf("\n%-22s", "  rms err/rms(ref)");
+            for (int i = 0; i < NV7; ++i) printf(" %24.2e", erms[i]);
+            printf("   fp32 fma chain: %.2e\n", f32rms);
+            hipFree(A); hipFree(B); hipFree(C);
         }
         return 0;
     }
