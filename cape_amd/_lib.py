@@ -36,7 +36,8 @@ class CapeCondLayer(C.Structure):
 class CapeSpmmTerm(C.Structure):
     _fields_ = [("x", C.c_void_p), ("x_sample_stride", C.c_int64), ("ldx", C.c_int32),
                 ("rowptr", C.c_void_p), ("colidx", C.c_void_p), ("vals", C.c_void_p),
-                ("y", C.c_void_p), ("y_sample_stride", C.c_int64), ("ldy", C.c_int32), ("scale", C.c_float)]
+                ("y", C.c_void_p), ("y_sample_stride", C.c_int64), ("ldy", C.c_int32), ("scale", C.c_float),
+                ("ell_width", C.c_int32)]
 
 
 class CapeBwdPrepItem(C.Structure):
@@ -90,7 +91,7 @@ SIGNATURES = {
     "cape_bwd_prep": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p, _i32, _p,
                                 _i64, _i32, _i32, _i32, _i32, _p, _i64, _p]),
     "cape_bwd_prep_finalize": (C.c_int, [C.c_void_p, _i32, _p]),
-    "cape_spmm": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _i32, _f32, _p, _i64, _i32, _f32, _p, _i64, _i32,
+    "cape_spmm": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _i32, _i32, _f32, _p, _i64, _i32, _f32, _p, _i64, _i32,
                             _i32, _i32, _i32, _p]),
     "cape_spmm_multi": (C.c_int, [C.POINTER(CapeSpmmTerm), _i32, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "cape_spmm_combine": (C.c_int, [C.POINTER(CapeSpmmTerm), _i32, C.c_uint32, C.POINTER(CapeRank), _p, _i32, _i32, _i32, _p, _p,

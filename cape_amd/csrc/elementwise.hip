@@ -108,10 +108,61 @@ __device__ __forceinline__ void cape_gather_row(const T *xb, long long ldx, cons
     }
 }
 
+// ELL form of the same row (arrays [rows, ew], ew in {4, 8, 12}; entries in CSR order packed to the front, slots past the
+// row's end hold (column of slot 0, 0.0f)): there is no row pointer to wait for, the index / value quads of the whole row
+// are three independent 16-byte loads, and a row of <= 8 entries (every row of L~ but a handful) costs TWO dependent memory
+// round trips instead of five (row pointer; per group of four: entries, rows).  These kernels are bound by exactly that
+// chain times the occupancy (profiles/README.md), not by bytes.  Same entries in the same order as the CSR form: the sums
+// are bit-identical.  An all-zero value quad ends the row (padding, or entries that contribute nothing).
+template <int VW, typename T>
+__device__ __forceinline__ void cape_gather_row_ell(const T *xb, long long ldx, const int *ec, const float *ev, int ew, int r,
+                                                    float (&acc)[VW]) {
+#pragma unroll
+    for (int u = 0; u < VW; ++u) acc[u] = 0.f;
+    const int4 *c4 = reinterpret_cast<const int4 *>(ec + (long long)r * ew);
+    const float4 *v4 = reinterpret_cast<const float4 *>(ev + (long long)r * ew);
+    int4 c0 = c4[0], c1 = c0, c2 = c0;
+    float4 v0 = v4[0], v1 = make_float4(0.f, 0.f, 0.f, 0.f), v2 = v1;
+    if (ew > 4) { c1 = c4[1]; v1 = v4[1]; }
+    if (ew > 8) { c2 = c4[2]; v2 = v4[2]; }
+    auto live = [](const float4 &v) { return v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f; };
+    auto gather4 = [&](const int4 &c, float (&xv)[4][VW]) {
+        cape_ldv<VW>(xb + (long long)c.x * ldx, xv[0]); cape_ldv<VW>(xb + (long long)c.y * ldx, xv[1]);
+        cape_ldv<VW>(xb + (long long)c.z * ldx, xv[2]); cape_ldv<VW>(xb + (long long)c.w * ldx, xv[3]);
+    };
+    auto fma4 = [&](const float4 &v, const float (&xv)[4][VW]) {
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int u = 0; u < VW; ++u) acc[u] = fmaf(vv[j], xv[j][u], acc[u]);
+    };
+    float xa[4][VW], xb2[4][VW];
+    const bool g1 = live(v1);
+    gather4(c0, xa);
+    if (g1) gather4(c1, xb2);                     // both groups in flight together
+    fma4(v0, xa);
+    if (g1) {
+        fma4(v1, xb2);
+        if (live(v2)) {
+            gather4(c2, xa);
+            fma4(v2, xa);
+        }
+    }
+}
+
+// one output row, either form (ew = 0: CSR)
+template <int VW, int U, typename T>
+__device__ __forceinline__ void cape_gather(const T *xb, long long ldx, const int *rp, const int *ci, const float *va, int ew, int r,
+                                            float (&acc)[VW]) {
+    if (ew) cape_gather_row_ell<VW>(xb, ldx, ci, va, ew, r, acc);
+    else cape_gather_row<VW, U>(xb, ldx, rp, ci, va, r, acc);
+}
+
 // ---- spmm: y[n,r,:] = alpha * S x[n] + beta * z[n,r,:] ------------------------------------
 // work item = (sample, output row, VW channels); VW = 1 for unaligned / odd channel counts
 template <int VW, typename T = float, int U = 0>
-__global__ __launch_bounds__(256) void spmm_kernel(CViewT<T> x, const int *rp, const int *ci, const float *va,
+__global__ __launch_bounds__(256) void spmm_kernel(CViewT<T> x, const int *rp, const int *ci, const float *va, int ew,
                                                    float alpha, CViewT<T> z, float beta, ViewT<T> y, int N, int Mo, int C) {
     const int cq = (C + VW - 1) / VW;
     // block -> (sample, 256 work items of that sample), all blocks of a sample on ONE XCD (spmm_grid / cape_map_block): the
@@ -124,7 +175,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(CViewT<T> x, const int *rp, c
     const int r = i / cq;
     const int c = (i - r * cq) * VW;
     float acc[VW];
-    cape_gather_row<VW, U>(x.p + (long long)n * x.ss + c, x.ld, rp, ci, va, r, acc);
+    cape_gather<VW, U>(x.p + (long long)n * x.ss + c, x.ld, rp, ci, va, ew, r, acc);
 #pragma unroll
     for (int u = 0; u < VW; ++u) acc[u] *= alpha;
     if (z.p) {
@@ -144,9 +195,10 @@ __global__ __launch_bounds__(256) void spmm_kernel(CViewT<T> x, const int *rp, c
 struct SpmmTerms {
     struct T {
         const void *x; long long xs; int ldx;       // elements of the launch's storage type
-        const int *rp; const int *ci; const float *va;
+        const int *rp; const int *ci; const float *va;      // ew > 0: ci / va are the ELL arrays [rows, ew]
         void *y; long long ys; int ldy;
         float scale;
+        int ew;
     } t[CAPE_MAX_SPMM_TERMS];
     int n;
 };
@@ -168,7 +220,7 @@ __global__ __launch_bounds__(256) void spmm_multi_kernel(SpmmTerms P, int sum, V
         const T *xb = reinterpret_cast<const T *>(Tm.x) + (long long)n * Tm.xs + c;
         float acc[VW];
         if (!Tm.rp) cape_ldv<VW>(xb + (long long)r * Tm.ldx, acc);
-        else cape_gather_row<VW, U>(xb, Tm.ldx, Tm.rp, Tm.ci, Tm.va, r, acc);
+        else cape_gather<VW, U>(xb, Tm.ldx, Tm.rp, Tm.ci, Tm.va, Tm.ew, r, acc);
 #pragma unroll
         for (int u = 0; u < VW; ++u) acc[u] *= Tm.scale;
         if (sum) {
@@ -219,7 +271,7 @@ __global__ __launch_bounds__(256) void spmm_combine_kernel(CombineParams Q, View
         const T *xb = reinterpret_cast<const T *>(Tm.x) + (long long)n * Tm.xs + c;
         float acc[VW];
         if (!Tm.rp) cape_ldv<VW>(xb + (long long)r * Tm.ldx, acc);
-        else cape_gather_row<VW, U>(xb, Tm.ldx, Tm.rp, Tm.ci, Tm.va, r, acc);
+        else cape_gather<VW, U>(xb, Tm.ldx, Tm.rp, Tm.ci, Tm.va, Tm.ew, r, acc);
         if ((Q.to2 >> k) & 1u) {
 #pragma unroll
             for (int u = 0; u < VW; ++u) a2[u] = fmaf(Tm.scale, acc[u], a2[u]);
@@ -792,12 +844,19 @@ inline int grid_for(long long total) {
 }  // namespace
 
 namespace {
+// ELL operands: width 4, 8 or 12, 16-byte aligned arrays (0 = the operator is given in CSR form)
+inline bool ell_ok(int ew, const void *ec, const void *ev) {
+    if (ew == 0) return true;
+    return (ew == 4 || ew == 8 || ew == 12) && ec && ev && ((reinterpret_cast<uintptr_t>(ec) | reinterpret_cast<uintptr_t>(ev)) & 15) == 0;
+}
+
 template <typename T>
 int spmm_impl(const T *x, int64_t x_sample_stride, int32_t ldx, const int32_t *rowptr,
-              const int32_t *colidx, const float *vals, int32_t max_row_nnz, float alpha, const T *z,
+              const int32_t *colidx, const float *vals, int32_t max_row_nnz, int32_t ell_width, float alpha, const T *z,
               int64_t z_sample_stride, int32_t ldz, float beta, T *y, int64_t y_sample_stride,
               int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
     if (!x || !rowptr || !colidx || !vals || !y || N < 1 || Mo < 1 || C < 1 || ldx < C || ldy < C) return CAPE_EINVAL;
+    if (!ell_ok(ell_width, colidx, vals)) return CAPE_EINVAL;
     if (z && ldz < C) return CAPE_EINVAL;
     if ((long long)Mo * C >= (1LL << 31)) return CAPE_EINVAL;       // 32-bit work-item index per sample
     constexpr int es = (int)sizeof(T);
@@ -813,9 +872,10 @@ int spmm_impl(const T *x, int64_t x_sample_stride, int32_t ldx, const int32_t *r
                           (!z || aligned8(z, z_sample_stride, ldz, C, es));
         const bool hint4 = max_row_nnz >= 1 && max_row_nnz <= 4;
         CAPE_LAUNCH_SP(spmm_kernel, T, wide, hint4, dim3((unsigned)(N * spmm_bps(Mo, C / (wide ? 8 : 4)))), dim3(256), 0, st, xv, rowptr,
-                       colidx, vals, alpha, zv, beta, yv, N, Mo, C);
+                       colidx, vals, ell_width, alpha, zv, beta, yv, N, Mo, C);
     } else {
-        CAPE_LAUNCH((spmm_kernel<1, T, 0>), dim3((unsigned)(N * spmm_bps(Mo, C))), dim3(256), 0, st, xv, rowptr, colidx, vals, alpha, zv, beta, yv, N, Mo, C);
+        if (ell_width) return CAPE_EINVAL;                    // the scalar fallback reads CSR only
+        CAPE_LAUNCH((spmm_kernel<1, T, 0>), dim3((unsigned)(N * spmm_bps(Mo, C))), dim3(256), 0, st, xv, rowptr, colidx, vals, 0, alpha, zv, beta, yv, N, Mo, C);
     }
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
@@ -823,18 +883,18 @@ int spmm_impl(const T *x, int64_t x_sample_stride, int32_t ldx, const int32_t *r
 }  // namespace
 
 extern "C" int cape_spmm(const float *x, int64_t x_sample_stride, int32_t ldx, const int32_t *rowptr,
-                         const int32_t *colidx, const float *vals, int32_t max_row_nnz, float alpha, const float *z,
-                         int64_t z_sample_stride, int32_t ldz, float beta, float *y, int64_t y_sample_stride,
+                         const int32_t *colidx, const float *vals, int32_t max_row_nnz, int32_t ell_width, float alpha,
+                         const float *z, int64_t z_sample_stride, int32_t ldz, float beta, float *y, int64_t y_sample_stride,
                          int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
-    return spmm_impl<float>(x, x_sample_stride, ldx, rowptr, colidx, vals, max_row_nnz, alpha, z, z_sample_stride, ldz, beta, y,
+    return spmm_impl<float>(x, x_sample_stride, ldx, rowptr, colidx, vals, max_row_nnz, ell_width, alpha, z, z_sample_stride, ldz, beta, y,
                             y_sample_stride, ldy, N, Mo, C, stream);
 }
 
 extern "C" int cape_spmm_bf16(const void *x, int64_t x_sample_stride, int32_t ldx, const int32_t *rowptr,
-                              const int32_t *colidx, const float *vals, int32_t max_row_nnz, float alpha, const void *z,
-                              int64_t z_sample_stride, int32_t ldz, float beta, void *y, int64_t y_sample_stride,
+                              const int32_t *colidx, const float *vals, int32_t max_row_nnz, int32_t ell_width, float alpha,
+                              const void *z, int64_t z_sample_stride, int32_t ldz, float beta, void *y, int64_t y_sample_stride,
                               int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
-    return spmm_impl<cape_bf16>((const cape_bf16 *)x, x_sample_stride, ldx, rowptr, colidx, vals, max_row_nnz, alpha,
+    return spmm_impl<cape_bf16>((const cape_bf16 *)x, x_sample_stride, ldx, rowptr, colidx, vals, max_row_nnz, ell_width, alpha,
                                 (const cape_bf16 *)z, z_sample_stride, ldz, beta, (cape_bf16 *)y, y_sample_stride, ldy, N, Mo, C, stream);
 }
 
@@ -850,6 +910,7 @@ int spmm_multi_impl(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, 
     P.n = nterms;
     bool vec = !sum || aligned4(y, y_sample_stride, ldy, C, es);
     bool wide = spmm_wide() && (!sum || aligned8(y, y_sample_stride, ldy, C, es));
+    bool any_ell = false;
     for (int k = 0; k < nterms; ++k) {
         const cape_spmm_term_t &t = terms[k];
         if (!t.x || t.ldx < C) return CAPE_EINVAL;
@@ -859,6 +920,9 @@ int spmm_multi_impl(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, 
         P.t[k].rp = t.rowptr; P.t[k].ci = t.colidx; P.t[k].va = t.vals;
         P.t[k].y = t.y; P.t[k].ys = t.y_sample_stride; P.t[k].ldy = t.ldy;
         P.t[k].scale = t.scale;
+        P.t[k].ew = t.rowptr ? t.ell_width : 0;
+        if (t.rowptr && !ell_ok(t.ell_width, t.colidx, t.vals)) return CAPE_EINVAL;
+        any_ell = any_ell || P.t[k].ew;
         vec = vec && aligned4(t.x, t.x_sample_stride, t.ldx, C, es) && (sum || aligned4(t.y, t.y_sample_stride, t.ldy, C, es));
         wide = wide && aligned8(t.x, t.x_sample_stride, t.ldx, C, es) && (sum || aligned8(t.y, t.y_sample_stride, t.ldy, C, es));
     }
@@ -866,6 +930,7 @@ int spmm_multi_impl(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, 
     ViewT<T> yv{y, y_sample_stride, ldy};
     hipStream_t st = (hipStream_t)stream;
     if (vec) CAPE_LAUNCH_SP(spmm_multi_kernel, T, wide, false, dim3((unsigned)(N * spmm_bps(Mo, C / (wide ? 8 : 4)))), dim3(256), 0, st, P, sum, yv, N, Mo, C);
+    else if (any_ell) return CAPE_EINVAL;                      // the scalar fallback reads CSR only
     else CAPE_LAUNCH((spmm_multi_kernel<1, T, 0>), dim3((unsigned)(N * spmm_bps(Mo, C))), dim3(256), 0, st, P, sum, yv, N, Mo, C);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
@@ -898,6 +963,7 @@ int spmm_combine_impl(const cape_spmm_term_t *terms, int32_t nterms, uint32_t to
     Q.P.n = nterms;
     bool vec = aligned4(y, y_sample_stride, ldy, F, es);
     bool wide = spmm_wide() && aligned8(y, y_sample_stride, ldy, F, es);
+    bool any_ell = false;
     for (int k = 0; k < nterms; ++k) {
         const cape_spmm_term_t &t = terms[k];
         if (!t.x || t.ldx < F) return CAPE_EINVAL;
@@ -906,6 +972,9 @@ int spmm_combine_impl(const cape_spmm_term_t *terms, int32_t nterms, uint32_t to
         Q.P.t[k].rp = t.rowptr; Q.P.t[k].ci = t.colidx; Q.P.t[k].va = t.vals;
         Q.P.t[k].y = nullptr; Q.P.t[k].ys = 0; Q.P.t[k].ldy = 0;
         Q.P.t[k].scale = t.scale;
+        Q.P.t[k].ew = t.rowptr ? t.ell_width : 0;
+        if (t.rowptr && !ell_ok(t.ell_width, t.colidx, t.vals)) return CAPE_EINVAL;
+        any_ell = any_ell || Q.P.t[k].ew;
         vec = vec && aligned4(t.x, t.x_sample_stride, t.ldx, F, es);
         wide = wide && aligned8(t.x, t.x_sample_stride, t.ldx, F, es);
     }
@@ -922,6 +991,7 @@ int spmm_combine_impl(const cape_spmm_term_t *terms, int32_t nterms, uint32_t to
     ViewT<T> yv{y, y_sample_stride, ldy};
     hipStream_t st = (hipStream_t)stream;
     if (vec) CAPE_LAUNCH_SP(spmm_combine_kernel, T, wide, false, dim3((unsigned)(N * spmm_bps(Mo, F / (wide ? 8 : 4)))), dim3(256), 0, st, Q, yv, N, Mo, F);
+    else if (any_ell) return CAPE_EINVAL;
     else CAPE_LAUNCH((spmm_combine_kernel<1, T, 0>), dim3((unsigned)(N * spmm_bps(Mo, F))), dim3(256), 0, st, Q, yv, N, Mo, F);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;

@@ -26,6 +26,9 @@ FUSED_RECURRENCE = int(_os.environ.get("CAPE_FUSED_RECURRENCE", "1"))
 # GraphCMR decoder block: 1 = its two closing 1x1 filters, the addition and the condition concat as one two-source
 # contraction (ResidualLinearFn), 0 = the reference's op-by-op formulation (the A/B reference)
 CMR_FUSED_TAIL = int(_os.environ.get("CAPE_CMR_FUSED_TAIL", "1"))
+# sparse operators with at most 12 entries per row are handed to the streaming kernels in ELL form (no row pointer in
+# the dependent-load chain, csrc/elementwise.hip cape_gather_row_ell); 0 = always CSR (the A/B reference, same sums bit for bit)
+SPMM_ELL = int(_os.environ.get("CAPE_SPMM_ELL", "1"))
 
 _ACT_OF = {"b1leakyrelu": ("leaky", _lib.BIAS_CHANNEL), "b1relu": ("relu", _lib.BIAS_CHANNEL),
            "b1tanh": ("tanh", _lib.BIAS_CHANNEL), "b2relu": ("relu", _lib.BIAS_VERTEX)}
@@ -83,6 +86,18 @@ def _v(t):
     return C.c_void_p(t.data_ptr()), int(ss), int(ld)
 
 
+def _vec_ok(*views):
+    """The condition under which the streaming sparse kernels take their vector form (csrc/elementwise.hip aligned4): four
+    consecutive elements of every row addressable as one access.  Only that form reads ELL operands."""
+    for t in views:
+        if t is None:
+            continue
+        p, ss, ld = _v(t)
+        if (p.value % (4 * t.element_size())) or (ss & 3) or (ld & 3) or (t.shape[2] & 3):
+            return False
+    return True
+
+
 def _ptr(t, offset_elems=0):
     if t is None:
         return None
@@ -109,6 +124,31 @@ class DeviceCSR(object):
         self.vals_t = torch.from_numpy(host.vals).to(device)
         if not host.identity:
             self.rowptr, self.colidx, self.vals = self.rowptr_t, self.colidx_t, self.vals_t
+        # ELL form for the streaming sparse kernels: width 4 / 8 / 12, entries in CSR order packed to the front, the slots
+        # past a row's end = (column of slot 0, 0.0) -- an empty row gets column 0
+        self.ell_w, self.ell_col_t, self.ell_val_t = 0, None, None
+        if 1 <= host.max_row <= 12:
+            w = (int(host.max_row) + 3) // 4 * 4
+            rows = host.shape[0]
+            rp = host.rowptr.astype(np.int64)
+            deg = (rp[1:] - rp[:-1]).astype(np.int64)
+            first = np.where(deg > 0, host.colidx[np.minimum(rp[:-1], max(host.nnz - 1, 0))], 0).astype(np.int32)
+            ec = np.repeat(first[:, None], w, axis=1)
+            ev = np.zeros((rows, w), dtype=np.float32)
+            slot = np.arange(host.nnz, dtype=np.int64) - np.repeat(rp[:-1], deg)
+            rr = np.repeat(np.arange(rows, dtype=np.int64), deg)
+            ec[rr, slot] = host.colidx
+            ev[rr, slot] = host.vals
+            self.ell_w = w
+            self.ell_col_t = torch.from_numpy(np.ascontiguousarray(ec)).to(device)
+            self.ell_val_t = torch.from_numpy(np.ascontiguousarray(ev)).to(device)
+
+    def operands(self):
+        """(rowptr, colidx, vals, ell_width) pointers for the streaming sparse kernels: the ELL arrays when the operator
+        has them and the knob is on, the CSR arrays otherwise."""
+        if SPMM_ELL and self.ell_w:
+            return self.rowptr_t.data_ptr(), self.ell_col_t.data_ptr(), self.ell_val_t.data_ptr(), self.ell_w
+        return self.rowptr_t.data_ptr(), self.colidx_t.data_ptr(), self.vals_t.data_ptr(), 0
 
 
 class DeviceConvOps(object):
@@ -413,9 +453,11 @@ def spmm(x, csr, y=None, alpha=1.0, z=None, beta=0.0):
         zp, zs, zl = _v(z)
     else:
         zp, zs, zl = None, 0, 0
+    rp_, ci_, va_, ew_ = csr.operands() if _vec_ok(x, y, z) else \
+        (csr.rowptr_t.data_ptr(), csr.colidx_t.data_ptr(), csr.vals_t.data_ptr(), 0)          # scalar fallback: CSR only
+
     def launch():
-        rc = _fn("cape_spmm", x)(xp, xs, xl, C.c_void_p(csr.rowptr_t.data_ptr()), C.c_void_p(csr.colidx_t.data_ptr()),
-                           C.c_void_p(csr.vals_t.data_ptr()), int(csr.max_row),
+        rc = _fn("cape_spmm", x)(xp, xs, xl, C.c_void_p(rp_), C.c_void_p(ci_), C.c_void_p(va_), int(csr.max_row), ew_,
                            float(alpha), zp, zs, zl, float(beta), yp, ys, yl, N, Mo, Cn, _stream())
         check(rc, "cape_spmm")
 
@@ -436,6 +478,7 @@ def spmm_multi(xs, csrs, sum=False, scales=None):
     Mo = next((c.shape[0] for c, i in zip(csrs, ident) if not i), xs[0].shape[1])
     arr = (_lib.CapeSpmmTerm * n)()
     outs = []
+    vec_ok = _vec_ok(*xs)          # (fresh outputs are row-padded: only the inputs decide; the ELL form needs the vector kernels)
     for k in range(n):
         assert xs[k].shape[0] == N and xs[k].shape[2] == Cn and (not ident[k] or xs[k].shape[1] == Mo)
         t = arr[k]
@@ -446,7 +489,8 @@ def spmm_multi(xs, csrs, sum=False, scales=None):
             t.rowptr = t.colidx = t.vals = None
         else:
             assert csrs[k].shape[0] == Mo and csrs[k].shape[1] == xs[k].shape[1]
-            t.rowptr, t.colidx, t.vals = csrs[k].rowptr_t.data_ptr(), csrs[k].colidx_t.data_ptr(), csrs[k].vals_t.data_ptr()
+            t.rowptr, t.colidx, t.vals, t.ell_width = csrs[k].operands() if vec_ok else \
+                (csrs[k].rowptr_t.data_ptr(), csrs[k].colidx_t.data_ptr(), csrs[k].vals_t.data_ptr(), 0)
         assert xs[k].dtype == xs[0].dtype
         if not sum:
             yk = alloc_act(N, Mo, Cn, xs[0].device, dtype=xs[0].dtype)
@@ -474,6 +518,7 @@ def spmm_combine(xs, csrs, y, to_acc2=0, rank=None, bias=None, bias_mode=_lib.BI
     n = len(xs)
     N, Mo, F = y.shape
     arr = (_lib.CapeSpmmTerm * n)()
+    vec_ok = _vec_ok(y, *xs)
     for k in range(n):
         t = arr[k]
         xp, t.x_sample_stride, t.ldx = _v(xs[k])
@@ -484,7 +529,8 @@ def spmm_combine(xs, csrs, y, to_acc2=0, rank=None, bias=None, bias_mode=_lib.BI
             t.rowptr = t.colidx = t.vals = None
         else:
             assert csrs[k].shape[0] == Mo and csrs[k].shape[1] == xs[k].shape[1]
-            t.rowptr, t.colidx, t.vals = csrs[k].rowptr_t.data_ptr(), csrs[k].colidx_t.data_ptr(), csrs[k].vals_t.data_ptr()
+            t.rowptr, t.colidx, t.vals, t.ell_width = csrs[k].operands() if vec_ok else \
+                (csrs[k].rowptr_t.data_ptr(), csrs[k].colidx_t.data_ptr(), csrs[k].vals_t.data_ptr(), 0)
         t.y, t.y_sample_stride, t.ldy = None, 0, 0
     rk = None
     if rank is not None:

@@ -261,9 +261,13 @@ int cape_bwd_prep_finalize(const cape_bwd_prep_item_t *items, int32_t nitems, vo
 /* y[n,r,:] = alpha * sum_e vals[e]*x[n,colidx[e],:] + beta * z[n,r,:]   (z may be NULL, may alias y).
  * max_row_nnz: upper bound on the entries of any row if the caller knows it, 0 = unknown.  A hint only: it picks
  * the width of the unrolled entry groups (4 for the up-/down-sampling matrices, 8 otherwise); any row length is
- * handled either way. */
+ * handled either way.
+ * ell_width: 0 = colidx / vals are the CSR arrays.  4, 8 or 12 = they are the ELL form of the same operator: [rows, ell_width]
+ * arrays (16-byte aligned), every row's entries in CSR order packed to the front, the slots past its end holding
+ * (column of slot 0, 0.0f); rowptr is then not read (but must still be non-NULL: NULL means "identity" in the term lists
+ * below).  Same sums bit for bit; two dependent memory round trips per row of <= 8 entries instead of five. */
 int cape_spmm(const float *x, int64_t x_sample_stride, int32_t ldx, const int32_t *rowptr,
-              const int32_t *colidx, const float *vals, int32_t max_row_nnz, float alpha, const float *z,
+              const int32_t *colidx, const float *vals, int32_t max_row_nnz, int32_t ell_width, float alpha, const float *z,
               int64_t z_sample_stride, int32_t ldz, float beta, float *y,
               int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t C,
               void *stream);
@@ -286,6 +290,7 @@ typedef struct cape_spmm_term {
     int64_t y_sample_stride;
     int32_t ldy;
     float scale;             /* the term is scale * S_k x_k (1.0f for a plain application) */
+    int32_t ell_width;       /* 0: colidx / vals in CSR form; 4 / 8 / 12: ELL form (see cape_spmm)      */
 } cape_spmm_term_t;
 int cape_spmm_multi(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, float *y, int64_t y_sample_stride,
                     int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream);
@@ -484,8 +489,8 @@ int cape_gconv_dw_stage_bf16(const cape_src_t *srcs, int32_t nsrc, const void *d
 int cape_gconv_dw_plan_bf16(const cape_src_t *srcs, int32_t nsrc, const void *dz, int64_t dz_sample_stride, int32_t lddz,
                             const void *dz2, uint32_t dz2_mask, int32_t N, int32_t Mo, int32_t F, int32_t plan[4]);
 int cape_spmm_bf16(const void *x, int64_t x_sample_stride, int32_t ldx, const int32_t *rowptr,
-                   const int32_t *colidx, const float *vals, int32_t max_row_nnz, float alpha, const void *z,
-                   int64_t z_sample_stride, int32_t ldz, float beta, void *y, int64_t y_sample_stride,
+                   const int32_t *colidx, const float *vals, int32_t max_row_nnz, int32_t ell_width, float alpha,
+                   const void *z, int64_t z_sample_stride, int32_t ldz, float beta, void *y, int64_t y_sample_stride,
                    int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream);
 int cape_spmm_multi_bf16(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, void *y, int64_t y_sample_stride,
                          int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream);

@@ -244,6 +244,53 @@ def test_residual_linear(shape, dev):
         assert mat_err(hc.grad.cpu().numpy(), tc.grad.numpy()) < TOL
 
 
+def test_sparse_kernels_ell_form_is_bit_identical_to_csr(mesh_ops, dev):
+    """The streaming sparse kernels read operators with <= 12 entries per row in ELL form by default (ops.SPMM_ELL): same
+    entries, same order -> the three entry points must reproduce their CSR results bit for bit (fp32 and bf16 storage)."""
+    import scipy.sparse as sp
+    from cape_amd import ops
+    from cape_amd.graph import HostCSR, ConvOperators
+    L, U = mesh_ops["L"], mesh_ops["U"]
+    host = ConvOperators(L[0], 2, unpool=U[0])
+    dops = ops.DeviceConvOps(host, dev)
+    Lc = ops.DeviceCSR(HostCSR(sp.csr_matrix(L[0], dtype=np.float64)), dev)
+    assert Lc.ell_w == 12 and all(c.identity or c.ell_w in (4, 8, 12) for c in dops.fwd + dops.bwd)
+    rng = np.random.default_rng(5)
+    results = {}
+    saved = ops.SPMM_ELL
+    try:
+        for ell in (1, 0):
+            ops.SPMM_ELL = ell
+            out = []
+            for dt in (torch.float32, torch.bfloat16):
+                x = torch.tensor(rng.standard_normal((3, 6890, 64)), dtype=torch.float32, device=dev).to(dt) if ell else results["x", dt]
+                results["x", dt] = x
+                xa = ops.alloc_act(3, 6890, 64, dev, dtype=dt)
+                xa.copy_(x)
+                out.append(ops.spmm(xa, Lc).float().cpu().numpy())
+                z = ops.spmm(xa, Lc, alpha=2.0, z=xa, beta=-1.0)
+                out.append(z.float().cpu().numpy())
+                xi = ops.alloc_act(3, dops.Mi, 64, dev, dtype=dt)
+                xi.copy_(x[:, :dops.Mi])
+                ys = ops.spmm_multi([xi] * dops.K, list(dops.fwd))
+                out += [t.float().cpu().numpy() for t in ys]
+                go = ops.alloc_act(3, dops.Mo, 64, dev, dtype=dt)
+                go.copy_(x[:, :dops.Mo])
+                out.append(ops.spmm_multi([go] * dops.K, list(dops.bwd), sum=True).float().cpu().numpy())
+                yc = ops.alloc_act(3, dops.Mo, 64, dev, dtype=dt)
+                ops.spmm_combine([xi] * dops.K, list(dops.fwd), yc, act="relu")
+                out.append(yc.float().cpu().numpy())
+            results[ell] = out
+    finally:
+        ops.SPMM_ELL = saved
+    assert len(results[1]) == len(results[0])
+    for a, b in zip(results[1], results[0]):
+        assert np.array_equal(a, b)
+    # and the ELL path agrees with the matrix itself
+    ref = np.stack([np.asarray(L[0] @ results["x", torch.float32][n].cpu().numpy().astype(np.float64)) for n in range(3)])
+    assert vertex_err(results[1][0], ref) < TOL
+
+
 def test_recon_edge_loss(mesh_ops, dev):
     from cape_amd import ops
     from cape_amd.graph import vertex_edge_table

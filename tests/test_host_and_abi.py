@@ -40,7 +40,8 @@ def test_sparse_entry_points_reject_bad_arguments_before_launching():
     from cape_amd._lib import lib
     P = C.c_void_p
     x, y, rp, ci, va = P(0x100000), P(0x200000), P(0x300000), P(0x400000), P(0x500000)
-    args = lambda **kw: [kw.get("x", x), 64 * 64, kw.get("ldx", 64), rp, ci, va, 8, 1.0, None, 0, 0, 0.0, kw.get("y", y),
+    args = lambda **kw: [kw.get("x", x), 64 * 64, kw.get("ldx", 64), rp, kw.get("ci", ci), va, 8, kw.get("ew", 0), 1.0, None, 0, 0, 0.0,
+                         kw.get("y", y),
                          64 * 64, kw.get("ldy", 64), kw.get("N", 2), kw.get("Mo", 64), kw.get("C", 64), None]
     assert lib.cape_spmm(*args(x=None)) == -1
     assert lib.cape_spmm(*args(y=None)) == -1
@@ -49,6 +50,8 @@ def test_sparse_entry_points_reject_bad_arguments_before_launching():
     big = 1 << 20                                                  # Mo * C = 2^31: beyond the 32-bit item index
     assert lib.cape_spmm(*args(Mo=big, C=2048, ldx=2048, ldy=2048)) == -1
     assert lib.cape_spmm_bf16(*args(Mo=big, C=2048, ldx=2048, ldy=2048)) == -1
+    assert lib.cape_spmm(*args(ew=5)) == -1                        # ELL operands: width 4, 8 or 12 ...
+    assert lib.cape_spmm(*args(ew=8, ci=P(0x400004))) == -1        # ... and 16-byte aligned arrays
 
 
 def test_compute_entry_points_fail_loudly_without_gpu():
@@ -249,3 +252,38 @@ def test_bench_exact_fp32_comparison_is_fault_tolerant(monkeypatch):
 
     monkeypatch.setattr(subprocess, "run", lambda *a, **k: types.SimpleNamespace(stdout=b"no json here\n"))
     assert "error" in bench.exact_fp32_run(args)
+
+
+def test_ell_form_of_the_operators_matches_csr(mesh_ops):
+    """DeviceCSR's ELL arrays (what the streaming sparse kernels read): same entries in CSR order packed to the front, the
+    padding slots (column of slot 0, 0.0); operators with more than 12 entries per row have none."""
+    import scipy.sparse as sp
+    import torch
+    from cape_amd import ops
+    from cape_amd.graph import HostCSR, ConvOperators
+    pack = mesh_ops["pack"] if "pack" in mesh_ops else None
+    L = mesh_ops["L"][0] if "L" in mesh_ops else None
+    mats = []
+    if L is not None:
+        mats.append(sp.csr_matrix(L, dtype=np.float64))
+    rng = np.random.default_rng(3)
+    R = sp.random(50, 40, density=0.1, random_state=5, format="csr", dtype=np.float64)
+    R.data = rng.standard_normal(R.nnz)
+    mats.append(R)                                       # ragged rows, some empty
+    for Mtx in mats:
+        Mtx.sort_indices()
+        d = ops.DeviceCSR(HostCSR(Mtx), torch.device("cpu"))
+        deg = np.diff(Mtx.indptr)
+        if deg.max() > 12:
+            assert d.ell_w == 0
+            continue
+        assert d.ell_w == (deg.max() + 3) // 4 * 4 and d.ell_w in (4, 8, 12)
+        ec, ev = d.ell_col_t.numpy(), d.ell_val_t.numpy()
+        assert ec.shape == (Mtx.shape[0], d.ell_w) and ec.dtype == np.int32 and ev.dtype == np.float32
+        for r in range(Mtx.shape[0]):
+            a, b = Mtx.indptr[r], Mtx.indptr[r + 1]
+            assert np.array_equal(ec[r, :b - a], Mtx.indices[a:b])
+            assert np.array_equal(ev[r, :b - a], Mtx.data[a:b].astype(np.float32))
+            assert np.all(ev[r, b - a:] == 0) and np.all(ec[r, b - a:] == (Mtx.indices[a] if b > a else 0))
+    wide = sp.random(30, 30, density=0.6, random_state=1, format="csr", dtype=np.float64)
+    assert ops.DeviceCSR(HostCSR(wide), torch.device("cpu")).ell_w == 0
