@@ -900,16 +900,28 @@ class CAPE(base_model):
             # ONE discriminator pass over the generated batch serves both losses (the reference builds D(fake) once,
             # lib/models.py:299-302): loss_g is differentiated w.r.t. the generator/condition variables only and
             # loss_d w.r.t. the discriminator variables only (backward_to_flat), so neither gradient leaks.
-            d_fake = self.discriminator(x_hat, y_g, y2_g)
+            if self.bug_compat or not ops.merged_d_pass(x_hat.shape[0]):
+                d_fake = self.discriminator(x_hat, y_g, y2_g)
+                y_d, y2_d = self._conditions(cond_d, cond2_d)
+                if self.bug_compat:
+                    with torch.no_grad():
+                        d_real = self.discriminator(data_d, y_d, y2_d)
+                else:
+                    d_real = self.discriminator(data_d, y_d.detach(), y2_d.detach())
+            else:
+                # D(fake) and D(real) share weights and every operator on the path is per sample (:648-678; group norm
+                # included): the two evaluations run as ONE pass over the concatenated batch [generated ; real] -- half
+                # the launches of the discriminator's forward and of its weight-gradient sweep, and one weight-gradient
+                # contraction per layer instead of two whose results autograd then adds.
+                y_d, y2_d = self._conditions(cond_d, cond2_d)
+                d_all = self.discriminator(torch.cat([x_hat, data_d.to(x_hat.dtype)], 0),
+                                           torch.cat([y_g, y_d.detach()], 0), torch.cat([y2_g, y2_d.detach()], 0))
+                nb = x_hat.shape[0]
+                d_fake, d_real = d_all[:nb], d_all[nb:]
             out['gan_g'] = self._bce(d_fake, 1 - smooth)
             loss_g = loss_g + out['gan_g'] * self.lambda_gan
-            y_d, y2_d = self._conditions(cond_d, cond2_d)
             if self.bug_compat:
-                with torch.no_grad():
-                    d_real = self.discriminator(data_d, y_d, y2_d)
                 d_fake = d_fake.detach()
-            else:
-                d_real = self.discriminator(data_d, y_d.detach(), y2_d.detach())
             out['gan_d'] = self._bce(d_real, 1 - smooth) + self._bce(d_fake, smooth)
             out['loss_d'] = out['gan_d'] * self.lambda_gan
         out['loss_g'] = loss_g

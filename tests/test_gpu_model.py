@@ -67,13 +67,26 @@ def _run_twin(twin, x, gt, xd, cond, cond_d, clo, clo_d, eps, signs=None, l1_sig
     """``signs``: branch patterns recorded by the device forward (ops.ACT_TRACE), replayed site by site -- the sub-networks
     run in the order cape_amd.models.CAPE.forward_losses evaluates them."""
     import collections
+    merged = False
+    if signs is not None:
+        # the device evaluates D(generated) and D(real) as one pass over the concatenated batch (cape_amd.ops.MERGED_D_PASS):
+        # its discriminator sites carry 2N rows -- first half the generated samples, second half the real ones
+        nb = x.shape[0]
+        merged = any(m.shape[0] == 2 * nb for m in signs)
+        if merged:
+            dsites = [m for m in signs if m.shape[0] == 2 * nb]
+            signs = [m for m in signs if m.shape[0] != 2 * nb] + [m[:nb] for m in dsites] + [m[nb:] for m in dsites]
     twin.forced_signs = None if signs is None else collections.deque(signs)
     twin.flip_log = []
     try:
         y, y2 = twin.cond_embeddings(cond, clo)
         xh, zm, zl = twin.generator(x, y, y2, eps)
-        d_fake = twin.discriminator(xh, y, y2)
-        yd, y2d = twin.cond_embeddings(cond_d, clo_d)
+        if merged:                              # device order: both condition networks, then the discriminator
+            yd, y2d = twin.cond_embeddings(cond_d, clo_d)
+            d_fake = twin.discriminator(xh, y, y2)
+        else:
+            d_fake = twin.discriminator(xh, y, y2)
+            yd, y2d = twin.cond_embeddings(cond_d, clo_d)
         d_real = twin.discriminator(xd, yd, y2d)
         assert not twin.forced_signs, "%d recorded activation sites were not consumed" % len(twin.forced_signs)
     finally:
@@ -437,3 +450,32 @@ def test_training_step_is_bitwise_reproducible(cfg, gan, mesh_ops):
         assert torch.equal(runs[0][key], runs[1][key]), key
         moved = moved or not torch.equal(runs[0][key], start[key[0]][key[1]])
     assert moved                                         # the steps did update something
+
+
+def test_merged_discriminator_pass_equals_two_passes(mesh_ops):
+    """D(generated) and D(real) as one pass over the concatenated batch (ops.MERGED_D_PASS, the default up to 16 + 16 meshes)
+    against the two passes the reference builds (lib/models.py:299-302): same losses, same gradients of both groups."""
+    from cape_amd import ops
+    N = 2
+    P, twin, model = _build("affine_nz64", mesh_ops, N)
+    x, gt, xd, cond, cond_d, clo, clo_d, eps = _inputs(N, P["nz"])
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=model.device)
+    args = (t(x), t(cond), t(clo), t(gt), t(xd), t(cond_d), t(clo_d))
+    res, saved = {}, ops.MERGED_D_PASS
+    try:
+        for mode in ("1", "0"):
+            ops.MERGED_D_PASS = mode
+            out = model.forward_losses(*args, eps=t(eps))
+            gg = torch.autograd.grad(out['loss_g'], [model._vars[n] for n in model._g_names], retain_graph=True, allow_unused=True)
+            gd = torch.autograd.grad(out['loss_d'], [model._vars[n] for n in model._d_names], allow_unused=True)
+            res[mode] = ({k: float(out[k]) for k in ('loss_g', 'loss_d', 'gan_g', 'gan_d')}, gg + gd)
+    finally:
+        ops.MERGED_D_PASS = saved
+    for k, v in res["1"][0].items():
+        assert abs(v - res["0"][0][k]) <= 1e-6 * max(abs(v), 1e-3), k
+    for n, a, b in zip(model._g_names + model._d_names, res["1"][1], res["0"][1]):
+        if a is None or b is None:
+            assert a is None and b is None, n
+            continue
+        den = float(b.norm())
+        assert float((a - b).norm()) <= 2e-6 * max(den, 1e-12) + 1e-12, (n, float((a - b).norm()), den)
