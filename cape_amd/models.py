@@ -101,6 +101,7 @@ class base_model(object):
         self._csr_cache = {}
         self._init_rng = np.random.default_rng(seed)
         self._grad_views = {}      # TF variable name -> view of the flat gradient bucket (train phase)
+        self._grad_views_d = {}    # the same for the discriminator variables, used while D runs as a single merged pass
         self._conv_meta = {}       # conv weight name -> (feature channels, K, Fout), recorded while tracing
         self._cond_plan = None     # consumers of the decoder's condition vector, recorded on the first pass
         self._cond_rec = None      # ... while recording
@@ -787,6 +788,10 @@ class CAPE(base_model):
                 # fake pass (two contributions that autograd must add) and keep private gradient tensors.
                 for nm, view in zip(names, views):
                     self._grad_views[nm] = view
+            else:
+                # ... unless the step evaluates D(generated) and D(real) as ONE pass (forward_losses, ops.merged_d_pass):
+                # _grad_views hands these out only while that pass is traced (self._d_single_use)
+                self._grad_views_d = dict(zip(names, views))
             n_early = self._g_early if grp == 'g' else len(names)
             split_off = offsets[names[n_early]][0] if n_early < len(names) else total
             st = {'params': params, 'flat': flat, 'flat_grad': flat_grad, 'grad_views': views, 'offsets': offsets,
@@ -914,8 +919,18 @@ class CAPE(base_model):
                 # the launches of the discriminator's forward and of its weight-gradient sweep, and one weight-gradient
                 # contraction per layer instead of two whose results autograd then adds.
                 y_d, y2_d = self._conditions(cond_d, cond2_d)
-                d_all = self.discriminator(torch.cat([x_hat, data_d.to(x_hat.dtype)], 0),
-                                           torch.cat([y_g, y_d.detach()], 0), torch.cat([y2_g, y2_d.detach()], 0))
+                # every discriminator variable is then used exactly once per step: its gradient kernels may write the
+                # bucket directly and queue their reductions like the generator's (backward_to_flat flushes them)
+                single = bool(reg_via_bucket and self._grad_views_d)
+                if single:
+                    self._grad_views.update(self._grad_views_d)
+                try:
+                    d_all = self.discriminator(torch.cat([x_hat, data_d.to(x_hat.dtype)], 0),
+                                               torch.cat([y_g, y_d.detach()], 0), torch.cat([y2_g, y2_d.detach()], 0))
+                finally:
+                    if single:
+                        for nm in self._grad_views_d:
+                            self._grad_views.pop(nm, None)
                 nb = x_hat.shape[0]
                 d_fake, d_real = d_all[:nb], d_all[nb:]
             out['gan_g'] = self._bce(d_fake, 1 - smooth)
