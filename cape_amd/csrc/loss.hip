@@ -104,6 +104,48 @@ __global__ __launch_bounds__(LB) void loss_final_kernel(const float *part_e, int
     }
 }
 
+// ---- adversarial losses on the discriminator's logits (lib/models.py:381-390) -----------------------------------------------
+//   gan_g = mean_i bce(fake_i, 1 - smooth)            gan_d = mean_j bce(real_j, 1 - smooth) + mean_i bce(fake_i, smooth)
+//   bce(x, t) = max(x, 0) - x t + log1p(exp(-|x|))   (tf.nn.sigmoid_cross_entropy_with_logits),  d bce / dx = sigmoid(x) - t
+// One workgroup (the logits are N x 431 values): both means by a fixed-order block reduction, and the gradients of
+// scale * gan_g and scale * gan_d w.r.t. every logit in the same pass -- the op-by-op form is ~25 launches of 5 us each.
+// Logit (n, m) of a tensor is at p[n * ss + m * ld].  ga / gb: gradients of the two losses, rows = the fake samples first,
+// then the real ones (ga is zero there), contiguous [Nf + Nr, M].
+__global__ __launch_bounds__(LB) void gan_bce_kernel(const float *fake, long long fss, int fld, const float *real, long long rss, int rld,
+                                                     int Nf, int Nr, int M, float smooth, float scale, float *out, float *scaled_g,
+                                                     float *scaled_d, float *ga, float *gb) {
+    __shared__ float red[4];
+    const float tr = 1.f - smooth, tf_ = smooth;
+    const float cf = scale / ((float)Nf * (float)M), cr = scale / ((float)Nr * (float)M);
+    float sg = 0.f, sdf = 0.f, sdr = 0.f;
+    for (int i = threadIdx.x; i < Nf * M; i += LB) {
+        const float x = fake[(long long)(i / M) * fss + (long long)(i % M) * fld];
+        const float sp = fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));          // softplus(x)
+        const float sig = 1.f / (1.f + expf(-x));
+        sg += sp - x * tr;
+        sdf += sp - x * tf_;
+        ga[i] = cf * (sig - tr);
+        gb[i] = cf * (sig - tf_);
+    }
+    for (int i = threadIdx.x; i < Nr * M; i += LB) {
+        const float x = real[(long long)(i / M) * rss + (long long)(i % M) * rld];
+        const float sp = fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+        sdr += sp - x * tr;
+        ga[Nf * M + i] = 0.f;
+        gb[Nf * M + i] = cr * (1.f / (1.f + expf(-x)) - tr);
+    }
+    sg = block_sum256(sg, red);
+    sdf = block_sum256(sdf, red);
+    sdr = block_sum256(sdr, red);
+    if (threadIdx.x == 0) {
+        const float g = sg / ((float)Nf * (float)M), d = sdr / ((float)Nr * (float)M) + sdf / ((float)Nf * (float)M);
+        out[0] = g;
+        out[1] = d;
+        *scaled_g = scale * g;
+        *scaled_d = scale * d;
+    }
+}
+
 inline int nblocks(long long total) {
     long long b = (total + LB - 1) / LB;
     if (b > 1024) b = 1024;
@@ -136,6 +178,18 @@ extern "C" int cape_recon_edge_loss_fwd_bwd(const float *pred, const float *gt, 
     CAPE_LAUNCH_CHECK();
     CAPE_LAUNCH(loss_final_kernel, dim3(1), dim3(LB), 0, st, part_e, ne, 1.0f / ((float)N * (float)E), part_v, nv,
                        1.0f / ((float)N * (float)M * 3.0f), loss_out, w_recon, w_edge, total_out);
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}
+
+extern "C" int cape_gan_bce_fwd_bwd(const float *fake, int64_t fake_sample_stride, int32_t ldf, const float *real,
+                                    int64_t real_sample_stride, int32_t ldr, int32_t Nf, int32_t Nr, int32_t M, float smooth,
+                                    float scale, float *loss_out, float *scaled_g, float *scaled_d, float *grad_g, float *grad_d,
+                                    void *stream) {
+    if (!fake || !real || !loss_out || !scaled_g || !scaled_d || !grad_g || !grad_d || Nf < 1 || Nr < 1 || M < 1 || ldf < 1 || ldr < 1) return CAPE_EINVAL;
+    if ((long long)(Nf + Nr) * M >= (1LL << 31)) return CAPE_EINVAL;
+    CAPE_LAUNCH(gan_bce_kernel, dim3(1), dim3(LB), 0, (hipStream_t)stream, fake, (long long)fake_sample_stride, ldf, real,
+                (long long)real_sample_stride, ldr, Nf, Nr, M, smooth, scale, loss_out, scaled_g, scaled_d, grad_g, grad_d);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }

@@ -905,6 +905,7 @@ class CAPE(base_model):
             # ONE discriminator pass over the generated batch serves both losses (the reference builds D(fake) once,
             # lib/models.py:299-302): loss_g is differentiated w.r.t. the generator/condition variables only and
             # loss_d w.r.t. the discriminator variables only (backward_to_flat), so neither gradient leaks.
+            d_all = None
             if self.bug_compat or not ops.merged_d_pass(x_hat.shape[0]):
                 d_fake = self.discriminator(x_hat, y_g, y2_g)
                 y_d, y2_d = self._conditions(cond_d, cond2_d)
@@ -933,12 +934,22 @@ class CAPE(base_model):
                             self._grad_views.pop(nm, None)
                 nb = x_hat.shape[0]
                 d_fake, d_real = d_all[:nb], d_all[nb:]
-            out['gan_g'] = self._bce(d_fake, 1 - smooth)
-            loss_g = loss_g + out['gan_g'] * self.lambda_gan
-            if self.bug_compat:
-                d_fake = d_fake.detach()
-            out['gan_d'] = self._bce(d_real, 1 - smooth) + self._bce(d_fake, smooth)
-            out['loss_d'] = out['gan_d'] * self.lambda_gan
+            if self.bug_compat or not d_fake.is_cuda or d_fake.dtype != torch.float32:
+                out['gan_g'] = self._bce(d_fake, 1 - smooth)
+                loss_g = loss_g + out['gan_g'] * self.lambda_gan
+                if self.bug_compat:
+                    d_fake = d_fake.detach()
+                out['gan_d'] = self._bce(d_real, 1 - smooth) + self._bce(d_fake, smooth)
+                out['loss_d'] = out['gan_d'] * self.lambda_gan
+            else:
+                # both adversarial terms (:381-390), scaled by lambda_gan (:393,397), and their gradients: one launch
+                if d_all is not None:
+                    lg, ld_, parts = ops.GanLossFn.apply(d_all, None, int(x_hat.shape[0]), smooth, float(self.lambda_gan))
+                else:
+                    lg, ld_, parts = ops.GanLossFn.apply(d_fake, d_real, int(d_fake.shape[0]), smooth, float(self.lambda_gan))
+                out['gan_g'], out['gan_d'] = parts[0], parts[1]
+                loss_g = loss_g + lg
+                out['loss_d'] = ld_
         out['loss_g'] = loss_g
         return out
 

@@ -1390,6 +1390,56 @@ class ReconEdgeLossFn(torch.autograd.Function):
         return dpred * gtotal, None, None, None, None, None, None, None
 
 
+class GanLossFn(torch.autograd.Function):
+    """(lambda * gan_g, lambda * gan_d, [gan_g, gan_d]) from the discriminator's logits (lib/models.py:381-390,397):
+    sigmoid cross entropy with smoothed labels, both means and both gradients in ONE launch (csrc/loss.hip gan_bce_kernel)
+    instead of ~25 element-wise ones.  ``logits``: the merged pass [Nf + Nr, M, 1] (generated samples first, ``real`` None)
+    or the generated samples' logits with ``real`` the second tensor.  The third output is not differentiable."""
+
+    @staticmethod
+    def forward(ctx, logits, real, nf, smooth, lam):
+        _lib.require_gpu()
+        logits = as_act(logits)
+        assert logits.dtype == torch.float32 and logits.shape[2] == 1
+        M = logits.shape[1]
+        if real is None:
+            fake, rl = logits[:nf], logits[nf:]
+        else:
+            fake, rl = logits, as_act(real)
+            assert rl.dtype == torch.float32 and rl.shape[1:] == logits.shape[1:] and nf == logits.shape[0]
+        Nf, Nr = fake.shape[0], rl.shape[0]
+        fp, fs, fl = _v(fake)
+        rp, rs, rld = _v(rl)
+        out = torch.empty(2, device=logits.device, dtype=torch.float32)
+        sg = torch.empty((), device=logits.device, dtype=torch.float32)
+        sd = torch.empty((), device=logits.device, dtype=torch.float32)
+        ga = torch.empty((Nf + Nr, M, 1), device=logits.device, dtype=torch.float32)
+        gb = torch.empty_like(ga)
+        check(lib.cape_gan_bce_fwd_bwd(fp, fs, fl, rp, rs, rld, Nf, Nr, M, float(smooth), float(lam), _ptr(out), _ptr(sg), _ptr(sd),
+                                       _ptr(ga), _ptr(gb), _stream()), "cape_gan_bce_fwd_bwd")
+        ctx.save_for_backward(ga, gb)
+        ctx.split = None if real is None else Nf
+        ctx.mark_non_differentiable(out)
+        return sg, sd, out
+
+    @staticmethod
+    def backward(ctx, gg, gd, _gout):
+        ga, gb = ctx.saved_tensors
+
+        def times(t, g):
+            if g is None:
+                return None
+            return t if (UNIT_GRAD is not None and g.data_ptr() == UNIT_GRAD.data_ptr()) else t * g
+
+        a, b = times(ga, gg), times(gb, gd)
+        tot = a if b is None else (b if a is None else a + b)
+        if tot is None:
+            return None, None, None, None, None
+        if ctx.split is None:
+            return tot, None, None, None, None
+        return tot[:ctx.split], tot[ctx.split:], None, None, None
+
+
 # --------------------------------------------------------------------------------------------
 # functional front-ends with the reference's operator names
 # --------------------------------------------------------------------------------------------

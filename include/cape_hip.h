@@ -33,6 +33,7 @@
  *   cape_fill_cond      lib/models.py:813-832 fit_cond_dim + tf.concat (:535,593,608,665).
  *   cape_groupnorm_fwd / cape_groupnorm_bwd
  *                       lib/models.py:681-712 gn (norm_type='group') and its gradient.
+ *   cape_gan_bce_fwd_bwd lib/models.py:381-390 the adversarial loss terms and their gradients w.r.t. the logits.
  *   cape_recon_edge_loss_fwd_bwd
  *                       lib/models.py:357-375 L1 reconstruction + lib/losses.py:9-25 edge loss
  *                       and their gradients w.r.t. the prediction.
@@ -377,6 +378,20 @@ int cape_recon_edge_loss_fwd_bwd(const float *pred, const float *gt, const float
                                  const int32_t *vert_edge_idx, int32_t N, int32_t M, int32_t E,
                                  float w_recon, float w_edge, float *loss_out, float *total_out, float *dpred,
                                  void *workspace, int64_t workspace_bytes, void *stream);
+
+/*
+ * Adversarial losses on the discriminator's logits (lib/models.py:381-390, tf.nn.sigmoid_cross_entropy_with_logits with
+ * label smoothing) and their gradients, one launch:
+ *   loss_out[0] = gan_g = mean bce(fake, 1 - smooth)
+ *   loss_out[1] = gan_d = mean bce(real, 1 - smooth) + mean bce(fake, smooth);   *scaled_g / *scaled_d = scale * the two
+ *   grad_g / grad_d [Nf + Nr, M] contiguous = d(scale * gan_g) / d logit and d(scale * gan_d) / d logit, the Nf fake samples
+ *   first, then the Nr real ones (grad_g is zero there).  Logit (n, m) of a tensor is at p[n * sample_stride + m * ld]
+ *   (the prediction map [N, 431, 1] of discriminator, :676-678, as a row-padded view).  Fixed-order sums.
+ */
+int cape_gan_bce_fwd_bwd(const float *fake, int64_t fake_sample_stride, int32_t ldf, const float *real,
+                         int64_t real_sample_stride, int32_t ldr, int32_t Nf, int32_t Nr, int32_t M, float smooth,
+                         float scale, float *loss_out, float *scaled_g, float *scaled_d, float *grad_g, float *grad_d,
+                         void *stream);
 
 /* coef of every layer <- cond [N, Cc] (row stride ldc).  N * Cc <= 10240. */
 int cape_cond_coef_fwd(const float *cond, int32_t ldc, int32_t N, int32_t Cc,

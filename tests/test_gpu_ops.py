@@ -291,6 +291,36 @@ def test_sparse_kernels_ell_form_is_bit_identical_to_csr(mesh_ops, dev):
     assert vertex_err(results[1][0], ref) < TOL
 
 
+@pytest.mark.parametrize("merged", [True, False])
+def test_gan_loss_matches_sigmoid_cross_entropy(merged, dev):
+    """GanLossFn (one launch) against the op-by-op float64 form of lib/models.py:381-390: both losses and the gradient
+    each of them sends to the logits, on row-padded prediction-map views."""
+    from cape_amd import ops
+    rng = np.random.default_rng(2)
+    Nf, Nr, M, smooth, lam = 3, 3, 431, 0.1, 0.7
+    lf, lr = 4 * rng.standard_normal((Nf, M, 1)), 4 * rng.standard_normal((Nr, M, 1))
+    tf_, tr = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (lf, lr))
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+    gan_g = bce(tf_, torch.full_like(tf_, 1 - smooth))
+    gan_d = bce(tr, torch.full_like(tr, 1 - smooth)) + bce(tf_, torch.full_like(tf_, smooth))
+    gg = torch.autograd.grad(lam * gan_g, [tf_], retain_graph=True)[0]
+    gd = torch.autograd.grad(lam * gan_d, [tf_, tr])
+    buf = ops.alloc_act(Nf + Nr, M, 1, dev)                        # ld = 4: the layout the discriminator's last layer writes
+    buf.copy_(torch.tensor(np.concatenate([lf, lr]), dtype=torch.float32))
+    hall = buf.detach().requires_grad_(True)
+    if merged:
+        lg, ld, parts = ops.GanLossFn.apply(hall, None, Nf, smooth, lam)
+    else:
+        hf, hr = hall[:Nf], hall[Nf:]
+        lg, ld, parts = ops.GanLossFn.apply(hf, hr, Nf, smooth, lam)
+    assert abs(float(parts[0]) - float(gan_g)) < 2e-6 * abs(float(gan_g)) and abs(float(parts[1]) - float(gan_d)) < 2e-6 * abs(float(gan_d))
+    assert abs(float(lg) - lam * float(gan_g)) < 2e-6 * abs(float(gan_g)) and abs(float(ld) - lam * float(gan_d)) < 2e-6 * abs(float(gan_d))
+    hg = torch.autograd.grad(lg, [hall], retain_graph=True)[0].cpu().numpy()
+    hd = torch.autograd.grad(ld, [hall])[0].cpu().numpy()
+    assert mat_err(hg[:Nf], gg.numpy()) < 1e-5 and np.all(hg[Nf:] == 0)
+    assert mat_err(hd[:Nf], gd[0].numpy()) < 1e-5 and mat_err(hd[Nf:], gd[1].numpy()) < 1e-5
+
+
 def test_recon_edge_loss(mesh_ops, dev):
     from cape_amd import ops
     from cape_amd.graph import vertex_edge_table
