@@ -111,34 +111,46 @@ __global__ __launch_bounds__(LB) void loss_final_kernel(const float *part_e, int
 // scale * gan_g and scale * gan_d w.r.t. every logit in the same pass -- the op-by-op form is ~25 launches of 5 us each.
 // Logit (n, m) of a tensor is at p[n * ss + m * ld].  ga / gb: gradients of the two losses, rows = the fake samples first,
 // then the real ones (ga is zero there), contiguous [Nf + Nr, M].
-__global__ __launch_bounds__(LB) void gan_bce_kernel(const float *fake, long long fss, int fld, const float *real, long long rss, int rld,
-                                                     int Nf, int Nr, int M, float smooth, float scale, float *out, float *scaled_g,
-                                                     float *scaled_d, float *ga, float *gb) {
-    __shared__ float red[4];
+constexpr int GAN_LB = 1024;
+__global__ __launch_bounds__(GAN_LB) void gan_bce_kernel(const float *fake, long long fss, int fld, const float *real, long long rss, int rld,
+                                                         int Nf, int Nr, int M, float smooth, float scale, float *out, float *scaled_g,
+                                                         float *scaled_d, float *ga, float *gb) {
+    __shared__ float red[3][GAN_LB / 64];
     const float tr = 1.f - smooth, tf_ = smooth;
     const float cf = scale / ((float)Nf * (float)M), cr = scale / ((float)Nr * (float)M);
     float sg = 0.f, sdf = 0.f, sdr = 0.f;
-    for (int i = threadIdx.x; i < Nf * M; i += LB) {
+    for (int i = threadIdx.x; i < Nf * M; i += GAN_LB) {
         const float x = fake[(long long)(i / M) * fss + (long long)(i % M) * fld];
-        const float sp = fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));          // softplus(x)
-        const float sig = 1.f / (1.f + expf(-x));
+        const float e = expf(-fabsf(x));                                  // exp(-|x|) in (0, 1]
+        const float sp = fmaxf(x, 0.f) + log1pf(e);                         // softplus(x)
+        const float sig = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);       // sigmoid(x) from the same exponential
         sg += sp - x * tr;
         sdf += sp - x * tf_;
         ga[i] = cf * (sig - tr);
         gb[i] = cf * (sig - tf_);
     }
-    for (int i = threadIdx.x; i < Nr * M; i += LB) {
+    for (int i = threadIdx.x; i < Nr * M; i += GAN_LB) {
         const float x = real[(long long)(i / M) * rss + (long long)(i % M) * rld];
-        const float sp = fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+        const float e = expf(-fabsf(x));
+        const float sp = fmaxf(x, 0.f) + log1pf(e);
+        const float sig = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
         sdr += sp - x * tr;
         ga[Nf * M + i] = 0.f;
-        gb[Nf * M + i] = cr * (1.f / (1.f + expf(-x)) - tr);
+        gb[Nf * M + i] = cr * (sig - tr);
     }
-    sg = block_sum256(sg, red);
-    sdf = block_sum256(sdf, red);
-    sdr = block_sum256(sdr, red);
+    // fixed-order reduction: xor shuffles inside each wave, then the 16 wave sums in order
+    float v[3] = {sg, sdf, sdr};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        for (int sh = 1; sh < 64; sh <<= 1) v[j] += __shfl_xor(v[j], sh);
+        if ((threadIdx.x & 63) == 0) red[j][threadIdx.x >> 6] = v[j];
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const float g = sg / ((float)Nf * (float)M), d = sdr / ((float)Nr * (float)M) + sdf / ((float)Nf * (float)M);
+        float t[3] = {0.f, 0.f, 0.f};
+        for (int j = 0; j < 3; ++j)
+            for (int w = 0; w < GAN_LB / 64; ++w) t[j] += red[j][w];
+        const float g = t[0] / ((float)Nf * (float)M), d = t[2] / ((float)Nr * (float)M) + t[1] / ((float)Nf * (float)M);
         out[0] = g;
         out[1] = d;
         *scaled_g = scale * g;
@@ -188,7 +200,7 @@ extern "C" int cape_gan_bce_fwd_bwd(const float *fake, int64_t fake_sample_strid
                                     void *stream) {
     if (!fake || !real || !loss_out || !scaled_g || !scaled_d || !grad_g || !grad_d || Nf < 1 || Nr < 1 || M < 1 || ldf < 1 || ldr < 1) return CAPE_EINVAL;
     if ((long long)(Nf + Nr) * M >= (1LL << 31)) return CAPE_EINVAL;
-    CAPE_LAUNCH(gan_bce_kernel, dim3(1), dim3(LB), 0, (hipStream_t)stream, fake, (long long)fake_sample_stride, ldf, real,
+    CAPE_LAUNCH(gan_bce_kernel, dim3(1), dim3(GAN_LB), 0, (hipStream_t)stream, fake, (long long)fake_sample_stride, ldf, real,
                 (long long)real_sample_stride, ldr, Nf, Nr, M, smooth, scale, loss_out, scaled_g, scaled_d, grad_g, grad_d);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;

@@ -649,8 +649,10 @@ class CAPE(base_model):
             x_hat = self.decoder_cond_vert(z_total, y, y2, use_res_block=self.use_res_block_dec)
         return x_hat, z_mean, z_logvar
 
-    def discriminator(self, x, y, y2):
-        cond = self._cat_cond(y, y2)
+    def discriminator(self, x, y, y2, cond=None):
+        """``cond``: the concatenated condition [y | y2] when the caller already holds it (then y / y2 are not read)."""
+        if cond is None:
+            cond = self._cat_cond(y, y2)
         if x.dtype != self.act_dtype:
             x = x.to(self.act_dtype)
         with self.variable_scope('discriminator'):
@@ -919,15 +921,22 @@ class CAPE(base_model):
                 # included): the two evaluations run as ONE pass over the concatenated batch [generated ; real] -- half
                 # the launches of the discriminator's forward and of its weight-gradient sweep, and one weight-gradient
                 # contraction per layer instead of two whose results autograd then adds.
+                ycat_g = self._ycat[2] if self._ycat is not None else None       # (the generator's, from _conditions above)
                 y_d, y2_d = self._conditions(cond_d, cond2_d)
+                ycat_d = self._ycat[2] if self._ycat is not None else None
                 # every discriminator variable is then used exactly once per step: its gradient kernels may write the
                 # bucket directly and queue their reductions like the generator's (backward_to_flat flushes them)
                 single = bool(reg_via_bucket and self._grad_views_d)
                 if single:
                     self._grad_views.update(self._grad_views_d)
                 try:
-                    d_all = self.discriminator(torch.cat([x_hat, data_d.to(x_hat.dtype)], 0),
-                                               torch.cat([y_g, y_d.detach()], 0), torch.cat([y2_g, y2_d.detach()], 0))
+                    x_all = torch.cat([x_hat, data_d.to(x_hat.dtype)], 0)
+                    if ycat_g is not None and ycat_d is not None:
+                        # the fused condition networks already produced [y | y2]: one concat over the batch, and the
+                        # gradient comes back to that tensor whole instead of through two slices
+                        d_all = self.discriminator(x_all, None, None, cond=torch.cat([ycat_g, ycat_d.detach()], 0))
+                    else:
+                        d_all = self.discriminator(x_all, torch.cat([y_g, y_d.detach()], 0), torch.cat([y2_g, y2_d.detach()], 0))
                 finally:
                     if single:
                         for nm in self._grad_views_d:
