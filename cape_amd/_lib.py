@@ -132,7 +132,7 @@ SIGNATURES = {
                                       _p, _p, _p, _p, _i32, _p, _i64, _p]),
     "cape_recon_edge_workspace_bytes": (_i64, [_i32, _i32, _i32]),
     "cape_recon_edge_loss_fwd_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _f32,
-                                               _p, _p, _p, _p, _i64, _p]),
+                                               _p, _p, _p, _f32, _p, _p, _p, _i64, _p]),
 }
 
 # bf16-storage variants with the argument list of their fp32 namesake (include/cape_hip.h, last section)

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(LB) void vert_kernel(const float *pred, const float
 }
 
 __global__ __launch_bounds__(LB) void loss_final_kernel(const float *part_e, int ne, float inv_e, const float *part_v, int nv,
-                                                        float inv_v, float *loss_out, float w_recon, float w_edge, float *total_out) {
+                                                        float inv_v, float *loss_out, float w_recon, float w_edge, float *total_out,
+                                                        const float *term_a, float w_a, const float *term_b) {
     __shared__ float red[4];
     float s = 0.f;
     for (int i = threadIdx.x; i < nv; i += LB) s += part_v[i];
@@ -100,7 +101,14 @@ __global__ __launch_bounds__(LB) void loss_final_kernel(const float *part_e, int
     if (threadIdx.x == 0) {
         loss_out[0] = s * inv_v;
         loss_out[1] = t * inv_e;
-        if (total_out) *total_out = w_recon * (s * inv_v) + w_edge * (t * inv_e);
+        if (total_out) {
+            // (+ w_a * term_a + term_b: the latent term and the regulariser value of the training loss, lib/models.py:393-394 --
+            // device scalars computed earlier in the step; folding them in here saves the element-wise launches of the sum)
+            float tot = w_recon * (s * inv_v) + w_edge * (t * inv_e);
+            if (term_a) tot = fmaf(w_a, *term_a, tot);
+            if (term_b) tot += *term_b;
+            *total_out = tot;
+        }
     }
 }
 
@@ -174,7 +182,8 @@ extern "C" int64_t cape_recon_edge_workspace_bytes(int32_t N, int32_t M, int32_t
 extern "C" int cape_recon_edge_loss_fwd_bwd(const float *pred, const float *gt, const float *verts_ref, const int32_t *edges,
                                             const int32_t *vert_edge_ptr, const int32_t *vert_edge_idx, int32_t N, int32_t M,
                                             int32_t E, float w_recon, float w_edge, float *loss_out, float *total_out,
-                                            float *dpred, void *workspace, int64_t workspace_bytes, void *stream) {
+                                            const float *term_a, float w_a, const float *term_b, float *dpred, void *workspace,
+                                            int64_t workspace_bytes, void *stream) {
     if (!pred || !gt || !verts_ref || !edges || !loss_out || !workspace || N < 1 || M < 1 || E < 1) return CAPE_EINVAL;
     if (dpred && (!vert_edge_ptr || !vert_edge_idx)) return CAPE_EINVAL;
     if (workspace_bytes < cape_recon_edge_workspace_bytes(N, M, E)) return CAPE_EWORKSPACE;
@@ -189,7 +198,7 @@ extern "C" int cape_recon_edge_loss_fwd_bwd(const float *pred, const float *gt, 
     CAPE_LAUNCH(vert_kernel, dim3(nv), dim3(LB), 0, st, pred, gt, unit, vert_edge_ptr, vert_edge_idx, N, M, E, cr, ce, dpred, part_v);
     CAPE_LAUNCH_CHECK();
     CAPE_LAUNCH(loss_final_kernel, dim3(1), dim3(LB), 0, st, part_e, ne, 1.0f / ((float)N * (float)E), part_v, nv,
-                       1.0f / ((float)N * (float)M * 3.0f), loss_out, w_recon, w_edge, total_out);
+                       1.0f / ((float)N * (float)M * 3.0f), loss_out, w_recon, w_edge, total_out, term_a, w_a, term_b);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }

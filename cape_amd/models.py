@@ -679,8 +679,22 @@ class CAPE(base_model):
     def loss_terms(self, g_outputs, g_gt, z_mean, z_logvar):
         """recon / latent / edge / fc-regularisation terms and their weighted sum (no GAN term)."""
         out = {}
+        lat = self._latent_term(z_mean, z_logvar)
+        reg = self._fc_regulariser()
+        out['latent'], out['fc_reg_g'] = lat, reg
         if self.which_loss == 'l1' and g_outputs.shape[-1] == 3:
             vr, ed, vptr, vidx = self._edge_tables()
+            # the latent term and the regulariser value join the weighted sum INSIDE the loss kernel when they are device
+            # scalars already (the fused sampling / KL op; the bucket path's detached regulariser): no element-wise launches
+            # for  total_re + lambda_latent * latent + reg  and none for their gradients
+            scalar = lambda t: torch.is_tensor(t) and t.dim() == 0 and t.is_cuda and t.dtype == torch.float32
+            reg_ok = (scalar(reg) and not reg.requires_grad) if torch.is_tensor(reg) else float(reg) == 0.0
+            if g_outputs.is_cuda and scalar(lat) and reg_ok:
+                total, parts = ops.ReconEdgeLossFn.apply(g_outputs, g_gt, vr, ed, vptr, vidx, float(self.lambda_l1),
+                                                         float(self.lambda_edge), lat, float(self.lambda_latent),
+                                                         reg if torch.is_tensor(reg) else None)
+                out['recon'], out['edge'], out['total_no_gan'] = parts[0], parts[1], total
+                return out
             total_re, parts = ops.ReconEdgeLossFn.apply(g_outputs, g_gt, vr, ed, vptr, vidx,
                                                         float(self.lambda_l1), float(self.lambda_edge))
             out['recon'], out['edge'] = parts[0], parts[1]
@@ -700,15 +714,20 @@ class CAPE(base_model):
                                                        float(self.lambda_edge))
             out['edge'] = parts[1]
             total_re = out['recon'] * self.lambda_l1 + e_total
+        out['total_no_gan'] = torch.add(total_re, lat, alpha=float(self.lambda_latent)) + reg      # two launches, not three
+        return out
+
+    def _latent_term(self, z_mean, z_logvar):
         if getattr(self, '_kl_inputs', None) is not None and self._kl_inputs[0] is z_mean and self._kl_inputs[1] is z_logvar:
-            out['latent'] = self._kl_of_last_sample            # computed together with the sampling
-        else:
-            lat = -0.5 * torch.sum(1 + z_logvar - z_mean * z_mean - torch.exp(z_logvar), dim=1)
-            out['latent'] = lat.mean()
-        # l2_regularizer(scale)(w) = scale*sum(w^2)/2 on dense kernels under 'generator', multiplied by
-        # `regularization` once more (reference :40, :378-379; quirk C6).  Its VALUE is reported here from
-        # detached kernels; its GRADIENT (regularization^2 * w) is added to the flat gradient bucket by
-        # backward_to_flat -- identical numbers, without recording 7M-element tape nodes for three kernels.
+            return self._kl_of_last_sample            # computed together with the sampling
+        lat = -0.5 * torch.sum(1 + z_logvar - z_mean * z_mean - torch.exp(z_logvar), dim=1)
+        return lat.mean()
+
+    def _fc_regulariser(self):
+        """l2_regularizer(scale)(w) = scale*sum(w^2)/2 on dense kernels under 'generator', multiplied by
+        `regularization` once more (reference :40, :378-379; quirk C6).  Its VALUE is reported here from
+        detached kernels; its GRADIENT (regularization^2 * w) is added to the flat gradient bucket by
+        backward_to_flat -- identical numbers, without recording 7M-element tape nodes for three kernels."""
         reg = 0.0
         self._reg_names = []
         if self.regularization:
@@ -723,9 +742,7 @@ class CAPE(base_model):
                 else:
                     reg = sum(0.5 * (self._vars[n] * self._vars[n]).sum() for n in self._reg_names) * coef
                     self._reg_in_bucket = False
-        out['fc_reg_g'] = reg
-        out['total_no_gan'] = torch.add(total_re, out['latent'], alpha=float(self.lambda_latent)) + reg      # two launches, not three
-        return out
+        return reg
 
     @staticmethod
     def _bce(logits, label):
@@ -822,10 +839,13 @@ class CAPE(base_model):
         (a CVAE-only step skips the discriminator's scalar: one tiny launch less per step)."""
         lr_g = self._lr_at(self.lr_g, self.global_step)
         lr_d = self._lr_at(self.lr_d, self.global_step)
-        if 'g' in groups:
-            self._opt_state['g']['neg_lr'].fill_(-lr_g)
-        if 'd' in groups:
-            self._opt_state['d']['neg_lr'].fill_(-lr_d)
+        for grp, lr in (('g', lr_g), ('d', lr_d)):
+            st = self._opt_state[grp]
+            # the staircase schedule holds a value for decay_steps steps: the scalar is rewritten only when it changes
+            # (a fill launch in front of every graph replay otherwise); checkpoint restores reset the cache
+            if grp in groups and st.get('neg_lr_host') != -lr:
+                st['neg_lr'].fill_(-lr)
+                st['neg_lr_host'] = -lr
         return lr_g, lr_d
 
     def _reg_ranges(self):

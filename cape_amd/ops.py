@@ -1356,12 +1356,27 @@ class GroupNormFn(torch.autograd.Function):
 UNIT_GRAD = None        # the 0-dim tensor holding 1.0 that the training step seeds its backward pass with (models._one_scalar)
 
 
+_SCALARS = {}
+
+
+def _const_scalar(value, device):
+    """A cached 0-dim device tensor holding ``value`` (gradients that are constants of the graph)."""
+    key = (float(value), str(device))
+    t = _SCALARS.get(key)
+    if t is None:
+        t = torch.full((), float(value), device=device, dtype=torch.float32)
+        _SCALARS[key] = t
+    return t
+
+
 class ReconEdgeLossFn(torch.autograd.Function):
-    """total = w_recon * mean|pred-gt| + w_edge * edge_loss  (lib/models.py:357-375,
-    lib/losses.py:9-25).  Returns (total, recon, edge); only ``total`` is differentiable."""
+    """total = w_recon * mean|pred-gt| + w_edge * edge_loss [+ w_a * term_a + term_b]  (lib/models.py:357-375, 393-394,
+    lib/losses.py:9-25).  Returns (total, [recon, edge]); only ``total`` is differentiable.  ``term_a`` (a 0-dim tensor, e.g. the
+    latent term; differentiable, its gradient is the constant w_a) and ``term_b`` (0-dim, a value without gradient: the
+    regulariser) are added by the kernel that finishes the loss, not by element-wise launches afterwards."""
 
     @staticmethod
-    def forward(ctx, pred, gt, verts_ref, edges, vptr, vidx, w_recon, w_edge):
+    def forward(ctx, pred, gt, verts_ref, edges, vptr, vidx, w_recon, w_edge, term_a=None, w_a=0.0, term_b=None):
         _lib.require_gpu()
         pred, gt = pred.contiguous(), gt.contiguous()
         N, M, _ = pred.shape
@@ -1373,21 +1388,27 @@ class ReconEdgeLossFn(torch.autograd.Function):
         out = torch.empty(2, device=pred.device, dtype=torch.float32)
         total = torch.empty((), device=pred.device, dtype=torch.float32)
         dpred = torch.empty_like(pred)
+        for t in (term_a, term_b):
+            assert t is None or (t.dim() == 0 and t.dtype == torch.float32 and t.device == pred.device)
         _log_launch("recon_edge_loss", 0, N * (E * 24 + M * 36),
                     lambda: check(lib.cape_recon_edge_loss_fwd_bwd(_ptr(pred), _ptr(gt), _ptr(verts_ref), _ptr(edges), _ptr(vptr),
                                                                    _ptr(vidx), N, M, E, float(w_recon), float(w_edge), _ptr(out),
-                                                                   _ptr(total), _ptr(dpred), _ptr(ws), need, _stream()),
+                                                                   _ptr(total), _ptr(term_a), float(w_a), _ptr(term_b), _ptr(dpred),
+                                                                   _ptr(ws), need, _stream()),
                                   "cape_recon_edge_loss_fwd_bwd"))
         ctx.save_for_backward(dpred)
+        ctx.w_a = float(w_a) if term_a is not None else None
         ctx.mark_non_differentiable(out)
         return total, out
 
     @staticmethod
     def backward(ctx, gtotal, _gout):
         (dpred,) = ctx.saved_tensors
-        if UNIT_GRAD is not None and gtotal.data_ptr() == UNIT_GRAD.data_ptr():
-            return dpred, None, None, None, None, None, None, None      # d(loss)/d(total) is the caller's constant 1
-        return dpred * gtotal, None, None, None, None, None, None, None
+        unit = UNIT_GRAD is not None and gtotal.data_ptr() == UNIT_GRAD.data_ptr()      # d(loss)/d(total) is the caller's constant 1
+        ga = None
+        if ctx.w_a is not None and ctx.needs_input_grad[8]:
+            ga = _const_scalar(ctx.w_a, dpred.device) if unit else gtotal * ctx.w_a
+        return (dpred if unit else dpred * gtotal), None, None, None, None, None, None, None, ga, None, None
 
 
 class GanLossFn(torch.autograd.Function):

@@ -368,7 +368,9 @@ int cape_groupnorm_bwd(const float *x, int64_t x_sample_stride, int32_t ldx, con
 /*
  * L1 reconstruction + edge loss (lib/models.py:357-375, lib/losses.py:9-25) and gradient:
  *   loss_out[0] = mean |pred - gt| ; loss_out[1] = mean_e || (p_i - p_j) - (g_i - g_j) ||
- *   *total_out = w_recon * loss_out[0] + w_edge * loss_out[1]      (total_out may be NULL)
+ *   *total_out = w_recon * loss_out[0] + w_edge * loss_out[1] [+ w_a * *term_a] [+ *term_b]     (total_out may be NULL)
+ *   term_a / term_b: NULL or device scalars computed earlier in the step (the latent term and the regulariser value of the
+ *   training loss, lib/models.py:393-394): the weighted sum of the loss is then complete after this launch
  *   dpred = w_recon * d(recon)/dpred + w_edge * d(edge)/dpred      (dpred may be NULL)
  * edges: device int32 [E,2].  workspace >= cape_recon_edge_workspace_bytes(N, M, E).
  */
@@ -376,7 +378,8 @@ int64_t cape_recon_edge_workspace_bytes(int32_t N, int32_t M, int32_t E);
 int cape_recon_edge_loss_fwd_bwd(const float *pred, const float *gt, const float *verts_ref,
                                  const int32_t *edges, const int32_t *vert_edge_ptr,
                                  const int32_t *vert_edge_idx, int32_t N, int32_t M, int32_t E,
-                                 float w_recon, float w_edge, float *loss_out, float *total_out, float *dpred,
+                                 float w_recon, float w_edge, float *loss_out, float *total_out,
+                                 const float *term_a, float w_a, const float *term_b, float *dpred,
                                  void *workspace, int64_t workspace_bytes, void *stream);
 
 /*

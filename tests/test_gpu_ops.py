@@ -343,6 +343,17 @@ def test_recon_edge_loss(mesh_ops, dev):
     assert abs(parts[0].item() - recon.item()) < 1e-5 * abs(recon.item())
     assert abs(parts[1].item() - edge.item()) < 1e-5 * abs(edge.item())
     assert vertex_err(hp.grad.cpu().numpy(), tp.grad.numpy()) < TOL
+    # the same with two more scalar terms folded into the weighted sum (latent term with its constant gradient, a value
+    # without gradient): total = 0.7 recon + 1.3 edge + 0.25 a + b
+    ha = torch.tensor(3.5, dtype=torch.float32, device=dev, requires_grad=True)
+    hb = torch.tensor(-0.75, dtype=torch.float32, device=dev)
+    hp2 = torch.tensor(pred, dtype=torch.float32, device=dev, requires_grad=True)
+    total2, _ = ops.ReconEdgeLossFn.apply(hp2, d(gt, torch.float32), d(vr, torch.float32), d(edges, torch.int32),
+                                          d(vptr, torch.int32), d(vidx, torch.int32), 0.7, 1.3, ha, 0.25, hb)
+    assert abs(total2.item() - (total.item() + 0.25 * 3.5 - 0.75)) < 1e-5 * abs(total.item())
+    (2.0 * total2).backward()
+    assert abs(ha.grad.item() - 0.5) < 1e-6
+    assert vertex_err(hp2.grad.cpu().numpy(), 2.0 * tp.grad.numpy()) < TOL
 
 
 def test_baseline_config2_full_size(mesh_ops, dev):
