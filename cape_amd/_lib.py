@@ -40,6 +40,11 @@ class CapeSpmmTerm(C.Structure):
                 ("ell_width", C.c_int32)]
 
 
+class CapeGnParamItem(C.Structure):
+    _fields_ = [("dgamma_partial", C.c_void_p), ("dbeta_partial", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+                ("N", C.c_int32), ("C", C.c_int32)]
+
+
 class CapeBwdPrepItem(C.Structure):
     _fields_ = [("workspace", C.c_void_p), ("N", C.c_int32), ("Mo", C.c_int32), ("F", C.c_int32), ("R", C.c_int32),
                 ("dbias", C.c_void_p), ("dcoef", C.c_void_p), ("dcoef_g", C.c_void_p), ("dcoef_sample_stride", C.c_int64)]
@@ -109,6 +114,7 @@ SIGNATURES = {
     "cape_groupnorm_bwd": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _p, _p, _p, _i32, _i32, _p, _i64, _i32,
                                      _p, _i64, _i32, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p]),
     "cape_gan_bce_fwd_bwd": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _p, _p, _p, _p, _p, _p]),
+    "cape_groupnorm_param_reduce_batch": (C.c_int, [C.c_void_p, _i32, _p]),
     "cape_cond_coef_fwd": (C.c_int, [_p, _i32, _i32, _i32, C.POINTER(CapeCondLayer), _i32, _p]),
     "cape_cond_coef_bwd": (C.c_int, [_p, _i32, _i32, _i32, C.POINTER(CapeCondLayer), _i32, _p, _i32, _i32, _p]),
     "cape_flat_workspace_bytes": (_i64, []),

@@ -279,6 +279,30 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *x, long 
     }
 }
 
+// The sums over the batch of the per-sample gamma / beta gradient partials of SEVERAL group-norm calls in one launch (the
+// results are only needed at the end of the backward pass: the training step queues them, like the weight-gradient slab
+// reductions).  thread = channel, samples added in index order.
+struct GnParamBatch {
+    cape_gn_param_item_t it[CAPE_MAX_GN_REDUCE_ITEMS];
+    int blk_off[CAPE_MAX_GN_REDUCE_ITEMS + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void gn_param_reduce_batch_kernel(GnParamBatch B) {
+    int i = 0;
+    while (i + 1 < B.n && (int)blockIdx.x >= B.blk_off[i + 1]) ++i;
+    const cape_gn_param_item_t &it = B.it[i];
+    const int c = ((int)blockIdx.x - B.blk_off[i]) * 256 + (int)threadIdx.x;
+    if (c >= it.C) return;
+    float sg = 0.f, sb = 0.f;
+    for (int n = 0; n < it.N; ++n) {
+        sg += it.dgamma_partial[(long long)n * it.C + c];
+        sb += it.dbeta_partial[(long long)n * it.C + c];
+    }
+    it.dgamma[c] = sg;
+    it.dbeta[c] = sb;
+}
+
 inline bool gn_aligned(const void *p, long long ss, int ld) {
     return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && ((ss & 3) == 0) && ((ld & 3) == 0);
 }
@@ -346,6 +370,24 @@ extern "C" int cape_groupnorm_bwd(const float *x, int64_t x_sample_stride, int32
     CAPE_LAUNCH(gn_bwd_apply_kernel, dim3(grid_for((long long)N * V * ((C + 3) / 4))), dim3(256), 0, st, x, (long long)x_sample_stride,
                 ldx, dy, (long long)dy_sample_stride, lddy, coef, (const float *)bcoef, relu, dx, (long long)dx_sample_stride, lddx,
                 dx_add, (long long)add_sample_stride, ldadd, N, V, C);
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}
+
+extern "C" int cape_groupnorm_param_reduce_batch(const cape_gn_param_item_t *items, int32_t nitems, void *stream) {
+    if (!items || nitems < 1 || nitems > CAPE_MAX_GN_REDUCE_ITEMS) return CAPE_EINVAL;
+    GnParamBatch B;
+    B.n = nitems;
+    int off = 0;
+    for (int i = 0; i < nitems; ++i) {
+        const cape_gn_param_item_t &t = items[i];
+        if (!t.dgamma_partial || !t.dbeta_partial || !t.dgamma || !t.dbeta || t.N < 1 || t.C < 1) return CAPE_EINVAL;
+        B.it[i] = t;
+        B.blk_off[i] = off;
+        off += (t.C + 255) / 256;
+    }
+    B.blk_off[nitems] = off;
+    CAPE_LAUNCH(gn_param_reduce_batch_kernel, dim3((unsigned)off), dim3(256), 0, (hipStream_t)stream, B);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }

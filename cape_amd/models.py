@@ -482,8 +482,10 @@ class CAPE(base_model):
             Cn = int(x.shape[-1])
             gamma = self._get_variable('gamma', (Cn,), 'gn_gamma')
             beta = self._get_variable('beta', (Cn,), 'gn_beta')
+            base = '/'.join(self._scope)
         Ge = ops.group_count(x.shape[0], Cn, G)      # the reference's free-dimension reshape, lib/models.py:698
-        return ops.GroupNormFn.apply(x, gamma, beta, Ge, eps, 1 if relu else 0, passthrough)
+        return ops.GroupNormFn.apply(x, gamma, beta, Ge, eps, 1 if relu else 0, passthrough,
+                                     self._grad_views.get(base + '/gamma'), self._grad_views.get(base + '/beta'))
 
     def _plain_weight(self, scope, shape):
         """A 1x1 filter's weight in ``scope`` with its gradient-bucket view (what chebyshev5 does for K = 1)."""
@@ -1002,6 +1004,7 @@ class CAPE(base_model):
         finally:
             ops.DEFERRED = None
             ops.DEFERRED_DW[:] = []
+            ops.DEFERRED_GN[:] = []
 
     @contextlib.contextmanager
     def _data_grad_only_through_d(self, active):

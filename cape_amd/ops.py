@@ -655,10 +655,22 @@ NO_WEIGHT_GRAD = None
 # flush_deferred() finishes all queued ones in ONE launch (csrc cape_bwd_prep_finalize).  Consumers flush before reading.
 DEFERRED = None
 DEFERRED_DW = []          # queued weight-gradient slab reductions (gconv_dw(defer=True)), same lifetime as DEFERRED
+DEFERRED_GN = []          # queued batch sums of group-norm parameter-gradient partials (GroupNormFn.backward), likewise
 
 
 def flush_deferred():
     global DEFERRED
+    if DEFERRED_GN:
+        queued, DEFERRED_GN[:] = list(DEFERRED_GN), []
+        nmax = 32                                    # CAPE_MAX_GN_REDUCE_ITEMS
+        for i0 in range(0, len(queued), nmax):
+            chunk = queued[i0:i0 + nmax]
+            arr = (_lib.CapeGnParamItem * len(chunk))()
+            for a, (dgb, dst_g, dst_b) in zip(arr, chunk):
+                a.dgamma_partial, a.dbeta_partial = dgb[0].data_ptr(), dgb[1].data_ptr()
+                a.dgamma, a.dbeta = dst_g.data_ptr(), dst_b.data_ptr()
+                a.N, a.C = int(dgb.shape[1]), int(dgb.shape[2])
+            check(lib.cape_groupnorm_param_reduce_batch(C.addressof(arr), len(chunk), _stream()), "cape_groupnorm_param_reduce_batch")
     if DEFERRED_DW:
         queued, DEFERRED_DW[:] = list(DEFERRED_DW), []
         nmax = 12                                    # CAPE_MAX_DW_REDUCE_ITEMS
@@ -1288,7 +1300,7 @@ class GroupNormFn(torch.autograd.Function):
     it autograd adds them with a separate element-wise launch per block."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, G, eps, relu, passthrough=False):
+    def forward(ctx, x, gamma, beta, G, eps, relu, passthrough=False, g_gamma=None, g_beta=None):
         _lib.require_gpu()
         x = as_act(x)
         assert x.dtype == torch.float32, "group norm reads fp32 activations"
@@ -1311,6 +1323,7 @@ class GroupNormFn(torch.autograd.Function):
         if relu:
             _trace_sign(y, "relu")             # y = relu(fma(a, x, b)): positive exactly where the kernel's fma was
         ctx.G, ctx.relu, ctx.passthrough = G, relu, bool(passthrough)
+        ctx.g_gamma, ctx.g_beta = g_gamma, g_beta          # bucket views of the parameter gradients (or None)
         ctx.save_for_backward(x, gamma, stats, coef)
         if passthrough:
             return y, x.view_as(x)
@@ -1330,7 +1343,7 @@ class GroupNormFn(torch.autograd.Function):
             return t
 
         if g is None:                              # only the pass-through output was used
-            return g_pass, None, None, None, None, None, None
+            return g_pass, None, None, None, None, None, None, None, None
         g = aligned(g)
         dx = alloc_act(N, V, Cn, x.device)
         dgb = torch.empty((2, N, Cn), device=x.device, dtype=torch.float32)        # per-sample dgamma / dbeta partials
@@ -1349,8 +1362,15 @@ class GroupNormFn(torch.autograd.Function):
                     lambda: check(lib.cape_groupnorm_bwd(xp, xs, xl, gp, gs, gl, _ptr(gamma), _ptr(stats), _ptr(coef), int(ctx.G),
                                                          int(ctx.relu), dp, ds, dl, ap, as_, al, _ptr(dgb[0]), _ptr(dgb[1]),
                                                          _ptr(bcoef), N, V, Cn, _ptr(ws), need, _stream()), "cape_groupnorm_bwd"))
+        gg, gb_ = ctx.g_gamma, ctx.g_beta
+        if (DEFERRED is not None and LAUNCH_LOG is None and gg is not None and gb_ is not None and gg.shape == (Cn,)
+                and gb_.shape == (Cn,) and gg.is_contiguous() and gb_.is_contiguous()):
+            # the sums over the batch of all group norms of the sweep run as one launch at its end (flush_deferred), straight
+            # into the gradient bucket
+            DEFERRED_GN.append((dgb, gg, gb_))
+            return dx, gg, gb_, None, None, None, None, None, None
         dgb = dgb.sum(1)                                                           # one launch for both parameter gradients
-        return dx, dgb[0], dgb[1], None, None, None, None
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None
 
 
 UNIT_GRAD = None        # the 0-dim tensor holding 1.0 that the training step seeds its backward pass with (models._one_scalar)

@@ -365,6 +365,19 @@ int cape_groupnorm_bwd(const float *x, int64_t x_sample_stride, int32_t ldx, con
                        int32_t ldadd, float *dgamma_partial, float *dbeta_partial, float *bcoef, int32_t N,
                        int32_t V, int32_t C, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* dgamma[c] = sum_n dgamma_partial[n, c] (likewise dbeta) for up to CAPE_MAX_GN_REDUCE_ITEMS earlier cape_groupnorm_bwd calls in
+ * ONE launch, samples added in index order (the training step needs the parameter gradients only at the end of the backward
+ * pass and queues these sums, as it does the weight-gradient slab reductions). */
+#define CAPE_MAX_GN_REDUCE_ITEMS 32
+typedef struct cape_gn_param_item {
+    const float *dgamma_partial;   /* [N, C] */
+    const float *dbeta_partial;    /* [N, C] */
+    float *dgamma;                 /* [C]    */
+    float *dbeta;                  /* [C]    */
+    int32_t N, C;
+} cape_gn_param_item_t;
+int cape_groupnorm_param_reduce_batch(const cape_gn_param_item_t *items, int32_t nitems, void *stream);
+
 /*
  * L1 reconstruction + edge loss (lib/models.py:357-375, lib/losses.py:9-25) and gradient:
  *   loss_out[0] = mean |pred - gt| ; loss_out[1] = mean_e || (p_i - p_j) - (g_i - g_j) ||

@@ -342,11 +342,13 @@ def test_model_matches_reference_golden(tag, mesh_ops):
     assert vertex_err(rec, g["out_op_decoder"].astype(np.float64)) < 1e-4
 
 
-def test_train_step_matches_manual_update(mesh_ops):
-    """train_step (flat buckets, fused sampling/KL op, regularisation gradient added in the bucket, clip +
-    momentum) equals a manual update computed from autograd gradients of the same losses."""
+@pytest.mark.parametrize("cfg", ["affine_nz64", "cmr_nz18"])
+def test_train_step_matches_manual_update(cfg, mesh_ops):
+    """train_step (flat buckets, fused sampling/KL op, regularisation gradient added in the bucket, queued reductions of the
+    weight / bias / group-norm parameter gradients, clip + momentum) equals a manual update computed from autograd gradients
+    of the same losses."""
     N = 2
-    P, twin, model = _build("affine_nz64", mesh_ops, N, dict(regularization=0.5, lr_warmup=False, decay_steps=1000))
+    P, twin, model = _build(cfg, mesh_ops, N, dict(regularization=0.5, lr_warmup=False, decay_steps=1000))
     x, gt, xd, cond, cond_d, clo, clo_d, eps = _inputs(N, P["nz"])
     dev = model.device
     t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
