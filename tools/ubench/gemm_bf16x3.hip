@@ -1290,7 +1290,7 @@ __device__ __forceinline__ void split8h(const float4 &u, const float4 &v, float 
 template <int PRE, int MINB>
 __global__ __launch_bounds__(256, MINB) void gemm_v7_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                             float *__restrict__ C, int N, int Mo, int K, int F, int row_tiles,
-                                                            int col_tiles, float SB) {
+                                                            int col_tiles, float SB, const float *__restrict__ rowmax) {
     constexpr int BM = 128, BN = 128, WTM = 64, WTN = 64, TM = 2, TN = 2;
     constexpr int LP = 32, APL = BM * LP, BPL = BN * LP, HALF = 2 * (APL + BPL);          // one k16 chunk: 16 KB
     __shared__ __attribute__((aligned(16))) unsigned char smem7[2 * HALF];
@@ -1315,7 +1315,14 @@ __global__ __launch_bounds__(256, MINB) void gemm_v7_kernel(const float *__restr
     const float *bp = B + (long long)min(f0 + r, F - 1) * K + 8 * q;
     const int total = K / 16;
     float sa = 1.f;
-    if (PRE) {
+    if (PRE == 2) {
+        // the row's absolute maximum comes with the tensor (written by the kernel that produced it): one 4-byte load
+        const float m = rowmax[(long long)n * Mo + min(r0 + r, Mo - 1)];
+        int e = (int)((fbits(m) >> 23) & 255);
+        e = max(e, 14);
+        sa = bitsf((unsigned)(267 - e) << 23);
+        if (q == 0) inv_scale[r] = bitsf((unsigned)(e - 13) << 23) / SB;
+    } else if (PRE) {
         // absolute maximum of row r (this thread: its half of every k16 chunk), then the power of two that puts it in [2^13, 2^14)
         float m0 = 0.f, m1 = 0.f;
 #pragma unroll 4
@@ -1410,7 +1417,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_v7_kernel(const float *__restr
 }
 
 template <int PRE, int MINB>
-static double run_v7(const Shape &s, const float *A, const float *B, float *C, int iters, float SB);
+static double run_v7(const Shape &s, const float *A, const float *B, float *C, int iters, float SB, const float *rowmax = nullptr);
 
 template <int SG>
 static double run_v6(const Shape &s, const float *A, const float *B, float *C, int iters);
@@ -1695,11 +1702,11 @@ static double run_v6(const Shape &s, const float *A, const float *B, float *C, i
 }
 
 template <int PRE, int MINB>
-static double run_v7(const Shape &s, const float *A, const float *B, float *C, int iters, float SB) {
+static double run_v7(const Shape &s, const float *A, const float *B, float *C, int iters, float SB, const float *rowmax) {
     const int rt = (s.Mo + 127) / 128, ct = (s.F + 127) / 128;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    auto launch = [&]() { gemm_v7_kernel<PRE, MINB><<<s.N * rt * ct, 256>>>(A, B, C, s.N, s.Mo, s.K, s.F, rt, ct, SB); };
+    auto launch = [&]() { gemm_v7_kernel<PRE, MINB><<<s.N * rt * ct, 256>>>(A, B, C, s.N, s.Mo, s.K, s.F, rt, ct, SB, rowmax); };
     launch();
     hipDeviceSynchronize();
     hipEventRecord(e0);
@@ -1825,7 +1832,7 @@ int main(int argc, char **argv) {
         return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "v7")) {
-        const char *vn[] = {"v2 128x128 interleaved", "v7 f16x3 no pre-pass", "v7 f16x3 + row scales", "v7 + row scales, 3 WG/CU"};
+        const char *vn[] = {"v2 128x128 interleaved", "v7 f16x3 no pre-pass", "v7 f16x3 + row scales", "v7 + row maxima given"};
         constexpr int NV7 = 4;
         printf("%-22s", "shape (N Mo K F)");
         for (int i = 0; i < NV7; ++i) printf(" %24s", vn[i]);
@@ -1862,7 +1869,18 @@ int main(int argc, char **argv) {
             clr(); us[0] = run_v2<128, 128, 2, 2, 2, false, false, false, false, 1>(s, A, B, C, iters); chk(0);
             clr(); us[1] = run_v7<0, 2>(s, A, B, C, iters, SB); chk(1);
             clr(); us[2] = run_v7<1, 2>(s, A, B, C, iters, SB); chk(2);
-            clr(); us[3] = run_v7<1, 3>(s, A, B, C, iters, SB); chk(3);
+            // row maxima as a producer kernel would deliver them (here from the host)
+            std::vector<float> hR((size_t)s.N * s.Mo);
+            for (size_t rr = 0; rr < hR.size(); ++rr) {
+                float m = 0.f;
+                for (int k = 0; k < s.K; ++k) m = fmaxf(m, fabsf(hA[rr * s.K + k]));
+                hR[rr] = m;
+            }
+            float *R;
+            hipMalloc(&R, hR.size() * 4);
+            hipMemcpy(R, hR.data(), hR.size() * 4, hipMemcpyHostToDevice);
+            clr(); us[3] = run_v7<2, 2>(s, A, B, C, iters, SB, R); chk(3);
+            hipFree(R);
             char name[64];
             snprintf(name, sizeof name, "%d %d %d %d", s.N, s.Mo, s.K, s.F);
             printf("%-22s", name);
