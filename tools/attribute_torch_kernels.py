@@ -1,5 +1,8 @@
-"""Which Python lines launch the at::native kernels of one training step?  (They are the sub-10-us dispatches of the
-step sequence: fills, adds, copies.)   python tools/attribute_torch_kernels.py [--gan] [--config NAME] [--batch N]"""
+"""Which aten operators launch the at::native kernels of one (eager) training step?  They are the sub-10-us dispatches of the
+step sequence: fills, adds, copies.  Prints operator, calls, device time and -- when the profiler delivers Python stacks (it
+does not on every build) -- the first frames inside this repository; together with the ordered dispatch list of
+tools/rocpd_step_seq.py (neighbouring kernels) that locates them.
+    python tools/attribute_torch_kernels.py [--gan] [--config NAME] [--batch N]"""
 import os, sys, argparse, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
