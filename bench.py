@@ -412,6 +412,28 @@ def extra_measurements(args, headline_ms, model):
     return extras, modelled_scaling(ms_by_batch, grad_bytes, late_fraction)
 
 
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks here (a harness valid
+    for world_size 1..8 however it is invoked), one process per GPU, rendezvous on 127.0.0.1, and hand their output through.
+    Refuses to run when the box has fewer than N devices unless the ranks are told to share one (CAPE_FORCE_DEVICE, the
+    1-GPU functional check over gloo) -- a silent one-rank line under an `n_gpus: N` request is the failure this prevents."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus and "CAPE_FORCE_DEVICE" not in os.environ:
+        raise SystemExit("--gpus %d but only %d HIP device(s) visible (set CAPE_FORCE_DEVICE=<id> with CAPE_DIST_BACKEND=gloo "
+                         "to let the ranks share one device for a functional check)" % (args.gpus, have))
+    with socket.socket() as sk:                       # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -438,6 +460,7 @@ def main():
                     help='hand every step a fresh batch of HOST numpy arrays (as fit() does): the PCIe-inclusive rate '
                          'quoted in DESIGN.md; never the headline value')
     args = ap.parse_args()
+    relaunch_under_torchrun(args)
 
     from cape_amd import dist as cdist
     from cape_amd.runtime import GraphedTrainStep

@@ -18,6 +18,7 @@
 //              b_k = G_k + 2 L~ b_{k+1} - b_{k+2} with G_k = dy W_k^T evaluated on the k-ring (L~ is symmetric:
 //              lib/mesh_sampling.py:10-38 builds I - D^-1/2 A D^-1/2), dx[patch] = G_0 + L~ b_1 - b_2.
 // One barrier per recurrence step.  Deterministic (no atomics).  fp32 storage; Cin in {8, 16, 24, 32}, Fout in {32, 64}.
+#include <atomic>
 #include "common.h"
 
 namespace {
@@ -584,16 +585,30 @@ inline int cf_dispatch(int Cin, int Fout, const ChebFusedP &p, size_t lds, hipSt
     return CAPE_EINVAL;
 }
 
+// The > 64 KB dynamic-LDS attribute is per (function, DEVICE): remembered per device in an atomic bit mask, so a process
+// that drives several GPUs sets it on each and concurrent first calls are harmless.
+inline bool cf_allow_big_lds(const void *fn) {
+    struct Seen { const void *fn; std::atomic<unsigned long long> devs; };
+    static Seen seen[16];
+    static std::atomic<int> nseen{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const unsigned long long bit = 1ull << (dev & 63);
+    const int n = nseen.load(std::memory_order_acquire);
+    for (int i = 0; i < n; ++i)
+        if (seen[i].fn == fn && (seen[i].devs.load(std::memory_order_relaxed) & bit)) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+    for (int i = 0; i < n; ++i)
+        if (seen[i].fn == fn) { seen[i].devs.fetch_or(bit, std::memory_order_relaxed); return true; }
+    const int slot = nseen.fetch_add(1, std::memory_order_acq_rel);
+    if (slot < 16) { seen[slot].fn = fn; seen[slot].devs.store(bit, std::memory_order_relaxed); }
+    return true;                                     // table full or raced: the attribute is set, only the memo is lost
+}
+
 template <int CIN, int FOUT>
 struct CfFwd {
     static int go(const ChebFusedP &p, size_t lds, hipStream_t st) {
-        static bool set = false;
-        if (!set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&cheb_fused_fwd_kernel<CIN, FOUT>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return CAPE_EINVAL;
-            set = true;
-        }
+        if (!cf_allow_big_lds(reinterpret_cast<const void *>(&cheb_fused_fwd_kernel<CIN, FOUT>))) return CAPE_EINVAL;
         CAPE_LAUNCH((cheb_fused_fwd_kernel<CIN, FOUT>), dim3(p.N * p.P), dim3(CF_THREADS), lds, st, p);
         CAPE_LAUNCH_CHECK();
         return CAPE_OK;
@@ -603,13 +618,7 @@ struct CfFwd {
 template <int CIN, int FOUT>
 struct CfDw {
     static int go(const ChebFusedP &p, size_t lds, hipStream_t st) {
-        static bool set = false;
-        if (!set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&cheb_fused_dw_kernel<CIN, FOUT>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return CAPE_EINVAL;
-            set = true;
-        }
+        if (!cf_allow_big_lds(reinterpret_cast<const void *>(&cheb_fused_dw_kernel<CIN, FOUT>))) return CAPE_EINVAL;
         CAPE_LAUNCH((cheb_fused_dw_kernel<CIN, FOUT>), dim3(p.N * p.P), dim3(CF_THREADS), lds, st, p);
         CAPE_LAUNCH_CHECK();
         return CAPE_OK;
@@ -619,13 +628,7 @@ struct CfDw {
 template <int CIN, int FOUT>
 struct CfDx {
     static int go(const ChebFusedP &p, size_t lds, hipStream_t st) {
-        static bool set = false;
-        if (!set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&cheb_fused_dx_kernel<CIN, FOUT>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return CAPE_EINVAL;
-            set = true;
-        }
+        if (!cf_allow_big_lds(reinterpret_cast<const void *>(&cheb_fused_dx_kernel<CIN, FOUT>))) return CAPE_EINVAL;
         CAPE_LAUNCH((cheb_fused_dx_kernel<CIN, FOUT>), dim3(p.N * p.P), dim3(CF_THREADS), lds, st, p);
         CAPE_LAUNCH_CHECK();
         return CAPE_OK;

@@ -990,21 +990,28 @@ class CAPE(base_model):
         ops.UNIT_GRAD = self._one                   # lets the loss op skip the multiplication by this constant
         return self._one
 
-    def _deferred_begin(self):
+    @contextlib.contextmanager
+    def _deferred_sweep(self):
+        """Queue the reductions of one backward sweep and finish them when the sweep is over.  When the sweep ITSELF raised,
+        the queues hold items whose buffers belong to an abandoned tape: they are dropped, not flushed, so that nothing
+        stale reaches the bucket of a later call.  The failure is tracked explicitly -- an ambient exception
+        of the caller (a step retried from inside an `except:` block) must not make a successful sweep drop its queued
+        weight / group-norm / bias reductions."""
         ops.DEFERRED = []
-
-    def _deferred_end(self):
-        """Finish the queued reductions of a backward sweep.  When the sweep itself raised, the queues hold items whose
-        buffers belong to an abandoned tape: they are dropped, not flushed, so that nothing stale reaches the bucket of a
-        later call."""
-        import sys
+        failed = False
         try:
-            if sys.exc_info()[0] is None:
-                ops.flush_deferred()
+            yield
+        except BaseException:
+            failed = True
+            raise
         finally:
-            ops.DEFERRED = None
-            ops.DEFERRED_DW[:] = []
-            ops.DEFERRED_GN[:] = []
+            try:
+                if not failed:
+                    ops.flush_deferred()
+            finally:
+                ops.DEFERRED = None
+                ops.DEFERRED_DW[:] = []
+                ops.DEFERRED_GN[:] = []
 
     @contextlib.contextmanager
     def _data_grad_only_through_d(self, active):
@@ -1026,8 +1033,7 @@ class CAPE(base_model):
         st = self._opt_state['g']
         ne = st['n_early']
         one = self._one_scalar()
-        self._deferred_begin()
-        try:
+        with self._deferred_sweep():
             heads = [t for t in (self._enc_feat_cut,) + tuple(self._y_pair) if t.requires_grad]
             with self._data_grad_only_through_d('loss_d' in out):
                 res = torch.autograd.grad(out['loss_g'], st['params'][:ne] + heads, grad_outputs=one, retain_graph=True, allow_unused=True)
@@ -1037,8 +1043,6 @@ class CAPE(base_model):
                 grads_d = torch.autograd.grad(out['loss_d'], self._opt_state['d']['params'], grad_outputs=one, retain_graph=True,
                                               allow_unused=True)
                 self.store_grads('d', grads_d)
-        finally:
-            self._deferred_end()
         # Adam path: the regularised dense kernels are all EARLY variables, so their regulariser gradient must be in
         # the bucket before the early range is handed to the asynchronous all-reduce (adding it in phase 2 would race
         # with the collective that reduces the same range in place)
@@ -1056,13 +1060,12 @@ class CAPE(base_model):
                 roots.append(self._enc_feat if h is self._enc_feat_cut else h)
                 seeds.append(g)
         late = st['params'][ne:]
-        self._deferred_begin()
         try:
-            if late:
-                res = torch.autograd.grad(roots, late, grad_outputs=seeds, allow_unused=True) if roots else [None] * len(late)
-                self.store_grads('g', res, ne, None)
+            with self._deferred_sweep():
+                if late:
+                    res = torch.autograd.grad(roots, late, grad_outputs=seeds, allow_unused=True) if roots else [None] * len(late)
+                    self.store_grads('g', res, ne, None)
         finally:
-            self._deferred_end()
             self._phase_heads = self._enc_feat = self._enc_feat_cut = None
 
     def backward_to_flat(self, out):
@@ -1074,11 +1077,8 @@ class CAPE(base_model):
         g_params = self._opt_state['g']['params']
         d_params = self._opt_state['d']['params']
         one = self._one_scalar()
-        self._deferred_begin()
-        try:
+        with self._deferred_sweep():
             self._backward_to_flat_single(out, g_params, d_params, one)
-        finally:
-            self._deferred_end()
 
     def _backward_to_flat_single(self, out, g_params, d_params, one):
         if 'loss_d' not in out:

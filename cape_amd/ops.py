@@ -116,6 +116,31 @@ def _ptr(t, offset_elems=0):
     return C.c_void_p(t.data_ptr() + 4 * int(offset_elems))
 
 
+def ell_arrays(host):
+    """ELL form of a host CSR operator for the streaming sparse kernels: width 4 / 8 / 12, entries in CSR order packed to the
+    front, the slots past a row's end = (column of slot 0, 0.0) -- an empty row gets column 0.  Returns (cols, vals) or None.
+    The kernel (csrc/elementwise.hip cape_gather_row_ell) stops at the first group of four whose values are all zero, so an
+    operator with a stored all-zero group IN FRONT of a non-zero one (explicit zeros, cancellation in a precomposed chain)
+    would lose entries: such operators keep the CSR form."""
+    if not (1 <= host.max_row <= 12):
+        return None
+    w = (int(host.max_row) + 3) // 4 * 4
+    rows = host.shape[0]
+    rp = host.rowptr.astype(np.int64)
+    deg = (rp[1:] - rp[:-1]).astype(np.int64)
+    first = np.where(deg > 0, host.colidx[np.minimum(rp[:-1], max(host.nnz - 1, 0))], 0).astype(np.int32)
+    ec = np.repeat(first[:, None], w, axis=1)
+    ev = np.zeros((rows, w), dtype=np.float32)
+    slot = np.arange(host.nnz, dtype=np.int64) - np.repeat(rp[:-1], deg)
+    rr = np.repeat(np.arange(rows, dtype=np.int64), deg)
+    ec[rr, slot] = host.colidx
+    ev[rr, slot] = host.vals
+    live = (ev.reshape(rows, w // 4, 4) != 0).any(axis=2)                # [rows, groups]
+    if w > 4 and bool((~live[:, :-1] & (np.cumsum(live[:, ::-1], axis=1)[:, ::-1][:, 1:] > 0)).any()):
+        return None
+    return np.ascontiguousarray(ec), np.ascontiguousarray(ev)
+
+
 class DeviceCSR(object):
     def __init__(self, host, device):
         assert isinstance(host, HostCSR)
@@ -136,24 +161,13 @@ class DeviceCSR(object):
         self.vals_t = torch.from_numpy(host.vals).to(device)
         if not host.identity:
             self.rowptr, self.colidx, self.vals = self.rowptr_t, self.colidx_t, self.vals_t
-        # ELL form for the streaming sparse kernels: width 4 / 8 / 12, entries in CSR order packed to the front, the slots
-        # past a row's end = (column of slot 0, 0.0) -- an empty row gets column 0
+        # ELL form for the streaming sparse kernels (None when the operator does not qualify)
         self.ell_w, self.ell_col_t, self.ell_val_t = 0, None, None
-        if 1 <= host.max_row <= 12:
-            w = (int(host.max_row) + 3) // 4 * 4
-            rows = host.shape[0]
-            rp = host.rowptr.astype(np.int64)
-            deg = (rp[1:] - rp[:-1]).astype(np.int64)
-            first = np.where(deg > 0, host.colidx[np.minimum(rp[:-1], max(host.nnz - 1, 0))], 0).astype(np.int32)
-            ec = np.repeat(first[:, None], w, axis=1)
-            ev = np.zeros((rows, w), dtype=np.float32)
-            slot = np.arange(host.nnz, dtype=np.int64) - np.repeat(rp[:-1], deg)
-            rr = np.repeat(np.arange(rows, dtype=np.int64), deg)
-            ec[rr, slot] = host.colidx
-            ev[rr, slot] = host.vals
-            self.ell_w = w
-            self.ell_col_t = torch.from_numpy(np.ascontiguousarray(ec)).to(device)
-            self.ell_val_t = torch.from_numpy(np.ascontiguousarray(ev)).to(device)
+        ell = ell_arrays(host)
+        if ell is not None:
+            self.ell_w = int(ell[0].shape[1])
+            self.ell_col_t = torch.from_numpy(ell[0]).to(device)
+            self.ell_val_t = torch.from_numpy(ell[1]).to(device)
 
     def operands(self):
         """(rowptr, colidx, vals, ell_width) pointers for the streaming sparse kernels: the ELL arrays when the operator
@@ -1277,13 +1291,15 @@ def group_count(N, Cn, G=32):
     reshapes [N, C, V] to [-1, G, C // G, V] with G = min(32, C) and a FREE leading dimension.  When G divides C that is G
     groups per sample; otherwise the rows of the [N*C, V] matrix are taken w = C // G at a time irrespective of the sample
     boundaries -- C / w groups of w consecutive channels per sample when w divides C (w = 1, i.e. G < C < 2G: a
-    per-(sample, channel) normalisation).  Groups that would straddle samples are refused (TensorFlow itself rejects the
-    reshape unless N*C is a multiple of G*w)."""
+    per-(sample, channel) normalisation).  Only groups that would straddle samples are refused (w does not divide C).
+    TensorFlow additionally rejects the reshape unless N*C is a multiple of G*w; where w divides C the groups are well
+    defined for any N, so small-batch / demo inference on such layers is accepted here and equals the reference wherever
+    the reference runs at all."""
     Ge = min(int(G), int(Cn))
     if Cn % Ge == 0:
         return Ge
     w = Cn // Ge
-    if Cn % w or (int(N) * Cn) % (Ge * w):
+    if Cn % w:
         raise ValueError("group norm: %d channels cannot be split into groups of %d inside each sample "
                          "(reference lib/models.py:698 reshape)" % (Cn, w))
     return Cn // w
@@ -1461,6 +1477,9 @@ class GanLossFn(torch.autograd.Function):
         ctx.save_for_backward(ga, gb)
         ctx.split = None if real is None else Nf
         ctx.mark_non_differentiable(out)
+        # each sweep differentiates ONE of the two losses: the other output's gradient must arrive as None, not as a
+        # materialised zero tensor (an extra multiply + add per sweep, and 0 * inf = NaN in the live term)
+        ctx.set_materialize_grads(False)
         return sg, sd, out
 
     @staticmethod

@@ -54,3 +54,30 @@ def test_split_step_with_one_rank_rccl_group():
                        stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
     assert '"split": true' in r.stdout.decode()
+
+
+def test_bench_gpus2_without_torchrun_launches_two_ranks():
+    """`python bench.py --gpus 2` invoked the way the driver invokes `--gpus 1` (no torchrun, no WORLD_SIZE) must start the
+    two ranks itself and report n_gpus 2 (harness valid for world_size 1..8); here both share device 0 over gloo."""
+    import json
+    env = _env(CAPE_DIST_BACKEND="gloo", CAPE_FORCE_DEVICE="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--no-cpu-baseline", "--no-extras", "--no-ab", "--no-roofline"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 4
+
+
+def test_bench_gpus_refuses_more_ranks_than_devices():
+    env = _env()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CAPE_FORCE_DEVICE"):
+        env.pop(k, None)
+    want = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want), "--steps", "1"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0 and b"HIP device(s) visible" in r.stderr

@@ -287,3 +287,32 @@ def test_ell_form_of_the_operators_matches_csr(mesh_ops):
             assert np.all(ev[r, b - a:] == 0) and np.all(ec[r, b - a:] == (Mtx.indices[a] if b > a else 0))
     wide = sp.random(30, 30, density=0.6, random_state=1, format="csr", dtype=np.float64)
     assert ops.DeviceCSR(HostCSR(wide), torch.device("cpu")).ell_w == 0
+    # an all-zero group of four stored IN FRONT of a non-zero entry would end the row early in the kernel: CSR is kept
+    Z = sp.csr_matrix((np.array([1., 2., 3., 4., 0., 0., 0., 0., 5.]), np.arange(9), np.array([0, 9])), shape=(1, 9))
+    assert ops.DeviceCSR(HostCSR(Z), torch.device("cpu")).ell_w == 0
+    Z2 = sp.csr_matrix((np.array([1., 2., 3., 4., 0., 0., 7., 0., 5.]), np.arange(9), np.array([0, 9])), shape=(1, 9))
+    assert ops.DeviceCSR(HostCSR(Z2), torch.device("cpu")).ell_w == 12          # zeros inside a live group are harmless
+    Z3 = sp.csr_matrix((np.array([1., 2., 3., 4., 0., 0., 0., 0.]), np.arange(8), np.array([0, 8])), shape=(1, 8))
+    assert ops.DeviceCSR(HostCSR(Z3), torch.device("cpu")).ell_w == 8           # a trailing zero group ends the row correctly
+
+
+def test_deferred_sweep_flushes_inside_a_callers_except_block(monkeypatch):
+    """a backward sweep that SUCCEEDS while the caller is handling another exception (a retry loop) must flush its
+    queued reductions; a sweep that itself raises must drop them."""
+    from cape_amd import ops
+    from cape_amd.models import CAPE
+    calls = []
+    monkeypatch.setattr(ops, "flush_deferred", lambda: calls.append(list(ops.DEFERRED)))
+    m = CAPE.__new__(CAPE)
+    try:
+        raise RuntimeError("ambient failure of the caller")
+    except RuntimeError:
+        with m._deferred_sweep():
+            ops.DEFERRED.append("queued reduction")
+    assert calls == [["queued reduction"]] and ops.DEFERRED is None
+    ops.DEFERRED_DW.append("stale")
+    with pytest.raises(ValueError):
+        with m._deferred_sweep():
+            ops.DEFERRED.append("abandoned")
+            raise ValueError("the sweep failed")
+    assert len(calls) == 1 and ops.DEFERRED is None and ops.DEFERRED_DW == [] and ops.DEFERRED_GN == []
