@@ -31,6 +31,8 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0    # same table, dense bf16
 # gemm_split_kernel computes every fp32 multiply-add as six bf16 MFMA products (exact three-way operand split): its
 # ceiling in ALGORITHMIC fp32 flops is the dense bf16 peak / 6
 BF16X6_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+# gemm_h2_kernel / dw_h2_kernel: three fp16 MFMA products per multiply-add (two-piece operands); dense fp16 peak = dense bf16 peak
+F16X3_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0
 HBM_PEAK_GBS = 8000.0
 
 
@@ -135,8 +137,10 @@ def kernel_roofline(runner):
     table = {k: dict(launches=v[0] // reps, avg_us=1e6 * v[1] / v[0], total_us=1e6 * v[1] / reps, tflops=v[2] / v[1] / 1e12,
                      alg_gbs=v[3] / v[1] / 1e9) for k, v in agg.items()}
     split = dom.startswith(("gemm_split_kernel", "dw_split_kernel"))
+    h2 = dom.startswith(("gemm_h2_kernel", "dw_h2_kernel"))   # fp16 two-piece operands: three fp16 MFMA products per multiply-add
     one_product = split and "unsigned short" in dom          # bf16 storage: one bf16 MFMA product per multiply-add
-    mfma_peak = BF16_MFMA_PEAK_TFLOPS if one_product else BF16X6_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+    mfma_peak = BF16_MFMA_PEAK_TFLOPS if one_product else BF16X6_PEAK_TFLOPS if split else F16X3_PEAK_TFLOPS if h2 else \
+        FP32_MFMA_PEAK_TFLOPS
     # the bound of THIS kernel: time at the HBM peak vs time at its matrix-pipe peak for its algorithmic work
     t_hbm, t_mfma = by / n / (HBM_PEAK_GBS * 1e9), fl / n / (mfma_peak * 1e12)
     bound = "mfma" if t_mfma >= t_hbm else "hbm"
@@ -144,7 +148,9 @@ def kernel_roofline(runner):
         achieved, peak, unit = fl / t / 1e12, mfma_peak, "TFLOP/s"
         basis = "bf16 operands, fp32 accumulate: dense bf16 MFMA peak" if one_product else \
             ("fp32 result on the bf16 MFMA pipe, 6 bf16 products per multiply-add: dense bf16 peak 2500 / 6; "
-             "achieved counts algorithmic fp32 flops (x6 = bf16 MFMA flops executed)") if split \
+             "achieved counts algorithmic fp32 flops (x6 = bf16 MFMA flops executed)") if split else \
+            ("fp32 result on the fp16 MFMA pipe, 3 fp16 products per multiply-add on two-piece operands: dense fp16 peak "
+             "2500 / 3; achieved counts algorithmic fp32 flops (x3 = fp16 MFMA flops executed)") if h2 \
             else "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)"
     else:
         achieved, peak, unit = by / t / 1e9, HBM_PEAK_GBS, "GB/s"

@@ -37,7 +37,7 @@ class CapeSpmmTerm(C.Structure):
     _fields_ = [("x", C.c_void_p), ("x_sample_stride", C.c_int64), ("ldx", C.c_int32),
                 ("rowptr", C.c_void_p), ("colidx", C.c_void_p), ("vals", C.c_void_p),
                 ("y", C.c_void_p), ("y_sample_stride", C.c_int64), ("ldy", C.c_int32), ("scale", C.c_float),
-                ("ell_width", C.c_int32)]
+                ("ell_width", C.c_int32), ("rowmax_out", C.c_void_p)]
 
 
 class CapeGnParamItem(C.Structure):
@@ -55,6 +55,24 @@ class CapeDwItem(C.Structure):
                 ("lddz", C.c_int32), ("dz2", C.c_void_p), ("dz2_mask", C.c_uint32), ("N", C.c_int32), ("Mo", C.c_int32),
                 ("F", C.c_int32), ("accumulate", C.c_int32), ("bf16", C.c_int32), ("workspace", C.c_void_p),
                 ("workspace_bytes", C.c_int64)]
+
+
+class CapeH2Src(C.Structure):
+    _fields_ = [("w_hi", C.c_void_p), ("w_lo", C.c_void_p), ("w_pitch", C.c_int64),
+                ("w2_hi", C.c_void_p), ("w2_lo", C.c_void_p), ("w2_pitch", C.c_int64),
+                ("rowmax", C.c_void_p), ("rowmax_w", C.c_int32)]
+
+
+class CapeH2(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("wscale_inv", C.c_void_p), ("w2scale_inv", C.c_void_p),
+                ("rowmax_out", C.c_void_p), ("rowmax_out_w", C.c_int32)]
+
+
+class CapeWpieceItem(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("Ch", C.c_int32), ("K", C.c_int32), ("F", C.c_int32), ("pair_K", C.c_int32),
+                ("pair_w", C.c_void_p),
+                ("f_hi", C.c_void_p), ("f_lo", C.c_void_p), ("b_hi", C.c_void_p), ("b_lo", C.c_void_p),
+                ("fscale_inv", C.c_void_p), ("bscale_inv", C.c_void_p), ("bscale_c_inv", C.c_void_p)]
 
 
 class CapeRank(C.Structure):
@@ -77,6 +95,12 @@ SIGNATURES = {
     "cape_gconv_fwd": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p, _i32, _i32, _p,
                                  C.POINTER(CapeRank), _i32, _p]),
     "cape_gconv_fwd_plan": (C.c_int, [_SRCP, _i32, _i32, _i32, _i32, C.POINTER(_i32)]),
+    "cape_gconv_fwd_h2": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p, _i32, _i32, _p,
+                                    C.POINTER(CapeRank), _i32, C.POINTER(CapeH2), _p]),
+    "cape_gconv_fwd_plan_h2": (C.c_int, [_SRCP, _i32, _i32, _i32, _i32, C.POINTER(CapeH2), C.POINTER(_i32)]),
+    "cape_rowmax": (C.c_int, [_p, _i64, _i32, _i32, _i32, _i32, _p, _i32, _p]),
+    "cape_weight_pieces_blocks": (C.c_int, [C.c_void_p, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
+    "cape_weight_pieces": (C.c_int, [_p, _i32, _p, _i32, _p, _i32, _p]),
     "cape_rowscale_reduce_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "cape_rowscale_reduce": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _i32, _i32, _p, _p, _i64, _p]),
     "cape_gconv_dw_workspace_bytes": (_i64, [_SRCP, _i32, _i32, _i32, _i32]),
@@ -94,13 +118,13 @@ SIGNATURES = {
     "cape_gconv_dw_plan_bf16": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _p, C.c_uint32, _i32, _i32, _i32, C.POINTER(_i32)]),
     "cape_bwd_prep_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "cape_bwd_prep": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _p, _p, _i64, _i32, _p, _p, _i32, _p, _i32, _p,
-                                _i64, _i32, _i32, _i32, _i32, _p, _i64, _p]),
+                                _i64, _i32, _i32, _i32, _i32, _p, _i64, _p, _p]),
     "cape_bwd_prep_finalize": (C.c_int, [C.c_void_p, _i32, _p]),
     "cape_spmm": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _i32, _i32, _f32, _p, _i64, _i32, _f32, _p, _i64, _i32,
-                            _i32, _i32, _i32, _p]),
-    "cape_spmm_multi": (C.c_int, [C.POINTER(CapeSpmmTerm), _i32, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p]),
+                            _i32, _i32, _i32, _p, _p]),
+    "cape_spmm_multi": (C.c_int, [C.POINTER(CapeSpmmTerm), _i32, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p, _p]),
     "cape_spmm_combine": (C.c_int, [C.POINTER(CapeSpmmTerm), _i32, C.c_uint32, C.POINTER(CapeRank), _p, _i32, _i32, _i32, _p, _p,
-                                    _i64, _i32, _i32, _i32, _i32, _p]),
+                                    _i64, _i32, _i32, _i32, _i32, _p, _p]),
     "cape_bias_act_fwd": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "cape_act_bwd": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "cape_colsum_workspace_bytes": (_i64, [_i32, _i32, _i32]),

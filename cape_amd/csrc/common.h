@@ -59,6 +59,24 @@ __device__ __forceinline__ float cape_sum_xor32(float v) {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return a + b;
 }
+// max over aligned groups of G consecutive lanes (G a power of two <= 64, wave-uniform): DPP inside the 16-lane rows
+// (quad permutations, half-row mirror, row mirror -- after each step all lanes of the merged group hold its maximum, so any
+// lane of the partner group is a valid source), ds_bpermute across them.
+#define CAPE_DPP_MAX(v, CTRL) fmaxf((v), __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (CTRL), 0xF, 0xF, false)))
+__device__ __forceinline__ float cape_group_max(float m, int G) {
+    if (G >= 2) m = CAPE_DPP_MAX(m, 0xB1);            // quad_perm [1,0,3,2]
+    if (G >= 4) m = CAPE_DPP_MAX(m, 0x4E);            // quad_perm [2,3,0,1]
+    if (G >= 8) m = CAPE_DPP_MAX(m, 0x141);           // row_half_mirror
+    if (G >= 16) m = CAPE_DPP_MAX(m, 0x140);          // row_mirror
+    if (G >= 32) m = fmaxf(m, __shfl_xor(m, 16));
+    if (G >= 64) m = fmaxf(m, __shfl_xor(m, 32));
+    return m;
+}
+// row bounds written by the kernels that own whole rows (one float4 per row: [bound, 0, 0, 0]; consumed by gemm_h2.h)
+__device__ __forceinline__ void cape_store_rowmax(float *rm, long long row, float m) {
+    *reinterpret_cast<float4 *>(rm + 4 * row) = make_float4(m, 0.f, 0.f, 0.f);
+}
+
 // VW (1, 4 or 8) consecutive elements, widened to fp32 / rounded back.  Alignment: VW elements of fp32 up to 16 bytes
 // (VW = 8: two 16-byte accesses), VW elements of bf16 (8 -> one 16-byte access).
 typedef unsigned cape_u32x4 __attribute__((ext_vector_type(4)));

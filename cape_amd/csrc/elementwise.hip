@@ -163,7 +163,7 @@ __device__ __forceinline__ void cape_gather(const T *xb, long long ldx, const in
 // work item = (sample, output row, VW channels); VW = 1 for unaligned / odd channel counts
 template <int VW, typename T = float, int U = 0>
 __global__ __launch_bounds__(256) void spmm_kernel(CViewT<T> x, const int *rp, const int *ci, const float *va, int ew,
-                                                   float alpha, CViewT<T> z, float beta, ViewT<T> y, int N, int Mo, int C) {
+                                                   float alpha, CViewT<T> z, float beta, ViewT<T> y, int N, int Mo, int C, float *rm) {
     const int cq = (C + VW - 1) / VW;
     // block -> (sample, 256 work items of that sample), all blocks of a sample on ONE XCD (spmm_grid / cape_map_block): the
     // ~7 neighbour rows an output row gathers are then served by the L2 that already holds that sample, instead of every
@@ -185,6 +185,13 @@ __global__ __launch_bounds__(256) void spmm_kernel(CViewT<T> x, const int *rp, c
         for (int u = 0; u < VW; ++u) acc[u] = fmaf(beta, zv[u], acc[u]);
     }
     cape_stv<VW>(y.p + (long long)n * y.ss + (long long)r * y.ld + c, acc);
+    if (rm) {                                               // row bound of y (the cq lanes of a row are consecutive and aligned)
+        float m = 0.f;
+#pragma unroll
+        for (int u = 0; u < VW; ++u) m = fmaxf(m, fabsf(acc[u]));
+        m = cape_group_max(m, cq);
+        if (c == 0) cape_store_rowmax(rm, (long long)n * Mo + r, m);
+    }
 }
 
 // ---- several operator applications in one launch -----------------------------------------------------------
@@ -199,12 +206,13 @@ struct SpmmTerms {
         void *y; long long ys; int ldy;
         float scale;
         int ew;
+        float *rm;                                  // row bounds of y (separate mode) or null
     } t[CAPE_MAX_SPMM_TERMS];
     int n;
 };
 
 template <int VW, typename T = float, int U = 0>
-__global__ __launch_bounds__(256) void spmm_multi_kernel(SpmmTerms P, int sum, ViewT<T> y, int N, int Mo, int C) {
+__global__ __launch_bounds__(256) void spmm_multi_kernel(SpmmTerms P, int sum, ViewT<T> y, int N, int Mo, int C, float *rm) {
     const int cq = (C + VW - 1) / VW;
     int n, t;
     cape_map_block(blockIdx.x, N, spmm_bps(Mo, cq), n, t);      // see spmm_kernel
@@ -228,9 +236,25 @@ __global__ __launch_bounds__(256) void spmm_multi_kernel(SpmmTerms P, int sum, V
             for (int u = 0; u < VW; ++u) tot[u] += acc[u];
         } else {
             cape_stv<VW>(reinterpret_cast<T *>(Tm.y) + (long long)n * Tm.ys + (long long)r * Tm.ldy + c, acc);
+            if (Tm.rm) {
+                float m = 0.f;
+#pragma unroll
+                for (int u = 0; u < VW; ++u) m = fmaxf(m, fabsf(acc[u]));
+                m = cape_group_max(m, cq);
+                if (c == 0) cape_store_rowmax(Tm.rm, (long long)n * Mo + r, m);
+            }
         }
     }
-    if (sum) cape_stv<VW>(y.p + (long long)n * y.ss + (long long)r * y.ld + c, tot);
+    if (sum) {
+        cape_stv<VW>(y.p + (long long)n * y.ss + (long long)r * y.ld + c, tot);
+        if (rm) {
+            float m = 0.f;
+#pragma unroll
+            for (int u = 0; u < VW; ++u) m = fmaxf(m, fabsf(tot[u]));
+            m = cape_group_max(m, cq);
+            if (c == 0) cape_store_rowmax(rm, (long long)n * Mo + r, m);
+        }
+    }
 }
 
 // ---- operator applications AFTER the dense contraction (up-sampling layers) ----------------------------------
@@ -249,6 +273,7 @@ struct CombineParams {
     int bias_mode, act, dual;
     unsigned *mask;
     int mask_words;
+    float *rm;                                      // row bounds of y or null
 };
 
 template <int VW, typename T = float, int U = 0>
@@ -315,6 +340,13 @@ __global__ __launch_bounds__(256) void spmm_combine_kernel(CombineParams Q, View
         if (live && (q & (LW - 1)) == 0) Q.mask[((long long)n * Mo + r) * Q.mask_words + (q / LW)] = w;
     }
     if (live) cape_stv<VW>(y.p + (long long)n * y.ss + (long long)r * y.ld + c, o);
+    if (Q.rm) {
+        float m = 0.f;
+#pragma unroll
+        for (int u = 0; u < VW; ++u) m = fmaxf(m, fabsf(o[u]));
+        m = cape_group_max(m, cq);                          // (dead lanes repeat the last row: same value, no harm)
+        if (live && c == 0) cape_store_rowmax(Q.rm, (long long)n * Mo + r, m);
+    }
 }
 
 // ---- bias + activation ----------------------------------------------------------------------
@@ -661,7 +693,7 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(CViewT<AT> g, CViewT<AT> 
 template <typename AT, int VW, int UR>
 __global__ __launch_bounds__(256) void bwd_prep_vec_kernel(CViewT<AT> g, CViewT<AT> y, int act, const unsigned *mask, ViewT<AT> dz,
                                                            const float *rowscale, int R, int rg, int want_bias, int want_g,
-                                                           int N, int Mo, int F, float *part, int chunks, int RB) {
+                                                           int N, int Mo, int F, float *part, int chunks, int RB, float *rm) {
     __shared__ float red[VW][256];
     const int n = blockIdx.x / chunks, ch = blockIdx.x % chunks;
     const int ra = ch * RB, rb = min(Mo, ra + RB);
@@ -707,6 +739,21 @@ __global__ __launch_bounds__(256) void bwd_prep_vec_kernel(CViewT<AT> g, CViewT<
                         else d[u] = gv[k][u];
                     }
                     cape_stv<VW>(zb + (long long)r * dz.ld + f, d);
+                    if (rm) {
+                        // row bound of dz: entry = column pass (F <= 4 * FB); the cvn lanes of a row are consecutive and aligned
+                        float m = 0.f;
+#pragma unroll
+                        for (int u = 0; u < VW; ++u) m = fmaxf(m, fabsf(d[u]));
+                        m = cape_group_max(m, cvn);
+                        if (q == 0) {
+                            // (each pass writes only its own entry -- different threads own a row in different passes --
+                            // and pass 0 zeroes the entries no pass owns)
+                            float *dst = rm + 4 * ((long long)n * Mo + r);
+                            dst[fbase / FB] = m;
+                            if (fbase == 0)
+                                for (int e = (F + FB - 1) / FB; e < 4; ++e) dst[e] = 0.f;
+                        }
+                    }
 #pragma unroll
                     for (int u = 0; u < VW; ++u) acc[0][u] += d[u];
 #pragma unroll
@@ -850,12 +897,22 @@ inline bool ell_ok(int ew, const void *ec, const void *ev) {
     return (ew == 4 || ew == 8 || ew == 12) && ec && ev && ((reinterpret_cast<uintptr_t>(ec) | reinterpret_cast<uintptr_t>(ev)) & 15) == 0;
 }
 
+// Row bounds of an output (cape_h2_src_t.rowmax, width 4): written by the kernel itself when the lanes of a row form one aligned
+// power-of-two group inside a wave, otherwise by one standalone pass over the finished output (csrc/pieces.hip).
+inline bool rm_fused(int lanes_per_row) { return lanes_per_row >= 1 && lanes_per_row <= 64 && (lanes_per_row & (lanes_per_row - 1)) == 0; }
+template <typename T>
+inline int rm_standalone(const T *y, int64_t ys, int32_t ldy, int32_t N, int32_t Mo, int32_t C, float *rowmax_out, void *stream) {
+    if (sizeof(T) != 4) return CAPE_EINVAL;
+    return cape_rowmax(reinterpret_cast<const float *>(y), ys, ldy, N, Mo, C, rowmax_out, 4, stream);
+}
+
 template <typename T>
 int spmm_impl(const T *x, int64_t x_sample_stride, int32_t ldx, const int32_t *rowptr,
               const int32_t *colidx, const float *vals, int32_t max_row_nnz, int32_t ell_width, float alpha, const T *z,
               int64_t z_sample_stride, int32_t ldz, float beta, T *y, int64_t y_sample_stride,
-              int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
+              int32_t ldy, int32_t N, int32_t Mo, int32_t C, float *rowmax_out, void *stream) {
     if (!x || !rowptr || !colidx || !vals || !y || N < 1 || Mo < 1 || C < 1 || ldx < C || ldy < C) return CAPE_EINVAL;
+    if (rowmax_out && sizeof(T) != 4) return CAPE_EINVAL;
     if (!ell_ok(ell_width, colidx, vals)) return CAPE_EINVAL;
     if (z && ldz < C) return CAPE_EINVAL;
     if ((long long)Mo * C >= (1LL << 31)) return CAPE_EINVAL;       // 32-bit work-item index per sample
@@ -871,13 +928,19 @@ int spmm_impl(const T *x, int64_t x_sample_stride, int32_t ldx, const int32_t *r
         const bool wide = spmm_wide() && aligned8(x, x_sample_stride, ldx, C, es) && aligned8(y, y_sample_stride, ldy, C, es) &&
                           (!z || aligned8(z, z_sample_stride, ldz, C, es));
         const bool hint4 = max_row_nnz >= 1 && max_row_nnz <= 4;
+        float *rm = rm_fused(C / (wide ? 8 : 4)) ? rowmax_out : nullptr;
         CAPE_LAUNCH_SP(spmm_kernel, T, wide, hint4, dim3((unsigned)(N * spmm_bps(Mo, C / (wide ? 8 : 4)))), dim3(256), 0, st, xv, rowptr,
-                       colidx, vals, ell_width, alpha, zv, beta, yv, N, Mo, C);
+                       colidx, vals, ell_width, alpha, zv, beta, yv, N, Mo, C, rm);
+        CAPE_LAUNCH_CHECK();
+        if (rowmax_out && !rm) return rm_standalone(y, y_sample_stride, ldy, N, Mo, C, rowmax_out, stream);
+        return CAPE_OK;
     } else {
         if (ell_width) return CAPE_EINVAL;                    // the scalar fallback reads CSR only
-        CAPE_LAUNCH((spmm_kernel<1, T, 0>), dim3((unsigned)(N * spmm_bps(Mo, C))), dim3(256), 0, st, xv, rowptr, colidx, vals, 0, alpha, zv, beta, yv, N, Mo, C);
+        CAPE_LAUNCH((spmm_kernel<1, T, 0>), dim3((unsigned)(N * spmm_bps(Mo, C))), dim3(256), 0, st, xv, rowptr, colidx, vals, 0, alpha, zv, beta, yv, N, Mo, C,
+                    (float *)nullptr);
     }
     CAPE_LAUNCH_CHECK();
+    if (rowmax_out) return rm_standalone(y, y_sample_stride, ldy, N, Mo, C, rowmax_out, stream);
     return CAPE_OK;
 }
 }  // namespace
@@ -885,24 +948,26 @@ int spmm_impl(const T *x, int64_t x_sample_stride, int32_t ldx, const int32_t *r
 extern "C" int cape_spmm(const float *x, int64_t x_sample_stride, int32_t ldx, const int32_t *rowptr,
                          const int32_t *colidx, const float *vals, int32_t max_row_nnz, int32_t ell_width, float alpha,
                          const float *z, int64_t z_sample_stride, int32_t ldz, float beta, float *y, int64_t y_sample_stride,
-                         int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
+                         int32_t ldy, int32_t N, int32_t Mo, int32_t C, float *rowmax_out, void *stream) {
     return spmm_impl<float>(x, x_sample_stride, ldx, rowptr, colidx, vals, max_row_nnz, ell_width, alpha, z, z_sample_stride, ldz, beta, y,
-                            y_sample_stride, ldy, N, Mo, C, stream);
+                            y_sample_stride, ldy, N, Mo, C, rowmax_out, stream);
 }
 
 extern "C" int cape_spmm_bf16(const void *x, int64_t x_sample_stride, int32_t ldx, const int32_t *rowptr,
                               const int32_t *colidx, const float *vals, int32_t max_row_nnz, int32_t ell_width, float alpha,
                               const void *z, int64_t z_sample_stride, int32_t ldz, float beta, void *y, int64_t y_sample_stride,
-                              int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
+                              int32_t ldy, int32_t N, int32_t Mo, int32_t C, float *rowmax_out, void *stream) {
     return spmm_impl<cape_bf16>((const cape_bf16 *)x, x_sample_stride, ldx, rowptr, colidx, vals, max_row_nnz, ell_width, alpha,
-                                (const cape_bf16 *)z, z_sample_stride, ldz, beta, (cape_bf16 *)y, y_sample_stride, ldy, N, Mo, C, stream);
+                                (const cape_bf16 *)z, z_sample_stride, ldz, beta, (cape_bf16 *)y, y_sample_stride, ldy, N, Mo, C,
+                                rowmax_out, stream);
 }
 
 namespace {
 template <typename T>
 int spmm_multi_impl(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, T *y, int64_t y_sample_stride,
-                    int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
+                    int32_t ldy, int32_t N, int32_t Mo, int32_t C, float *rowmax_out, void *stream) {
     if (!terms || nterms < 1 || nterms > CAPE_MAX_SPMM_TERMS || N < 1 || Mo < 1 || C < 1) return CAPE_EINVAL;
+    if (rowmax_out && (!sum || sizeof(T) != 4)) return CAPE_EINVAL;
     if (sum && (!y || ldy < C)) return CAPE_EINVAL;
     if ((long long)Mo * C >= (1LL << 31)) return CAPE_EINVAL;       // 32-bit work-item index per sample
     constexpr int es = (int)sizeof(T);
@@ -921,6 +986,8 @@ int spmm_multi_impl(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, 
         P.t[k].y = t.y; P.t[k].ys = t.y_sample_stride; P.t[k].ldy = t.ldy;
         P.t[k].scale = t.scale;
         P.t[k].ew = t.rowptr ? t.ell_width : 0;
+        P.t[k].rm = sum ? nullptr : t.rowmax_out;
+        if (t.rowmax_out && (sum || sizeof(T) != 4)) return CAPE_EINVAL;
         if (t.rowptr && !ell_ok(t.ell_width, t.colidx, t.vals)) return CAPE_EINVAL;
         any_ell = any_ell || P.t[k].ew;
         vec = vec && aligned4(t.x, t.x_sample_stride, t.ldx, C, es) && (sum || aligned4(t.y, t.y_sample_stride, t.ldy, C, es));
@@ -929,30 +996,47 @@ int spmm_multi_impl(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, 
     wide = wide && vec;
     ViewT<T> yv{y, y_sample_stride, ldy};
     hipStream_t st = (hipStream_t)stream;
-    if (vec) CAPE_LAUNCH_SP(spmm_multi_kernel, T, wide, false, dim3((unsigned)(N * spmm_bps(Mo, C / (wide ? 8 : 4)))), dim3(256), 0, st, P, sum, yv, N, Mo, C);
+    const bool fused = vec && rm_fused(C / (wide ? 8 : 4));
+    if (!fused)
+        for (int k = 0; k < nterms; ++k) P.t[k].rm = nullptr;
+    if (vec) CAPE_LAUNCH_SP(spmm_multi_kernel, T, wide, false, dim3((unsigned)(N * spmm_bps(Mo, C / (wide ? 8 : 4)))), dim3(256), 0, st, P, sum, yv, N, Mo, C,
+                            fused ? rowmax_out : (float *)nullptr);
     else if (any_ell) return CAPE_EINVAL;                      // the scalar fallback reads CSR only
-    else CAPE_LAUNCH((spmm_multi_kernel<1, T, 0>), dim3((unsigned)(N * spmm_bps(Mo, C))), dim3(256), 0, st, P, sum, yv, N, Mo, C);
+    else CAPE_LAUNCH((spmm_multi_kernel<1, T, 0>), dim3((unsigned)(N * spmm_bps(Mo, C))), dim3(256), 0, st, P, sum, yv, N, Mo, C, (float *)nullptr);
     CAPE_LAUNCH_CHECK();
+    if (!fused) {
+        if (rowmax_out) {
+            const int rc = rm_standalone(y, y_sample_stride, ldy, N, Mo, C, rowmax_out, stream);
+            if (rc) return rc;
+        }
+        for (int k = 0; k < nterms && !sum; ++k)
+            if (terms[k].rowmax_out) {
+                const int rc = rm_standalone(reinterpret_cast<const T *>(terms[k].y), terms[k].y_sample_stride, terms[k].ldy, N, Mo, C,
+                                             terms[k].rowmax_out, stream);
+                if (rc) return rc;
+            }
+    }
     return CAPE_OK;
 }
 }  // namespace
 
 extern "C" int cape_spmm_multi(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, float *y, int64_t y_sample_stride,
-                               int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
-    return spmm_multi_impl<float>(terms, nterms, sum, y, y_sample_stride, ldy, N, Mo, C, stream);
+                               int32_t ldy, int32_t N, int32_t Mo, int32_t C, float *rowmax_out, void *stream) {
+    return spmm_multi_impl<float>(terms, nterms, sum, y, y_sample_stride, ldy, N, Mo, C, rowmax_out, stream);
 }
 
 extern "C" int cape_spmm_multi_bf16(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, void *y, int64_t y_sample_stride,
-                                    int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream) {
-    return spmm_multi_impl<cape_bf16>(terms, nterms, sum, (cape_bf16 *)y, y_sample_stride, ldy, N, Mo, C, stream);
+                                    int32_t ldy, int32_t N, int32_t Mo, int32_t C, float *rowmax_out, void *stream) {
+    return spmm_multi_impl<cape_bf16>(terms, nterms, sum, (cape_bf16 *)y, y_sample_stride, ldy, N, Mo, C, rowmax_out, stream);
 }
 
 namespace {
 template <typename T>
 int spmm_combine_impl(const cape_spmm_term_t *terms, int32_t nterms, uint32_t to_acc2, const cape_rank_t *rank,
                       const float *bias, int32_t bias_mode, int32_t act, int32_t dual, uint32_t *mask_out, T *y,
-                      int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t F, void *stream) {
+                      int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t F, float *rowmax_out, void *stream) {
     constexpr int es = (int)sizeof(T);
+    if (rowmax_out && sizeof(T) != 4) return CAPE_EINVAL;
     if (!terms || nterms < 1 || nterms > CAPE_MAX_SPMM_TERMS || !y || N < 1 || Mo < 1 || F < 1 || ldy < F) return CAPE_EINVAL;
     if (bias_mode != CAPE_BIAS_NONE && !bias) return CAPE_EINVAL;
     if (act < CAPE_ACT_NONE || act > CAPE_ACT_TANH) return CAPE_EINVAL;
@@ -990,26 +1074,29 @@ int spmm_combine_impl(const cape_spmm_term_t *terms, int32_t nterms, uint32_t to
     if (mask_out && (!vec || (F & 31))) return CAPE_EINVAL;      // sign words are assembled from 8 float4 lanes
     ViewT<T> yv{y, y_sample_stride, ldy};
     hipStream_t st = (hipStream_t)stream;
+    const bool fused = vec && rm_fused(F / (wide ? 8 : 4));
+    Q.rm = fused ? rowmax_out : nullptr;
     if (vec) CAPE_LAUNCH_SP(spmm_combine_kernel, T, wide, false, dim3((unsigned)(N * spmm_bps(Mo, F / (wide ? 8 : 4)))), dim3(256), 0, st, Q, yv, N, Mo, F);
     else if (any_ell) return CAPE_EINVAL;
     else CAPE_LAUNCH((spmm_combine_kernel<1, T, 0>), dim3((unsigned)(N * spmm_bps(Mo, F))), dim3(256), 0, st, Q, yv, N, Mo, F);
     CAPE_LAUNCH_CHECK();
+    if (rowmax_out && !fused) return rm_standalone(y, y_sample_stride, ldy, N, Mo, F, rowmax_out, stream);
     return CAPE_OK;
 }
 }  // namespace
 
 extern "C" int cape_spmm_combine(const cape_spmm_term_t *terms, int32_t nterms, uint32_t to_acc2, const cape_rank_t *rank,
                                  const float *bias, int32_t bias_mode, int32_t act, int32_t dual, uint32_t *mask_out, float *y,
-                                 int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t F, void *stream) {
+                                 int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t F, float *rowmax_out, void *stream) {
     return spmm_combine_impl<float>(terms, nterms, to_acc2, rank, bias, bias_mode, act, dual, mask_out, y, y_sample_stride, ldy,
-                                    N, Mo, F, stream);
+                                    N, Mo, F, rowmax_out, stream);
 }
 
 extern "C" int cape_spmm_combine_bf16(const cape_spmm_term_t *terms, int32_t nterms, uint32_t to_acc2, const cape_rank_t *rank,
                                       const float *bias, int32_t bias_mode, int32_t act, int32_t dual, uint32_t *mask_out, void *y,
-                                      int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t F, void *stream) {
+                                      int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t F, float *rowmax_out, void *stream) {
     return spmm_combine_impl<cape_bf16>(terms, nterms, to_acc2, rank, bias, bias_mode, act, dual, mask_out, (cape_bf16 *)y,
-                                        y_sample_stride, ldy, N, Mo, F, stream);
+                                        y_sample_stride, ldy, N, Mo, F, rowmax_out, stream);
 }
 
 extern "C" int cape_bias_act_fwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *bias,
@@ -1151,8 +1238,9 @@ int bwd_prep_impl(const T *g, int64_t g_sample_stride, int32_t ldg, const T *y, 
                   int32_t ldy, int32_t act, const uint32_t *mask, T *dz, int64_t dz_sample_stride, int32_t lddz,
                   float *dbias, const float *rowscale, int32_t R, float *dcoef, int32_t rg, float *dcoef_g,
                   int64_t dcoef_sample_stride, int32_t finalize, int32_t N, int32_t Mo, int32_t F, void *workspace,
-                  int64_t workspace_bytes, void *stream) {
+                  int64_t workspace_bytes, float *rowmax_out, void *stream) {
     constexpr int es = (int)sizeof(T);
+    if (rowmax_out && es != 4) return CAPE_EINVAL;
     if (!g || !dz || !workspace || N < 1 || Mo < 1 || F < 1 || ldg < F || lddz < F || R < 0 || R > RSR_MAXR) return CAPE_EINVAL;
     if (act < CAPE_ACT_NONE || act > CAPE_ACT_TANH) return CAPE_EINVAL;
     if (!mask && act != CAPE_ACT_NONE && (!y || ldy < F)) return CAPE_EINVAL;
@@ -1178,7 +1266,7 @@ int bwd_prep_impl(const T *g, int64_t g_sample_stride, int32_t ldg, const T *y, 
     const int bp_ur = bp_ur_env ? bp_ur_env : (wide && es == 4) ? 1 : CAPE_BP_UNROLL_DEFAULT;
 #define CAPE_BP_LAUNCH(VW_, UR_)                                                                                                    \
     CAPE_LAUNCH((bwd_prep_vec_kernel<T, VW_, UR_>), dim3(N * chunks), dim3(256), 0, st, gv, yv, act, mask, zv, rowscale, R, rg,     \
-                dbias ? 1 : 0, dcoef_g ? 1 : 0, N, Mo, F, (float *)workspace, chunks, RB)
+                dbias ? 1 : 0, dcoef_g ? 1 : 0, N, Mo, F, (float *)workspace, chunks, RB, rowmax_out)
     if (vec && wide) {
         if (bp_ur >= 4) CAPE_BP_LAUNCH(8, 4);
         else if (bp_ur >= 2) CAPE_BP_LAUNCH(8, 2);
@@ -1193,6 +1281,10 @@ int bwd_prep_impl(const T *g, int64_t g_sample_stride, int32_t ldg, const T *y, 
         CAPE_LAUNCH((bwd_prep_kernel<T>), dim3(N * chunks), dim3(256), 0, st, gv, yv, act, mask, zv, rowscale, R, rg, dbias ? 1 : 0,
                     dcoef_g ? 1 : 0, N, Mo, F, (float *)workspace, chunks, RB);
     CAPE_LAUNCH_CHECK();
+    if (rowmax_out && !vec) {                                  // the scalar form does not own whole rows per lane group
+        const int rc = rm_standalone(dz, dz_sample_stride, lddz, N, Mo, F, rowmax_out, stream);
+        if (rc) return rc;
+    }
     if (finalize && (dbias || R > 0 || dcoef_g)) {
         const int fblocks = (F + 15) / 16;
         const int nblk = fblocks * (1 + N * (R + 1));
@@ -1209,19 +1301,20 @@ extern "C" int cape_bwd_prep(const float *g, int64_t g_sample_stride, int32_t ld
                              int32_t ldy, int32_t act, const uint32_t *mask, float *dz, int64_t dz_sample_stride, int32_t lddz,
                              float *dbias, const float *rowscale, int32_t R, float *dcoef, int32_t rg, float *dcoef_g,
                              int64_t dcoef_sample_stride, int32_t finalize, int32_t N, int32_t Mo, int32_t F, void *workspace,
-                             int64_t workspace_bytes, void *stream) {
+                             int64_t workspace_bytes, float *rowmax_out, void *stream) {
     return bwd_prep_impl<float>(g, g_sample_stride, ldg, y, y_sample_stride, ldy, act, mask, dz, dz_sample_stride, lddz, dbias,
-                                rowscale, R, dcoef, rg, dcoef_g, dcoef_sample_stride, finalize, N, Mo, F, workspace, workspace_bytes, stream);
+                                rowscale, R, dcoef, rg, dcoef_g, dcoef_sample_stride, finalize, N, Mo, F, workspace, workspace_bytes,
+                                rowmax_out, stream);
 }
 
 extern "C" int cape_bwd_prep_bf16(const void *g, int64_t g_sample_stride, int32_t ldg, const void *y, int64_t y_sample_stride,
                                   int32_t ldy, int32_t act, const uint32_t *mask, void *dz, int64_t dz_sample_stride, int32_t lddz,
                                   float *dbias, const float *rowscale, int32_t R, float *dcoef, int32_t rg, float *dcoef_g,
                                   int64_t dcoef_sample_stride, int32_t finalize, int32_t N, int32_t Mo, int32_t F, void *workspace,
-                                  int64_t workspace_bytes, void *stream) {
+                                  int64_t workspace_bytes, float *rowmax_out, void *stream) {
     return bwd_prep_impl<cape_bf16>((const cape_bf16 *)g, g_sample_stride, ldg, (const cape_bf16 *)y, y_sample_stride, ldy, act, mask,
                                     (cape_bf16 *)dz, dz_sample_stride, lddz, dbias, rowscale, R, dcoef, rg, dcoef_g,
-                                    dcoef_sample_stride, finalize, N, Mo, F, workspace, workspace_bytes, stream);
+                                    dcoef_sample_stride, finalize, N, Mo, F, workspace, workspace_bytes, rowmax_out, stream);
 }
 
 extern "C" int cape_bwd_prep_finalize(const cape_bwd_prep_item_t *items, int32_t nitems, void *stream) {

@@ -14,6 +14,7 @@
 #include "gconv_shared.h"
 #include "gemm_plain.h"
 #include "gemm_split.h"
+#include "gemm_h2.h"
 #include <stdlib.h>
 
 namespace {
@@ -611,6 +612,35 @@ inline int fill_src(SrcDev &d, const cape_src_t &s, int es = 4) {
     d.w = s.w; d.wrs = s.w_rs; d.wcs = s.w_cs;
     d.w2 = s.w2; d.w2rs = s.w2_rs; d.w2cs = s.w2_cs;
     d.vec = ((s.ldx & 3) == 0) && ((s.x_sample_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(s.x) & (4 * es - 1)) == 0);
+    d.wh = d.wl = d.wh2 = d.wl2 = nullptr;
+    d.wp = d.wp2 = 0;
+    d.rm = nullptr;
+    d.rmw = 0;
+    return CAPE_OK;
+}
+
+// fp16 two-piece operands of a launch (cape_h2_t, may be null): piece planes / row bounds per source, column scales, the
+// row-bound output of the epilogue
+inline int fill_h2(GconvParams &p, const cape_h2_t *h2, bool dual, int out_deinterleave) {
+    p.wsi = p.wsi2 = nullptr;
+    p.rm_out = nullptr;
+    p.rm_out_w = 0;
+    if (!h2) return CAPE_OK;
+    if (h2->rowmax_out) {
+        if (out_deinterleave > 1 || h2->rowmax_out_w < (p.F + 31) / 32 || (h2->rowmax_out_w & 3)) return CAPE_EINVAL;
+        p.rm_out = h2->rowmax_out;
+        p.rm_out_w = h2->rowmax_out_w;
+    }
+    if (!h2->src) return CAPE_OK;
+    p.wsi = h2->wscale_inv;
+    p.wsi2 = dual ? h2->w2scale_inv : nullptr;
+    for (int i = 0; i < p.nsrc; ++i) {
+        const cape_h2_src_t &h = h2->src[i];
+        SrcDev &d = p.s[i];
+        d.wh = h.w_hi; d.wl = h.w_lo; d.wp = h.w_pitch;
+        d.wh2 = d.w2 ? h.w2_hi : nullptr; d.wl2 = d.w2 ? h.w2_lo : nullptr; d.wp2 = h.w2_pitch;
+        d.rm = h.rowmax; d.rmw = h.rowmax_w;
+    }
     return CAPE_OK;
 }
 
@@ -749,6 +779,7 @@ inline int choose_dw(const cape_src_t *srcs, int nsrc, const float *dz, int64_t 
 struct FwdPlan {
     int family;   // 0: gather-GEMM (gconv_fwd_kernel), 1: pipelined plain GEMM (gemm_plain_kernel),
                   // 2: plain GEMM on the bf16 matrix pipe with exact three-way operand split (gemm_split_kernel)
+                  // 3: plain GEMM as three fp16 products on two-piece operands (gemm_h2_kernel; needs cape_h2_t operands)
     int BM, BN;
     int layout;   // family 1: 1 = weights contraction-contiguous, 0 = output-contiguous
 };
@@ -777,6 +808,12 @@ inline FwdPlan plan_fwd(const GconvParams &p, const cape_src_t *srcs, bool dual,
     for (int i = 0; i < p.nsrc && pl.layout >= 0; ++i) {
         const long long ws = srcs[i].w_cs > srcs[i].w_rs ? srcs[i].w_cs : srcs[i].w_rs;
         if ((long long)p.Mo * srcs[i].ldx >= (1LL << 31) || (long long)p.F * ws >= (1LL << 31)) pl.layout = -1;   // 32-bit offsets
+    }
+    if (pl.layout >= 0 && h2_eligible(p, dual)) {
+        pl.family = 3;
+        pl.layout = 1;                                  // the piece planes are contraction-contiguous in every launch form
+        h2_tile(dual, p.N, p.Mo, p.F, pl.BM, pl.BN);
+        return pl;
     }
     if (pl.layout >= 0) {
         // CAPE_GEMM_BF16X6=0: keep every contraction on the exact-fp32 MFMA (A/B switch)
@@ -816,13 +853,16 @@ inline int fill_fwd_srcs(GconvParams &p, const cape_src_t *srcs, int nsrc, bool 
 
 namespace {
 
-int gconv_fwd_plan_impl(const cape_src_t *srcs, int32_t nsrc, int32_t N, int32_t Mo, int32_t F, int32_t plan[4], bool bf16) {
+int gconv_fwd_plan_impl(const cape_src_t *srcs, int32_t nsrc, int32_t N, int32_t Mo, int32_t F, int32_t plan[4], bool bf16,
+                        const cape_h2_t *h2 = nullptr) {
     if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || N < 1 || Mo < 1 || F < 1 || !plan) return CAPE_EINVAL;
     GconvParams p;
     bool dual;
     int rc = fill_fwd_srcs(p, srcs, nsrc, dual, bf16 ? 2 : 4);
     if (rc) return rc;
     p.N = N; p.Mo = Mo; p.F = F;
+    rc = fill_h2(p, bf16 ? nullptr : h2, dual, 0);
+    if (rc) return rc;
     const FwdPlan pl = plan_fwd(p, srcs, dual, bf16);
     plan[0] = pl.family; plan[1] = pl.BM; plan[2] = pl.BN; plan[3] = pl.family ? pl.layout : 0;
     return CAPE_OK;
@@ -845,8 +885,9 @@ void launch_gather_fwd(const GconvParams &p, const FwdPlan &pl, bool dual, dim3 
 int gconv_fwd_impl(const cape_src_t *srcs, int32_t nsrc, float *y, int64_t y_sample_stride,
                    int32_t ldy, int32_t N, int32_t Mo, int32_t F, const float *bias,
                    int32_t bias_mode, int32_t act, uint32_t *mask_out, const cape_rank_t *rank,
-                   int32_t out_deinterleave, void *stream, bool bf16) {
+                   int32_t out_deinterleave, void *stream, bool bf16, const cape_h2_t *h2 = nullptr) {
     if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || !y || N < 1 || Mo < 1 || F < 1) return CAPE_EINVAL;
+    if (bf16 && h2) return CAPE_EINVAL;
     const int dK = out_deinterleave > 1 ? out_deinterleave : 1;
     const int dstride = dK > 1 ? ((F / dK + 3) & ~3) : 0;
     if (dK > 1 && (F % dK != 0 || mask_out || rank || ldy < dK * dstride)) return CAPE_EINVAL;
@@ -870,12 +911,16 @@ int gconv_fwd_impl(const cape_src_t *srcs, int32_t nsrc, float *y, int64_t y_sam
         if (rank->to_acc2 && !dual) return CAPE_EINVAL;
         p.rankR = rank->R; p.rowscale = rank->rowscale; p.coef = rank->coef; p.rank_to2 = rank->to_acc2;
     }
+    rc = fill_h2(p, h2, dual, dK);
+    if (rc) return rc;
     const FwdPlan pl = plan_fwd(p, srcs, dual, bf16);
     p.row_tiles = (Mo + pl.BM - 1) / pl.BM;
     p.col_tiles = (F + pl.BN - 1) / pl.BN;
     dim3 grid((unsigned)(N * p.row_tiles * p.col_tiles));
     hipStream_t st = (hipStream_t)stream;
-    if (pl.family == 2) {
+    if (pl.family == 3) {
+        h2_launch(p, dual, pl.BM, grid, st);
+    } else if (pl.family == 2) {
         gs_launch(p, dual, pl.BM, pl.layout, bf16, grid, st);
     } else if (pl.family == 1) {
         gp_launch(p, dual, pl.BM, pl.BN, pl.layout, grid, st);
@@ -904,6 +949,19 @@ extern "C" int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, in
                               int32_t out_deinterleave, void *stream) {
     return gconv_fwd_impl(srcs, nsrc, y, y_sample_stride, ldy, N, Mo, F, bias, bias_mode, act, mask_out, rank, out_deinterleave,
                           stream, false);
+}
+
+extern "C" int cape_gconv_fwd_h2(const cape_src_t *srcs, int32_t nsrc, float *y, int64_t y_sample_stride,
+                                 int32_t ldy, int32_t N, int32_t Mo, int32_t F, const float *bias,
+                                 int32_t bias_mode, int32_t act, uint32_t *mask_out, const cape_rank_t *rank,
+                                 int32_t out_deinterleave, const cape_h2_t *h2, void *stream) {
+    return gconv_fwd_impl(srcs, nsrc, y, y_sample_stride, ldy, N, Mo, F, bias, bias_mode, act, mask_out, rank, out_deinterleave,
+                          stream, false, h2);
+}
+
+extern "C" int cape_gconv_fwd_plan_h2(const cape_src_t *srcs, int32_t nsrc, int32_t N, int32_t Mo, int32_t F, const cape_h2_t *h2,
+                                      int32_t plan[4]) {
+    return gconv_fwd_plan_impl(srcs, nsrc, N, Mo, F, plan, false, h2);
 }
 
 extern "C" int cape_gconv_fwd_bf16(const cape_src_t *srcs, int32_t nsrc, void *y, int64_t y_sample_stride,

@@ -1,0 +1,369 @@
+// fp32 contraction of PLAIN sources as THREE fp16 MFMA products per multiply-add ("h2": two half-precision pieces).
+// Same contraction and epilogues as gemm_plain.h / gemm_split.h (y[n] = epilogue(sum_s X_s[n] @ B_s), reference
+// lib/models.py:99-102; DUAL: the affine block of :776-793), at half the matrix-pipe work of the six-product bf16 form and
+// a third of its staging arithmetic:
+//     x * s = hi + lo,   hi = fp16(x * s),  lo = fp16(x * s - hi)      (both round to nearest: 22 significant bits)
+//     a * b ~ (lo_a hi_b + hi_a lo_b + hi_a hi_b) / (s_a s_b)          (dropped lo_a lo_b: 2^-22 relative)
+// with s a power of two per activation ROW (from a bound of the row's absolute maximum that the kernel PRODUCING the tensor
+// wrote next to it: SrcDev::rm, see gconv_shared.h) and per weight COLUMN (planes prepared once per step by
+// cape_weight_pieces: SrcDev::wh / wl, contraction index contiguous for every launch form, so there is one kernel for the
+// forward and the data-gradient layout).  Measured against float64 the result is as accurate as the bf16 six-product form and
+// an fp32 FMA chain (tools/ubench/gemm_h2.hip, profiles/r04_ubench_h2*.txt: rms 3.6e-7 of the row rms at K = 1024 on rows
+// spanning 23 binades; fp32 chain 5.5e-7).  Range: fp16 keeps 22 bits for elements down to 2^-18 of the row bound and
+// degrades gracefully below (absolute error <= 2^-40 of the bound); a zero / denormal row bound is clamped.
+//
+// Structure (tools/ubench/gemm_h2.hip, AMODE 2): workgroup tile BM x BN, 4 waves as 2 x 2, k32 chunks, two LDS stages, ONE
+// barrier per chunk.  Weight pieces come in by LDS-DMA one chunk ahead (no registers, no VALU, no ds_write; L2-resident);
+// the activations through a buffer resource TWO chunks ahead in registers (the long-latency stream), split after the
+// multiply phase of the chunk in between.  vmcnt retires in order: the DMA of chunk i+1 is issued before the register loads
+// of chunk i+2, so "all but the newest PA*2" covers it.  LDS rows are 64 bytes with the 16-byte segments XOR-swizzled by
+// (row >> 2) & 3 (conflict-free ds_read_b128 for the 32x32x16 fragment pattern; the DMA applies it on the SOURCE address).
+// Against gemm_split_kernel on the model's shapes (same box): 1.25-1.55x on the 862 / 1723-vertex levels, 1.1-1.25x on the
+// fine ones (profiles/r04_ubench_h2_pf2.txt); the loads alone (448 MB through L2 for the widest layer) take 39 us of its
+// 57 -- the 128 x 128 tile's L2 traffic, not the matrix pipe, is the next bound.
+#pragma once
+#include <type_traits>
+
+#include "gconv_shared.h"
+
+namespace {
+
+typedef _Float16 h2_half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2_half2 __attribute__((ext_vector_type(2)));
+typedef unsigned h2_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int H2_KC = 32;          // contraction indices per staged chunk = two k16 MFMA steps
+constexpr int H2_ROW = 64;         // bytes per LDS row of one piece plane
+
+__device__ __forceinline__ unsigned h2_bits(float v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ float h2_float(unsigned v) { return __builtin_bit_cast(float, v); }
+
+// two scaled fp32 values -> their fp16 pieces, packed pairwise (first element in the low half)
+__device__ __forceinline__ void h2_split2(float x0, float x1, unsigned &hi, unsigned &lo) {
+    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+    const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
+    const h2_half2 H = {h0, h1}, L = {l0, l1};
+    hi = __builtin_bit_cast(unsigned, H);
+    lo = __builtin_bit_cast(unsigned, L);
+}
+
+// power of two that puts a bound m of the absolute maximum into [2^13, 2^14), and its reciprocal.  Zero / denormal bounds
+// are clamped (their rows hold nothing a half can represent anyway); inf / NaN bounds give inf / NaN results like the split
+// kernels do for such operands.
+__device__ __host__ __forceinline__ void h2_scale_of(float m, float &s, float &inv) {
+    unsigned u;
+    __builtin_memcpy(&u, &m, 4);
+    int e = (int)((u >> 23) & 255u);
+    e = e < 14 ? 14 : (e > 253 ? 253 : e);
+    const unsigned us = (unsigned)(267 - e) << 23, ui = (unsigned)(e - 13) << 23;
+    __builtin_memcpy(&s, &us, 4);
+    __builtin_memcpy(&inv, &ui, 4);
+}
+
+// one 1 KB LDS-DMA piece: lane L's 16 bytes land at lds_dst + 16 L (M0 = wave-uniform LDS byte address); source address =
+// 64-bit scalar base + 32-bit per-lane byte offset.  Untracked by hipcc: completion is counted by hand (vmcnt).
+__device__ __forceinline__ void h2_glds16(const void *sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+// BM x BN in {128 x 128, 64 x 64} (single), 128 x 64 (DUAL: second weight set / second accumulator tile)
+template <int BM, int BN, bool DUAL>
+__global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GconvParams p) {
+    constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32;
+    constexpr int PA = BM / 64;                          // A staging passes: 64 rows x 4 eight-float segments per pass
+    constexpr int APL = BM * H2_ROW, BPL = BN * H2_ROW;  // bytes of one piece plane
+    constexpr int NB = DUAL ? 2 : 1;
+    constexpr int STAGE = 2 * APL + 2 * NB * BPL;
+    constexpr int BPW = (2 * BPL / 1024) / 4;            // DMA pieces (16 rows x 64 B) per wave and weight set
+    static_assert(TM >= 1 && TN >= 1 && BPW >= 1, "tile");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+    __shared__ float inv_row[BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int q = tid & 3, r = tid >> 2;
+
+    int n, t;
+    cape_map_block(blockIdx.x, p.N, p.row_tiles * p.col_tiles, n, t);
+    const int r0 = (t / p.col_tiles) * BM;
+    const int f0 = (t % p.col_tiles) * BN;
+
+    f32x16 acc[TM][TN];
+    f32x16 acc2[DUAL ? TM : 1][DUAL ? TN : 1];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                acc[a][b][g] = 0.f;
+                if constexpr (DUAL) acc2[a][b][g] = 0.f;
+            }
+
+    int total = 0;
+    for (int si = 0; si < p.nsrc; ++si) total += p.s[si].C / H2_KC;
+
+    // ---- row scales: common to all sources (they add into one accumulator): bound = max over sources and column blocks
+    int rc[PA];
+    float sa[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        rc[i] = min(r0 + r + 64 * i, p.Mo - 1);
+        float m = 0.f;
+        for (int si = 0; si < p.nsrc; ++si) {
+            const SrcDev &S = p.s[si];
+            const float4 *rp = reinterpret_cast<const float4 *>(S.rm + ((long long)n * p.Mo + rc[i]) * S.rmw);
+            for (int j = q; j < (S.rmw >> 2); j += 4) {
+                const float4 v = rp[j];
+                m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            }
+        }
+        // the four lanes of a row (q = 0..3) hold different column blocks: quad all-reduce
+        m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF, 0xF, false)));   // quad_perm [1,0,3,2]
+        m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x4E, 0xF, 0xF, false)));   // quad_perm [2,3,0,1]
+        float inv;
+        h2_scale_of(m, sa[i], inv);
+        if (q == 0) inv_row[r + 64 * i] = inv;
+    }
+
+    // ---- DMA lanes: piece j of this wave covers 16 rows x 64 B of one plane; lane -> row drow, LDS slot lane & 3,
+    //      source segment (lane & 3) ^ ((row >> 2) & 3)
+    const int drow = lane >> 2, dseg = (lane & 3) ^ ((drow >> 2) & 3);
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    int bcol[BPW];                                       // output column (clamped) of this lane's row in piece j
+    unsigned bdst[BPW];                                  // LDS byte offset of piece j inside a stage (first weight set)
+    int bplane[BPW];
+#pragma unroll
+    for (int j = 0; j < BPW; ++j) {
+        const int i = wave * BPW + j, plane = i / (BN / 16), rb = i % (BN / 16);
+        bcol[j] = min(f0 + rb * 16 + drow, p.F - 1);
+        bdst[j] = 2 * APL + plane * BPL + rb * 1024;
+        bplane[j] = plane;
+    }
+
+    // ---- cursors over the chunk sequence (source, channel offset): B = DMA of the weight pieces (one chunk ahead of the
+    //      multiply), A = register loads of the activations (two ahead)
+    struct Cur { int si, c0; };
+    Cur cb = {0, 0}, ca = {0, 0};
+    unsigned bvoff[BPW], bvoff2[DUAL ? BPW : 1];
+    auto open_b = [&]() {
+        const SrcDev &S = p.s[cb.si];
+#pragma unroll
+        for (int j = 0; j < BPW; ++j) {
+            bvoff[j] = (unsigned)(((long long)bcol[j] * S.wp + 8 * dseg) * 2);
+            if constexpr (DUAL) bvoff2[j] = (unsigned)(((long long)bcol[j] * S.wp2 + 8 * dseg) * 2);
+        }
+    };
+    int avoff[PA];
+    __amdgpu_buffer_rsrc_t arsrc;
+    auto open_a = [&]() {
+        const SrcDev &S = p.s[ca.si];
+        arsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(S.x + (long long)n * S.xs), 0, 0x7FFFFFFC, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < PA; ++i) avoff[i] = (rc[i] * S.ldx + 8 * q) * 4;
+    };
+    unsigned has2 = 0;                                   // (DUAL) bit b: the chunk staged in LDS buffer b carries a second weight set
+    auto dma = [&](int buf) {
+        const SrcDev &S = p.s[cb.si];
+        const unsigned dst = lds0 + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < BPW; ++j)
+            h2_glds16((bplane[j] ? S.wl : S.wh) + cb.c0, bvoff[j], dst + bdst[j]);
+        if constexpr (DUAL) {
+            const bool two = S.wh2 != nullptr;
+            has2 = (has2 & ~(1u << buf)) | ((two ? 1u : 0u) << buf);
+            if (two) {
+#pragma unroll
+                for (int j = 0; j < BPW; ++j)
+                    h2_glds16((bplane[j] ? S.wl2 : S.wh2) + cb.c0, bvoff2[j], dst + bdst[j] + 2 * BPL);
+            }
+        }
+        cb.c0 += H2_KC;
+        if (cb.c0 >= S.C) {
+            cb.c0 = 0;
+            ++cb.si;
+            if (cb.si < p.nsrc) open_b();
+        }
+    };
+    auto load_a = [&](float4 (&ra)[PA][2]) {
+        const int so = ca.c0 * 4;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            ra[i][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, avoff[i], so, 0));
+            ra[i][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, avoff[i] + 16, so, 0));
+        }
+        ca.c0 += H2_KC;
+        if (ca.c0 >= p.s[ca.si].C) {
+            ca.c0 = 0;
+            ++ca.si;
+            if (ca.si < p.nsrc) open_a();
+        }
+    };
+    auto store_a = [&](int buf, const float4 (&ra)[PA][2]) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int row = r + 64 * i;
+            const float s = sa[i];
+            uint4 hi, lo;
+            h2_split2(ra[i][0].x * s, ra[i][0].y * s, hi.x, lo.x);
+            h2_split2(ra[i][0].z * s, ra[i][0].w * s, hi.y, lo.y);
+            h2_split2(ra[i][1].x * s, ra[i][1].y * s, hi.z, lo.z);
+            h2_split2(ra[i][1].z * s, ra[i][1].w * s, hi.w, lo.w);
+            unsigned char *d = smem + buf * STAGE + row * H2_ROW + 16 * (q ^ ((row >> 2) & 3));
+            *reinterpret_cast<uint4 *>(d) = hi;
+            *reinterpret_cast<uint4 *>(d + APL) = lo;
+        }
+    };
+
+    // ---- multiply one staged chunk.  Lane (li, lh) of v_mfma_f32_32x32x16_f16 supplies row / column li and the contraction
+    //      indices 8 lh .. 8 lh + 7 of the k16 step: one 16-byte LDS read per operand piece; the reads of step 1 ride between
+    //      the MFMAs of step 0 (a ds_read_b128 holds its wave's issue port ~29 cycles: DESIGN.md section 4, round 3)
+    const int fsw = (li >> 2) & 3;                       // swizzle term of this lane's fragment rows (tile offsets are multiples of 32)
+    auto compute = [&](int buf, auto W2) {
+        constexpr bool w2 = decltype(W2)::value;
+        const unsigned char *pa = smem + buf * STAGE + (wm * WTM + li) * H2_ROW;
+        const unsigned char *pb = smem + buf * STAGE + 2 * APL + (wn * WTN + li) * H2_ROW;
+        h2_half8 af[2][TM][2], bf[2][TN][2], bf2[2][w2 ? TN : 1][w2 ? 2 : 1];
+        auto rd = [&](int ks) {
+            const int so = 16 * ((2 * ks + lh) ^ fsw);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) af[ks][a][pc] = *reinterpret_cast<const h2_half8 *>(pa + pc * APL + a * 32 * H2_ROW + so);
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) {
+                    bf[ks][b][pc] = *reinterpret_cast<const h2_half8 *>(pb + pc * BPL + b * 32 * H2_ROW + so);
+                    if constexpr (w2) bf2[ks][b][pc] = *reinterpret_cast<const h2_half8 *>(pb + (2 + pc) * BPL + b * 32 * H2_ROW + so);
+                }
+        };
+        auto mm = [&](int ks) {
+#pragma unroll
+            for (int term = 0; term < 3; ++term)         // lo*hi, hi*lo, hi*hi: small products first
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][a][term == 0 ? 1 : 0], bf[ks][b][term == 1 ? 1 : 0],
+                                                                           acc[a][b], 0, 0, 0);
+                        if constexpr (w2)
+                            acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][a][term == 0 ? 1 : 0], bf2[ks][b][term == 1 ? 1 : 0],
+                                                                                acc2[a][b], 0, 0, 0);
+                    }
+        };
+        constexpr int NM = 3 * TM * TN * (w2 ? 2 : 1), NR = 2 * TM + 2 * TN * (w2 ? 2 : 1);
+        rd(0);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(1);
+        mm(0);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, NM / NR > 0 ? NM / NR : 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mm(1);
+    };
+    auto compute_buf = [&](int buf) {
+        if constexpr (DUAL) {
+            if ((has2 >> buf) & 1u) compute(buf, std::true_type{});
+            else compute(buf, std::false_type{});
+        } else {
+            compute(buf, std::false_type{});
+        }
+    };
+
+    float4 ra[PA][2], rb[PA][2];
+    open_b();
+    open_a();
+    dma(0);
+    load_a(ra);
+    if (total > 1) load_a(rb);
+    store_a(0, ra);
+    if (total > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // steady = true: chunks it+1 and it+2 exist -- no branches in the body, so hipcc's own vmcnt bookkeeping for the register
+    // loads stays exact (with the conditions inside, the merge of the paths made it wait for the newest loads as well)
+    auto body = [&](int it, float4 (&rfree)[PA][2], const float4 (&rnext)[PA][2], auto steady) {
+        constexpr bool ST = decltype(steady)::value;
+        const int buf = it & 1;
+        const bool m1 = ST || it + 1 < total, m2 = ST || it + 2 < total;
+        if (m1) dma(buf ^ 1);
+        if (m2) load_a(rfree);
+        compute_buf(buf);
+        if (m1) store_a(buf ^ 1, rnext);
+        if (m2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    int it = 0;
+    for (; it + 3 < total; it += 2) {
+        body(it, ra, rb, std::true_type{});
+        body(it + 1, rb, ra, std::true_type{});
+    }
+    for (; it < total; it += 2) {
+        body(it, ra, rb, std::false_type{});
+        if (it + 1 < total) body(it + 1, rb, ra, std::false_type{});
+    }
+
+    // ---- undo the scales (all powers of two: exact), then the shared epilogues
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int f = min(f0 + wn * WTN + b * 32 + li, p.F - 1);
+            const float wi = p.wsi[f];
+            float wi2 = 0.f;
+            if constexpr (DUAL) wi2 = p.wsi2[f];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float ir = inv_row[wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh];
+                acc[a][b][g] *= ir * wi;
+                if constexpr (DUAL) acc2[a][b][g] *= ir * wi2;
+            }
+        }
+    if (DUAL || p.rankR > 0 || p.bias_mode == CAPE_BIAS_VERTEX || p.act == CAPE_ACT_TANH) {
+        gconv_epilogue<BM, BN, 2, 2, DUAL, float>(p, acc, acc2, n, r0, f0, wm, wn, li, lh);
+        return;
+    }
+    gconv_epilogue_short<BM, BN, float>(p, acc, n, r0, f0, wm, wn, li, lh);
+}
+
+// Eligibility on top of the plain-source conditions of plan_fwd: fp32 storage, every source with piece planes and row bounds,
+// whole 32-channel chunks, rows addressable through a 32-bit buffer offset, an output of at least 64 columns.
+inline bool h2_eligible(const GconvParams &p, bool dual) {
+    static const int on = getenv("CAPE_GEMM_H2") ? atoi(getenv("CAPE_GEMM_H2")) : 1;      // 0: A/B against the six-product bf16 form
+    if (!on || p.F < 64 || !p.wsi || (dual && !p.wsi2)) return false;
+    for (int i = 0; i < p.nsrc; ++i) {
+        const SrcDev &S = p.s[i];
+        if (S.rp || !S.wh || !S.wl || !S.rm || S.rmw < 4 || (S.rmw & 3)) return false;
+        if (S.C % H2_KC != 0 || S.C < H2_KC) return false;
+        if ((S.ldx & 3) || (S.xs & 3) || (reinterpret_cast<uintptr_t>(S.x) & 15)) return false;
+        if ((long long)p.Mo * S.ldx >= (1LL << 29) || (long long)p.F * S.wp >= (1LL << 30)) return false;
+        if ((S.wp & 7) || (reinterpret_cast<uintptr_t>(S.wh) & 15) || (reinterpret_cast<uintptr_t>(S.wl) & 15)) return false;
+        if (S.w2) {
+            if (!dual || !S.wh2 || !S.wl2 || (S.wp2 & 7) || (long long)p.F * S.wp2 >= (1LL << 30)) return false;
+            if ((reinterpret_cast<uintptr_t>(S.wh2) & 15) || (reinterpret_cast<uintptr_t>(S.wl2) & 15)) return false;
+        }
+    }
+    return true;
+}
+
+inline void h2_tile(bool dual, int N, int Mo, int F, int &BM, int &BN) {
+    if (dual) { BM = 128; BN = 64; return; }
+    const long long big = (long long)N * ((Mo + 127) / 128) * ((F + 127) / 128);
+    if (F >= 128 && big >= 384) { BM = 128; BN = 128; }
+    else { BM = 64; BN = 64; }
+}
+
+inline void h2_launch(const GconvParams &p, bool dual, int BM, dim3 grid, hipStream_t st) {
+    if (dual) CAPE_LAUNCH((gemm_h2_kernel<128, 64, true>), grid, dim3(256), 0, st, p);
+    else if (BM == 128) CAPE_LAUNCH((gemm_h2_kernel<128, 128, false>), grid, dim3(256), 0, st, p);
+    else CAPE_LAUNCH((gemm_h2_kernel<64, 64, false>), grid, dim3(256), 0, st, p);
+}
+
+}  // namespace

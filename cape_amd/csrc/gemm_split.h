@@ -399,28 +399,7 @@ __global__ __launch_bounds__(256, (BM * BN * (DUAL ? 2 : 1) >= 128 * 128) ? GS_B
         gconv_epilogue<BM, BN, 2, 2, DUAL, AT>(p, acc, acc2, n, r0, f0, wm, wn, li, lh);
         return;
     }
-    // Short epilogue for the common launches (no rank-1 terms; channel bias or none; identity / ReLU / leaky ReLU as
-    // one negative-side slope).  With two workgroups per CU all tiles of a launch finish together, so the epilogue is
-    // not hidden behind other workgroups' multiplies: the general one (uniform branches per element) cost ~10 us here.
-    const float slope = p.act == CAPE_ACT_LEAKY ? 0.2f : 1.f;
-    const bool relu = p.act == CAPE_ACT_RELU;
-    AT *yb = reinterpret_cast<AT *>(p.y) + (long long)n * p.ys;
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int f = f0 + wn * WTN + b * 32 + li;
-            const bool fok = f < p.F;
-            const int fm = p.deintK > 1 ? (f % p.deintK) * p.deint_stride + f / p.deintK : f;
-            const float bch = (p.bias_mode == CAPE_BIAS_CHANNEL && fok) ? p.bias[f] : 0.f;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int row = r0 + wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
-                float v = acc[a][b][g] + bch;
-                v = v > 0.f ? v : (relu ? 0.f : slope * v);
-                if (fok && row < p.Mo) cape_st(&yb[(long long)row * p.ldy + fm], v);
-            }
-        }
+    gconv_epilogue_short<BM, BN, AT>(p, acc, n, r0, f0, wm, wn, li, lh);
 }
 
 // =============================================================================================================

@@ -1,0 +1,197 @@
+// Operand preparation of the fp16 two-piece contractions (gemm_h2.h): the weight piece planes, written once per step, and
+// a standalone row-maximum pass for activation tensors whose producer did not write bounds (tensors handed in from outside
+// the layer stack; the kernels inside the stack write them from their epilogues).  gfx950 only.
+//
+// Weight tensor of a Chebyshev layer, reference layout W[Ch*K (+ condition rows), F], row c*K + k (lib/models.py:97-101):
+//   forward planes   Pf[k][f][c] = piece(W[c*K + k, f] * sf[f])      sf[f]  from max over ALL feature rows of column f
+//   backward planes  Pb[c*K + k][f] = piece(W[c*K + k, f] * sb[c])   sb[c]  from max over the K rows of channel c
+// Forward launches contract over c (sources k = 0..K-1 add into one accumulator column f, hence one scale per f); the data
+// gradient contracts over f into output column c (de-interleaved form: column c*K + k), hence one scale per c.  Both plane
+// sets are contraction-contiguous, so gemm_h2_kernel has one staging path.  The reciprocal scales are stored replicated
+// (fsi[k*F + f], bsi[c*K + k]) so that every launch form indexes them by its own output column.
+#include <stdlib.h>
+
+#include "common.h"
+#include "gemm_h2.h"
+
+namespace {
+
+// ---- standalone row maxima: out[(n*M + r)*W + 0] = max_c |x[n, r, c]|, entries 1..W-1 = 0 --------------------------------
+// 16 lanes per row (one DPP row), 16 rows per 256-thread block
+__global__ __launch_bounds__(256) void rowmax_kernel(const float *x, long long xs, int ldx, int N, int M, int C, float *out, int W) {
+    const int l = threadIdx.x & 15;
+    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = row < (long long)N * M;
+    const long long rr = live ? row : 0;
+    const int n = (int)(rr / M), r = (int)(rr % M);
+    const float *p = x + (long long)n * xs + (long long)r * ldx;
+    float m = 0.f;
+    if (((ldx | C) & 3) == 0 && (xs & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        for (int j = l; j < (C >> 2); j += 16) {
+            const float4 v = *reinterpret_cast<const float4 *>(p + 4 * j);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+    } else {
+        for (int j = l; j < C; j += 16) m = fmaxf(m, fabsf(p[j]));
+    }
+    m = h2_max_ror(m);
+    if (live && l < W) out[rr * W + l] = l == 0 ? m : 0.f;
+}
+
+// ---- weight pieces ---------------------------------------------------------------------------------------------------
+struct WItem {                      // device-resident copy of cape_wpiece_item_t (identical layout)
+    const float *w;
+    int Ch, K, F, pairK;
+    const float *pw;
+    unsigned short *f_hi, *f_lo, *b_hi, *b_lo;
+    float *fsi, *bsi, *bsc;
+};
+
+// block -> (item, local block) through the prefix table off[nitems + 1]
+__device__ __forceinline__ int w_find(const int *off, int nitems, int b) {
+    int i = 0;
+    while (i + 1 < nitems && b >= off[i + 1]) ++i;
+    return i;
+}
+
+// pass 1: the maxima.  Local blocks [0, ceil(F/64)): column strips of 64 (thread = column x 4 row lanes);
+// then ceil(Ch/4) blocks of four channels (one wave per channel: its K rows, lanes over the columns).
+__global__ __launch_bounds__(256) void wmax_kernel(const WItem *items, int nitems, const int *off) {
+    const int it = w_find(off, nitems, blockIdx.x);
+    const WItem I = items[it];
+    const int b = blockIdx.x - off[it];
+    const int cstrips = (I.F + 63) / 64;
+    const int rows = I.Ch * I.K;
+    __shared__ float part[4][64];
+    if (b < cstrips) {
+        const int f = b * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+        float m = 0.f;
+        if (f < I.F)
+            for (int j = rl; j < rows; j += 4) m = fmaxf(m, fabsf(I.w[(long long)j * I.F + f]));
+        part[rl][threadIdx.x & 63] = m;
+        __syncthreads();
+        if (rl == 0 && f < I.F) {
+            m = fmaxf(fmaxf(part[0][threadIdx.x], part[1][threadIdx.x]), fmaxf(part[2][threadIdx.x], part[3][threadIdx.x]));
+            float s, inv;
+            h2_scale_of(m, s, inv);
+            for (int k = 0; k < I.K; ++k) I.fsi[(long long)k * I.F + f] = inv;
+        }
+    } else {
+        const int c = (b - cstrips) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (c >= I.Ch) return;
+        float m = 0.f;
+        const float *p = I.w + (long long)c * I.K * I.F;                 // the K rows of channel c are contiguous: K * F floats
+        for (int j = lane; j < I.K * I.F; j += 64) m = fmaxf(m, fabsf(p[j]));
+        if (I.pw) {                                                       // the partner's rows of the same channel
+            const float *pp = I.pw + (long long)c * I.pairK * I.F;
+            for (int j = lane; j < I.pairK * I.F; j += 64) m = fmaxf(m, fabsf(pp[j]));
+        }
+        m = h2_max_ror(m);
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        if (lane < I.K) {
+            float s, inv;
+            h2_scale_of(m, s, inv);
+            I.bsi[c * I.K + lane] = inv;
+            if (lane == 0) I.bsc[c] = inv;
+        }
+    }
+}
+
+// pass 2: the planes.  Local blocks [0, K * (Ch/32) * ceil(F/64)): forward planes, one 32-channel x 64-column tile of order k
+// per block, transposed through LDS (rows of W are read along f, the planes are written along c: both sides coalesced;
+// only when Ch % 32 == 0 -- other layers never take the forward kernel).  Then ceil(Ch*K*F / 2048) blocks of the
+// backward planes (same order as W: thread = eight consecutive columns).
+__device__ __forceinline__ int w_fwd_blocks(const WItem &I) { return (I.Ch & 31) ? 0 : I.K * (I.Ch >> 5) * ((I.F + 63) >> 6); }
+
+__global__ __launch_bounds__(256) void wplanes_kernel(const WItem *items, int nitems, const int *off) {
+    const int it = w_find(off, nitems, blockIdx.x);
+    const WItem I = items[it];
+    const int b = blockIdx.x - off[it];
+    const int nfb = w_fwd_blocks(I);
+    if (b < nfb) {
+        __shared__ unsigned short th[64][40], tl[64][40];                  // [column][channel], 80-byte rows: 16-byte aligned segments
+        const int ftiles = (I.F + 63) >> 6, ctiles = I.Ch >> 5;
+        const int ft = b % ftiles, ct = (b / ftiles) % ctiles, k = b / (ftiles * ctiles);
+        const int c0 = ct * 32, f0 = ft * 64;
+        {
+            const int cl = threadIdx.x >> 3, fq = threadIdx.x & 7, f = f0 + 8 * fq;
+            if (f < I.F) {
+                const float *src = I.w + ((long long)(c0 + cl) * I.K + k) * I.F + f;
+                const float4 a = *reinterpret_cast<const float4 *>(src), bb = *reinterpret_cast<const float4 *>(src + 4);
+                const float4 ia = *reinterpret_cast<const float4 *>(I.fsi + f), ib = *reinterpret_cast<const float4 *>(I.fsi + f + 4);
+                const float v[8] = {a.x / ia.x, a.y / ia.y, a.z / ia.z, a.w / ia.w, bb.x / ib.x, bb.y / ib.y, bb.z / ib.z, bb.w / ib.w};   // powers of two: exact
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const _Float16 h = (_Float16)v[j], l = (_Float16)(v[j] - (float)h);
+                    th[8 * fq + j][cl] = __builtin_bit_cast(unsigned short, h);
+                    tl[8 * fq + j][cl] = __builtin_bit_cast(unsigned short, l);
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const int fl = threadIdx.x >> 2, cq = threadIdx.x & 3, f = f0 + fl;
+            if (f < I.F) {
+                const long long d = ((long long)k * I.F + f) * I.Ch + c0 + 8 * cq;
+                *reinterpret_cast<uint4 *>(I.f_hi + d) = *reinterpret_cast<const uint4 *>(&th[fl][8 * cq]);
+                *reinterpret_cast<uint4 *>(I.f_lo + d) = *reinterpret_cast<const uint4 *>(&tl[fl][8 * cq]);
+            }
+        }
+        return;
+    }
+    const long long e = (long long)(b - nfb) * 256 + threadIdx.x;
+    if (e >= (long long)I.Ch * I.K * (I.F >> 3)) return;
+    const int f8 = (int)(e % (I.F >> 3));
+    const long long j = e / (I.F >> 3);                                   // row c*K + k
+    const float s = 1.f / I.bsi[j];
+    const float4 a = *reinterpret_cast<const float4 *>(I.w + j * I.F + 8 * f8), bb = *reinterpret_cast<const float4 *>(I.w + j * I.F + 8 * f8 + 4);
+    uint4 hi, lo;
+    h2_split2(a.x * s, a.y * s, hi.x, lo.x);
+    h2_split2(a.z * s, a.w * s, hi.y, lo.y);
+    h2_split2(bb.x * s, bb.y * s, hi.z, lo.z);
+    h2_split2(bb.z * s, bb.w * s, hi.w, lo.w);
+    *reinterpret_cast<uint4 *>(I.b_hi + j * I.F + 8 * f8) = hi;
+    *reinterpret_cast<uint4 *>(I.b_lo + j * I.F + 8 * f8) = lo;
+}
+
+}  // namespace
+
+extern "C" int cape_rowmax(const float *x, int64_t x_sample_stride, int32_t ldx, int32_t N, int32_t M, int32_t C, float *out,
+                           int32_t out_w, void *stream) {
+    if (!x || !out || N < 1 || M < 1 || C < 1 || ldx < C || out_w < 4 || out_w > 16 || (out_w & 3)) return CAPE_EINVAL;
+    const long long rows = (long long)N * M;
+    CAPE_LAUNCH(rowmax_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x, (long long)x_sample_stride, ldx,
+                N, M, C, out, out_w);
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}
+
+extern "C" int cape_weight_pieces_blocks(const cape_wpiece_item_t *host_items, int32_t nitems, int32_t *max_off, int32_t *planes_off) {
+    if (!host_items || nitems < 1 || !max_off || !planes_off) return CAPE_EINVAL;
+    static_assert(sizeof(WItem) == sizeof(cape_wpiece_item_t), "layout");
+    max_off[0] = planes_off[0] = 0;
+    for (int i = 0; i < nitems; ++i) {
+        const cape_wpiece_item_t &I = host_items[i];
+        if (!I.w || I.Ch < 8 || (I.Ch & 7) || I.K < 1 || I.K > 16 || I.F < 8 || (I.F & 7)) return CAPE_EINVAL;
+        if (!I.f_hi || !I.f_lo || !I.b_hi || !I.b_lo || !I.fscale_inv || !I.bscale_inv || !I.bscale_c_inv) return CAPE_EINVAL;
+        if (I.pair_w && (I.pair_K < 1 || I.pair_K > 16)) return CAPE_EINVAL;
+        const long long bwd = (long long)I.Ch * I.K * (I.F / 8);
+        const int fwd = (I.Ch & 31) ? 0 : I.K * (I.Ch / 32) * ((I.F + 63) / 64);
+        max_off[i + 1] = max_off[i] + (I.F + 63) / 64 + (I.Ch + 3) / 4;
+        planes_off[i + 1] = planes_off[i] + fwd + (int)((bwd + 255) / 256);
+    }
+    return CAPE_OK;
+}
+
+extern "C" int cape_weight_pieces(const cape_wpiece_item_t *dev_items, int32_t nitems, const int32_t *dev_max_off, int32_t max_blocks,
+                                  const int32_t *dev_planes_off, int32_t planes_blocks, void *stream) {
+    if (!dev_items || nitems < 1 || !dev_max_off || !dev_planes_off || max_blocks < 1 || planes_blocks < 1) return CAPE_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    CAPE_LAUNCH(wmax_kernel, dim3((unsigned)max_blocks), dim3(256), 0, st, reinterpret_cast<const WItem *>(dev_items), nitems, dev_max_off);
+    CAPE_LAUNCH_CHECK();
+    CAPE_LAUNCH(wplanes_kernel, dim3((unsigned)planes_blocks), dim3(256), 0, st, reinterpret_cast<const WItem *>(dev_items), nitems,
+                dev_planes_off);
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}

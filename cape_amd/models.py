@@ -103,6 +103,9 @@ class base_model(object):
         self._grad_views = {}      # TF variable name -> view of the flat gradient bucket (train phase)
         self._grad_views_d = {}    # the same for the discriminator variables, used while D runs as a single merged pass
         self._conv_meta = {}       # conv weight name -> (feature channels, K, Fout), recorded while tracing
+        self._conv_pairs = {}      # graph_conv weight <-> affine weight of a res_block_affine (they share a data-gradient accumulator)
+        self._piece_plan = None    # ops.PiecePlan over every conv weight that qualifies (fp16 two-piece contractions)
+        self._pieces_dirty = True  # the planes do not reflect the current weights
         self._cond_plan = None     # consumers of the decoder's condition vector, recorded on the first pass
         self._cond_rec = None      # ... while recording
         self._cond_bank = None     # iterator over the precomputed coefficient tensors of the current pass
@@ -197,6 +200,45 @@ class base_model(object):
                                     ops.DeviceCSR(HostCSR(P64.T), self.device), P)
         return self._csr_cache[key][:2]
 
+    # ---- fp16 two-piece contractions: piece planes of the conv weights ----------------------------------
+    def _build_piece_plan(self):
+        specs = []
+        for name, (Ch, K, Fout) in sorted(self._conv_meta.items()):
+            W = self._vars.get(name)
+            if W is None or W.dtype != torch.float32 or not W.is_cuda or Ch % 8 or Fout % 8 or W.shape[0] < Ch * K:
+                continue
+            if not ((Ch % 32 == 0 and Fout >= 64) or (Fout % 32 == 0 and Ch >= 64)):
+                continue
+            pair = None
+            pn = self._conv_pairs.get(name)
+            if pn is not None and pn in self._conv_meta and pn in self._vars:
+                pair = (self._vars[pn].detach(), self._conv_meta[pn][1])
+            specs.append(dict(W=W.detach(), Ch=Ch, K=K, pair=pair))
+        self._piece_plan_key = tuple(sorted(self._conv_meta.items()))
+        self._piece_plan = ops.PiecePlan(specs, self.device) if specs else None
+
+    def prepare_pieces(self):
+        """(Re)write the piece planes of all conv weights from their CURRENT values: two launches.  Runs at the start of
+        every forward_losses (so a captured training step always contains it) and lazily before the first contraction of
+        any other pass once the weights may have changed (``_pieces_dirty``: optimiser step, restore, in-place edits)."""
+        if not ops.H2 or self.act_dtype != torch.float32 or not self._conv_meta:
+            return
+        if self._piece_plan is None or getattr(self, '_piece_plan_key', None) != tuple(sorted(self._conv_meta.items())):
+            self._build_piece_plan()
+        if self._piece_plan is None:
+            return
+        for wp in self._piece_plan.run():
+            ops.PIECES[wp.W.data_ptr()] = wp
+        self._pieces_dirty = False
+        self._pieces_versions = tuple(int(st['flat']._version) for st in self._opt_state.values()) if getattr(self, '_opt_state', None) else None
+
+    def _ensure_pieces(self):
+        if self._piece_plan is None:
+            return                      # first trace: the layers prepare their planes on demand
+        vers = tuple(int(st['flat']._version) for st in self._opt_state.values()) if getattr(self, '_opt_state', None) else None
+        if self._pieces_dirty or vers != getattr(self, '_pieces_versions', None):
+            self.prepare_pieces()
+
     # ---- the reference's named operators (plug-points) --------------------------------------------
     def chebyshev5(self, x, L, Fout, K, activation=None, bias=None, pool=None, unpool=None, cond=None,
                    W_affine=None, cond_in=None):
@@ -214,6 +256,9 @@ class base_model(object):
         bname = '/'.join(self._scope + ['bias'])
         Ch = int(x.shape[-1])
         self._conv_meta[wname] = (Ch, int(K), int(Fout))
+        if W_affine is not None:
+            self._conv_pairs[wname], self._conv_pairs[waname] = waname, wname
+        self._ensure_pieces()
         gW = self._grad_views.get(wname)
         gB = self._grad_views.get(bname) if bias is not None else None      # channel bias [1,1,F] or vertex bias [1,M,F]
         gWa = None
@@ -906,6 +951,7 @@ class CAPE(base_model):
                 ranges, coef = self._reg_ranges(), self.regularization * self.regularization
             ops.flat_gradnorm(g, flat, ranges, coef, st['sumsq'], st['ws'])
             ops.flat_momentum_update(flat, g, m, self.momentum, clip, st['sumsq'], st['neg_lr'], ranges, coef)
+            self._pieces_dirty = True           # (the kernel writes through raw pointers: no version bump to detect)
         return st['sumsq']
 
     # ======================= training step ========================================================
@@ -916,6 +962,7 @@ class CAPE(base_model):
         regularisation gradient to the flat bucket itself (the loss then carries only its value)."""
         self._reg_via_bucket = reg_via_bucket
         self._reg_in_bucket = False
+        self.prepare_pieces()                   # unconditionally: a captured step must contain the refresh of the piece planes
         y_g, y2_g = self._conditions(cond_g, cond2_g)
         # heads of the two-phase backward: the tensors the decoder / discriminator actually consume
         self._y_pair = (self._ycat[2],) if self._ycat is not None else (y_g, y2_g)

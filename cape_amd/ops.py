@@ -334,7 +334,7 @@ def _log_launch(name, flops, byts, fn):
     return out
 
 
-_FWD_FAMILY = {0: "gconv_fwd_kernel", 1: "gemm_plain_kernel", 2: "gemm_split_kernel"}
+_FWD_FAMILY = {0: "gconv_fwd_kernel", 1: "gemm_plain_kernel", 2: "gemm_split_kernel", 3: "gemm_h2_kernel"}
 _DW_FAMILY = {0: "gconv_dw_kernel", 1: "dw_plain_kernel", 2: "dw_packed_kernel", 3: "dw_split_kernel"}
 
 
@@ -343,6 +343,8 @@ def fwd_kernel_name(fam, bm, bn, layout, dual, bf16=False):
     waves = "2, 2" if (bm, bn) in ((64, 128), (128, 128), (64, 64)) else "4, 1"
     tf = lambda b: "true" if b else "false"
     at = ", unsigned short" if bf16 else ", float"
+    if fam == 3:
+        return "gemm_h2_kernel<%d, %d, %s>" % (bm, bn, tf(dual))
     if fam == 2:
         return "gemm_split_kernel<%d, %d, %s, %s%s>" % (bm, bn, tf(layout), tf(dual), at)
     if fam == 1:
@@ -358,11 +360,188 @@ def dw_kernel_name(fam, ct, ft, bf16=False):
 
 
 # --------------------------------------------------------------------------------------------
+# fp16 two-piece contractions (csrc/gemm_h2.h): row bounds of activation tensors and piece planes of the weights
+# --------------------------------------------------------------------------------------------
+# H2 = 0 keeps every contraction on the bf16 six-product kernels (the A/B reference of round 3)
+H2 = int(_os.environ.get("CAPE_H2", "1"))
+
+
+def rm_width(F):
+    """Entries per row of a row-bound tensor for ``F`` channels: one per 32-column block, padded to a multiple of 4."""
+    return ((int(F) + 31) // 32 + 3) // 4 * 4
+
+
+def alloc_rm(t, F=None):
+    """Fresh row-bound tensor [N, M, W] for activation tensor ``t`` (filled by the kernel that produces ``t``)."""
+    return torch.empty((t.shape[0], t.shape[1], rm_width(t.shape[2] if F is None else F)), device=t.device, dtype=torch.float32)
+
+
+def set_rm(t, rm):
+    """Attach the row bounds ``rm`` to activation tensor ``t``.  The attribute travels with the tensor object through
+    autograd.Function.apply, saved tensors and the backward pass (PyTorch preserves the Python object of a live tensor);
+    views are new objects and do not inherit it, and every in-place writer of ``t`` must drop it (``drop_rm``)."""
+    if rm is not None:
+        t._cape_rm = rm
+    return t
+
+
+def drop_rm(t):
+    if getattr(t, "_cape_rm", None) is not None:
+        t._cape_rm = None
+
+
+def rm_of(t):
+    rm = getattr(t, "_cape_rm", None)
+    if rm is None or rm.shape[0] != t.shape[0] or rm.shape[1] != t.shape[1] or rm.device != t.device:
+        return None
+    return rm
+
+
+def _want_rm(t, Cn=None):
+    """Row bounds are worth writing for an output that can be an operand of the fp16 two-piece contraction: fp32, whole
+    32-channel chunks."""
+    Cn = t.shape[2] if Cn is None else Cn
+    return bool(H2) and t.dtype == torch.float32 and Cn % 32 == 0 and Cn >= 32
+
+
+def _new_rm(t):
+    return torch.empty((t.shape[0], t.shape[1], 4), device=t.device, dtype=torch.float32)
+
+
+def rowmax(t):
+    """Row bounds of ``t``: the ones its producer attached, else one standalone pass (csrc/pieces.hip rowmax_kernel)."""
+    rm = rm_of(t)
+    if rm is not None:
+        return rm
+    _lib.require_gpu()
+    t = as_act(t)
+    assert t.dtype == torch.float32
+    rm = torch.empty((t.shape[0], t.shape[1], 4), device=t.device, dtype=torch.float32)
+    p, ss, ld = _v(t)
+    _log_launch("rowmax_kernel", 0, 4 * t.shape[0] * t.shape[1] * (t.shape[2] + 4),
+                lambda: check(lib.cape_rowmax(p, ss, ld, t.shape[0], t.shape[1], t.shape[2], _ptr(rm), 4, _stream()), "cape_rowmax"))
+    set_rm(t, rm)
+    return rm
+
+
+class WeightPieces(object):
+    """Piece planes of one Chebyshev-layer weight W[Ch*K (+ condition rows), F] (views of a PiecePlan's arena):
+    forward planes [K][F][Ch], backward planes [Ch*K][F], reciprocal scales (include/cape_hip.h cape_wpiece_item_t)."""
+    __slots__ = ("W", "Ch", "K", "F", "pair", "f_hi", "f_lo", "b_hi", "b_lo", "fsi", "bsi", "bsc")
+
+    def fwd(self, k):
+        """(hi pointer, lo pointer, pitch) of forward source k (contraction over the Ch feature channels)."""
+        o = 2 * k * self.F * self.Ch
+        return self.f_hi.data_ptr() + o, self.f_lo.data_ptr() + o, self.Ch
+
+    def bwd(self, k):
+        """Data-gradient source k (contraction over F, output column = channel c): rows c*K + k of the backward planes."""
+        o = 2 * k * self.F
+        return self.b_hi.data_ptr() + o, self.b_lo.data_ptr() + o, self.K * self.F
+
+
+class PiecePlan(object):
+    """All piece planes of a set of weights in two launches (cape_weight_pieces).  ``specs``: dicts W (tensor), Ch, K and
+    optionally pair = (W2, K2): a second weight whose data-gradient term adds into the same accumulator."""
+
+    def __init__(self, specs, device):
+        self.items, sizes = [], []
+        for sp in specs:
+            W, Ch, K = sp["W"], int(sp["Ch"]), int(sp["K"])
+            F = int(W.shape[1])
+            assert W.is_contiguous() and W.dtype == torch.float32 and W.shape[0] >= Ch * K and Ch % 8 == 0 and F % 8 == 0
+            sizes.append((Ch, K, F))
+        al = lambda nbytes: (nbytes + 255) // 256 * 256
+        total = sum(4 * al(2 * Ch * K * F) + al(4 * K * F) + al(4 * Ch * K) + al(4 * Ch) for Ch, K, F in sizes)
+        self.arena = torch.empty(max(total, 256), device=device, dtype=torch.uint8)
+        off = 0
+
+        def take(nbytes, dtype):
+            nonlocal off
+            t = self.arena[off:off + nbytes].view(dtype)
+            off += al(nbytes)
+            return t
+
+        arr = (_lib.CapeWpieceItem * len(specs))()
+        for a, sp, (Ch, K, F) in zip(arr, specs, sizes):
+            wp = WeightPieces()
+            wp.W, wp.Ch, wp.K, wp.F, wp.pair = sp["W"], Ch, K, F, sp.get("pair")
+            wp.f_hi, wp.f_lo = take(2 * Ch * K * F, torch.int16), take(2 * Ch * K * F, torch.int16)
+            wp.b_hi, wp.b_lo = take(2 * Ch * K * F, torch.int16), take(2 * Ch * K * F, torch.int16)
+            wp.fsi, wp.bsi, wp.bsc = take(4 * K * F, torch.float32), take(4 * Ch * K, torch.float32), take(4 * Ch, torch.float32)
+            a.w, a.Ch, a.K, a.F = sp["W"].data_ptr(), Ch, K, F
+            a.pair_w, a.pair_K = (wp.pair[0].data_ptr(), int(wp.pair[1])) if wp.pair is not None else (None, 0)
+            a.f_hi, a.f_lo, a.b_hi, a.b_lo = wp.f_hi.data_ptr(), wp.f_lo.data_ptr(), wp.b_hi.data_ptr(), wp.b_lo.data_ptr()
+            a.fscale_inv, a.bscale_inv, a.bscale_c_inv = wp.fsi.data_ptr(), wp.bsi.data_ptr(), wp.bsc.data_ptr()
+            self.items.append(wp)
+        n = len(specs)
+        mo, po = (C.c_int32 * (n + 1))(), (C.c_int32 * (n + 1))()
+        check(lib.cape_weight_pieces_blocks(C.addressof(arr), n, mo, po), "cape_weight_pieces_blocks")
+        self.n, self.max_blocks, self.planes_blocks = n, int(mo[n]), int(po[n])
+        raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+        self.table = torch.from_numpy(raw).to(device)
+        self.max_off = torch.tensor(list(mo), dtype=torch.int32, device=device)
+        self.planes_off = torch.tensor(list(po), dtype=torch.int32, device=device)
+        self.flops_bytes = sum(12 * Ch * K * F for Ch, K, F in sizes)
+
+    def run(self):
+        _lib.require_gpu()
+        _log_launch("wplanes_kernel", 0, self.flops_bytes,
+                    lambda: check(lib.cape_weight_pieces(_ptr(self.table), self.n, _ptr(self.max_off), self.max_blocks,
+                                                         _ptr(self.planes_off), self.planes_blocks, _stream()), "cape_weight_pieces"))
+        return self.items
+
+
+# weight data_ptr -> WeightPieces of the model-level plan (models.CAPE keeps it fresh: re-run at the start of every
+# forward pass); weights outside it get their planes on demand (two small launches per call: unit tests, first trace)
+PIECES = {}
+
+
+def pieces_for(W, Ch, K, pair=None):
+    """Piece planes of W for ``Ch`` feature channels at order K, or None when the layer does not qualify."""
+    if not H2 or not W.is_cuda or W.dtype != torch.float32 or Ch % 8 or W.shape[1] % 8 or not W.is_contiguous():
+        return None
+    wp = PIECES.get(W.data_ptr())
+    if wp is not None and (wp.Ch, wp.K, wp.F) == (Ch, K, int(W.shape[1])) and \
+            (wp.pair[0].data_ptr() if wp.pair is not None else None) == (pair[0].data_ptr() if pair is not None else None):
+        return wp
+    return PiecePlan([dict(W=W.detach(), Ch=Ch, K=K, pair=pair)], W.device).run()[0]
+
+
+def _h2_arg(entries, N, wsi=None, wsi2=None, rm_out=None):
+    """cape_h2_t for a launch: entries carry "p" = (hi, lo, pitch) [and "p2"] and "rm" when the launch may take the fp16
+    two-piece kernel; ``rm_out``: row-bound tensor the epilogue fills.  Returns (struct or None, keep-alive)."""
+    full = wsi is not None and all(e.get("p") is not None and e.get("rm") is not None for e in entries)
+    if not full and rm_out is None:
+        return None, None
+    h = _lib.CapeH2()
+    keep = None
+    if full:
+        arr = (_lib.CapeH2Src * len(entries))()
+        for a, e in zip(arr, entries):
+            a.w_hi, a.w_lo, a.w_pitch = e["p"]
+            if e.get("p2") is not None:
+                a.w2_hi, a.w2_lo, a.w2_pitch = e["p2"]
+            rm = e["rm"]
+            assert rm.is_contiguous() and rm.shape[0] == N and rm.shape[1] == e["x"].shape[1]
+            a.rowmax, a.rowmax_w = rm.data_ptr(), int(rm.shape[2])
+        h.src, keep = C.addressof(arr), arr
+        h.wscale_inv = wsi
+        h.w2scale_inv = wsi2
+    if rm_out is not None:
+        h.rowmax_out, h.rowmax_out_w = rm_out.data_ptr(), int(rm_out.shape[2])
+    return h, keep
+
+
+# --------------------------------------------------------------------------------------------
 # raw kernel wrappers (no autograd)
 # --------------------------------------------------------------------------------------------
-def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=None, rank=None, deinterleave=0, F=None):
+def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=None, rank=None, deinterleave=0, F=None,
+              wsi=None, wsi2=None, rm_out=None):
     """rank = (rowscale [R,Mo], coef [N,R,F], to_acc2 bitmask) or None.  ``deinterleave`` = K: the launch computes
-    ``F`` = K*C output columns (column c*K + k) and stores them as K channel blocks of ``y`` [N, Mo, K*round_up(C,4)]."""
+    ``F`` = K*C output columns (column c*K + k) and stores them as K channel blocks of ``y`` [N, Mo, K*round_up(C,4)].
+    fp16 two-piece operands (csrc/gemm_h2.h): entries with "p" / "p2" (piece planes) and "rm" (row bounds) plus ``wsi`` /
+    ``wsi2`` (pointers to the reciprocal column scales); ``rm_out``: row-bound tensor of y for the epilogue to fill."""
     _lib.require_gpu()
     arr = _mk_srcs(entries)
     N, Mo = y.shape[0], y.shape[1]
@@ -377,7 +556,15 @@ def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=
 
     assert all(e["x"].dtype == y.dtype for e in entries), "sources and output share one storage type"
 
+    h2, h2_keep = (None, None) if y.dtype != torch.float32 else _h2_arg(entries, N, wsi, wsi2, rm_out)
+
     def launch():
+        if h2 is not None:
+            rc = lib.cape_gconv_fwd_h2(arr, len(entries), p, ss, ld, N, Mo, F, _ptr(bias),
+                                       bias_mode if bias is not None else _lib.BIAS_NONE, _lib.ACT[act],
+                                       _ptr(mask), C.byref(rk) if rk is not None else None, int(deinterleave), C.byref(h2), _stream())
+            check(rc, "cape_gconv_fwd_h2")
+            return
         rc = _fn("cape_gconv_fwd", y)(arr, len(entries), p, ss, ld, N, Mo, F, _ptr(bias),
                                 bias_mode if bias is not None else _lib.BIAS_NONE, _lib.ACT[act],
                                 _ptr(mask), C.byref(rk) if rk is not None else None, int(deinterleave), _stream())
@@ -389,7 +576,10 @@ def gconv_fwd(entries, y, bias=None, bias_mode=_lib.BIAS_NONE, act="none", mask=
         # the library reports the kernel it selects; names as rocprofv3 prints them
         dual = any(e.get("w2") is not None for e in entries)
         plan = (C.c_int32 * 4)()
-        check(_fn("cape_gconv_fwd_plan", y)(arr, len(entries), N, Mo, F, plan), "cape_gconv_fwd_plan")
+        if h2 is not None:
+            check(lib.cape_gconv_fwd_plan_h2(arr, len(entries), N, Mo, F, C.byref(h2), plan), "cape_gconv_fwd_plan_h2")
+        else:
+            check(_fn("cape_gconv_fwd_plan", y)(arr, len(entries), N, Mo, F, plan), "cape_gconv_fwd_plan")
         fam, bm, bn, layout = list(plan)
         bf = y.dtype == torch.bfloat16
         if PLAN_LOG is not None:
@@ -482,14 +672,17 @@ def spmm(x, csr, y=None, alpha=1.0, z=None, beta=0.0):
     rp_, ci_, va_, ew_ = csr.operands() if _vec_ok(x, y, z) else \
         (csr.rowptr_t.data_ptr(), csr.colidx_t.data_ptr(), csr.vals_t.data_ptr(), 0)          # scalar fallback: CSR only
 
+    drop_rm(y)                           # (y may be a caller's tensor written in place)
+    rm = _new_rm(y) if _want_rm(y) else None
+
     def launch():
         rc = _fn("cape_spmm", x)(xp, xs, xl, C.c_void_p(rp_), C.c_void_p(ci_), C.c_void_p(va_), int(csr.max_row), ew_,
-                           float(alpha), zp, zs, zl, float(beta), yp, ys, yl, N, Mo, Cn, _stream())
+                           float(alpha), zp, zs, zl, float(beta), yp, ys, yl, N, Mo, Cn, _ptr(rm), _stream())
         check(rc, "cape_spmm")
 
     _log_launch("spmm_kernel", 2 * N * csr.nnz * Cn, es * N * Cn * (Mi + Mo * (2 if z is not None else 1)) + 8 * csr.nnz + 4 * (Mo + 1),
                 launch)
-    return y
+    return set_rm(y, rm)
 
 
 def spmm_multi(xs, csrs, sum=False, scales=None):
@@ -522,10 +715,18 @@ def spmm_multi(xs, csrs, sum=False, scales=None):
             yk = alloc_act(N, Mo, Cn, xs[0].device, dtype=xs[0].dtype)
             yp, t.y_sample_stride, t.ldy = _v(yk)
             t.y = yp.value
+            if _want_rm(yk):
+                rmk = _new_rm(yk)
+                t.rowmax_out = rmk.data_ptr()
+                set_rm(yk, rmk)
             outs.append(yk)
+    rm = None
     if sum:
         y = alloc_act(N, Mo, Cn, xs[0].device, dtype=xs[0].dtype)
         yp, ys, yl = _v(y)
+        if _want_rm(y):
+            rm = _new_rm(y)
+            set_rm(y, rm)
     else:
         y, yp, ys, yl = None, None, 0, 0
     es = xs[0].element_size()
@@ -534,7 +735,7 @@ def spmm_multi(xs, csrs, sum=False, scales=None):
         flops += 2 * N * (Mo if ident[k] else csrs[k].nnz) * Cn
         byts += es * N * Cn * xs[k].shape[1] + (0 if ident[k] else _csr_bytes(csrs[k]))
     _log_launch("spmm_multi_kernel", flops, byts,
-                lambda: check(_fn("cape_spmm_multi", xs[0])(arr, n, 1 if sum else 0, yp, ys, yl, N, Mo, Cn, _stream()), "cape_spmm_multi"))
+                lambda: check(_fn("cape_spmm_multi", xs[0])(arr, n, 1 if sum else 0, yp, ys, yl, N, Mo, Cn, _ptr(rm), _stream()), "cape_spmm_multi"))
     return y if sum else outs
 
 
@@ -564,15 +765,17 @@ def spmm_combine(xs, csrs, y, to_acc2=0, rank=None, bias=None, bias_mode=_lib.BI
         assert coef.is_contiguous() and rowscale.is_contiguous() and coef.shape[0] == N and coef.shape[2] == F
         rk = _lib.CapeRank(int(coef.shape[1]), rowscale.data_ptr(), coef.data_ptr(), int(to2))
     yp, ys, yl = _v(y)
+    drop_rm(y)
+    rm = _new_rm(y) if _want_rm(y) else None
     flops = sum(2 * N * (Mo if (c is None or c.identity) else c.nnz) * F for c in csrs)
     es = y.element_size()
     byts = sum(es * N * F * xs[k].shape[1] + _csr_bytes(csrs[k]) for k in range(n)) + es * N * Mo * F
     _log_launch("spmm_combine_kernel", flops, byts,
                 lambda: check(_fn("cape_spmm_combine", y)(arr, n, int(to_acc2), C.byref(rk) if rk is not None else None, _ptr(bias),
                                                     bias_mode if bias is not None else _lib.BIAS_NONE, _lib.ACT[act],
-                                                    1 if dual else 0, _ptr(mask), yp, ys, yl, N, Mo, F, _stream()),
+                                                    1 if dual else 0, _ptr(mask), yp, ys, yl, N, Mo, F, _ptr(rm), _stream()),
                               "cape_spmm_combine"))
-    return y
+    return set_rm(y, rm)
 
 
 def bias_act_fwd(x, bias, bias_mode, act, y=None):
@@ -741,10 +944,13 @@ def bwd_prep(g, y=None, act="none", mask=None, want_bias=False, rowscale=None, R
         yp, ys, yl = _v(y)
     else:
         yp, ys, yl = None, 0, 0
+    rm = _new_rm(dz) if _want_rm(dz) else None
+    set_rm(dz, rm)
+
     def launch():
         rc = _fn("cape_bwd_prep", g)(gp, gs, gl, yp, ys, yl, _lib.ACT[act] if mask is None else 0, _ptr(mask), zp, zs, zl,
                                _ptr(dbias), _ptr(rowscale), R, _ptr(dcoef), 0 if rg is None else int(rg), _ptr(dcoef_g),
-                               cstride, 0 if (defer and DEFERRED is not None) else 1, N, Mo, F, _ptr(ws), need, _stream())
+                               cstride, 0 if (defer and DEFERRED is not None) else 1, N, Mo, F, _ptr(ws), need, _ptr(rm), _stream())
         check(rc, "cape_bwd_prep")
 
     # one pass: read g (+ y or the 1-bit mask), write dz
@@ -834,12 +1040,21 @@ class ChebConvFn(torch.autograd.Function):
             elif ks:                                   # X_k = S_k x of all orders in one launch
                 for k, xk in zip(ks, spmm_multi([x] * len(ks), [ops.fwd[k] for k in ks])):
                     xs[k] = xk
+        P, Pa = ChebConvFn._pieces(x, W, W_aff, Ch, K, Fout, twopass)
+        fw_ok = P is not None and Ch % 32 == 0 and Fout >= 64            # (the forward planes exist for whole 32-channel chunks)
         entries = []
         for k in range(K):
             e = dict(x=xs[k], csr=None if twopass else ops.fwd[k], w=(W, k * Fout, K * Fout, 1))
             if W_aff is not None and k == 0:
                 e["w2"] = (W_aff, 0, Fout, 1)
+            if fw_ok:
+                e["p"], e["rm"] = P.fwd(k), rowmax(xs[k])
+                if "w2" in e:
+                    e["p2"] = Pa.fwd(0)
             entries.append(e)
+        h2kw = dict(wsi=_ptr(P.fsi), wsi2=_ptr(Pa.fsi) if Pa is not None else None) if fw_ok else {}
+        # the epilogue writes the row bounds of y next to it (consumed by the next contraction; csrc/gconv_shared.h)
+        rm_y = alloc_rm(y) if (H2 and y.dtype == torch.float32) else None
         rank = None
         if coef is not None:
             assert coef.is_contiguous() and coef.shape == (N, K + (1 if W_aff is not None else 0), Fout)
@@ -859,16 +1074,19 @@ class ChebConvFn(torch.autograd.Function):
         mask = None
         if W_aff is not None:
             mask = torch.empty((N, ops.Mo, (Fout + 31) // 32), device=x.device, dtype=torch.int32)
-            gconv_fwd(entries, y, mask=mask, rank=rank)
+            gconv_fwd(entries, y, mask=mask, rank=rank, rm_out=rm_y, **h2kw)
             _trace_mask_bits(mask, Fout)
         else:
-            gconv_fwd(entries, y, bias=bias, bias_mode=bias_mode, act=act, rank=rank)
+            gconv_fwd(entries, y, bias=bias, bias_mode=bias_mode, act=act, rank=rank, rm_out=rm_y, **h2kw)
             _trace_sign(y, act)
         if Co:
             fill_cond(cond_out.contiguous(), yfull[:, :, Fout:])
+        elif rm_y is not None:
+            set_rm(yfull, rm_y)
         ctx.ops, ctx.act, ctx.bias_mode, ctx.Fout, ctx.Co, ctx.Cc = ops, act, bias_mode, Fout, Co, Cc
         ctx.has_bias, ctx.twopass, ctx.xshape = bias is not None, twopass, (N, Mi, Ch)
         ctx.gW, ctx.gWa, ctx.gB, ctx.banked = gW, gWa, gB, banked
+        ctx.pieces = (P, Pa)
         # up-sampling layers (Mo > Mi): the data gradient needs T_k = S_k^T dz at the Mi input rows anyway, and
         # dW_k = X_k^T dz = x^T T_k -- the weight gradient contracts over the COARSE rows (half the flops) and the
         # fine-level X_k need not be kept for the backward pass at all
@@ -878,20 +1096,43 @@ class ChebConvFn(torch.autograd.Function):
         return yfull
 
     @staticmethod
+    def _pieces(x, W, W_aff, Ch, K, Fout, twopass):
+        """Piece planes of the layer's weights when its contractions may run on the fp16 two-piece kernel (fp32 storage,
+        two-pass mode, whole 32-channel chunks on one side at least), else (None, None)."""
+        if not (H2 and twopass and x.dtype == torch.float32 and Ch % 8 == 0 and Fout % 8 == 0 and
+                ((Ch % 32 == 0 and Fout >= 64) or (Fout % 32 == 0 and Ch >= 64))):
+            return None, None
+        P = pieces_for(W, Ch, K, pair=(W_aff.detach(), 1) if W_aff is not None else None)
+        Pa = pieces_for(W_aff, Ch, 1, pair=(W.detach(), K)) if (W_aff is not None and P is not None) else None
+        if W_aff is not None and Pa is None:
+            return None, None
+        return P, Pa
+
+    @staticmethod
     def _forward_coarse(ctx, x, W, bias, W_aff, cond_in, cond_out, ops, act, bias_mode, gW, gWa, gB, coef, banked, Cc, yfull, y):
         """(S_k x) W_k = S_k (x W_k): one GEMM on the Mi input rows for all K orders (the feature rows of W viewed
         as [Ch, K*Fout]), one for the affine weights, then cape_spmm_combine applies the operators, the rank-1 terms
         and the epilogue.  Backward is the ordinary one in its coarse weight-gradient form (needs only x)."""
         N, Mi, Ch = x.shape
         K, Fout = ops.K, W.shape[1]
+        P, Pa = ChebConvFn._pieces(x, W, W_aff, Ch, K, Fout, True)
+        fwd_ok = P is not None and Ch % 32 == 0
+        rmx = rowmax(x) if fwd_ok else None
         Z = alloc_act(N, Mi, K * Fout, x.device, dtype=x.dtype)
-        gconv_fwd([dict(x=x, csr=None, w=(W, 0, K * Fout, 1))], Z)
+        if fwd_ok:
+            gconv_fwd([dict(x=x, csr=None, w=(W, 0, K * Fout, 1), p=(P.f_hi.data_ptr(), P.f_lo.data_ptr(), Ch), rm=rmx)], Z,
+                      wsi=_ptr(P.fsi))
+        else:
+            gconv_fwd([dict(x=x, csr=None, w=(W, 0, K * Fout, 1))], Z)
         zs = [Z[:, :, k * Fout:(k + 1) * Fout] for k in range(K)]
         csrs = [ops.fwd[k] for k in range(K)]
         to2 = 0
         if W_aff is not None:
             Za = alloc_act(N, Mi, Fout, x.device, dtype=x.dtype)
-            gconv_fwd([dict(x=x, csr=None, w=(W_aff, 0, Fout, 1))], Za)
+            if fwd_ok:
+                gconv_fwd([dict(x=x, csr=None, w=(W_aff, 0, Fout, 1), p=Pa.fwd(0), rm=rmx)], Za, wsi=_ptr(Pa.fsi))
+            else:
+                gconv_fwd([dict(x=x, csr=None, w=(W_aff, 0, Fout, 1))], Za)
             zs.append(Za)
             csrs.append(ops.fwd[0])
             to2 = 1 << K
@@ -922,6 +1163,7 @@ class ChebConvFn(torch.autograd.Function):
         ctx.has_bias, ctx.twopass, ctx.xshape = bias is not None, True, (N, Mi, Ch)
         ctx.gW, ctx.gWa, ctx.gB, ctx.banked = gW, gWa, gB, banked
         ctx.coarse_dw = True
+        ctx.pieces = (P, Pa)
         ctx.save_for_backward(W, W_aff, mask, yfull if (act != "none" and W_aff is None) else None, cond_in, x)
         return yfull
 
@@ -935,6 +1177,7 @@ class ChebConvFn(torch.autograd.Function):
         Mo, dev = ops.Mo, W.device
         gfull = as_act(gfull)
         g = gfull[:, :, :Fout]
+        set_rm(g, rm_of(gfull))            # a bound over a superset of the channels is still a bound
         need_x, need_w, need_b, need_wa, need_ci, need_co = (ctx.needs_input_grad[i] for i in range(6))
         if NO_WEIGHT_GRAD and W.data_ptr() in NO_WEIGHT_GRAD:
             need_w = need_b = need_wa = False       # data-gradient-only sweep through this layer (see NO_WEIGHT_GRAD)
@@ -1011,25 +1254,39 @@ class ChebConvFn(torch.autograd.Function):
                 wT = lambda k: (W, k * Fout, 1, K * Fout)
                 waT = (W_aff, 0, 1, Fout) if W_aff is not None else None
                 contract_first = (Mo < Mi) or (Mo == Mi and Ch < Fout)
+                # fp16 two-piece operands of the data gradient: contraction over the Fout columns (backward planes)
+                P, Pa = ctx.pieces
+                bw_ok = P is not None and Fout % 32 == 0 and Ch >= 64 and dz.dtype == torch.float32
+
+                def src(xk, k, aff=False):
+                    e = dict(x=xk, csr=None, w=waT if aff else wT(k))
+                    if bw_ok:
+                        e["p"], e["rm"] = (Pa.bwd(0) if aff else P.bwd(k)), rowmax(xk)
+                    return e
+                bkw = dict(wsi=_ptr(P.bsc)) if bw_ok else {}
                 if contract_first and W_aff is None and K > 1:
                     # all K orders in ONE launch: G = dz W[:Ch*K]^T has column c*K + k; the epilogue stores it as K
                     # channel blocks G_k (de-interleave), then dx = sum_k S_k^T G_k
                     ChP = _pad4(Ch)
                     Gall = alloc_act(N, Mo, K * ChP, dev, dtype=gfull.dtype)
-                    gconv_fwd([dict(x=dz, csr=None, w=(W, 0, 1, Fout))], Gall, deinterleave=K, F=K * Ch)
+                    if bw_ok:
+                        gconv_fwd([dict(x=dz, csr=None, w=(W, 0, 1, Fout), p=(P.b_hi.data_ptr(), P.b_lo.data_ptr(), Fout), rm=rowmax(dz))],
+                                  Gall, deinterleave=K, F=K * Ch, wsi=_ptr(P.bsi))
+                    else:
+                        gconv_fwd([dict(x=dz, csr=None, w=(W, 0, 1, Fout))], Gall, deinterleave=K, F=K * Ch)
                     dx = spmm_multi([Gall[:, :, k * ChP:k * ChP + Ch] for k in range(K)], [ops.bwd[k] for k in range(K)], sum=True)
                 elif contract_first:
                     # G_k = dz W_k^T at the Mo output rows, then dx = sum_k S_k^T G_k
                     first = True
                     for k in range(K):
-                        ent = [dict(x=dz, csr=None, w=wT(k))]
+                        ent = [src(dz, k)]
                         if W_aff is not None and k == 0:
-                            ent.append(dict(x=g, csr=None, w=waT))
+                            ent.append(src(g, 0, aff=True))
                         if ops.bwd[k].identity and first:
-                            gconv_fwd(ent, dx)
+                            gconv_fwd(ent, dx, **bkw)
                         else:
                             Gk = alloc_act(N, Mo, Ch, dev, dtype=gfull.dtype)
-                            gconv_fwd(ent, Gk)
+                            gconv_fwd(ent, Gk, **bkw)
                             if ops.bwd[k].identity:
                                 dx.add_(Gk)
                             elif first:
@@ -1057,10 +1314,12 @@ class ChebConvFn(torch.autograd.Function):
                         for k in range(1, K):
                             dxv.addcmul_(Ts[k][:, :, :1], Wm[:, k])
                     else:
-                        ent = [dict(x=Ts[k], csr=None, w=wT(k)) for k in range(K)]
+                        ent = [src(Ts[k], k) for k in range(K)]
                         if W_aff is not None:
-                            ent.append(dict(x=Ts[K], csr=None, w=waT))
-                        gconv_fwd(ent, dx)
+                            ent.append(src(Ts[K], 0, aff=True))
+                        rm_dx = alloc_rm(dx) if (H2 and dx.dtype == torch.float32) else None
+                        gconv_fwd(ent, dx, rm_out=rm_dx, **bkw)
+                        set_rm(dx, rm_dx)
                     if ctx.coarse_dw:
                         # dW_k^T[f, c] = sum_{n, r} T_k[n, r, f] x[n, r, c]: the T_k are the sources, x the gradient operand
                         wen = []

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define CAPE_ABI_VERSION 10
+#define CAPE_ABI_VERSION 11
 #define CAPE_MAX_SRC 8
 
 /* error codes (negative = argument error; positive values are hipError_t) */
@@ -158,6 +158,71 @@ int cape_gconv_fwd(const cape_src_t *srcs, int32_t nsrc, float *y, int64_t y_sam
                    int32_t bias_mode, int32_t act, uint32_t *mask_out, const cape_rank_t *rank,
                    int32_t out_deinterleave, void *stream);
 
+/*
+ * fp16 two-piece operands ("h2") of the trailing contraction (reference lib/models.py:99-102) -- the default arithmetic of
+ * every eligible fp32 launch since ABI 11: each fp32 operand, scaled by a power of two, is the sum of two fp16 numbers
+ * (22 significant bits) and three cross products per multiply-add are accumulated in fp32 on v_mfma_f32_32x32x16_f16; as
+ * accurate as an fp32 FMA chain, not bit-identical to the other kernels.  The scales come from
+ *   - per activation row: a BOUND of the row's absolute maximum, cape_h2_src_t.rowmax [N, rows, rowmax_w] (rowmax_w a
+ *     multiple of 4; the bound of a row is the maximum over its rowmax_w entries), written by the kernel that produced the
+ *     tensor (rowmax_out below and of cape_spmm* / cape_bwd_prep) or by cape_rowmax;
+ *   - per weight column: the piece planes and reciprocal scales cape_weight_pieces prepares once per step.
+ * Launches whose sources are plain (no CSR), whole 32-channel chunks, 16-byte aligned, with F >= 64 and all of the above
+ * given take gemm_h2_kernel; everything else is computed as before (the row-bound output works with every kernel).
+ */
+typedef struct cape_h2_src {
+    const uint16_t *w_hi, *w_lo;   /* fp16 pieces of weight block 1: element (f, c) at [f * w_pitch + c] (contraction contiguous) */
+    int64_t w_pitch;
+    const uint16_t *w2_hi, *w2_lo; /* of weight block 2 (DUAL), NULL otherwise                                                  */
+    int64_t w2_pitch;
+    const float *rowmax;           /* row bounds of x: [N, rows, rowmax_w]                                                      */
+    int32_t rowmax_w;
+} cape_h2_src_t;
+typedef struct cape_h2 {
+    const cape_h2_src_t *src;      /* nsrc entries, or NULL (then only rowmax_out is used)                                      */
+    const float *wscale_inv;       /* [F] reciprocal column scales of the block-1 planes                                        */
+    const float *w2scale_inv;      /* [F] of the block-2 planes (DUAL)                                                          */
+    float *rowmax_out;             /* NULL or [N, Mo, rowmax_out_w]: entry j of row r = bound of |y[n, r, 32 j .. 32 j + 31]|    */
+    int32_t rowmax_out_w;          /* multiple of 4, >= ceil(F / 32); entries beyond ceil(F / 32) are written as 0              */
+} cape_h2_t;
+/* cape_gconv_fwd with the operands above (h2 == NULL: identical to cape_gconv_fwd).  fp32 storage only. */
+int cape_gconv_fwd_h2(const cape_src_t *srcs, int32_t nsrc, float *y, int64_t y_sample_stride,
+                      int32_t ldy, int32_t N, int32_t Mo, int32_t F, const float *bias,
+                      int32_t bias_mode, int32_t act, uint32_t *mask_out, const cape_rank_t *rank,
+                      int32_t out_deinterleave, const cape_h2_t *h2, void *stream);
+/* plan query of cape_gconv_fwd_h2: plan[0] = 3 for gemm_h2_kernel, otherwise as cape_gconv_fwd_plan */
+int cape_gconv_fwd_plan_h2(const cape_src_t *srcs, int32_t nsrc, int32_t N, int32_t Mo, int32_t F, const cape_h2_t *h2,
+                           int32_t plan[4]);
+
+/* Row bounds of a tensor whose producer wrote none: out[(n*M + r)*out_w] = max_c |x[n, r, c]|, the other entries 0. */
+int cape_rowmax(const float *x, int64_t x_sample_stride, int32_t ldx, int32_t N, int32_t M, int32_t C, float *out,
+                int32_t out_w, void *stream);
+
+/*
+ * Piece planes of Chebyshev-layer weights W[Ch*K (+ further rows), F], row c*K + k (lib/models.py:97-101), for all layers
+ * of a model in two launches (maxima, planes):
+ *   forward   f_hi / f_lo [K][F][Ch]:  piece(W[c*K+k, f] * sf[f]),  fscale_inv[k*F + f] = 1 / sf[f]   (replicated over k)
+ *   backward  b_hi / b_lo [Ch*K][F]:   piece(W[c*K+k, f] * sb[c]),  bscale_inv[c*K + k] = bscale_c_inv[c] = 1 / sb[c]
+ * Forward source k of a layer: w_hi = f_hi + k*F*Ch, w_pitch = Ch, wscale_inv = fscale_inv (the coarse form with K*F output
+ * columns reads all K blocks as one [K*F][Ch] plane).  Data gradient: source k: w_hi = b_hi + k*F, w_pitch = K*F,
+ * wscale_inv = bscale_c_inv (the de-interleaved single launch: w_hi = b_hi, w_pitch = F, column j = c*K + k, bscale_inv).
+ * Ch and F must be multiples of 8.  The item table and the two block-offset tables live in DEVICE memory (they are static
+ * per model); cape_weight_pieces_blocks computes the offset tables on the host.
+ */
+typedef struct cape_wpiece_item {
+    const float *w;
+    int32_t Ch, K, F, pair_K;
+    const float *pair_w;           /* NULL, or a second weight tensor [Ch*pair_K (+ ...), F] whose data-gradient term adds into the
+                                    * same accumulator (res_block_affine: graph_conv + affine, lib/models.py:780-789): the
+                                    * backward scale of channel c then covers the rows of BOTH tensors                     */
+    uint16_t *f_hi, *f_lo, *b_hi, *b_lo;
+    float *fscale_inv, *bscale_inv;
+    float *bscale_c_inv;           /* [Ch]: 1 / sb[c] once per channel (the multi-source data-gradient form's column index) */
+} cape_wpiece_item_t;
+int cape_weight_pieces_blocks(const cape_wpiece_item_t *host_items, int32_t nitems, int32_t *max_off, int32_t *planes_off);
+int cape_weight_pieces(const cape_wpiece_item_t *dev_items, int32_t nitems, const int32_t *dev_max_off, int32_t max_blocks,
+                       const int32_t *dev_planes_off, int32_t planes_blocks, void *stream);
+
 /* Which kernel cape_gconv_fwd would run for these arguments (pure query, no launch):
  * plan[0] = family (0: gather-GEMM gconv_fwd_kernel, 1: pipelined plain-source gemm_plain_kernel, 2: the same on
  * the bf16 pipe with the exact three-way operand split, gemm_split_kernel),
@@ -243,7 +308,7 @@ int cape_bwd_prep(const float *g, int64_t g_sample_stride, int32_t ldg, const fl
                   int64_t y_sample_stride, int32_t ldy, int32_t act, const uint32_t *mask, float *dz,
                   int64_t dz_sample_stride, int32_t lddz, float *dbias, const float *rowscale,
                   int32_t R, float *dcoef, int32_t rg, float *dcoef_g, int64_t dcoef_sample_stride, int32_t finalize,
-                  int32_t N, int32_t Mo, int32_t F, void *workspace, int64_t workspace_bytes, void *stream);
+                  int32_t N, int32_t Mo, int32_t F, void *workspace, int64_t workspace_bytes, float *rowmax_out, void *stream);
 
 /* finalize = 0 above leaves the reductions as partial slabs in the workspace; this entry finishes up to
  * CAPE_MAX_BWD_PREP_ITEMS of them in ONE launch (same N, Mo, F, R and destinations as the deferred calls, whose
@@ -271,7 +336,7 @@ int cape_spmm(const float *x, int64_t x_sample_stride, int32_t ldx, const int32_
               const int32_t *colidx, const float *vals, int32_t max_row_nnz, int32_t ell_width, float alpha, const float *z,
               int64_t z_sample_stride, int32_t ldz, float beta, float *y,
               int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t C,
-              void *stream);
+              float *rowmax_out, void *stream);
 
 /*
  * Several operator applications in one launch (all operators have Mo rows, all operands C channels):
@@ -280,6 +345,10 @@ int cape_spmm(const float *x, int64_t x_sample_stride, int32_t ldx, const int32_
  * A term with rowptr == NULL is the identity (its input then has Mo rows).  y / terms[k].y must not alias an input.
  */
 #define CAPE_MAX_SPMM_TERMS 4
+/* rowmax_out (cape_spmm, cape_spmm_multi in sum mode, cape_spmm_combine, cape_bwd_prep; fp32 storage only): NULL or
+ * [N, Mo, 4]: the bound of max_c |out[n, r, c]| of the row the call writes (y / dz), as cape_h2_src_t.rowmax with
+ * rowmax_w = 4 -- written by the same kernel where the lanes of a row form one power-of-two group, by a standalone pass
+ * (cape_rowmax) inside the call otherwise. */
 typedef struct cape_spmm_term {
     const float *x;
     int64_t x_sample_stride;
@@ -292,9 +361,10 @@ typedef struct cape_spmm_term {
     int32_t ldy;
     float scale;             /* the term is scale * S_k x_k (1.0f for a plain application) */
     int32_t ell_width;       /* 0: colidx / vals in CSR form; 4 / 8 / 12: ELL form (see cape_spmm)      */
+    float *rowmax_out;       /* separate mode of cape_spmm_multi (fp32): NULL or [N, Mo, 4] row bounds of y (cape_h2_src_t.rowmax) */
 } cape_spmm_term_t;
 int cape_spmm_multi(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, float *y, int64_t y_sample_stride,
-                    int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream);
+                    int32_t ldy, int32_t N, int32_t Mo, int32_t C, float *rowmax_out, void *stream);
 
 /*
  * Operators applied AFTER the dense contraction, with the layer epilogue -- for up-sampling layers, where
@@ -305,7 +375,7 @@ int cape_spmm_multi(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, 
  */
 int cape_spmm_combine(const cape_spmm_term_t *terms, int32_t nterms, uint32_t to_acc2, const cape_rank_t *rank,
                       const float *bias, int32_t bias_mode, int32_t act, int32_t dual, uint32_t *mask_out, float *y,
-                      int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t F, void *stream);
+                      int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t F, float *rowmax_out, void *stream);
 
 /* y = act(x + bias) over [N, M, C] views (y may alias x). */
 int cape_bias_act_fwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *bias,
@@ -522,18 +592,18 @@ int cape_gconv_dw_plan_bf16(const cape_src_t *srcs, int32_t nsrc, const void *dz
 int cape_spmm_bf16(const void *x, int64_t x_sample_stride, int32_t ldx, const int32_t *rowptr,
                    const int32_t *colidx, const float *vals, int32_t max_row_nnz, int32_t ell_width, float alpha,
                    const void *z, int64_t z_sample_stride, int32_t ldz, float beta, void *y, int64_t y_sample_stride,
-                   int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream);
+                   int32_t ldy, int32_t N, int32_t Mo, int32_t C, float *rowmax_out, void *stream);
 int cape_spmm_multi_bf16(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, void *y, int64_t y_sample_stride,
-                         int32_t ldy, int32_t N, int32_t Mo, int32_t C, void *stream);
+                         int32_t ldy, int32_t N, int32_t Mo, int32_t C, float *rowmax_out, void *stream);
 int cape_spmm_combine_bf16(const cape_spmm_term_t *terms, int32_t nterms, uint32_t to_acc2, const cape_rank_t *rank,
                            const float *bias, int32_t bias_mode, int32_t act, int32_t dual, uint32_t *mask_out, void *y,
-                           int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t F, void *stream);
+                           int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo, int32_t F, float *rowmax_out, void *stream);
 /* workspace size and cape_bwd_prep_finalize as for cape_bwd_prep (fp32 partials) */
 int cape_bwd_prep_bf16(const void *g, int64_t g_sample_stride, int32_t ldg, const void *y, int64_t y_sample_stride,
                        int32_t ldy, int32_t act, const uint32_t *mask, void *dz, int64_t dz_sample_stride, int32_t lddz,
                        float *dbias, const float *rowscale, int32_t R, float *dcoef, int32_t rg, float *dcoef_g,
                        int64_t dcoef_sample_stride, int32_t finalize, int32_t N, int32_t Mo, int32_t F, void *workspace,
-                       int64_t workspace_bytes, void *stream);
+                       int64_t workspace_bytes, float *rowmax_out, void *stream);
 /* out[m, c] (+)= sum_n x[n, m, c]: gradient of the per-vertex output bias [1, M, F] (lib/models.py:615) from a bf16 dz */
 int cape_colsum_vertex_bf16(const void *x, int64_t x_sample_stride, int32_t ldx, int32_t N, int32_t M, int32_t C,
                             int32_t accumulate, float *out, void *stream);

@@ -42,7 +42,7 @@ def test_sparse_entry_points_reject_bad_arguments_before_launching():
     x, y, rp, ci, va = P(0x100000), P(0x200000), P(0x300000), P(0x400000), P(0x500000)
     args = lambda **kw: [kw.get("x", x), 64 * 64, kw.get("ldx", 64), rp, kw.get("ci", ci), va, 8, kw.get("ew", 0), 1.0, None, 0, 0, 0.0,
                          kw.get("y", y),
-                         64 * 64, kw.get("ldy", 64), kw.get("N", 2), kw.get("Mo", 64), kw.get("C", 64), None]
+                         64 * 64, kw.get("ldy", 64), kw.get("N", 2), kw.get("Mo", 64), kw.get("C", 64), None, None]
     assert lib.cape_spmm(*args(x=None)) == -1
     assert lib.cape_spmm(*args(y=None)) == -1
     assert lib.cape_spmm(*args(ldx=32)) == -1                      # leading dimension below the channel count
