@@ -68,6 +68,11 @@ class CapeH2(C.Structure):
                 ("rowmax_out", C.c_void_p), ("rowmax_out_w", C.c_int32)]
 
 
+class CapeH2Dw(C.Structure):
+    _fields_ = [("src_rowmax", C.c_void_p * MAX_SRC), ("src_rowmax_w", C.c_int32 * MAX_SRC),
+                ("dz_rowmax", C.c_void_p), ("dz_rowmax_w", C.c_int32), ("dz2_rowmax", C.c_void_p), ("dz2_rowmax_w", C.c_int32)]
+
+
 class CapeWpieceItem(C.Structure):
     _fields_ = [("w", C.c_void_p), ("Ch", C.c_int32), ("K", C.c_int32), ("F", C.c_int32), ("pair_K", C.c_int32),
                 ("pair_w", C.c_void_p),
@@ -98,6 +103,10 @@ SIGNATURES = {
     "cape_gconv_fwd_h2": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p, _i32, _i32, _p,
                                     C.POINTER(CapeRank), _i32, C.POINTER(CapeH2), _p]),
     "cape_gconv_fwd_plan_h2": (C.c_int, [_SRCP, _i32, _i32, _i32, _i32, C.POINTER(CapeH2), C.POINTER(_i32)]),
+    "cape_gconv_dw_stage_h2": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _p, C.c_uint32, _i32, _i32, _i32, _i32, _p, _i64, _i32,
+                                         C.POINTER(CapeH2Dw), _p]),
+    "cape_gconv_dw_plan_h2": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _p, C.c_uint32, _i32, _i32, _i32, C.POINTER(CapeH2Dw),
+                                        C.POINTER(_i32)]),
     "cape_rowmax": (C.c_int, [_p, _i64, _i32, _i32, _i32, _i32, _p, _i32, _p]),
     "cape_weight_pieces_blocks": (C.c_int, [C.c_void_p, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "cape_weight_pieces": (C.c_int, [_p, _i32, _p, _i32, _p, _i32, _p]),

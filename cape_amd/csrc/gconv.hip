@@ -733,6 +733,16 @@ inline bool dw_dz_vec(const float *dz, int64_t dz_sample_stride, int32_t lddz, c
            (!dz2 || (reinterpret_cast<uintptr_t>(dz2) & (4 * es - 1)) == 0);
 }
 
+// row bounds of the weight gradient's operands (cape_h2_dw_t, may be null)
+inline void fill_h2_dw(DwParams &p, const cape_h2_dw_t *h2) {
+    p.dzrm = p.dz2rm = nullptr;
+    p.dzrmw = p.dz2rmw = 0;
+    if (!h2) return;
+    for (int i = 0; i < p.nsrc; ++i) { p.s[i].rm = h2->src_rowmax[i]; p.s[i].rmw = h2->src_rowmax_w[i]; }
+    p.dzrm = h2->dz_rowmax; p.dzrmw = h2->dz_rowmax_w;
+    p.dz2rm = h2->dz2_rowmax; p.dz2rmw = h2->dz2_rowmax_w;
+}
+
 // Kernel choice of one weight-gradient launch (pure function of the arguments): 0 = gather form (gconv_dw_kernel),
 // 1 = pipelined plain kernel on the exact-fp32 MFMA (dw_plain_kernel), 2 = packed narrow sources (dw_packed_kernel),
 // 3 = plain sources on the bf16 pipe with the exact three-way operand split (dw_split_kernel).  Fills the tile plan.
@@ -989,10 +999,17 @@ extern "C" int64_t cape_gconv_dw_workspace_bytes(const cape_src_t *srcs, int32_t
 namespace {
 int gconv_dw_plan_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz, int64_t dz_sample_stride,
                        int32_t lddz, const float *dz2, uint32_t dz2_mask, int32_t N, int32_t Mo, int32_t F,
-                       int32_t plan[4], bool bf16) {
+                       int32_t plan[4], bool bf16, const cape_h2_dw_t *h2 = nullptr) {
     if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || !dz || N < 1 || Mo < 1 || F < 1 || lddz < F || !plan) return CAPE_EINVAL;
     DwPlan pl;
     plan[0] = choose_dw(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, N, Mo, F, pl, bf16);
+    if (plan[0] == 3 && !bf16 && h2) {
+        DwParams p;
+        p.nsrc = nsrc;
+        p.dz2_mask = dz2 ? dz2_mask : 0u;
+        fill_h2_dw(p, h2);
+        if (h2_dw_eligible(p)) plan[0] = 4;
+    }
     plan[1] = pl.ct; plan[2] = pl.ft; plan[3] = pl.ngroups * pl.rsplit;
     return CAPE_OK;
 }
@@ -1001,13 +1018,29 @@ int gconv_dw_stage_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz,
                         int64_t dz_sample_stride, int32_t lddz, const float *dz2, uint32_t dz2_mask,
                         int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
                         int64_t workspace_bytes, int32_t stage, void *stream, bool bf16,
-                        DwReduceParams *batch_rp = nullptr, int *batch_vec = nullptr, int *batch_blocks = nullptr);
+                        DwReduceParams *batch_rp = nullptr, int *batch_vec = nullptr, int *batch_blocks = nullptr,
+                        const cape_h2_dw_t *h2 = nullptr);
 }  // namespace
 
 extern "C" int cape_gconv_dw_plan(const cape_src_t *srcs, int32_t nsrc, const float *dz, int64_t dz_sample_stride,
                                   int32_t lddz, const float *dz2, uint32_t dz2_mask, int32_t N, int32_t Mo, int32_t F,
                                   int32_t plan[4]) {
     return gconv_dw_plan_impl(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, N, Mo, F, plan, false);
+}
+
+extern "C" int cape_gconv_dw_plan_h2(const cape_src_t *srcs, int32_t nsrc, const float *dz, int64_t dz_sample_stride,
+                                     int32_t lddz, const float *dz2, uint32_t dz2_mask, int32_t N, int32_t Mo, int32_t F,
+                                     const cape_h2_dw_t *h2, int32_t plan[4]) {
+    return gconv_dw_plan_impl(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, N, Mo, F, plan, false, h2);
+}
+
+extern "C" int cape_gconv_dw_stage_h2(const cape_src_t *srcs, int32_t nsrc, const float *dz,
+                                      int64_t dz_sample_stride, int32_t lddz, const float *dz2, uint32_t dz2_mask,
+                                      int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
+                                      int64_t workspace_bytes, int32_t stage, const cape_h2_dw_t *h2, void *stream) {
+    if (stage > 2) return CAPE_EINVAL;
+    return gconv_dw_stage_impl(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, N, Mo, F, accumulate, workspace,
+                               workspace_bytes, stage, stream, false, nullptr, nullptr, nullptr, h2);
 }
 
 extern "C" int cape_gconv_dw_plan_bf16(const cape_src_t *srcs, int32_t nsrc, const void *dz, int64_t dz_sample_stride,
@@ -1055,7 +1088,7 @@ int gconv_dw_stage_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz,
                         int64_t dz_sample_stride, int32_t lddz, const float *dz2, uint32_t dz2_mask,
                         int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
                         int64_t workspace_bytes, int32_t stage, void *stream, bool bf16,
-                        DwReduceParams *batch_rp, int *batch_vec, int *batch_blocks) {
+                        DwReduceParams *batch_rp, int *batch_vec, int *batch_blocks, const cape_h2_dw_t *h2) {
     if (stage < 0 || stage > 3 || (stage == 3 && (!batch_rp || !batch_vec || !batch_blocks))) return CAPE_EINVAL;
     if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || !dz || N < 1 || Mo < 1 || F < 1 || lddz < F || !workspace)
         return CAPE_EINVAL;
@@ -1089,10 +1122,13 @@ int gconv_dw_stage_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz,
     p.rsplit = pl.rsplit; p.rows_per_split = pl.rows_per_split;
     p.ngroups = pl.ngroups; p.samples_per_group = pl.samples_per_group;
     p.ws = (float *)workspace; p.slab = pl.slab;
+    fill_h2_dw(p, bf16 ? nullptr : h2);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(pl.ntiles * ((pl.ngroups * pl.rsplit + 7) / 8) * 8)), block(256);     // cape_map_dw_block
     if (stage >= 2) {
         // reduction only: the partial slabs of an earlier stage-1 call with the same arguments are in the workspace
+    } else if (!bf16 && dw_split && h2_dw_eligible(p)) {
+        h2_dw_launch(p, pl.ct, pl.ft, grid, st);                // fp16 two-piece operands: same tiles, splits and slabs
     } else if (bf16 && dw_split) {
         if (pl.ct == 64 && pl.ft == 64) CAPE_LAUNCH((dw_split_kernel<64, 64, cape_bf16>), grid, block, 0, st, p);
         else if (pl.ct == 64) CAPE_LAUNCH((dw_split_kernel<64, 128, cape_bf16>), grid, block, 0, st, p);

@@ -114,6 +114,9 @@ struct DwParams {
     int ngroups, samples_per_group;
     float *ws;
     long long slab;   // elements per split slab
+    // fp16 two-piece form (dw_h2_kernel): row bounds of the gradient operands (the sources' are in SrcDev::rm)
+    const float *dzrm, *dz2rm;
+    int dzrmw, dz2rmw;
     // dw_plain_kernel: tiles run over a VIRTUAL channel axis on which source s occupies [vstart[s], vstart[s] + C_s);
     // sources are packed back to back when they share dz (small layers: one tile holds several sources), otherwise
     // each source starts on a tile boundary.  vstart[nsrc] = length of the axis.

@@ -333,6 +333,199 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GconvParams p) {
     gconv_epilogue_short<BM, BN, float>(p, acc, n, r0, f0, wm, wn, li, lh);
 }
 
+// =============================================================================================================
+// Weight gradient of plain sources on the same arithmetic:  dW_s[c, f] = sum_{n, r} X_s[n, r, c] * dz[n, r, f].
+// Decomposition, staging and partial-slab output of dw_split_kernel (gemm_split.h): the contraction runs over the vertices,
+// BOTH operands are activations and are transposed in the stage (a thread reads 8 consecutive rows of its 1-2 channels,
+// splits them and writes one 16-byte row segment per piece plane [channel][row]).  The scales must be constant along the
+// contraction, i.e. over the rows of a workgroup's (sample group, row range): one power of two per operand and workgroup,
+// from the maximum of the row bounds of its range (read in a prologue: <= 4 floats per row).  A row far below the range's
+// maximum loses relative precision, but its contribution to the sum is smaller by the same factor: the error of an element
+// is <= 2^-22 |x| + 2^-40 max|x|, against fp32's own 2^-24 |x z| per term.
+// =============================================================================================================
+template <int CT, int FT>
+__global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? 2 : 3) void dw_h2_kernel(DwParams p) {
+    constexpr int RK = 32, PITCH = 80;                // bytes per LDS row of one piece plane: 32 halfs + 16 B pad
+    constexpr int WTM = CT / 2, WTN = FT / 2;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int CPA = CT / 64, CPB = FT / 64;       // channels per thread (8 rows each)
+    constexpr int APLANE = CT * PITCH, BPLANE = FT * PITCH;
+    static_assert(TM >= 1 && TN >= 1 && (CT == 64 || CT == 128) && (FT == 64 || FT == 128), "tile");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (APLANE + BPLANE)];
+    __shared__ float red[2][4];
+    unsigned char *sA = smem, *sB = smem + 2 * APLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int rg = tid >> 6;
+    const int ca = (tid & 63) * CPA, fb = (tid & 63) * CPB;
+
+    const int ntiles = p.tile_off[p.nsrc];
+    int tile, split;
+    if (!cape_map_dw_block(blockIdx.x, ntiles, p.ngroups * p.rsplit, tile, split)) return;
+    const int grp = split / p.rsplit;
+    const int rs = split % p.rsplit;
+    const int n_begin = grp * p.samples_per_group;
+    const int n_end = min(p.N, n_begin + p.samples_per_group);
+    int si = 0;
+    while (si + 1 < p.nsrc && tile >= p.tile_off[si + 1]) ++si;
+    const SrcDev &S = p.s[si];
+    const int lt = tile - p.tile_off[si];
+    const int c0 = (lt / p.ftiles) * CT;
+    const int f0 = (lt % p.ftiles) * FT;
+    const int ra = rs * p.rows_per_split;
+    const int rb = min(p.Mo, ra + p.rows_per_split);
+    const bool two = ((p.dz2_mask >> si) & 1u) != 0;
+    const float *dz0 = two ? p.dz2 : p.dz;
+
+    // ---- scales of this workgroup's range
+    float sx, sz, inv;
+    {
+        const float *rmz = two ? p.dz2rm : p.dzrm;
+        const int wz = two ? p.dz2rmw : p.dzrmw;
+        float mx = 0.f, mz = 0.f;
+        for (int n = n_begin; n < n_end; ++n) {
+            const float *px = S.rm + ((long long)n * p.Mo + ra) * S.rmw;
+            const float *pz = rmz + ((long long)n * p.Mo + ra) * wz;
+            for (int i = tid; i < (rb - ra) * S.rmw; i += 256) mx = fmaxf(mx, px[i]);
+            for (int i = tid; i < (rb - ra) * wz; i += 256) mz = fmaxf(mz, pz[i]);
+        }
+        mx = h2_max_ror(mx); mz = h2_max_ror(mz);
+        mx = fmaxf(mx, __shfl_xor(mx, 16)); mz = fmaxf(mz, __shfl_xor(mz, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32)); mz = fmaxf(mz, __shfl_xor(mz, 32));
+        if (lane == 0) { red[0][wave] = mx; red[1][wave] = mz; }
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+        mz = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+        float ix, iz;
+        h2_scale_of(mx, sx, ix);
+        h2_scale_of(mz, sz, iz);
+        inv = ix * iz;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
+
+    const int a_col = (c0 + ca < S.C) ? c0 + ca : 0;
+    const int b_col = (f0 + fb < p.F) ? f0 + fb : 0;
+    const int chunks = (rb - ra + RK - 1) / RK;
+    const int total = (n_end - n_begin) * chunks;
+    int l_n = n_begin, l_r = ra;
+    float xa[CPA][8], xz[CPB][8];
+    unsigned ok = 0;
+
+    auto load_regs = [&]() {
+        const float *xb = S.x + (long long)l_n * S.xs + a_col;
+        const float *zb = dz0 + (long long)l_n * p.dzs + b_col;
+        ok = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = l_r + 8 * rg + j;
+            ok |= (r < rb ? 1u : 0u) << j;
+            const int rr = min(r, rb - 1);
+            if constexpr (CPA == 2) {
+                const float2 v = cape_ld2(xb + (long long)rr * S.ldx);
+                xa[0][j] = v.x; xa[1][j] = v.y;
+            } else {
+                xa[0][j] = cape_ld(xb + (long long)rr * S.ldx);
+            }
+            if constexpr (CPB == 2) {
+                const float2 v = cape_ld2(zb + (long long)rr * p.lddz);
+                xz[0][j] = v.x; xz[1][j] = v.y;
+            } else {
+                xz[0][j] = cape_ld(zb + (long long)rr * p.lddz);
+            }
+        }
+        l_r += RK;
+        if (l_r >= rb) { l_r = ra; ++l_n; }
+    };
+    auto store8 = [&](unsigned char *dst, int plane, const float (&v)[8], float s) {
+        uint4 hi, lo;
+        h2_split2(((ok >> 0) & 1u) ? v[0] * s : 0.f, ((ok >> 1) & 1u) ? v[1] * s : 0.f, hi.x, lo.x);
+        h2_split2(((ok >> 2) & 1u) ? v[2] * s : 0.f, ((ok >> 3) & 1u) ? v[3] * s : 0.f, hi.y, lo.y);
+        h2_split2(((ok >> 4) & 1u) ? v[4] * s : 0.f, ((ok >> 5) & 1u) ? v[5] * s : 0.f, hi.z, lo.z);
+        h2_split2(((ok >> 6) & 1u) ? v[6] * s : 0.f, ((ok >> 7) & 1u) ? v[7] * s : 0.f, hi.w, lo.w);
+        *reinterpret_cast<uint4 *>(dst) = hi;
+        *reinterpret_cast<uint4 *>(dst + plane) = lo;
+    };
+    auto store_regs = [&]() {
+#pragma unroll
+        for (int ch = 0; ch < CPA; ++ch) store8(sA + (ca + ch) * PITCH + 16 * rg, APLANE, xa[ch], sx);
+#pragma unroll
+        for (int ch = 0; ch < CPB; ++ch) store8(sB + (fb + ch) * PITCH + 16 * rg, BPLANE, xz[ch], sz);
+    };
+    auto compute = [&]() {
+        const unsigned char *pa = sA + (wm * WTM + li) * PITCH;
+        const unsigned char *pb = sB + (wn * WTN + li) * PITCH;
+        h2_half8 af[2][TM][2], bf[2][TN][2];
+        auto rd = [&](int ks) {
+            const int so = 16 * (lh + 2 * ks);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) af[ks][a][pc] = *reinterpret_cast<const h2_half8 *>(pa + pc * APLANE + a * 32 * PITCH + so);
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) bf[ks][b][pc] = *reinterpret_cast<const h2_half8 *>(pb + pc * BPLANE + b * 32 * PITCH + so);
+        };
+        auto mm = [&](int ks) {
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][a][term == 0 ? 1 : 0], bf[ks][b][term == 1 ? 1 : 0],
+                                                                           acc[a][b], 0, 0, 0);
+        };
+        constexpr int NM = 3 * TM * TN, NR = 2 * (TM + TN);
+        rd(0);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(1);
+        mm(0);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, NM / NR > 0 ? NM / NR : 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mm(1);
+    };
+
+    if (total > 0) {
+        load_regs();
+        store_regs();
+        __syncthreads();
+        for (int it = 0; it < total; ++it) {
+            const bool more = it + 1 < total;
+            if (more) load_regs();
+            compute();
+            __syncthreads();
+            if (more) store_regs();
+            __syncthreads();
+        }
+    }
+
+    float *out = p.ws + (long long)split * p.slab + p.part_off[si];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int f = f0 + wn * WTN + b * 32 + li;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int c = c0 + wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                if (c < S.C && f < p.F) out[(long long)c * p.F + f] = acc[a][b][g] * inv;
+            }
+        }
+}
+
 // Eligibility on top of the plain-source conditions of plan_fwd: fp32 storage, every source with piece planes and row bounds,
 // whole 32-channel chunks, rows addressable through a 32-bit buffer offset, an output of at least 64 columns.
 inline bool h2_eligible(const GconvParams &p, bool dual) {
@@ -358,6 +551,22 @@ inline void h2_tile(bool dual, int N, int Mo, int F, int &BM, int &BN) {
     const long long big = (long long)N * ((Mo + 127) / 128) * ((F + 127) / 128);
     if (F >= 128 && big >= 384) { BM = 128; BN = 128; }
     else { BM = 64; BN = 64; }
+}
+
+// weight gradient: the dw_split plan (family 3) with row bounds on every operand
+inline bool h2_dw_eligible(const DwParams &p) {
+    static const int on = getenv("CAPE_DW_H2") ? atoi(getenv("CAPE_DW_H2")) : 1;          // 0: A/B against dw_split_kernel
+    if (!on || !p.dzrm || p.dzrmw < 1 || (p.dz2_mask && (!p.dz2rm || p.dz2rmw < 1))) return false;
+    for (int i = 0; i < p.nsrc; ++i)
+        if (!p.s[i].rm || p.s[i].rmw < 1) return false;
+    return true;
+}
+
+inline void h2_dw_launch(const DwParams &p, int ct, int ft, dim3 grid, hipStream_t st) {
+    if (ct == 64 && ft == 64) CAPE_LAUNCH((dw_h2_kernel<64, 64>), grid, dim3(256), 0, st, p);
+    else if (ct == 64) CAPE_LAUNCH((dw_h2_kernel<64, 128>), grid, dim3(256), 0, st, p);
+    else if (ft == 64) CAPE_LAUNCH((dw_h2_kernel<128, 64>), grid, dim3(256), 0, st, p);
+    else CAPE_LAUNCH((dw_h2_kernel<128, 128>), grid, dim3(256), 0, st, p);
 }
 
 inline void h2_launch(const GconvParams &p, bool dual, int BM, dim3 grid, hipStream_t st) {

@@ -54,24 +54,28 @@ __device__ __forceinline__ int w_find(const int *off, int nitems, int b) {
     return i;
 }
 
-// pass 1: the maxima.  Local blocks [0, ceil(F/64)): column strips of 64 (thread = column x 4 row lanes);
+// pass 1: the maxima.  Local blocks [0, ceil(F/16)): column strips of 16 (thread = column x 16 row lanes: 64-byte row
+// segments, rows/16 iterations per thread -- the strips of all layers together fill the chip);
 // then ceil(Ch/4) blocks of four channels (one wave per channel: its K rows, lanes over the columns).
 __global__ __launch_bounds__(256) void wmax_kernel(const WItem *items, int nitems, const int *off) {
     const int it = w_find(off, nitems, blockIdx.x);
     const WItem I = items[it];
     const int b = blockIdx.x - off[it];
-    const int cstrips = (I.F + 63) / 64;
+    const int cstrips = (I.F + 15) / 16;
     const int rows = I.Ch * I.K;
-    __shared__ float part[4][64];
+    __shared__ float part[16][17];
     if (b < cstrips) {
-        const int f = b * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+        const int fl = threadIdx.x & 15, rl = threadIdx.x >> 4, f = b * 16 + fl;
         float m = 0.f;
-        if (f < I.F)
-            for (int j = rl; j < rows; j += 4) m = fmaxf(m, fabsf(I.w[(long long)j * I.F + f]));
-        part[rl][threadIdx.x & 63] = m;
+        if (f < I.F) {
+#pragma unroll 8
+            for (int j = rl; j < rows; j += 16) m = fmaxf(m, fabsf(I.w[(long long)j * I.F + f]));
+        }
+        part[rl][fl] = m;
         __syncthreads();
         if (rl == 0 && f < I.F) {
-            m = fmaxf(fmaxf(part[0][threadIdx.x], part[1][threadIdx.x]), fmaxf(part[2][threadIdx.x], part[3][threadIdx.x]));
+#pragma unroll
+            for (int l = 1; l < 16; ++l) m = fmaxf(m, part[l][fl]);
             float s, inv;
             h2_scale_of(m, s, inv);
             for (int k = 0; k < I.K; ++k) I.fsi[(long long)k * I.F + f] = inv;
@@ -81,6 +85,7 @@ __global__ __launch_bounds__(256) void wmax_kernel(const WItem *items, int nitem
         if (c >= I.Ch) return;
         float m = 0.f;
         const float *p = I.w + (long long)c * I.K * I.F;                 // the K rows of channel c are contiguous: K * F floats
+#pragma unroll 4
         for (int j = lane; j < I.K * I.F; j += 64) m = fmaxf(m, fabsf(p[j]));
         if (I.pw) {                                                       // the partner's rows of the same channel
             const float *pp = I.pw + (long long)c * I.pairK * I.F;
@@ -178,7 +183,7 @@ extern "C" int cape_weight_pieces_blocks(const cape_wpiece_item_t *host_items, i
         if (I.pair_w && (I.pair_K < 1 || I.pair_K > 16)) return CAPE_EINVAL;
         const long long bwd = (long long)I.Ch * I.K * (I.F / 8);
         const int fwd = (I.Ch & 31) ? 0 : I.K * (I.Ch / 32) * ((I.F + 63) / 64);
-        max_off[i + 1] = max_off[i] + (I.F + 63) / 64 + (I.Ch + 3) / 4;
+        max_off[i + 1] = max_off[i] + (I.F + 15) / 16 + (I.Ch + 3) / 4;
         planes_off[i + 1] = planes_off[i] + fwd + (int)((bwd + 255) / 256);
     }
     return CAPE_OK;

@@ -335,7 +335,7 @@ def _log_launch(name, flops, byts, fn):
 
 
 _FWD_FAMILY = {0: "gconv_fwd_kernel", 1: "gemm_plain_kernel", 2: "gemm_split_kernel", 3: "gemm_h2_kernel"}
-_DW_FAMILY = {0: "gconv_dw_kernel", 1: "dw_plain_kernel", 2: "dw_packed_kernel", 3: "dw_split_kernel"}
+_DW_FAMILY = {0: "gconv_dw_kernel", 1: "dw_plain_kernel", 2: "dw_packed_kernel", 3: "dw_split_kernel", 4: "dw_h2_kernel"}
 
 
 def fwd_kernel_name(fam, bm, bn, layout, dual, bf16=False):
@@ -353,6 +353,8 @@ def fwd_kernel_name(fam, bm, bn, layout, dual, bf16=False):
 
 
 def dw_kernel_name(fam, ct, ft, bf16=False):
+    if fam == 4:
+        return "dw_h2_kernel<%d, %d>" % (ct, ft)
     if fam == 3 or fam == 0:
         return "%s<%d, %d, %s>" % (_DW_FAMILY[fam], ct, ft, "unsigned short" if bf16 else "float")
     waves = "4, 1" if (fam == 2 and ft == 32) else "2, 2"
@@ -364,6 +366,7 @@ def dw_kernel_name(fam, ct, ft, bf16=False):
 # --------------------------------------------------------------------------------------------
 # H2 = 0 keeps every contraction on the bf16 six-product kernels (the A/B reference of round 3)
 H2 = int(_os.environ.get("CAPE_H2", "1"))
+RM_TRACE = int(_os.environ.get("CAPE_RM_TRACE", "0"))      # debugging: print who needed a standalone row-bound pass
 
 
 def rm_width(F):
@@ -416,6 +419,9 @@ def rowmax(t):
     _lib.require_gpu()
     t = as_act(t)
     assert t.dtype == torch.float32
+    if RM_TRACE:
+        import traceback
+        print("standalone rowmax for", tuple(t.shape), "<-", " <- ".join("%s:%d" % (f.name, f.lineno) for f in traceback.extract_stack()[-6:-1]), flush=True)
     rm = torch.empty((t.shape[0], t.shape[1], 4), device=t.device, dtype=torch.float32)
     p, ss, ld = _v(t)
     _log_launch("rowmax_kernel", 0, 4 * t.shape[0] * t.shape[1] * (t.shape[2] + 4),
@@ -612,19 +618,42 @@ def gconv_dw(entries, dz, accumulate=False, dz2=None, defer=False):
                 mask |= 1 << i
     assert all(e["x"].dtype == dz.dtype for e in entries), "sources and gradient share one storage type"
     bf = dz.dtype == torch.bfloat16
+    # fp16 two-piece form (csrc/gemm_h2.h dw_h2_kernel): taken when every operand already carries its row bounds
+    h2 = None
+    if H2 and not bf:
+        rms = [rm_of(e["x"]) for e in entries] + [rm_of(dz)] + ([rm_of(dz2)] if dz2 is not None else [])
+        if all(r is not None for r in rms):
+            h2 = _lib.CapeH2Dw()
+            for i, r in enumerate(rms[:len(entries)]):
+                h2.src_rowmax[i], h2.src_rowmax_w[i] = r.data_ptr(), int(r.shape[2])
+            h2.dz_rowmax, h2.dz_rowmax_w = rms[len(entries)].data_ptr(), int(rms[len(entries)].shape[2])
+            if dz2 is not None:
+                h2.dz2_rowmax, h2.dz2_rowmax_w = rms[-1].data_ptr(), int(rms[-1].shape[2])
+            h2._keep = rms
+
+    def dw_plan(plan):
+        if h2 is not None:
+            check(lib.cape_gconv_dw_plan_h2(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, C.byref(h2), plan), "cape_gconv_dw_plan_h2")
+        else:
+            check(_fn("cape_gconv_dw_plan", dz)(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, plan), "cape_gconv_dw_plan")
+
+    def dw_stage(which):
+        if h2 is not None:
+            check(lib.cape_gconv_dw_stage_h2(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, 1 if accumulate else 0,
+                                             C.c_void_p(ws.data_ptr()), need, which, C.byref(h2), _stream()), "cape_gconv_dw_stage_h2")
+        else:
+            check(_fn("cape_gconv_dw_stage", dz)(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, 1 if accumulate else 0,
+                                                 C.c_void_p(ws.data_ptr()), need, which, _stream()), "cape_gconv_dw_stage")
 
     def launch():
-        rc = _fn("cape_gconv_dw", dz)(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, 1 if accumulate else 0,
-                                      C.c_void_p(ws.data_ptr()), need, _stream())
-        check(rc, "cape_gconv_dw")
+        dw_stage(0)
 
     if defer and DEFERRED is not None and LAUNCH_LOG is None:
         if PLAN_LOG is not None:
             plan = (C.c_int32 * 4)()
-            check(_fn("cape_gconv_dw_plan", dz)(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, plan), "cape_gconv_dw_plan")
+            dw_plan(plan)
             PLAN_LOG.add(("dw", plan[0], plan[1], plan[2]) + (("bf16",) if bf else ()))
-        check(_fn("cape_gconv_dw_stage", dz)(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, 1 if accumulate else 0,
-                                             C.c_void_p(ws.data_ptr()), need, 1, _stream()), "cape_gconv_dw_stage")
+        dw_stage(1)
         it = _lib.CapeDwItem()
         it.srcs, it.nsrc = C.addressof(arr), len(entries)
         it.dz, it.dz_sample_stride, it.lddz = p.value, ss, ld
@@ -637,7 +666,7 @@ def gconv_dw(entries, dz, accumulate=False, dz2=None, defer=False):
         launch()
     else:
         plan = (C.c_int32 * 4)()
-        check(_fn("cape_gconv_dw_plan", dz)(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, plan), "cape_gconv_dw_plan")
+        dw_plan(plan)
         fam, ct, ft, nslab = list(plan)
         if PLAN_LOG is not None:
             PLAN_LOG.add(("dw", fam, ct, ft) + (("bf16",) if bf else ()))
@@ -646,13 +675,9 @@ def gconv_dw(entries, dz, accumulate=False, dz2=None, defer=False):
             return
         flops, byts = _dw_work(entries, N, Mo, F, bool(mask))
         sumCF = sum(int(e.get("C", e["x"].shape[2])) for e in entries) * F
-
-        def stage(which):
-            check(_fn("cape_gconv_dw_stage", dz)(arr, len(entries), p, ss, ld, p2, mask, N, Mo, F, 1 if accumulate else 0,
-                                                 C.c_void_p(ws.data_ptr()), need, which, _stream()), "cape_gconv_dw_stage")
         # the contraction kernel and its fixed-order slab reduction, each with its own bracket
-        _log_launch(dw_kernel_name(fam, ct, ft, bf), flops, byts, lambda: stage(1))
-        _log_launch("dw_reduce", 0, 4 * sumCF * (nslab + 1), lambda: stage(2))
+        _log_launch(dw_kernel_name(fam, ct, ft, bf), flops, byts, lambda: dw_stage(1))
+        _log_launch("dw_reduce", 0, 4 * sumCF * (nslab + 1), lambda: dw_stage(2))
 
 
 def spmm(x, csr, y=None, alpha=1.0, z=None, beta=0.0):
@@ -944,8 +969,14 @@ def bwd_prep(g, y=None, act="none", mask=None, want_bias=False, rowscale=None, R
         yp, ys, yl = _v(y)
     else:
         yp, ys, yl = None, 0, 0
-    rm = _new_rm(dz) if _want_rm(dz) else None
-    set_rm(dz, rm)
+    # |dz| <= |g| element by element (|act'| <= 1, or the 0 / 1 mask): the bound of g's rows bounds dz's -- no reduction needed
+    # when g carries one (the data-gradient contraction / summed operator application that produced it wrote it)
+    rm, rm_g = None, rm_of(g)
+    if rm_g is not None:
+        set_rm(dz, rm_g)
+    elif _want_rm(dz):
+        rm = _new_rm(dz)
+        set_rm(dz, rm)
 
     def launch():
         rc = _fn("cape_bwd_prep", g)(gp, gs, gl, yp, ys, yl, _lib.ACT[act] if mask is None else 0, _ptr(mask), zp, zs, zl,
@@ -1159,6 +1190,8 @@ class ChebConvFn(torch.autograd.Function):
         Co = 0 if cond_out is None else cond_out.shape[1]
         if Co:
             fill_cond(cond_out.contiguous(), yfull[:, :, Fout:])
+        else:
+            set_rm(yfull, rm_of(y))         # (y is a view of yfull: the bounds spmm_combine wrote belong to the returned object too)
         ctx.ops, ctx.act, ctx.bias_mode, ctx.Fout, ctx.Co, ctx.Cc = ops, act, bias_mode, Fout, Co, Cc
         ctx.has_bias, ctx.twopass, ctx.xshape = bias is not None, True, (N, Mi, Ch)
         ctx.gW, ctx.gWa, ctx.gB, ctx.banked = gW, gWa, gB, banked

@@ -264,6 +264,25 @@ int cape_gconv_dw_stage(const cape_src_t *srcs, int32_t nsrc, const float *dz,
                         int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
                         int64_t workspace_bytes, int32_t stage, void *stream);
 
+/* The weight gradient with fp16 two-piece operands (see cape_h2_t): row bounds of every source and of dz / dz2; launches that
+ * would take dw_split_kernel (plan family 3) then run dw_h2_kernel (family 4) on the same tiles, splits and slabs -- the
+ * reduction stage and cape_gconv_dw_reduce_batch are unchanged.  h2 == NULL: identical to cape_gconv_dw_stage / _plan. */
+typedef struct cape_h2_dw {
+    const float *src_rowmax[CAPE_MAX_SRC];
+    int32_t src_rowmax_w[CAPE_MAX_SRC];
+    const float *dz_rowmax;
+    int32_t dz_rowmax_w;
+    const float *dz2_rowmax;
+    int32_t dz2_rowmax_w;
+} cape_h2_dw_t;
+int cape_gconv_dw_stage_h2(const cape_src_t *srcs, int32_t nsrc, const float *dz,
+                           int64_t dz_sample_stride, int32_t lddz, const float *dz2, uint32_t dz2_mask,
+                           int32_t N, int32_t Mo, int32_t F, int32_t accumulate, void *workspace,
+                           int64_t workspace_bytes, int32_t stage, const cape_h2_dw_t *h2, void *stream);
+int cape_gconv_dw_plan_h2(const cape_src_t *srcs, int32_t nsrc, const float *dz, int64_t dz_sample_stride, int32_t lddz,
+                          const float *dz2, uint32_t dz2_mask, int32_t N, int32_t Mo, int32_t F, const cape_h2_dw_t *h2,
+                          int32_t plan[4]);
+
 /* The reductions (stage 2) of up to CAPE_MAX_DW_REDUCE_ITEMS earlier stage-1 calls in ONE launch: each item repeats the
  * arguments of its cape_gconv_dw_stage(..., stage = 1, ...) call (bf16 != 0: it was the _bf16 entry); the workspaces must
  * still hold the partial slabs.  The training step defers every layer's reduction to the end of the backward pass. */

@@ -254,8 +254,8 @@ def test_batch16_parity_covers_every_bench_kernel(mesh_ops):
     assert not missing, "kernels launched by the benchmarked step without a parity case: %s" % _plan_names(missing)
     # the instantiations the headline rests on: the fp16 two-piece contraction in all three tile forms (family 3: 128 x 128,
     # 64 x 64, the DUAL 128 x 64 of the affine blocks; one weight layout -- the piece planes are contraction-contiguous),
-    # the 128 x 128 weight-gradient kernel
-    for need in (("fwd", 3, 128, 128, 1, 0), ("fwd", 3, 64, 64, 1, 0), ("fwd", 3, 128, 64, 1, 1), ("dw", 3, 128, 128)):
+    # the 128 x 128 weight-gradient kernel on the same arithmetic (family 4: dw_h2_kernel)
+    for need in (("fwd", 3, 128, 128, 1, 0), ("fwd", 3, 64, 64, 1, 0), ("fwd", 3, 128, 64, 1, 1), ("dw", 4, 128, 128)):
         assert need in bench_plans, (need, sorted(bench_plans))
     print("kernel instantiations of the benchmarked step, all covered at batch 16:", _plan_names(bench_plans))
 
