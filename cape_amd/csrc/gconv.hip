@@ -822,7 +822,9 @@ inline FwdPlan plan_fwd(const GconvParams &p, const cape_src_t *srcs, bool dual,
     if (pl.layout >= 0 && h2_eligible(p, dual)) {
         pl.family = 3;
         pl.layout = 1;                                  // the piece planes are contraction-contiguous in every launch form
-        h2_tile(dual, p.N, p.Mo, p.F, pl.BM, pl.BN);
+        int ktot = 0;
+        for (int i = 0; i < p.nsrc; ++i) ktot += p.s[i].C;
+        h2_tile(dual, p.N, p.Mo, p.F, ktot, pl.BM, pl.BN);
         return pl;
     }
     if (pl.layout >= 0) {
@@ -929,7 +931,7 @@ int gconv_fwd_impl(const cape_src_t *srcs, int32_t nsrc, float *y, int64_t y_sam
     dim3 grid((unsigned)(N * p.row_tiles * p.col_tiles));
     hipStream_t st = (hipStream_t)stream;
     if (pl.family == 3) {
-        h2_launch(p, dual, pl.BM, grid, st);
+        h2_launch(p, dual, pl.BM, pl.BN, grid, st);
     } else if (pl.family == 2) {
         gs_launch(p, dual, pl.BM, pl.layout, bf16, grid, st);
     } else if (pl.family == 1) {

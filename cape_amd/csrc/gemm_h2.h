@@ -22,6 +22,8 @@
 // fine ones (profiles/r04_ubench_h2_pf2.txt); the loads alone (448 MB through L2 for the widest layer) take 39 us of its
 // 57 -- the 128 x 128 tile's L2 traffic, not the matrix pipe, is the next bound.
 #pragma once
+#include <stdio.h>
+#include <stdlib.h>
 #include <type_traits>
 
 #include "gconv_shared.h"
@@ -105,29 +107,10 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GconvParams p) {
     int total = 0;
     for (int si = 0; si < p.nsrc; ++si) total += p.s[si].C / H2_KC;
 
-    // ---- row scales: common to all sources (they add into one accumulator): bound = max over sources and column blocks
     int rc[PA];
     float sa[PA];
 #pragma unroll
-    for (int i = 0; i < PA; ++i) {
-        rc[i] = min(r0 + r + 64 * i, p.Mo - 1);
-        float m = 0.f;
-        for (int si = 0; si < p.nsrc; ++si) {
-            const SrcDev &S = p.s[si];
-            const float4 *rp = reinterpret_cast<const float4 *>(S.rm + ((long long)n * p.Mo + rc[i]) * S.rmw);
-            for (int j = q; j < (S.rmw >> 2); j += 4) {
-                const float4 v = rp[j];
-                m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
-            }
-        }
-        // the four lanes of a row (q = 0..3) hold different column blocks: quad all-reduce
-        m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF, 0xF, false)));   // quad_perm [1,0,3,2]
-        m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x4E, 0xF, 0xF, false)));   // quad_perm [2,3,0,1]
-        float inv;
-        h2_scale_of(m, sa[i], inv);
-        if (q == 0) inv_row[r + 64 * i] = inv;
-    }
-
+    for (int i = 0; i < PA; ++i) rc[i] = min(r0 + r + 64 * i, p.Mo - 1);
     // ---- DMA lanes: piece j of this wave covers 16 rows x 64 B of one plane; lane -> row drow, LDS slot lane & 3,
     //      source segment (lane & 3) ^ ((row >> 2) & 3)
     const int drow = lane >> 2, dseg = (lane & 3) ^ ((drow >> 2) & 3);
@@ -282,6 +265,27 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GconvParams p) {
     dma(0);
     load_a(ra);
     if (total > 1) load_a(rb);
+    // ---- row scales: common to all sources (they add into one accumulator): bound = max over sources and column blocks.
+    //      Read AFTER the first chunks' loads are in flight: one memory round trip less in front of the first split.
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        float m = 0.f;
+        for (int si = 0; si < p.nsrc; ++si) {
+            const SrcDev &S = p.s[si];
+            const float4 *rp = reinterpret_cast<const float4 *>(S.rm + ((long long)n * p.Mo + rc[i]) * S.rmw);
+            for (int j = q; j < (S.rmw >> 2); j += 4) {
+                const float4 v = rp[j];
+                m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            }
+        }
+        // the four lanes of a row (q = 0..3) hold different column blocks: quad all-reduce
+        m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF, 0xF, false)));   // quad_perm [1,0,3,2]
+        m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x4E, 0xF, 0xF, false)));   // quad_perm [2,3,0,1]
+        float inv;
+        h2_scale_of(m, sa[i], inv);
+        if (q == 0) inv_row[r + 64 * i] = inv;
+    }
+
     store_a(0, ra);
     if (total > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PA) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -531,6 +535,12 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? 2 : 3) void dw_h2_ker
 inline bool h2_eligible(const GconvParams &p, bool dual) {
     static const int on = getenv("CAPE_GEMM_H2") ? atoi(getenv("CAPE_GEMM_H2")) : 1;      // 0: A/B against the six-product bf16 form
     if (!on || p.F < 64 || !p.wsi || (dual && !p.wsi2)) return false;
+    // short contractions (one to four chunks) are latency-bound launches in which this kernel's longer prologue (row bounds,
+    // DMA set-up, two LDS stages -> four instead of five workgroups per CU) costs more than the halved matrix work returns:
+    // 0.70-0.85x of the six-product form at 64 / 128 contraction indices with 64 output columns (profiles/r04_h2_bench_*.txt)
+    int ktot = 0;
+    for (int i = 0; i < p.nsrc; ++i) ktot += p.s[i].C;
+    if (!(ktot >= 256 || (ktot >= 128 && p.F >= 128))) return false;
     for (int i = 0; i < p.nsrc; ++i) {
         const SrcDev &S = p.s[i];
         if (S.rp || !S.wh || !S.wl || !S.rm || S.rmw < 4 || (S.rmw & 3)) return false;
@@ -546,10 +556,19 @@ inline bool h2_eligible(const GconvParams &p, bool dual) {
     return true;
 }
 
-inline void h2_tile(bool dual, int N, int Mo, int F, int &BM, int &BN) {
+inline void h2_tile(bool dual, int N, int Mo, int F, int Ktot, int &BM, int &BN) {
     if (dual) { BM = 128; BN = 64; return; }
+    // CAPE_H2_TILE=BMxBN (experiments, tools/ubench/h2_bench.cpp): force one of the four single-accumulator tiles
+    static const char *force = getenv("CAPE_H2_TILE");
+    if (force && sscanf(force, "%dx%d", &BM, &BN) == 2 && (BM == 64 || BM == 128) && (BN == 64 || BN == 128)) {
+        if (BN == 128 && F < 128) BN = 64;
+        return;
+    }
+    // measured over the model's shapes (tools/ubench/h2_bench.cpp, profiles/r04_h2_bench_tiles.txt): the 128 x 128 tile wins
+    // only where the contraction is long (its fewer L2 re-reads matter) and still gives every CU its two workgroups; short
+    // contractions are latency-bound launches of one or two rounds of tiles and want as many workgroups in flight as fit
     const long long big = (long long)N * ((Mo + 127) / 128) * ((F + 127) / 128);
-    if (F >= 128 && big >= 384) { BM = 128; BN = 128; }
+    if (F >= 128 && big >= 384 && Ktot >= 512) { BM = 128; BN = 128; }
     else { BM = 64; BN = 64; }
 }
 
@@ -569,9 +588,11 @@ inline void h2_dw_launch(const DwParams &p, int ct, int ft, dim3 grid, hipStream
     else CAPE_LAUNCH((dw_h2_kernel<128, 128>), grid, dim3(256), 0, st, p);
 }
 
-inline void h2_launch(const GconvParams &p, bool dual, int BM, dim3 grid, hipStream_t st) {
+inline void h2_launch(const GconvParams &p, bool dual, int BM, int BN, dim3 grid, hipStream_t st) {
     if (dual) CAPE_LAUNCH((gemm_h2_kernel<128, 64, true>), grid, dim3(256), 0, st, p);
-    else if (BM == 128) CAPE_LAUNCH((gemm_h2_kernel<128, 128, false>), grid, dim3(256), 0, st, p);
+    else if (BM == 128 && BN == 128) CAPE_LAUNCH((gemm_h2_kernel<128, 128, false>), grid, dim3(256), 0, st, p);
+    else if (BM == 128) CAPE_LAUNCH((gemm_h2_kernel<128, 64, false>), grid, dim3(256), 0, st, p);
+    else if (BN == 128) CAPE_LAUNCH((gemm_h2_kernel<64, 128, false>), grid, dim3(256), 0, st, p);
     else CAPE_LAUNCH((gemm_h2_kernel<64, 64, false>), grid, dim3(256), 0, st, p);
 }
 
