@@ -9,8 +9,9 @@
 // cape_weight_pieces: SrcDev::wh / wl, contraction index contiguous for every launch form, so there is one kernel for the
 // forward and the data-gradient layout).  Measured against float64 the result is as accurate as the bf16 six-product form and
 // an fp32 FMA chain (tools/ubench/gemm_h2.hip, profiles/r04_ubench_h2*.txt: rms 3.6e-7 of the row rms at K = 1024 on rows
-// spanning 23 binades; fp32 chain 5.5e-7).  Range: fp16 keeps 22 bits for elements down to 2^-18 of the row bound and
-// degrades gracefully below (absolute error <= 2^-40 of the bound); a zero / denormal row bound is clamped.
+// spanning 23 binades; fp32 chain 5.5e-7).  Range: fp16 keeps 22 bits for elements down to 2^-16 of the row bound and
+// degrades gracefully below (absolute error <= 2^-38 of the bound; tests/test_h2_numerics.py); a zero / denormal row
+// bound is clamped.
 //
 // Structure (tools/ubench/gemm_h2.hip, AMODE 2): workgroup tile BM x BN, 4 waves as 2 x 2, k32 chunks, two LDS stages, ONE
 // barrier per chunk.  Weight pieces come in by LDS-DMA one chunk ahead (no registers, no VALU, no ds_write; L2-resident);
