@@ -47,7 +47,8 @@ class CapeGnParamItem(C.Structure):
 
 class CapeBwdPrepItem(C.Structure):
     _fields_ = [("workspace", C.c_void_p), ("N", C.c_int32), ("Mo", C.c_int32), ("F", C.c_int32), ("R", C.c_int32),
-                ("dbias", C.c_void_p), ("dcoef", C.c_void_p), ("dcoef_g", C.c_void_p), ("dcoef_sample_stride", C.c_int64)]
+                ("dbias", C.c_void_p), ("dcoef", C.c_void_p), ("dcoef_g", C.c_void_p), ("dcoef_sample_stride", C.c_int64),
+                ("chunks", C.c_int32)]
 
 
 class CapeDwItem(C.Structure):
@@ -132,6 +133,8 @@ SIGNATURES = {
     "cape_spmm": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _i32, _i32, _f32, _p, _i64, _i32, _f32, _p, _i64, _i32,
                             _i32, _i32, _i32, _p, _p]),
     "cape_spmm_multi": (C.c_int, [C.POINTER(CapeSpmmTerm), _i32, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p, _p]),
+    "cape_spmm_multi_actgrad_chunks": (_i32, [_p, _i64, _i32, _p, _i64, _i32, _i32, _i32]),
+    "cape_spmm_multi_actgrad": (C.c_int, [C.POINTER(CapeSpmmTerm), _i32, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _i64, _i32, _i32, _p, _p]),
     "cape_spmm_combine": (C.c_int, [C.POINTER(CapeSpmmTerm), _i32, C.c_uint32, C.POINTER(CapeRank), _p, _i32, _i32, _i32, _p, _p,
                                     _i64, _i32, _i32, _i32, _i32, _p, _p]),
     "cape_bias_act_fwd": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p]),

@@ -211,15 +211,28 @@ struct SpmmTerms {
     int n;
 };
 
+// Sum mode with the activation gradient of the layer BELOW fused in (encoder chain, reference lib/models.py:154-171 cnp): the
+// summed application is that layer's incoming gradient g; its own backward would next read g and its output x = act(z) once
+// more to form dz = g * act'(x) and the channel-bias gradient sum_{n,r} dz (cape_bwd_prep: three tensor passes, one launch).
+// Here the epilogue multiplies by act'(x) before the store and leaves the bias sums of the block's rows as partials in the
+// layout cape_bwd_prep_finalize reads ([sample][block][2][C], term 0), so that layer needs no backward-prep launch at all.
+struct SpmmActGrad {
+    const void *ax; long long axs; int ldax;     // x = act(z) of the layer below: same rows / channels as the output; null = off
+    int act;
+    float *part;
+};
+
 template <int VW, typename T = float, int U = 0>
-__global__ __launch_bounds__(256) void spmm_multi_kernel(SpmmTerms P, int sum, ViewT<T> y, int N, int Mo, int C, float *rm) {
+__global__ __launch_bounds__(256) void spmm_multi_kernel(SpmmTerms P, int sum, ViewT<T> y, int N, int Mo, int C, float *rm, SpmmActGrad G) {
     const int cq = (C + VW - 1) / VW;
     int n, t;
     cape_map_block(blockIdx.x, N, spmm_bps(Mo, cq), n, t);      // see spmm_kernel
     const int i = t * 256 + (int)threadIdx.x;
-    if (i >= Mo * cq) return;
-    const int r = i / cq;
-    const int c = (i - r * cq) * VW;
+    const bool live = i < Mo * cq;
+    if (!live && !G.ax) return;                             // (the fused form keeps whole blocks alive for its barrier)
+    const int ii = live ? i : Mo * cq - 1;
+    const int r = ii / cq;
+    const int c = (ii - r * cq) * VW;
     float tot[VW];
 #pragma unroll
     for (int u = 0; u < VW; ++u) tot[u] = 0.f;
@@ -245,14 +258,35 @@ __global__ __launch_bounds__(256) void spmm_multi_kernel(SpmmTerms P, int sum, V
             }
         }
     }
-    if (sum) {
-        cape_stv<VW>(y.p + (long long)n * y.ss + (long long)r * y.ld + c, tot);
-        if (rm) {
-            float m = 0.f;
+    if (!sum) return;
+    if (G.ax) {
+        float xv[VW];
+        cape_ldv<VW>(reinterpret_cast<const T *>(G.ax) + (long long)n * G.axs + (long long)r * G.ldax + c, xv);
 #pragma unroll
-            for (int u = 0; u < VW; ++u) m = fmaxf(m, fabsf(tot[u]));
-            m = cape_group_max(m, cq);
-            if (c == 0) cape_store_rowmax(rm, (long long)n * Mo + r, m);
+        for (int u = 0; u < VW; ++u) tot[u] = live ? tot[u] * cape_act_grad_from_out(xv[u], G.act) : 0.f;
+    }
+    if (live) cape_stv<VW>(y.p + (long long)n * y.ss + (long long)r * y.ld + c, tot);
+    if (rm) {
+        float m = 0.f;
+#pragma unroll
+        for (int u = 0; u < VW; ++u) m = fmaxf(m, fabsf(tot[u]));
+        m = cape_group_max(m, cq);
+        if (live && c == 0) cape_store_rowmax(rm, (long long)n * Mo + r, m);
+    }
+    if (G.ax) {
+        // column sums over the block's 256 / cq rows, fixed order: thread q < cq adds the rows' values of its column group
+        __shared__ float cs[256 * (VW > 1 ? VW : 1)];
+#pragma unroll
+        for (int u = 0; u < VW; ++u) cs[u * 256 + threadIdx.x] = tot[u];
+        __syncthreads();
+        if ((int)threadIdx.x < cq) {
+            float s[VW];
+#pragma unroll
+            for (int u = 0; u < VW; ++u) s[u] = 0.f;
+            for (int j = (int)threadIdx.x; j < 256; j += cq)
+#pragma unroll
+                for (int u = 0; u < VW; ++u) s[u] += cs[u * 256 + j];
+            cape_stv<VW>(G.part + (((long long)n * spmm_bps(Mo, cq) + t) * 2) * C + (int)threadIdx.x * VW, s);
         }
     }
 }
@@ -965,7 +999,7 @@ extern "C" int cape_spmm_bf16(const void *x, int64_t x_sample_stride, int32_t ld
 namespace {
 template <typename T>
 int spmm_multi_impl(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, T *y, int64_t y_sample_stride,
-                    int32_t ldy, int32_t N, int32_t Mo, int32_t C, float *rowmax_out, void *stream) {
+                    int32_t ldy, int32_t N, int32_t Mo, int32_t C, float *rowmax_out, void *stream, const SpmmActGrad *ag = nullptr) {
     if (!terms || nterms < 1 || nterms > CAPE_MAX_SPMM_TERMS || N < 1 || Mo < 1 || C < 1) return CAPE_EINVAL;
     if (rowmax_out && (!sum || sizeof(T) != 4)) return CAPE_EINVAL;
     if (sum && (!y || ldy < C)) return CAPE_EINVAL;
@@ -996,13 +1030,21 @@ int spmm_multi_impl(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, 
     wide = wide && vec;
     ViewT<T> yv{y, y_sample_stride, ldy};
     hipStream_t st = (hipStream_t)stream;
+    SpmmActGrad G;
+    G.ax = nullptr; G.axs = 0; G.ldax = 0; G.act = 0; G.part = nullptr;
+    if (ag) {
+        // the fused activation gradient: sum mode, vector form, the lanes of a row one aligned power-of-two group
+        wide = wide && aligned8(ag->ax, ag->axs, ag->ldax, C, es);
+        if (!sum || !vec || !aligned4(ag->ax, ag->axs, ag->ldax, C, es) || !rm_fused(C / (wide ? 8 : 4)) || !ag->part) return CAPE_EINVAL;
+        G = *ag;
+    }
     const bool fused = vec && rm_fused(C / (wide ? 8 : 4));
     if (!fused)
         for (int k = 0; k < nterms; ++k) P.t[k].rm = nullptr;
     if (vec) CAPE_LAUNCH_SP(spmm_multi_kernel, T, wide, false, dim3((unsigned)(N * spmm_bps(Mo, C / (wide ? 8 : 4)))), dim3(256), 0, st, P, sum, yv, N, Mo, C,
-                            fused ? rowmax_out : (float *)nullptr);
+                            fused ? rowmax_out : (float *)nullptr, G);
     else if (any_ell) return CAPE_EINVAL;                      // the scalar fallback reads CSR only
-    else CAPE_LAUNCH((spmm_multi_kernel<1, T, 0>), dim3((unsigned)(N * spmm_bps(Mo, C))), dim3(256), 0, st, P, sum, yv, N, Mo, C, (float *)nullptr);
+    else CAPE_LAUNCH((spmm_multi_kernel<1, T, 0>), dim3((unsigned)(N * spmm_bps(Mo, C))), dim3(256), 0, st, P, sum, yv, N, Mo, C, (float *)nullptr, G);
     CAPE_LAUNCH_CHECK();
     if (!fused) {
         if (rowmax_out) {
@@ -1028,6 +1070,31 @@ extern "C" int cape_spmm_multi(const cape_spmm_term_t *terms, int32_t nterms, in
 extern "C" int cape_spmm_multi_bf16(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, void *y, int64_t y_sample_stride,
                                     int32_t ldy, int32_t N, int32_t Mo, int32_t C, float *rowmax_out, void *stream) {
     return spmm_multi_impl<cape_bf16>(terms, nterms, sum, (cape_bf16 *)y, y_sample_stride, ldy, N, Mo, C, rowmax_out, stream);
+}
+
+// blocks per sample (= partial-sum chunks of the fused form) for a launch of C channels in the vector form it will take
+static int actgrad_cq(const void *y, int64_t ys, int32_t ldy, const void *ax, int64_t axs, int32_t ldax, int32_t C) {
+    const bool wide = spmm_wide() && aligned8(y, ys, ldy, C, 4) && aligned8(ax, axs, ldax, C, 4);
+    return C / (wide ? 8 : 4);
+}
+
+extern "C" int32_t cape_spmm_multi_actgrad_chunks(const float *y, int64_t y_sample_stride, int32_t ldy, const float *act_x,
+                                                  int64_t act_x_sample_stride, int32_t ld_act_x, int32_t Mo, int32_t C) {
+    if (!y || !act_x || Mo < 1 || C < 4 || (C & 3)) return CAPE_EINVAL;
+    return spmm_bps(Mo, actgrad_cq(y, y_sample_stride, ldy, act_x, act_x_sample_stride, ld_act_x, C));
+}
+
+extern "C" int cape_spmm_multi_actgrad(const cape_spmm_term_t *terms, int32_t nterms, float *y, int64_t y_sample_stride, int32_t ldy,
+                                       int32_t N, int32_t Mo, int32_t C, float *rowmax_out, const float *act_x,
+                                       int64_t act_x_sample_stride, int32_t ld_act_x, int32_t act, float *bias_partials, void *stream) {
+    if (!act_x || !bias_partials || ld_act_x < C || (act != CAPE_ACT_LEAKY && act != CAPE_ACT_RELU)) return CAPE_EINVAL;
+    // every term must allow the 8-wide form exactly when y and act_x do (the chunk count above assumes it)
+    SpmmActGrad G;
+    G.ax = act_x; G.axs = act_x_sample_stride; G.ldax = ld_act_x; G.act = act; G.part = bias_partials;
+    const int cq = actgrad_cq(y, y_sample_stride, ldy, act_x, act_x_sample_stride, ld_act_x, C);
+    for (int k = 0; k < nterms && terms; ++k)
+        if (cq == C / 8 && !aligned8(terms[k].x, terms[k].x_sample_stride, terms[k].ldx, C, 4)) return CAPE_EINVAL;
+    return spmm_multi_impl<float>(terms, nterms, 1, y, y_sample_stride, ldy, N, Mo, C, rowmax_out, stream, &G);
 }
 
 namespace {
@@ -1327,7 +1394,7 @@ extern "C" int cape_bwd_prep_finalize(const cape_bwd_prep_item_t *items, int32_t
         if (!t.workspace || t.N < 1 || t.Mo < 1 || t.F < 1 || t.R < 0 || t.R > RSR_MAXR || (t.R > 0 && !t.dcoef)) return CAPE_EINVAL;
         const int RB = bp_rows(t.N, t.Mo);
         B.it[i].part = (const float *)t.workspace;
-        B.it[i].chunks = (t.Mo + RB - 1) / RB;
+        B.it[i].chunks = t.chunks > 0 ? t.chunks : (t.Mo + RB - 1) / RB;
         B.it[i].N = t.N; B.it[i].F = t.F; B.it[i].R = t.R;
         B.it[i].dbias = t.dbias; B.it[i].dcoef = t.dcoef; B.it[i].dcoef_g = t.dcoef_g;
         B.it[i].cs = t.dcoef_sample_stride ? (long long)t.dcoef_sample_stride : (long long)t.R * t.F;

@@ -609,14 +609,17 @@ class CAPE(base_model):
         if x.dtype != self.act_dtype:
             x = x.to(self.act_dtype)                                   # bf16 storage: the mesh tensors from here on
         with self.variable_scope('encoder'):
-            for i in range(len(self.out_channels)):
-                if use_res_block:
-                    x = self.res_block(x, i, 'encoder_resblock{}'.format(i + 1))
-                else:
-                    x = self.cnp(x, i, 'encoder_conv{}'.format(i + 1), cond_in=cond_in if i == 0 else None)
-            if self.reduce_dim > 0:
-                with self.variable_scope('1x1-conv'):
-                    x = self.filter(x, self.Laplacian[-1], self.out_channels[-1] // self.reduce_rate, K=1)
+            # the plain stack hands each layer's output to exactly one consumer (the next layer): its backward pass may fuse
+            # the activation gradient of the layer below into the kernel that produces that layer's incoming gradient
+            with ops.sole_consumer_chain(not use_res_block):
+                for i in range(len(self.out_channels)):
+                    if use_res_block:
+                        x = self.res_block(x, i, 'encoder_resblock{}'.format(i + 1))
+                    else:
+                        x = self.cnp(x, i, 'encoder_conv{}'.format(i + 1), cond_in=cond_in if i == 0 else None)
+                if self.reduce_dim > 0:
+                    with self.variable_scope('1x1-conv'):
+                        x = self.filter(x, self.Laplacian[-1], self.out_channels[-1] // self.reduce_rate, K=1)
             if getattr(self, 'split_backward', False) and torch.is_grad_enabled() and x.requires_grad:
                 # two-phase backward (data-parallel overlap, see backward_phase1/2): the graph is cut here, below the
                 # dense layers -- everything downstream of the cut is differentiated first

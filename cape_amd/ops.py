@@ -362,6 +362,31 @@ def dw_kernel_name(fam, ct, ft, bf16=False):
 
 
 # --------------------------------------------------------------------------------------------
+# sole-consumer chains: inside ``with sole_consumer_chain():`` every ChebConvFn may assume that its INPUT tensor has no other
+# consumer (the model's plain encoder stack, reference lib/models.py:541-545: x = cnp(x) in a loop).  Its backward then hands
+# the layer below dz = dx * act'(x) instead of dx (the derivative of that layer's own fused bias + (leaky-)ReLU epilogue, taken
+# from the sign of x) together with the bias-gradient partial sums, all from the epilogue of the summed operator application
+# that produces dx (csrc/elementwise.hip spmm_multi_kernel, SpmmActGrad) -- and that layer skips its backward-prep launch.
+# FUSE_ACT_GRAD = 0 keeps the op-by-op form (the A/B reference).
+# --------------------------------------------------------------------------------------------
+FUSE_ACT_GRAD = int(_os.environ.get("CAPE_FUSE_ACT_GRAD", "1"))
+_CHAIN = [False]
+
+
+class sole_consumer_chain(object):
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev, _CHAIN[0] = _CHAIN[0], self.on
+        return self
+
+    def __exit__(self, *exc):
+        _CHAIN[0] = self.prev
+        return False
+
+
+# --------------------------------------------------------------------------------------------
 # fp16 two-piece contractions (csrc/gemm_h2.h): row bounds of activation tensors and piece planes of the weights
 # --------------------------------------------------------------------------------------------
 # H2 = 0 keeps every contraction on the bf16 six-product kernels (the A/B reference of round 3)
@@ -398,6 +423,12 @@ def rm_of(t):
     if rm is None or rm.shape[0] != t.shape[0] or rm.shape[1] != t.shape[1] or rm.device != t.device:
         return None
     return rm
+
+
+def h2_shape_ok(ktot, F):
+    """Mirror of csrc/gemm_h2.h h2_eligible's size rule: short contractions stay on the six-product kernel, so their operands
+    need no row bounds."""
+    return F >= 64 and (ktot >= 256 or (ktot >= 128 and F >= 128))
 
 
 def _want_rm(t, Cn=None):
@@ -710,10 +741,11 @@ def spmm(x, csr, y=None, alpha=1.0, z=None, beta=0.0):
     return set_rm(y, rm)
 
 
-def spmm_multi(xs, csrs, sum=False, scales=None):
+def spmm_multi(xs, csrs, sum=False, scales=None, act_x=None, act=None):
     """Several operator applications in one launch: ``sum=False`` -> [s_k S_k x_k for k]; ``sum=True`` -> sum_k s_k S_k x_k
     (``scales`` default 1).  ``csrs[k]`` None or an identity DeviceCSR = identity term.  All operators have the same
-    number of rows."""
+    number of rows.  ``act_x`` (sum mode, fp32): the fused activation-gradient form (cape_spmm_multi_actgrad): returns
+    (y * act'(act_x), bias partials, chunks) or None when the arguments do not allow it."""
     _lib.require_gpu()
     n = len(xs)
     assert 1 <= n <= 4 and len(csrs) == n
@@ -759,9 +791,30 @@ def spmm_multi(xs, csrs, sum=False, scales=None):
     for k in range(n):
         flops += 2 * N * (Mo if ident[k] else csrs[k].nnz) * Cn
         byts += es * N * Cn * xs[k].shape[1] + (0 if ident[k] else _csr_bytes(csrs[k]))
+    if act_x is not None:
+        assert sum and y.dtype == torch.float32 and act in ("leaky", "relu") and act_x.shape == y.shape
+        ap, as_, al = _v(act_x)
+        chunks = int(lib.cape_spmm_multi_actgrad_chunks(yp, ys, yl, ap, as_, al, Mo, Cn))
+        part = torch.empty((N, chunks, 2, Cn), device=y.device, dtype=torch.float32)
+        _log_launch("spmm_multi_kernel", flops, byts + es * N * Mo * Cn,
+                    lambda: check(lib.cape_spmm_multi_actgrad(arr, n, yp, ys, yl, N, Mo, Cn, _ptr(rm), ap, as_, al, _lib.ACT[act],
+                                                              _ptr(part), _stream()), "cape_spmm_multi_actgrad"))
+        return y, part, chunks
     _log_launch("spmm_multi_kernel", flops, byts,
                 lambda: check(_fn("cape_spmm_multi", xs[0])(arr, n, 1 if sum else 0, yp, ys, yl, N, Mo, Cn, _ptr(rm), _stream()), "cape_spmm_multi"))
     return y if sum else outs
+
+
+def actgrad_fusable(xs, act_x, Cn):
+    """The fused activation-gradient form of spmm_multi needs the 8-wide vector kernel with the lanes of a row forming one
+    power-of-two group of at most 64: 64..512 channels in powers of two, every operand 32-byte aligned (fresh outputs are)."""
+    if not (FUSE_ACT_GRAD and H2 is not None and Cn in (64, 128, 256, 512)) or _os.environ.get("CAPE_SPMM_WIDE", "1") == "0":
+        return False
+    for t in list(xs) + [act_x]:
+        p, ss, ld = _v(t)
+        if t.dtype != torch.float32 or (p.value % 32) or (ss % 8) or (ld % 8):
+            return False
+    return True
 
 
 def spmm_combine(xs, csrs, y, to_acc2=0, rank=None, bias=None, bias_mode=_lib.BIAS_NONE, act="none", dual=False, mask=None):
@@ -923,6 +976,12 @@ def flush_deferred():
     if not DEFERRED:
         return
     items, DEFERRED[:] = list(DEFERRED), []
+    _finalize_bwd_prep(items)
+
+
+def _finalize_bwd_prep(items):
+    """The final reductions of queued backward-prep partials (cape_bwd_prep_finalize, up to 16 layers per launch); ``chunks``:
+    partials written by another producer (spmm_multi's fused activation-gradient form)."""
     for i0 in range(0, len(items), 16):
         chunk = items[i0:i0 + 16]
         arr = (_lib.CapeBwdPrepItem * len(chunk))()
@@ -933,6 +992,7 @@ def flush_deferred():
             a.dcoef = None if it["dcoef"] is None else it["dcoef"].data_ptr()
             a.dcoef_g = None if it["dcoef_g"] is None else it["dcoef_g"].data_ptr()
             a.dcoef_sample_stride = it["cstride"]
+            a.chunks = int(it.get("chunks", 0))
         check(lib.cape_bwd_prep_finalize(arr, len(chunk), _stream()), "cape_bwd_prep_finalize")
 
 
@@ -1072,7 +1132,7 @@ class ChebConvFn(torch.autograd.Function):
                 for k, xk in zip(ks, spmm_multi([x] * len(ks), [ops.fwd[k] for k in ks])):
                     xs[k] = xk
         P, Pa = ChebConvFn._pieces(x, W, W_aff, Ch, K, Fout, twopass)
-        fw_ok = P is not None and Ch % 32 == 0 and Fout >= 64            # (the forward planes exist for whole 32-channel chunks)
+        fw_ok = P is not None and Ch % 32 == 0 and h2_shape_ok(Ch * K, Fout)      # (forward planes: whole 32-channel chunks)
         entries = []
         for k in range(K):
             e = dict(x=xs[k], csr=None if twopass else ops.fwd[k], w=(W, k * Fout, K * Fout, 1))
@@ -1118,12 +1178,19 @@ class ChebConvFn(torch.autograd.Function):
         ctx.has_bias, ctx.twopass, ctx.xshape = bias is not None, twopass, (N, Mi, Ch)
         ctx.gW, ctx.gWa, ctx.gB, ctx.banked = gW, gWa, gB, banked
         ctx.pieces = (P, Pa)
+        # sole-consumer chain (see sole_consumer_chain): x is the output of a layer whose bias + (leaky-)ReLU epilogue this
+        # layer's backward may differentiate for it; our own output is tagged the same way for the layer above
+        ctx.prev_act = getattr(x, "_cape_act_out", None) if (_CHAIN[0] and FUSE_ACT_GRAD and twopass) else None
+        ctx.offers_dz = bool(W_aff is None and Co == 0 and Cc == 0 and bias is not None and bias_mode == _lib.BIAS_CHANNEL
+                             and act in ("leaky", "relu") and y.dtype == torch.float32 and gB is not None)
+        if ctx.offers_dz:
+            yfull._cape_act_out = (act, gB)
         # up-sampling layers (Mo > Mi): the data gradient needs T_k = S_k^T dz at the Mi input rows anyway, and
         # dW_k = X_k^T dz = x^T T_k -- the weight gradient contracts over the COARSE rows (half the flops) and the
         # fine-level X_k need not be kept for the backward pass at all
         ctx.coarse_dw = bool(twopass and ops.Mo > Mi and ctx.needs_input_grad[0] and not any(ops.fwd[k].identity for k in range(K)))
         ctx.save_for_backward(W, W_aff, mask, yfull if (act != "none" and W_aff is None) else None, cond_in,
-                              *([x] if ctx.coarse_dw else xs))
+                              *(([x] if ctx.coarse_dw else list(xs)) + ([x] if ctx.prev_act is not None else [])))
         return yfull
 
     @staticmethod
@@ -1147,7 +1214,7 @@ class ChebConvFn(torch.autograd.Function):
         N, Mi, Ch = x.shape
         K, Fout = ops.K, W.shape[1]
         P, Pa = ChebConvFn._pieces(x, W, W_aff, Ch, K, Fout, True)
-        fwd_ok = P is not None and Ch % 32 == 0
+        fwd_ok = P is not None and Ch % 32 == 0 and h2_shape_ok(Ch, Fout)          # (K * Fout and Fout output columns)
         rmx = rowmax(x) if fwd_ok else None
         Z = alloc_act(N, Mi, K * Fout, x.device, dtype=x.dtype)
         if fwd_ok:
@@ -1204,6 +1271,9 @@ class ChebConvFn(torch.autograd.Function):
     def backward(ctx, gfull):
         W, W_aff, mask, ysaved, cond_in = ctx.saved_tensors[:5]
         xs = ctx.saved_tensors[5:]
+        act_x = None
+        if getattr(ctx, "prev_act", None) is not None:
+            xs, act_x = xs[:-1], xs[-1]                 # (the layer input itself: the output of the layer below)
         ops, act, Fout, Co, Cc = ctx.ops, ctx.act, ctx.Fout, ctx.Co, ctx.Cc
         K, twopass = ops.K, ctx.twopass
         N, Mi, Ch = ctx.xshape
@@ -1219,8 +1289,14 @@ class ChebConvFn(torch.autograd.Function):
         # condition-term gradients
         chan_bias = need_b and ctx.has_bias and ctx.bias_mode != _lib.BIAS_VERTEX
         plain = (W_aff is None and act == "none" and not chan_bias and not Cc)
+        tag = getattr(gfull, "_cape_is_dz", None)
+        if tag is not None and not getattr(ctx, "offers_dz", False):
+            raise RuntimeError("a pre-activated gradient reached a layer that did not offer it (sole_consumer_chain misuse)")
         if plain:
             dz, dbv, dcoef, dca = g, None, None, None
+        elif tag is not None:
+            # the layer above already multiplied by act'(y) and left the bias sums with the deferred reductions (or in ``dbias``)
+            dz, dbv, dcoef, dca = g, (tag["dbias"] if tag["dbias"] is not None else ctx.gB), None, None
         else:
             dz, dbv, dcoef, dca = bwd_prep(g, y=None if ysaved is None else ysaved[:, :, :Fout], act=act, mask=mask,
                                            want_bias=chan_bias, rowscale=ops.rowscale if Cc else None,
@@ -1289,7 +1365,10 @@ class ChebConvFn(torch.autograd.Function):
                 contract_first = (Mo < Mi) or (Mo == Mi and Ch < Fout)
                 # fp16 two-piece operands of the data gradient: contraction over the Fout columns (backward planes)
                 P, Pa = ctx.pieces
-                bw_ok = P is not None and Fout % 32 == 0 and Ch >= 64 and dz.dtype == torch.float32
+                # contraction length of the shortest launch of the branch taken: one order per launch (contract_first) or all
+                # orders (+ the affine term) as sources of one launch
+                ktot_bw = Fout if contract_first else Fout * (K + (1 if W_aff is not None else 0))
+                bw_ok = P is not None and Fout % 32 == 0 and Ch >= 64 and dz.dtype == torch.float32 and h2_shape_ok(ktot_bw, Ch)
 
                 def src(xk, k, aff=False):
                     e = dict(x=xk, csr=None, w=waT if aff else wT(k))
@@ -1307,7 +1386,23 @@ class ChebConvFn(torch.autograd.Function):
                                   Gall, deinterleave=K, F=K * Ch, wsi=_ptr(P.bsi))
                     else:
                         gconv_fwd([dict(x=dz, csr=None, w=(W, 0, 1, Fout))], Gall, deinterleave=K, F=K * Ch)
-                    dx = spmm_multi([Gall[:, :, k * ChP:k * ChP + Ch] for k in range(K)], [ops.bwd[k] for k in range(K)], sum=True)
+                    Gs = [Gall[:, :, k * ChP:k * ChP + Ch] for k in range(K)]
+                    fused = None
+                    if act_x is not None and actgrad_fusable(Gs, act_x, Ch) and tuple(act_x.shape) == (N, Mi, Ch):
+                        fused = spmm_multi(Gs, [ops.bwd[k] for k in range(K)], sum=True, act_x=act_x, act=ctx.prev_act[0])
+                    if fused is not None:
+                        dx, part, chunks = fused
+                        gB_prev = ctx.prev_act[1]
+                        item = dict(ws=part, N=N, Mo=Mi, F=Ch, R=0, dbias=gB_prev.view(Ch), dcoef=None, dcoef_g=None, cstride=0, chunks=chunks)
+                        if DEFERRED is not None:
+                            DEFERRED.append(item)
+                            dx._cape_is_dz = dict(dbias=None)
+                        else:
+                            db = torch.empty(Ch, device=dev, dtype=torch.float32)
+                            _finalize_bwd_prep([dict(item, dbias=db)])
+                            dx._cape_is_dz = dict(dbias=db)
+                    else:
+                        dx = spmm_multi(Gs, [ops.bwd[k] for k in range(K)], sum=True)
                 elif contract_first:
                     # G_k = dz W_k^T at the Mo output rows, then dx = sum_k S_k^T G_k
                     first = True

@@ -340,6 +340,8 @@ typedef struct cape_bwd_prep_item {
     float *dcoef;
     float *dcoef_g;
     int64_t dcoef_sample_stride;
+    int32_t chunks;            /* 0: the partial layout of cape_bwd_prep itself; > 0: partials of another producer with this many
+                                * chunks per sample (cape_spmm_multi_actgrad)                                                  */
 } cape_bwd_prep_item_t;
 int cape_bwd_prep_finalize(const cape_bwd_prep_item_t *items, int32_t nitems, void *stream);
 
@@ -384,6 +386,22 @@ typedef struct cape_spmm_term {
 } cape_spmm_term_t;
 int cape_spmm_multi(const cape_spmm_term_t *terms, int32_t nterms, int32_t sum, float *y, int64_t y_sample_stride,
                     int32_t ldy, int32_t N, int32_t Mo, int32_t C, float *rowmax_out, void *stream);
+
+/*
+ * cape_spmm_multi in sum mode with the activation gradient of the layer BELOW fused in (fp32, vector form): the summed operator
+ * application is that layer's incoming gradient g (reference cnp chain, lib/models.py:154-171: conv -> bias + (leaky-)ReLU ->
+ * pool, differentiated by tf.gradients :460); act_x [N, Mo, >= C] is that layer's OUTPUT.  Writes
+ *     y[n,r,c] = (sum_k scale_k S_k x_k)[n,r,c] * act'(act_x[n,r,c])            (= dz of the layer below)
+ * and the bias-gradient partial sums of y over the rows of every block: bias_partials [N, chunks, 2, C] floats (term 0) in the
+ * layout cape_bwd_prep_finalize reads with cape_bwd_prep_item_t.chunks = cape_spmm_multi_actgrad_chunks(...), R = 0.
+ * That layer then needs no cape_bwd_prep launch.  act in {CAPE_ACT_LEAKY, CAPE_ACT_RELU}.
+ */
+int32_t cape_spmm_multi_actgrad_chunks(const float *y, int64_t y_sample_stride, int32_t ldy, const float *act_x,
+                                       int64_t act_x_sample_stride, int32_t ld_act_x, int32_t Mo, int32_t C);
+int cape_spmm_multi_actgrad(const cape_spmm_term_t *terms, int32_t nterms, float *y, int64_t y_sample_stride, int32_t ldy,
+                            int32_t N, int32_t Mo, int32_t C, float *rowmax_out, const float *act_x,
+                            int64_t act_x_sample_stride, int32_t ld_act_x, int32_t act, float *bias_partials, void *stream);
+
 
 /*
  * Operators applied AFTER the dense contraction, with the layer epilogue -- for up-sampling layers, where

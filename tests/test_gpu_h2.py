@@ -283,3 +283,46 @@ def test_dw_h2(case):
     for e, w in zip(ent, want):
         got = e["w"][0].cpu().numpy().astype(np.float64)
         assert np.abs(got - w).max() / np.abs(w).max() < 2e-6
+
+
+def test_fused_activation_gradient_chain_equals_op_by_op(mesh_ops):
+    """sole_consumer_chain: the layer above differentiates the bias + leaky-ReLU epilogue of the layer below inside the summed
+    operator application that produces its incoming gradient (cape_spmm_multi_actgrad).  Same gradients as the op-by-op form for
+    every input, weight and bias; the two lower layers run no backward-prep launch."""
+    from cape_amd import ops
+    from cape_amd.graph import ConvOperators
+    dev = torch.device(DEV)
+    L, D = mesh_ops["L"], mesh_ops["D"]
+    rng = np.random.default_rng(11)
+    N = 3
+    # 1723 vertices: conv (64 -> 64), conv + row-selection pool to 862 (64 -> 128), conv on 862 (128 -> 128)
+    specs = [(L[4], None, 64, 64), (L[5], D[5], 64, 128), (L[6], None, 128, 128)]
+    dops = [ops.DeviceConvOps(ConvOperators(Lm, 2, pool=Dm), dev) for Lm, Dm, _, _ in specs]
+    x0 = torch.tensor(rng.standard_normal((N, 1723, 64)), dtype=torch.float32, device=dev)
+    Ws = [torch.tensor(rng.standard_normal((2 * ci, co)) * 0.1, dtype=torch.float32, device=dev) for _, _, ci, co in specs]
+    bs = [torch.tensor(rng.standard_normal((1, 1, co)) * 0.1, dtype=torch.float32, device=dev) for _, _, _, co in specs]
+    gy = torch.tensor(rng.standard_normal((N, 862, 128)), dtype=torch.float32, device=dev)
+
+    def run(chain):
+        x = x0.clone().requires_grad_(True)
+        W = [w.clone().requires_grad_(True) for w in Ws]
+        b = [t.clone().requires_grad_(True) for t in bs]
+        gB = [torch.zeros_like(t) for t in bs]                  # the bias-gradient "bucket" views the fused form writes into
+        ops.LAUNCH_LOG = []
+        try:
+            with ops.sole_consumer_chain(chain):
+                h = x
+                for k in range(3):
+                    h = ops.chebyshev5(h, W[k], dops[k], bias=b[k], activation="b1leakyrelu", bias_grad_buf=gB[k])
+            grads = torch.autograd.grad(h, [x] + W + b, grad_outputs=gy)
+            names = [e[0] for e in ops.LAUNCH_LOG]
+        finally:
+            ops.LAUNCH_LOG = None
+        torch.cuda.synchronize()
+        return [g.cpu().numpy().astype(np.float64) for g in grads], names
+
+    ref, names_ref = run(False)
+    got, names = run(True)
+    assert names_ref.count("bwd_prep") == 3 and names.count("bwd_prep") == 1, (names_ref.count("bwd_prep"), names.count("bwd_prep"))
+    for a, b_ in zip(got, ref):
+        assert np.abs(a - b_).max() <= 2e-6 * np.abs(b_).max()
