@@ -78,7 +78,8 @@ class CapeWpieceItem(C.Structure):
     _fields_ = [("w", C.c_void_p), ("Ch", C.c_int32), ("K", C.c_int32), ("F", C.c_int32), ("pair_K", C.c_int32),
                 ("pair_w", C.c_void_p),
                 ("f_hi", C.c_void_p), ("f_lo", C.c_void_p), ("b_hi", C.c_void_p), ("b_lo", C.c_void_p),
-                ("fscale_inv", C.c_void_p), ("bscale_inv", C.c_void_p), ("bscale_c_inv", C.c_void_p)]
+                ("fscale_inv", C.c_void_p), ("bscale_inv", C.c_void_p), ("bscale_c_inv", C.c_void_p),
+                ("fpair_w", C.c_void_p), ("fpair_rows", C.c_int32), ("reserved", C.c_int32)]
 
 
 class CapeRank(C.Structure):

@@ -274,19 +274,29 @@ __global__ __launch_bounds__(256) void spmm_multi_kernel(SpmmTerms P, int sum, V
         if (live && c == 0) cape_store_rowmax(rm, (long long)n * Mo + r, m);
     }
     if (G.ax) {
-        // column sums over the block's 256 / cq rows, fixed order: thread q < cq adds the rows' values of its column group
-        __shared__ float cs[256 * (VW > 1 ? VW : 1)];
+        // column sums over the block's 256 / cq rows (cq a power of two <= 64): inside each wave over the lanes that hold the
+        // same column group (strides cq .. 32: one DPP row rotation, the 16- and 32-lane swaps -- no LDS traffic), then the four
+        // waves through LDS in a fixed order.  (A first version let cq threads add 256 / cq LDS rows each: +10 us per launch.)
+        __shared__ float cs[4][64 * (VW > 1 ? VW : 1)];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-        for (int u = 0; u < VW; ++u) cs[u * 256 + threadIdx.x] = tot[u];
+        for (int u = 0; u < VW; ++u) {
+            float v = tot[u];
+            if (cq <= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));   // row_ror:8
+            if (cq <= 16) v = cape_sum_xor16(v);
+            if (cq <= 32) v = cape_sum_xor32(v);
+            tot[u] = v;
+        }
+        if (lane < cq)
+#pragma unroll
+            for (int u = 0; u < VW; ++u) cs[wave][lane * VW + u] = tot[u];
         __syncthreads();
         if ((int)threadIdx.x < cq) {
-            float s[VW];
+            float s4[VW];
 #pragma unroll
-            for (int u = 0; u < VW; ++u) s[u] = 0.f;
-            for (int j = (int)threadIdx.x; j < 256; j += cq)
-#pragma unroll
-                for (int u = 0; u < VW; ++u) s[u] += cs[u * 256 + j];
-            cape_stv<VW>(G.part + (((long long)n * spmm_bps(Mo, cq) + t) * 2) * C + (int)threadIdx.x * VW, s);
+            for (int u = 0; u < VW; ++u)
+                s4[u] = ((cs[0][threadIdx.x * VW + u] + cs[1][threadIdx.x * VW + u]) + cs[2][threadIdx.x * VW + u]) + cs[3][threadIdx.x * VW + u];
+            cape_stv<VW>(G.part + (((long long)n * spmm_bps(Mo, cq) + t) * 2) * C + (int)threadIdx.x * VW, s4);
         }
     }
 }

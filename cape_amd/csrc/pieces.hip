@@ -45,6 +45,8 @@ struct WItem {                      // device-resident copy of cape_wpiece_item_
     const float *pw;
     unsigned short *f_hi, *f_lo, *b_hi, *b_lo;
     float *fsi, *bsi, *bsc;
+    const float *fpw;
+    int fprows, reserved;
 };
 
 // block -> (item, local block) through the prefix table off[nitems + 1].  The table is first copied to LDS by the whole block: a
@@ -80,6 +82,8 @@ __global__ __launch_bounds__(256) void wmax_kernel(const WItem *items, int nitem
         if (f < I.F) {
 #pragma unroll 8
             for (int j = rl; j < rows; j += 16) m = fmaxf(m, fabsf(I.w[(long long)j * I.F + f]));
+            if (I.fpw)                                                    // the partner's column of the same output
+                for (int j = rl; j < I.fprows; j += 16) m = fmaxf(m, fabsf(I.fpw[(long long)j * I.F + f]));
         }
         part[rl][fl] = m;
         __syncthreads();
@@ -192,6 +196,7 @@ extern "C" int cape_weight_pieces_blocks(const cape_wpiece_item_t *host_items, i
         if (!I.w || I.Ch < 8 || (I.Ch & 7) || I.K < 1 || I.K > 16 || I.F < 8 || (I.F & 7)) return CAPE_EINVAL;
         if (!I.f_hi || !I.f_lo || !I.b_hi || !I.b_lo || !I.fscale_inv || !I.bscale_inv || !I.bscale_c_inv) return CAPE_EINVAL;
         if (I.pair_w && (I.pair_K < 1 || I.pair_K > 16)) return CAPE_EINVAL;
+        if (I.fpair_w && I.fpair_rows < 1) return CAPE_EINVAL;
         const long long bwd = (long long)I.Ch * I.K * (I.F / 8);
         const int fwd = (I.Ch & 31) ? 0 : I.K * (I.Ch / 32) * ((I.F + 63) / 64);
         max_off[i + 1] = max_off[i] + (I.F + 15) / 16 + (I.Ch + 3) / 4;

@@ -103,6 +103,7 @@ class base_model(object):
         self._grad_views = {}      # TF variable name -> view of the flat gradient bucket (train phase)
         self._grad_views_d = {}    # the same for the discriminator variables, used while D runs as a single merged pass
         self._conv_meta = {}       # conv weight name -> (feature channels, K, Fout), recorded while tracing
+        self._conv_fpairs = {}     # graph_linear_2 <-> graph_linear_input of a GraphCMR block (they share a forward accumulator)
         self._conv_pairs = {}      # graph_conv weight <-> affine weight of a res_block_affine (they share a data-gradient accumulator)
         self._piece_plan = None    # ops.PiecePlan over every conv weight that qualifies (fp16 two-piece contractions)
         self._pieces_dirty = True  # the planes do not reflect the current weights
@@ -213,7 +214,11 @@ class base_model(object):
             pn = self._conv_pairs.get(name)
             if pn is not None and pn in self._conv_meta and pn in self._vars:
                 pair = (self._vars[pn].detach(), self._conv_meta[pn][1])
-            specs.append(dict(W=W.detach(), Ch=Ch, K=K, pair=pair))
+            fpair = None
+            fn = self._conv_fpairs.get(name)
+            if fn is not None and fn in self._conv_meta and fn in self._vars:
+                fpair = (self._vars[fn].detach(), self._conv_meta[fn][0] * self._conv_meta[fn][1])
+            specs.append(dict(W=W.detach(), Ch=Ch, K=K, pair=pair, fpair=fpair))
         self._piece_plan_key = tuple(sorted(self._conv_meta.items()))
         self._piece_plan = ops.PiecePlan(specs, self.device) if specs else None
 
@@ -561,6 +566,8 @@ class CAPE(base_model):
             if fuse_tail:
                 W2, gW2 = self._plain_weight('graph_linear_2', [int(x.shape[-1]), Fi])
                 Wi, gWi = self._plain_weight('graph_linear_input', [int(xu.shape[-1]), Fi])
+                n2, ni = '/'.join(self._scope + ['graph_linear_2', 'weights']), '/'.join(self._scope + ['graph_linear_input', 'weights'])
+                self._conv_fpairs[n2], self._conv_fpairs[ni] = ni, n2      # their products share one accumulator
                 return ops.ResidualLinearFn.apply(x, xu, W2, Wi, cond, gW2, gWi)
             with self.variable_scope('graph_linear_2'):
                 x = self.filter(x, Lm, Fi, 1)

@@ -464,7 +464,7 @@ def rowmax(t):
 class WeightPieces(object):
     """Piece planes of one Chebyshev-layer weight W[Ch*K (+ condition rows), F] (views of a PiecePlan's arena):
     forward planes [K][F][Ch], backward planes [Ch*K][F], reciprocal scales (include/cape_hip.h cape_wpiece_item_t)."""
-    __slots__ = ("W", "Ch", "K", "F", "pair", "f_hi", "f_lo", "b_hi", "b_lo", "fsi", "bsi", "bsc")
+    __slots__ = ("W", "Ch", "K", "F", "pair", "fpair", "f_hi", "f_lo", "b_hi", "b_lo", "fsi", "bsi", "bsc")
 
     def fwd(self, k):
         """(hi pointer, lo pointer, pitch) of forward source k (contraction over the Ch feature channels)."""
@@ -479,7 +479,8 @@ class WeightPieces(object):
 
 class PiecePlan(object):
     """All piece planes of a set of weights in two launches (cape_weight_pieces).  ``specs``: dicts W (tensor), Ch, K and
-    optionally pair = (W2, K2): a second weight whose data-gradient term adds into the same accumulator."""
+    optionally pair = (W2, K2): a second weight whose data-gradient term adds into the same accumulator; fpair = (W2, rows): a
+    second weight whose FORWARD product adds into the same accumulator."""
 
     def __init__(self, specs, device):
         self.items, sizes = [], []
@@ -502,12 +503,13 @@ class PiecePlan(object):
         arr = (_lib.CapeWpieceItem * len(specs))()
         for a, sp, (Ch, K, F) in zip(arr, specs, sizes):
             wp = WeightPieces()
-            wp.W, wp.Ch, wp.K, wp.F, wp.pair = sp["W"], Ch, K, F, sp.get("pair")
+            wp.W, wp.Ch, wp.K, wp.F, wp.pair, wp.fpair = sp["W"], Ch, K, F, sp.get("pair"), sp.get("fpair")
             wp.f_hi, wp.f_lo = take(2 * Ch * K * F, torch.int16), take(2 * Ch * K * F, torch.int16)
             wp.b_hi, wp.b_lo = take(2 * Ch * K * F, torch.int16), take(2 * Ch * K * F, torch.int16)
             wp.fsi, wp.bsi, wp.bsc = take(4 * K * F, torch.float32), take(4 * Ch * K, torch.float32), take(4 * Ch, torch.float32)
             a.w, a.Ch, a.K, a.F = sp["W"].data_ptr(), Ch, K, F
             a.pair_w, a.pair_K = (wp.pair[0].data_ptr(), int(wp.pair[1])) if wp.pair is not None else (None, 0)
+            a.fpair_w, a.fpair_rows = (wp.fpair[0].data_ptr(), int(wp.fpair[1])) if wp.fpair is not None else (None, 0)
             a.f_hi, a.f_lo, a.b_hi, a.b_lo = wp.f_hi.data_ptr(), wp.f_lo.data_ptr(), wp.b_hi.data_ptr(), wp.b_lo.data_ptr()
             a.fscale_inv, a.bscale_inv, a.bscale_c_inv = wp.fsi.data_ptr(), wp.bsi.data_ptr(), wp.bsc.data_ptr()
             self.items.append(wp)
@@ -534,15 +536,15 @@ class PiecePlan(object):
 PIECES = {}
 
 
-def pieces_for(W, Ch, K, pair=None):
+def pieces_for(W, Ch, K, pair=None, fpair=None):
     """Piece planes of W for ``Ch`` feature channels at order K, or None when the layer does not qualify."""
     if not H2 or not W.is_cuda or W.dtype != torch.float32 or Ch % 8 or W.shape[1] % 8 or not W.is_contiguous():
         return None
+    ptr = lambda pr: pr[0].data_ptr() if pr is not None else None
     wp = PIECES.get(W.data_ptr())
-    if wp is not None and (wp.Ch, wp.K, wp.F) == (Ch, K, int(W.shape[1])) and \
-            (wp.pair[0].data_ptr() if wp.pair is not None else None) == (pair[0].data_ptr() if pair is not None else None):
+    if wp is not None and (wp.Ch, wp.K, wp.F) == (Ch, K, int(W.shape[1])) and ptr(wp.pair) == ptr(pair) and ptr(wp.fpair) == ptr(fpair):
         return wp
-    return PiecePlan([dict(W=W.detach(), Ch=Ch, K=K, pair=pair)], W.device).run()[0]
+    return PiecePlan([dict(W=W.detach(), Ch=Ch, K=K, pair=pair, fpair=fpair)], W.device).run()[0]
 
 
 def _h2_arg(entries, N, wsi=None, wsi2=None, rm_out=None):
@@ -1312,6 +1314,8 @@ class ChebConvFn(torch.autograd.Function):
                 colsum(dz, dB, per_vertex=True)
             else:
                 dB = dbv.view(1, 1, Fout)
+        if H2 and twopass and dz.dtype == torch.float32 and rm_of(dz) is None and Fout % 32 == 0 and Fout >= 64 and (need_w or need_x):
+            rowmax(dz)      # (a gradient without bounds, e.g. from a group norm: one pass now serves the weight AND the data gradient)
         csr_of = (lambda k: None) if twopass else (lambda k: ops.fwd[k])
         if need_w:
             dW = _grad_buffer(W, ctx.gW)
@@ -1362,7 +1366,8 @@ class ChebConvFn(torch.autograd.Function):
                 # pipelined plain GEMM stages either weight layout at the same speed, so no transposed copy)
                 wT = lambda k: (W, k * Fout, 1, K * Fout)
                 waT = (W_aff, 0, 1, Fout) if W_aff is not None else None
-                contract_first = (Mo < Mi) or (Mo == Mi and Ch < Fout)
+                # (a tie goes to the form whose summed operator application can carry the activation gradient of the layer below)
+                contract_first = (Mo < Mi) or (Mo == Mi and (Ch < Fout or (Ch == Fout and act_x is not None and W_aff is None and K > 1)))
                 # fp16 two-piece operands of the data gradient: contraction over the Fout columns (backward planes)
                 P, Pa = ctx.pieces
                 # contraction length of the shortest launch of the branch taken: one order per launch (contract_first) or all
@@ -1633,10 +1638,23 @@ class ResidualLinearFn(torch.autograd.Function):
         assert W.shape == (Cx, F) and Wr.shape == (Cr, F) and W.is_contiguous() and Wr.is_contiguous() and r.shape[:2] == (N, M)
         Cc = 0 if cond is None else cond.shape[1]
         yfull = alloc_act(N, M, F + Cc, x.device, dtype=x.dtype)
-        gconv_fwd([dict(x=x, csr=None, w=(W, 0, F, 1)), dict(x=r, csr=None, w=(Wr, 0, F, 1))], yfull[:, :, :F])
+        e = [dict(x=x, csr=None, w=(W, 0, F, 1)), dict(x=r, csr=None, w=(Wr, 0, F, 1))]
+        # fp16 two-piece operands: the two products add into one accumulator, so the two weights share their column scales
+        P = Pr = None
+        if H2 and x.dtype == torch.float32 and Cx % 32 == 0 and Cr % 32 == 0 and F % 8 == 0 and h2_shape_ok(Cx + Cr, F):
+            P = pieces_for(W, Cx, 1, fpair=(Wr.detach(), Cr))
+            Pr = pieces_for(Wr, Cr, 1, fpair=(W.detach(), Cx)) if P is not None else None
+        kw = {}
+        if Pr is not None:
+            e[0]["p"], e[0]["rm"], e[1]["p"], e[1]["rm"] = P.fwd(0), rowmax(x), Pr.fwd(0), rowmax(r)
+            kw = dict(wsi=_ptr(P.fsi))
+        rm_y = alloc_rm(yfull, F) if (H2 and x.dtype == torch.float32) else None
+        gconv_fwd(e, yfull[:, :, :F], rm_out=rm_y, **kw)
         if Cc:
             fill_cond(cond.contiguous(), yfull[:, :, F:])
-        ctx.F, ctx.Cc, ctx.gW, ctx.gWr = F, Cc, gW, gWr
+        elif rm_y is not None:
+            set_rm(yfull, rm_y)
+        ctx.F, ctx.Cc, ctx.gW, ctx.gWr, ctx.pieces = F, Cc, gW, gWr, (P, Pr)
         ctx.save_for_backward(x, r, W, Wr)
         return yfull
 
@@ -1646,11 +1664,16 @@ class ResidualLinearFn(torch.autograd.Function):
         F = ctx.F
         gfull = _row_aligned(as_act(gfull))
         g = gfull[:, :, :F]
+        set_rm(g, rm_of(gfull))
         N, M, Cx = x.shape
         Cr = r.shape[2]
         need_x, need_r, need_w, need_wr, need_c = (ctx.needs_input_grad[i] for i in range(5))
         if NO_WEIGHT_GRAD and W.data_ptr() in NO_WEIGHT_GRAD:
             need_w = need_wr = False
+        P, Pr = ctx.pieces
+        bw = Pr is not None and F % 32 == 0 and g.dtype == torch.float32
+        if (bw or H2) and g.dtype == torch.float32 and F % 32 == 0 and F >= 64:
+            rowmax(g)                                   # one pass serves both data-gradient contractions and the weight gradient
         dx = dr = dW = dWr = dc = None
         ent = []
         if need_w:
@@ -1664,10 +1687,16 @@ class ResidualLinearFn(torch.autograd.Function):
             gconv_dw(ent, g, defer=in_bucket(dW, ctx.gW) and in_bucket(dWr, ctx.gWr))
         if need_x:
             dx = alloc_act(N, M, Cx, x.device, dtype=g.dtype)
-            gconv_fwd([dict(x=g, csr=None, w=(W, 0, 1, F))], dx)              # W^T read in place (contraction index contiguous)
+            if bw and Cx >= 64 and h2_shape_ok(F, Cx):
+                gconv_fwd([dict(x=g, csr=None, w=(W, 0, 1, F), p=P.bwd(0), rm=rowmax(g))], dx, wsi=_ptr(P.bsc))
+            else:
+                gconv_fwd([dict(x=g, csr=None, w=(W, 0, 1, F))], dx)          # W^T read in place (contraction index contiguous)
         if need_r:
             dr = alloc_act(N, M, Cr, x.device, dtype=g.dtype)
-            gconv_fwd([dict(x=g, csr=None, w=(Wr, 0, 1, F))], dr)
+            if bw and Cr >= 64 and h2_shape_ok(F, Cr):
+                gconv_fwd([dict(x=g, csr=None, w=(Wr, 0, 1, F), p=Pr.bwd(0), rm=rowmax(g))], dr, wsi=_ptr(Pr.bsc))
+            else:
+                gconv_fwd([dict(x=g, csr=None, w=(Wr, 0, 1, F))], dr)
         if ctx.Cc and need_c:
             dc = reduce_cond(gfull[:, :, F:])
         return dx, dr, dW, dWr, dc, None, None

@@ -218,6 +218,10 @@ typedef struct cape_wpiece_item {
     uint16_t *f_hi, *f_lo, *b_hi, *b_lo;
     float *fscale_inv, *bscale_inv;
     float *bscale_c_inv;           /* [Ch]: 1 / sb[c] once per channel (the multi-source data-gradient form's column index) */
+    const float *fpair_w;          /* NULL, or a second weight tensor [fpair_rows, F] whose FORWARD product adds into the same
+                                    * accumulator (the two-source tail of res_block_decoder, lib/models.py:763-774): the forward
+                                    * scale of column f then covers the columns of both tensors                             */
+    int32_t fpair_rows, reserved;
 } cape_wpiece_item_t;
 int cape_weight_pieces_blocks(const cape_wpiece_item_t *host_items, int32_t nitems, int32_t *max_off, int32_t *planes_off);
 int cape_weight_pieces(const cape_wpiece_item_t *dev_items, int32_t nitems, const int32_t *dev_max_off, int32_t max_blocks,

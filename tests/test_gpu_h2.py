@@ -288,7 +288,8 @@ def test_dw_h2(case):
 def test_fused_activation_gradient_chain_equals_op_by_op(mesh_ops):
     """sole_consumer_chain: the layer above differentiates the bias + leaky-ReLU epilogue of the layer below inside the summed
     operator application that produces its incoming gradient (cape_spmm_multi_actgrad).  Same gradients as the op-by-op form for
-    every input, weight and bias; the two lower layers run no backward-prep launch."""
+    every input, weight and bias; the two lower layers run no backward-prep launch (the top layer's own epilogue gradient is
+    taken by its backward-prep as before)."""
     from cape_amd import ops
     from cape_amd.graph import ConvOperators
     dev = torch.device(DEV)
