@@ -268,23 +268,31 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GconvParams p) {
     if (total > 1) load_a(rb);
     // ---- row scales: common to all sources (they add into one accumulator): bound = max over sources and column blocks.
     //      Read AFTER the first chunks' loads are in flight: one memory round trip less in front of the first split.
+    {
+        // (all loads first -- predicated over the CAPE_MAX_SRC slots -- then the maxima: inside a source loop hipcc waits
+        // for every load before issuing the next, one L2 round trip per source and row)
+        float4 bv[PA][CAPE_MAX_SRC];
 #pragma unroll
-    for (int i = 0; i < PA; ++i) {
-        float m = 0.f;
-        for (int si = 0; si < p.nsrc; ++si) {
-            const SrcDev &S = p.s[si];
-            const float4 *rp = reinterpret_cast<const float4 *>(S.rm + ((long long)n * p.Mo + rc[i]) * S.rmw);
-            for (int j = q; j < (S.rmw >> 2); j += 4) {
-                const float4 v = rp[j];
-                m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+        for (int i = 0; i < PA; ++i)
+#pragma unroll
+            for (int si = 0; si < CAPE_MAX_SRC; ++si) {
+                bv[i][si] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (si < p.nsrc && 4 * q < p.s[si].rmw)
+                    bv[i][si] = *reinterpret_cast<const float4 *>(p.s[si].rm + ((long long)n * p.Mo + rc[i]) * p.s[si].rmw + 4 * q);
             }
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            float m = 0.f;
+#pragma unroll
+            for (int si = 0; si < CAPE_MAX_SRC; ++si)
+                m = fmaxf(m, fmaxf(fmaxf(bv[i][si].x, bv[i][si].y), fmaxf(bv[i][si].z, bv[i][si].w)));
+            // the four lanes of a row (q = 0..3) hold different column blocks: quad all-reduce
+            m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF, 0xF, false)));   // quad_perm [1,0,3,2]
+            m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x4E, 0xF, 0xF, false)));   // quad_perm [2,3,0,1]
+            float inv;
+            h2_scale_of(m, sa[i], inv);
+            if (q == 0) inv_row[r + 64 * i] = inv;
         }
-        // the four lanes of a row (q = 0..3) hold different column blocks: quad all-reduce
-        m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF, 0xF, false)));   // quad_perm [1,0,3,2]
-        m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x4E, 0xF, 0xF, false)));   // quad_perm [2,3,0,1]
-        float inv;
-        h2_scale_of(m, sa[i], inv);
-        if (q == 0) inv_row[r + 64 * i] = inv;
     }
 
     store_a(0, ra);
@@ -392,8 +400,13 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? 2 : 3) void dw_h2_ker
         for (int n = n_begin; n < n_end; ++n) {
             const float *px = S.rm + ((long long)n * p.Mo + ra) * S.rmw;
             const float *pz = rmz + ((long long)n * p.Mo + ra) * wz;
-            for (int i = tid; i < (rb - ra) * S.rmw; i += 256) mx = fmaxf(mx, px[i]);
-            for (int i = tid; i < (rb - ra) * wz; i += 256) mz = fmaxf(mz, pz[i]);
+            // (row widths are multiples of 4 and the arrays 16-byte aligned: float4 loads, four in flight per thread)
+            const float4 *px4 = reinterpret_cast<const float4 *>(px), *pz4 = reinterpret_cast<const float4 *>(pz);
+            const int nx = (rb - ra) * (S.rmw >> 2), nz = (rb - ra) * (wz >> 2);
+#pragma unroll 4
+            for (int i = tid; i < nx; i += 256) { const float4 v = px4[i]; mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w))); }
+#pragma unroll 4
+            for (int i = tid; i < nz; i += 256) { const float4 v = pz4[i]; mz = fmaxf(mz, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w))); }
         }
         mx = h2_max_ror(mx); mz = h2_max_ror(mz);
         mx = fmaxf(mx, __shfl_xor(mx, 16)); mz = fmaxf(mz, __shfl_xor(mz, 16));
@@ -544,7 +557,7 @@ inline bool h2_eligible(const GconvParams &p, bool dual) {
     if (!(ktot >= 256 || (ktot >= 128 && p.F >= 128))) return false;
     for (int i = 0; i < p.nsrc; ++i) {
         const SrcDev &S = p.s[i];
-        if (S.rp || !S.wh || !S.wl || !S.rm || S.rmw < 4 || (S.rmw & 3)) return false;
+        if (S.rp || !S.wh || !S.wl || !S.rm || S.rmw < 4 || S.rmw > 16 || (S.rmw & 3)) return false;
         if (S.C % H2_KC != 0 || S.C < H2_KC) return false;
         if ((S.ldx & 3) || (S.xs & 3) || (reinterpret_cast<uintptr_t>(S.x) & 15)) return false;
         if ((long long)p.Mo * S.ldx >= (1LL << 29) || (long long)p.F * S.wp >= (1LL << 30)) return false;
@@ -576,9 +589,9 @@ inline void h2_tile(bool dual, int N, int Mo, int F, int Ktot, int &BM, int &BN)
 // weight gradient: the dw_split plan (family 3) with row bounds on every operand
 inline bool h2_dw_eligible(const DwParams &p) {
     static const int on = getenv("CAPE_DW_H2") ? atoi(getenv("CAPE_DW_H2")) : 1;          // 0: A/B against dw_split_kernel
-    if (!on || !p.dzrm || p.dzrmw < 1 || (p.dz2_mask && (!p.dz2rm || p.dz2rmw < 1))) return false;
+    if (!on || !p.dzrm || p.dzrmw < 4 || (p.dzrmw & 3) || (p.dz2_mask && (!p.dz2rm || p.dz2rmw < 4 || (p.dz2rmw & 3)))) return false;
     for (int i = 0; i < p.nsrc; ++i)
-        if (!p.s[i].rm || p.s[i].rmw < 1) return false;
+        if (!p.s[i].rm || p.s[i].rmw < 4 || (p.s[i].rmw & 3)) return false;
     return true;
 }
 

@@ -1147,7 +1147,10 @@ class ChebConvFn(torch.autograd.Function):
             entries.append(e)
         h2kw = dict(wsi=_ptr(P.fsi), wsi2=_ptr(Pa.fsi) if Pa is not None else None) if fw_ok else {}
         # the epilogue writes the row bounds of y next to it (consumed by the next contraction; csrc/gconv_shared.h)
-        rm_y = alloc_rm(y) if (H2 and y.dtype == torch.float32) else None
+        # (only for outputs wide enough that their consumers take the two-piece kernels: on the short 64-column launches the
+        # bound reduction costs 10-20 % of the kernel -- profiles/r04_h2_bench_*.txt -- and a consumer that does qualify falls
+        # back to one standalone pass)
+        rm_y = alloc_rm(y) if (H2 and y.dtype == torch.float32 and Fout >= 128) else None
         rank = None
         if coef is not None:
             assert coef.is_contiguous() and coef.shape == (N, K + (1 if W_aff is not None else 0), Fout)
@@ -1450,7 +1453,7 @@ class ChebConvFn(torch.autograd.Function):
                         ent = [src(Ts[k], k) for k in range(K)]
                         if W_aff is not None:
                             ent.append(src(Ts[K], 0, aff=True))
-                        rm_dx = alloc_rm(dx) if (H2 and dx.dtype == torch.float32) else None
+                        rm_dx = alloc_rm(dx) if (H2 and dx.dtype == torch.float32 and Ch >= 128) else None
                         gconv_fwd(ent, dx, rm_out=rm_dx, **bkw)
                         set_rm(dx, rm_dx)
                     if ctx.coarse_dw:
@@ -1648,7 +1651,7 @@ class ResidualLinearFn(torch.autograd.Function):
         if Pr is not None:
             e[0]["p"], e[0]["rm"], e[1]["p"], e[1]["rm"] = P.fwd(0), rowmax(x), Pr.fwd(0), rowmax(r)
             kw = dict(wsi=_ptr(P.fsi))
-        rm_y = alloc_rm(yfull, F) if (H2 and x.dtype == torch.float32) else None
+        rm_y = alloc_rm(yfull, F) if (H2 and x.dtype == torch.float32 and F >= 128) else None
         gconv_fwd(e, yfull[:, :, :F], rm_out=rm_y, **kw)
         if Cc:
             fill_cond(cond.contiguous(), yfull[:, :, F:])
