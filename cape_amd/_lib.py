@@ -79,7 +79,7 @@ class CapeWpieceItem(C.Structure):
                 ("pair_w", C.c_void_p),
                 ("f_hi", C.c_void_p), ("f_lo", C.c_void_p), ("b_hi", C.c_void_p), ("b_lo", C.c_void_p),
                 ("fscale_inv", C.c_void_p), ("bscale_inv", C.c_void_p), ("bscale_c_inv", C.c_void_p),
-                ("fpair_w", C.c_void_p), ("fpair_rows", C.c_int32), ("reserved", C.c_int32)]
+                ("fpair_w", C.c_void_p), ("fpair_rows", C.c_int32), ("reserved", C.c_int32), ("colmax_partial", C.c_void_p)]
 
 
 class CapeRank(C.Structure):

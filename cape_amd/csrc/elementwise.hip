@@ -784,10 +784,12 @@ __global__ __launch_bounds__(256) void bwd_prep_vec_kernel(CViewT<AT> g, CViewT<
                     }
                     cape_stv<VW>(zb + (long long)r * dz.ld + f, d);
                     if (rm) {
-                        // row bound of dz: entry = column pass (F <= 4 * FB); the cvn lanes of a row are consecutive and aligned
+                        // row bound of g -- and therefore of dz (|dz| <= |g| element by element): the affine block's backward
+                        // contracts BOTH, one reduction serves the two.  Entry = column pass (F <= 4 * FB); the cvn lanes of a row
+                        // are consecutive and aligned
                         float m = 0.f;
 #pragma unroll
-                        for (int u = 0; u < VW; ++u) m = fmaxf(m, fabsf(d[u]));
+                        for (int u = 0; u < VW; ++u) m = fmaxf(m, fabsf(gv[k][u]));
                         m = cape_group_max(m, cvn);
                         if (q == 0) {
                             // (each pass writes only its own entry -- different threads own a row in different passes --

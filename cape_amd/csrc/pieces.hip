@@ -47,6 +47,7 @@ struct WItem {                      // device-resident copy of cape_wpiece_item_
     float *fsi, *bsi, *bsc;
     const float *fpw;
     int fprows, reserved;
+    float *pc;                      // partial column maxima [row patches of 64][F]
 };
 
 // block -> (item, local block) through the prefix table off[nitems + 1].  The table is first copied to LDS by the whole block: a
@@ -65,37 +66,48 @@ __device__ __forceinline__ int w_find(const int *off, int nitems, int b, int &fi
     return lo;
 }
 
-// pass 1: the maxima.  Local blocks [0, ceil(F/16)): column strips of 16 (thread = column x 16 row lanes: 64-byte row
-// segments, rows/16 iterations per thread -- the strips of all layers together fill the chip);
-// then ceil(Ch/4) blocks of four channels (one wave per channel: its K rows, lanes over the columns).
+// pass 1: the maxima.  Local blocks [0, ceil(F/64) * ceil(R/64)), R = Ch*K feature rows (+ the forward partner's rows): one
+// 64-row x 64-column patch each, thread = (16 row lanes) x (float4 of columns): four independent 16-byte loads per thread and a
+// 16-lane LDS reduction -> partial column maxima pc[row patch][F] (no atomics; the planes pass and the last phase below take
+// their maximum).  Then ceil(Ch/4) blocks of four channels (one wave per channel: its K rows, lanes over the columns).
+// (The first version ran one block per 16-column strip over ALL rows: 64 dependent iterations, 18 us for the nz64 model.)
+__device__ __forceinline__ int w_rpatches(const WItem &I) { return (I.Ch * I.K + (I.fpw ? I.fprows : 0) + 63) >> 6; }
+
 __global__ __launch_bounds__(256) void wmax_kernel(const WItem *items, int nitems, const int *off) {
     int first;
     const int it = w_find(off, nitems, blockIdx.x, first);
     const WItem I = items[it];
     const int b = blockIdx.x - first;
-    const int cstrips = (I.F + 15) / 16;
+    const int cstrips = (I.F + 63) >> 6, rp = w_rpatches(I);
     const int rows = I.Ch * I.K;
-    __shared__ float part[16][17];
-    if (b < cstrips) {
-        const int fl = threadIdx.x & 15, rl = threadIdx.x >> 4, f = b * 16 + fl;
-        float m = 0.f;
+    __shared__ float4 part[16][17];
+    if (b < cstrips * rp) {
+        const int cs = b % cstrips, rpi = b / cstrips;
+        const int fq = threadIdx.x & 15, rl = threadIdx.x >> 4, f = cs * 64 + 4 * fq;
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
         if (f < I.F) {
-#pragma unroll 8
-            for (int j = rl; j < rows; j += 16) m = fmaxf(m, fabsf(I.w[(long long)j * I.F + f]));
-            if (I.fpw)                                                    // the partner's column of the same output
-                for (int j = rl; j < I.fprows; j += 16) m = fmaxf(m, fabsf(I.fpw[(long long)j * I.F + f]));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = rpi * 64 + rl + 16 * u;                        // row of the concatenation [W's feature rows | partner's rows]
+                const float *src = j < rows ? I.w + (long long)j * I.F : (j - rows < (I.fpw ? I.fprows : 0) ? I.fpw + (long long)(j - rows) * I.F : nullptr);
+                if (src) {
+                    const float4 v = *reinterpret_cast<const float4 *>(src + f);
+                    m.x = fmaxf(m.x, fabsf(v.x)); m.y = fmaxf(m.y, fabsf(v.y)); m.z = fmaxf(m.z, fabsf(v.z)); m.w = fmaxf(m.w, fabsf(v.w));
+                }
+            }
         }
-        part[rl][fl] = m;
+        part[rl][fq] = m;
         __syncthreads();
         if (rl == 0 && f < I.F) {
 #pragma unroll
-            for (int l = 1; l < 16; ++l) m = fmaxf(m, part[l][fl]);
-            float s, inv;
-            h2_scale_of(m, s, inv);
-            for (int k = 0; k < I.K; ++k) I.fsi[(long long)k * I.F + f] = inv;
+            for (int l = 1; l < 16; ++l) {
+                const float4 v = part[l][fq];
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+            *reinterpret_cast<float4 *>(I.pc + (long long)rpi * I.F + f) = m;
         }
     } else {
-        const int c = (b - cstrips) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        const int c = (b - cstrips * rp) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
         if (c >= I.Ch) return;
         float m = 0.f;
         const float *p = I.w + (long long)c * I.K * I.F;                 // the K rows of channel c are contiguous: K * F floats
@@ -103,6 +115,7 @@ __global__ __launch_bounds__(256) void wmax_kernel(const WItem *items, int nitem
         for (int j = lane; j < I.K * I.F; j += 64) m = fmaxf(m, fabsf(p[j]));
         if (I.pw) {                                                       // the partner's rows of the same channel
             const float *pp = I.pw + (long long)c * I.pairK * I.F;
+#pragma unroll 4
             for (int j = lane; j < I.pairK * I.F; j += 64) m = fmaxf(m, fabsf(pp[j]));
         }
         m = h2_max_ror(m);
@@ -115,6 +128,16 @@ __global__ __launch_bounds__(256) void wmax_kernel(const WItem *items, int nitem
             if (lane == 0) I.bsc[c] = inv;
         }
     }
+}
+
+// reciprocal forward scale of column f from the partial maxima (a handful of L2-resident loads)
+__device__ __forceinline__ float w_fscale_inv(const WItem &I, int f) {
+    float m = 0.f;
+    const int rp = w_rpatches(I);
+    for (int r = 0; r < rp; ++r) m = fmaxf(m, I.pc[(long long)r * I.F + f]);
+    float s, inv;
+    h2_scale_of(m, s, inv);
+    return inv;
 }
 
 // pass 2: the planes.  Local blocks [0, K * (Ch/32) * ceil(F/64)): forward planes, one 32-channel x 64-column tile of order k
@@ -139,8 +162,13 @@ __global__ __launch_bounds__(256) void wplanes_kernel(const WItem *items, int ni
             if (f < I.F) {
                 const float *src = I.w + ((long long)(c0 + cl) * I.K + k) * I.F + f;
                 const float4 a = *reinterpret_cast<const float4 *>(src), bb = *reinterpret_cast<const float4 *>(src + 4);
-                const float4 ia = *reinterpret_cast<const float4 *>(I.fsi + f), ib = *reinterpret_cast<const float4 *>(I.fsi + f + 4);
-                const float v[8] = {a.x / ia.x, a.y / ia.y, a.z / ia.z, a.w / ia.w, bb.x / ib.x, bb.y / ib.y, bb.z / ib.z, bb.w / ib.w};   // powers of two: exact
+                float inv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) inv[j] = w_fscale_inv(I, f + j);
+                if (ct == 0 && cl == 0)                                   // one publisher per (k, column): the launches' epilogues read it
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) I.fsi[(long long)k * I.F + f + j] = inv[j];
+                const float v[8] = {a.x / inv[0], a.y / inv[1], a.z / inv[2], a.w / inv[3], bb.x / inv[4], bb.y / inv[5], bb.z / inv[6], bb.w / inv[7]};   // powers of two: exact
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const _Float16 h = (_Float16)v[j], l = (_Float16)(v[j] - (float)h);
@@ -199,7 +227,9 @@ extern "C" int cape_weight_pieces_blocks(const cape_wpiece_item_t *host_items, i
         if (I.fpair_w && I.fpair_rows < 1) return CAPE_EINVAL;
         const long long bwd = (long long)I.Ch * I.K * (I.F / 8);
         const int fwd = (I.Ch & 31) ? 0 : I.K * (I.Ch / 32) * ((I.F + 63) / 64);
-        max_off[i + 1] = max_off[i] + (I.F + 15) / 16 + (I.Ch + 3) / 4;
+        const int rpatch = (I.Ch * I.K + (I.fpair_w ? I.fpair_rows : 0) + 63) / 64;
+        if (!I.colmax_partial) return CAPE_EINVAL;
+        max_off[i + 1] = max_off[i] + ((I.F + 63) / 64) * rpatch + (I.Ch + 3) / 4;
         planes_off[i + 1] = planes_off[i] + fwd + (int)((bwd + 255) / 256);
     }
     return CAPE_OK;

@@ -490,7 +490,9 @@ class PiecePlan(object):
             assert W.is_contiguous() and W.dtype == torch.float32 and W.shape[0] >= Ch * K and Ch % 8 == 0 and F % 8 == 0
             sizes.append((Ch, K, F))
         al = lambda nbytes: (nbytes + 255) // 256 * 256
-        total = sum(4 * al(2 * Ch * K * F) + al(4 * K * F) + al(4 * Ch * K) + al(4 * Ch) for Ch, K, F in sizes)
+        rpatch = lambda sp, Ch, K: (Ch * K + (int(sp["fpair"][1]) if sp.get("fpair") is not None else 0) + 63) // 64
+        total = sum(4 * al(2 * Ch * K * F) + al(4 * K * F) + al(4 * Ch * K) + al(4 * Ch) + al(4 * rpatch(sp, Ch, K) * F)
+                    for sp, (Ch, K, F) in zip(specs, sizes))
         self.arena = torch.empty(max(total, 256), device=device, dtype=torch.uint8)
         off = 0
 
@@ -512,6 +514,7 @@ class PiecePlan(object):
             a.fpair_w, a.fpair_rows = (wp.fpair[0].data_ptr(), int(wp.fpair[1])) if wp.fpair is not None else (None, 0)
             a.f_hi, a.f_lo, a.b_hi, a.b_lo = wp.f_hi.data_ptr(), wp.f_lo.data_ptr(), wp.b_hi.data_ptr(), wp.b_lo.data_ptr()
             a.fscale_inv, a.bscale_inv, a.bscale_c_inv = wp.fsi.data_ptr(), wp.bsi.data_ptr(), wp.bsc.data_ptr()
+            a.colmax_partial = take(4 * rpatch(sp, Ch, K) * F, torch.float32).data_ptr()
             self.items.append(wp)
         n = len(specs)
         mo, po = (C.c_int32 * (n + 1))(), (C.c_int32 * (n + 1))()
@@ -1037,8 +1040,9 @@ def bwd_prep(g, y=None, act="none", mask=None, want_bias=False, rowscale=None, R
     if rm_g is not None:
         set_rm(dz, rm_g)
     elif _want_rm(dz):
-        rm = _new_rm(dz)
+        rm = _new_rm(dz)                 # the kernel bounds the rows of g: valid for g and for dz
         set_rm(dz, rm)
+        set_rm(g, rm)
 
     def launch():
         rc = _fn("cape_bwd_prep", g)(gp, gs, gl, yp, ys, yl, _lib.ACT[act] if mask is None else 0, _ptr(mask), zp, zs, zl,

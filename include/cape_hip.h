@@ -222,6 +222,7 @@ typedef struct cape_wpiece_item {
                                     * accumulator (the two-source tail of res_block_decoder, lib/models.py:763-774): the forward
                                     * scale of column f then covers the columns of both tensors                             */
     int32_t fpair_rows, reserved;
+    float *colmax_partial;         /* scratch [ceil((Ch*K + fpair_rows) / 64)][F]: partial column maxima of the first pass      */
 } cape_wpiece_item_t;
 int cape_weight_pieces_blocks(const cape_wpiece_item_t *host_items, int32_t nitems, int32_t *max_off, int32_t *planes_off);
 int cape_weight_pieces(const cape_wpiece_item_t *dev_items, int32_t nitems, const int32_t *dev_max_off, int32_t max_blocks,
@@ -371,7 +372,8 @@ int cape_spmm(const float *x, int64_t x_sample_stride, int32_t ldx, const int32_
  */
 #define CAPE_MAX_SPMM_TERMS 4
 /* rowmax_out (cape_spmm, cape_spmm_multi in sum mode, cape_spmm_combine, cape_bwd_prep; fp32 storage only): NULL or
- * [N, Mo, 4]: the bound of max_c |out[n, r, c]| of the row the call writes (y / dz), as cape_h2_src_t.rowmax with
+ * [N, Mo, 4]: the bound of max_c |out[n, r, c]| of the row the call writes (y / dz; cape_bwd_prep bounds its INPUT g, which
+ * bounds dz as well), as cape_h2_src_t.rowmax with
  * rowmax_w = 4 -- written by the same kernel where the lanes of a row form one power-of-two group, by a standalone pass
  * (cape_rowmax) inside the call otherwise. */
 typedef struct cape_spmm_term {

@@ -246,7 +246,9 @@ def test_row_bounds_of_the_row_owning_producers(mesh_ops):
         dz = ops.bwd_prep(g, y=yv, act="leaky")[0]
         rm = ops.rm_of(dz).cpu().numpy()
         true = np.abs(dz.cpu().numpy()).max(-1)
-        assert np.array_equal(rm.max(-1), true)
+        assert np.array_equal(rm.max(-1), np.abs(g.cpu().numpy()).max(-1)) and np.all(rm.max(-1) >= true)      # the bound of g bounds dz
+        assert ops.rm_of(g) is ops.rm_of(dz)
+        ops.drop_rm(g)
         ops.rowmax(g)
         dz2 = ops.bwd_prep(g, y=yv, act="leaky")[0]
         assert ops.rm_of(dz2) is ops.rm_of(g) and np.all(ops.rm_of(dz2).cpu().numpy().max(-1) >= true)

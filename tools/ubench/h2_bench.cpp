@@ -20,17 +20,18 @@ static float *dev_rand(size_t n, unsigned seed, float scale) {
     return d;
 }
 
-struct Pieces { uint16_t *fh, *fl, *bh, *bl; float *fsi, *bsi, *bsc; };
+struct Pieces { uint16_t *fh, *fl, *bh, *bl; float *fsi, *bsi, *bsc, *pc; };
 
 static Pieces make_pieces(const float *W, int Ch, int K, int F, const float *pair, int pairK) {
     Pieces P;
     const size_t n = (size_t)Ch * K * F;
     hipMalloc(&P.fh, n * 2); hipMalloc(&P.fl, n * 2); hipMalloc(&P.bh, n * 2); hipMalloc(&P.bl, n * 2);
     hipMalloc(&P.fsi, (size_t)K * F * 4); hipMalloc(&P.bsi, (size_t)Ch * K * 4); hipMalloc(&P.bsc, (size_t)Ch * 4);
+    hipMalloc(&P.pc, (size_t)((Ch * K + 63) / 64) * F * 4);
     cape_wpiece_item_t it;
     memset(&it, 0, sizeof it);
     it.w = W; it.Ch = Ch; it.K = K; it.F = F; it.pair_w = pair; it.pair_K = pairK;
-    it.f_hi = P.fh; it.f_lo = P.fl; it.b_hi = P.bh; it.b_lo = P.bl; it.fscale_inv = P.fsi; it.bscale_inv = P.bsi; it.bscale_c_inv = P.bsc;
+    it.f_hi = P.fh; it.f_lo = P.fl; it.b_hi = P.bh; it.b_lo = P.bl; it.fscale_inv = P.fsi; it.bscale_inv = P.bsi; it.bscale_c_inv = P.bsc; it.colmax_partial = P.pc;
     int32_t mo[2], po[2];
     if (cape_weight_pieces_blocks(&it, 1, mo, po)) { printf("pieces: bad item\n"); exit(1); }
     cape_wpiece_item_t *dit; int32_t *dmo, *dpo;
