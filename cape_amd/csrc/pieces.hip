@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void wmax_kernel(const WItem *items, int nitem
 __device__ __forceinline__ float w_fscale_inv(const WItem &I, int f) {
     float m = 0.f;
     const int rp = w_rpatches(I);
+#pragma unroll 4
     for (int r = 0; r < rp; ++r) m = fmaxf(m, I.pc[(long long)r * I.F + f]);
     float s, inv;
     h2_scale_of(m, s, inv);
@@ -157,6 +158,14 @@ __global__ __launch_bounds__(256) void wplanes_kernel(const WItem *items, int ni
         const int ftiles = (I.F + 63) >> 6, ctiles = I.Ch >> 5;
         const int ft = b % ftiles, ct = (b / ftiles) % ctiles, k = b / (ftiles * ctiles);
         const int c0 = ct * 32, f0 = ft * 64;
+        // the tile's 64 column scales from the partial maxima, once per block (threads 0..63); the ct == 0 tiles publish them
+        __shared__ float sinv[64];
+        if (threadIdx.x < 64 && f0 + (int)threadIdx.x < I.F) {
+            const float inv = w_fscale_inv(I, f0 + threadIdx.x);
+            sinv[threadIdx.x] = inv;
+            if (ct == 0) I.fsi[(long long)k * I.F + f0 + threadIdx.x] = inv;
+        }
+        __syncthreads();
         {
             const int cl = threadIdx.x >> 3, fq = threadIdx.x & 7, f = f0 + 8 * fq;
             if (f < I.F) {
@@ -164,10 +173,7 @@ __global__ __launch_bounds__(256) void wplanes_kernel(const WItem *items, int ni
                 const float4 a = *reinterpret_cast<const float4 *>(src), bb = *reinterpret_cast<const float4 *>(src + 4);
                 float inv[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) inv[j] = w_fscale_inv(I, f + j);
-                if (ct == 0 && cl == 0)                                   // one publisher per (k, column): the launches' epilogues read it
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) I.fsi[(long long)k * I.F + f + j] = inv[j];
+                for (int j = 0; j < 8; ++j) inv[j] = sinv[8 * fq + j];
                 const float v[8] = {a.x / inv[0], a.y / inv[1], a.z / inv[2], a.w / inv[3], bb.x / inv[4], bb.y / inv[5], bb.z / inv[6], bb.w / inv[7]};   // powers of two: exact
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
