@@ -158,8 +158,8 @@ SIGNATURES = {
     "cape_flat_gradnorm": (C.c_int, [_p, _p, _i64, C.POINTER(_i64), _i32, _f32, _p, _p, _i64, _p]),
     "cape_flat_momentum_update": (C.c_int, [_p, _p, _p, _i64, _f32, _f32, _p, _p, C.POINTER(_i64), _i32, _f32, _p]),
     "cape_sumsq_ranges": (C.c_int, [_p, C.POINTER(_i64), _i32, _f32, _p, _p, _i64, _p]),
-    "cape_vae_sample_kl_fwd": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _p]),
-    "cape_vae_sample_kl_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p]),
+    "cape_vae_sample_kl_fwd": (C.c_int, [_p, _p, _p, _p, _i32, _p, _i32, _i32, _p, _i32, _i32, _p]),
+    "cape_vae_sample_kl_bwd": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _i32, _i32, _p]),
     "cape_fc_long_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "cape_fc_long_fwd": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), _p, _i64, _p]),
     "cape_fc_long_bwd": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p),

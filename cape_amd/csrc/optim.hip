@@ -114,27 +114,31 @@ inline int fill_ranges(Ranges &R, const int64_t *ranges, int nr, float coef) {
 inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---- VAE sampling + KL (reference lib/models.py:193-196, :371-372) on [N, nz] tensors: one block
-__global__ __launch_bounds__(256) void vae_fwd_kernel(const float *mean, const float *logvar, const float *eps, float *z, float *kl,
-                                                      int N, int nz) {
+// z is written with row stride ldz; cond (may be null) [N, Cc] is copied behind it: the decoder's input [z | cond] of
+// lib/models.py:296 (tf.concat) comes out of the sampling launch itself
+__global__ __launch_bounds__(256) void vae_fwd_kernel(const float *mean, const float *logvar, const float *eps, float *z, int ldz, float *kl,
+                                                      int N, int nz, const float *cond, int ldc, int Cc) {
     __shared__ float red[256];
     float s = 0.f;
     for (int i = threadIdx.x; i < N * nz; i += 256) {
         const float lv = logvar[i], mu = mean[i];
         const float sd = expf(0.5f * lv);
-        z[i] = fmaf(sd, eps[i], mu);
+        z[(i / nz) * ldz + (i % nz)] = fmaf(sd, eps[i], mu);
         s += 1.f + lv - mu * mu - sd * sd;
     }
+    if (cond)
+        for (int i = threadIdx.x; i < N * Cc; i += 256) z[(i / Cc) * ldz + nz + (i % Cc)] = cond[(i / Cc) * ldc + (i % Cc)];
     const float t = block_sum(s, red);
     if (threadIdx.x == 0) *kl = (-0.5f / (float)N) * t;
 }
 
-__global__ __launch_bounds__(256) void vae_bwd_kernel(const float *mean, const float *logvar, const float *eps, const float *gz,
+__global__ __launch_bounds__(256) void vae_bwd_kernel(const float *mean, const float *logvar, const float *eps, const float *gz, int ldgz,
                                                       const float *gkl, float *dmean, float *dlogvar, int N, int nz) {
     const float c = (gkl ? *gkl : 0.f) / (float)N;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < N * nz; i += gridDim.x * 256) {
         const float lv = logvar[i], mu = mean[i];
         const float sd = expf(0.5f * lv);
-        const float g = gz ? gz[i] : 0.f;
+        const float g = gz ? gz[(i / nz) * ldgz + (i % nz)] : 0.f;
         dmean[i] = fmaf(c, mu, g);
         dlogvar[i] = 0.5f * (g * sd * eps[i] + c * (sd * sd - 1.f));
     }
@@ -190,19 +194,19 @@ extern "C" int cape_flat_momentum_update(float *w, const float *g, float *m, int
     return CAPE_OK;
 }
 
-extern "C" int cape_vae_sample_kl_fwd(const float *mean, const float *logvar, const float *eps, float *z, float *kl,
-                                      int32_t N, int32_t nz, void *stream) {
-    if (!mean || !logvar || !eps || !z || !kl || N < 1 || nz < 1) return CAPE_EINVAL;
-    CAPE_LAUNCH(vae_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mean, logvar, eps, z, kl, N, nz);
+extern "C" int cape_vae_sample_kl_fwd(const float *mean, const float *logvar, const float *eps, float *z, int32_t ldz, float *kl,
+                                      int32_t N, int32_t nz, const float *cond, int32_t ldc, int32_t Cc, void *stream) {
+    if (!mean || !logvar || !eps || !z || !kl || N < 1 || nz < 1 || ldz < nz + (cond ? Cc : 0) || (cond && (Cc < 1 || ldc < Cc))) return CAPE_EINVAL;
+    CAPE_LAUNCH(vae_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mean, logvar, eps, z, ldz, kl, N, nz, cond, ldc, cond ? Cc : 0);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }
 
-extern "C" int cape_vae_sample_kl_bwd(const float *mean, const float *logvar, const float *eps, const float *gz,
+extern "C" int cape_vae_sample_kl_bwd(const float *mean, const float *logvar, const float *eps, const float *gz, int32_t ldgz,
                                       const float *gkl, float *dmean, float *dlogvar, int32_t N, int32_t nz, void *stream) {
-    if (!mean || !logvar || !eps || !dmean || !dlogvar || N < 1 || nz < 1) return CAPE_EINVAL;
+    if (!mean || !logvar || !eps || !dmean || !dlogvar || N < 1 || nz < 1 || (gz && ldgz < nz)) return CAPE_EINVAL;
     const int blocks = (N * nz + 255) / 256 > 64 ? 64 : (N * nz + 255) / 256;
-    CAPE_LAUNCH(vae_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mean, logvar, eps, gz, gkl, dmean, dlogvar, N, nz);
+    CAPE_LAUNCH(vae_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mean, logvar, eps, gz, ldgz, gkl, dmean, dlogvar, N, nz);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }

@@ -700,9 +700,9 @@ class CAPE(base_model):
             if eps is None:
                 eps = torch.randn((z_mean.shape[0], int(self.nz)), device=z_mean.device, dtype=torch.float32)
             # sampling (:193-196) and the KL term (:371-372) share one hand-differentiated op
-            z, self._kl_of_last_sample = ops.VaeSampleKLFn.apply(z_mean, z_logvar, eps)
+            # (the op also appends the condition: [z | y | y2], the decoder's input of :296, without a concat launch)
+            z_total, self._kl_of_last_sample = ops.VaeSampleKLFn.apply(z_mean, z_logvar, eps, self._cat_cond(y, y2))
             self._kl_inputs = (z_mean, z_logvar)
-            z_total = torch.cat([z, self._cat_cond(y, y2)], dim=1)
             x_hat = self.decoder_cond_vert(z_total, y, y2, use_res_block=self.use_res_block_dec)
         return x_hat, z_mean, z_logvar
 

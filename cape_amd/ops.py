@@ -2270,15 +2270,21 @@ class VaeSampleKLFn(torch.autograd.Function):
     ~25 an op-by-op autograd tape replays on these [N, nz] tensors."""
 
     @staticmethod
-    def forward(ctx, mean, logvar, eps):
+    def forward(ctx, mean, logvar, eps, cond=None):
+        """``cond`` [N, Cc]: returned z is [z | cond] (the decoder's input, lib/models.py:296 tf.concat) from the same launch."""
         _lib.require_gpu()
         mean, logvar, eps = mean.contiguous(), logvar.contiguous(), eps.contiguous()
         N, nz = mean.shape
-        z = torch.empty_like(mean)
+        Cc = 0 if cond is None else int(cond.shape[1])
+        if cond is not None and cond.stride(1) != 1:
+            cond = cond.contiguous()
+        z = torch.empty((N, nz + Cc), device=mean.device, dtype=torch.float32)
         kl = torch.empty((), device=mean.device, dtype=torch.float32)
-        p = lambda t: C.c_void_p(t.data_ptr())
-        check(lib.cape_vae_sample_kl_fwd(p(mean), p(logvar), p(eps), p(z), p(kl), N, nz, _stream()), "cape_vae_sample_kl_fwd")
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        check(lib.cape_vae_sample_kl_fwd(p(mean), p(logvar), p(eps), p(z), nz + Cc, p(kl), N, nz, p(cond),
+                                         0 if cond is None else int(cond.stride(0)), Cc, _stream()), "cape_vae_sample_kl_fwd")
         ctx.save_for_backward(mean, logvar, eps)
+        ctx.Cc = Cc
         return z, kl
 
     @staticmethod
@@ -2286,9 +2292,11 @@ class VaeSampleKLFn(torch.autograd.Function):
         mean, logvar, eps = ctx.saved_tensors
         N, nz = mean.shape
         dmean, dlv = torch.empty_like(mean), torch.empty_like(mean)
-        gz = None if gz is None else gz.contiguous()
+        if gz is not None and gz.stride(1) != 1:
+            gz = gz.contiguous()
         gkl = None if gkl is None else gkl.contiguous()
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
-        check(lib.cape_vae_sample_kl_bwd(p(mean), p(logvar), p(eps), p(gz), p(gkl), p(dmean), p(dlv), N, nz, _stream()),
-              "cape_vae_sample_kl_bwd")
-        return dmean, dlv, None
+        check(lib.cape_vae_sample_kl_bwd(p(mean), p(logvar), p(eps), p(gz), 0 if gz is None else int(gz.stride(0)), p(gkl), p(dmean), p(dlv),
+                                         N, nz, _stream()), "cape_vae_sample_kl_bwd")
+        dcond = gz[:, nz:] if (ctx.Cc and gz is not None) else None          # (a view: the condition's own gradient, no copy)
+        return dmean, dlv, None, dcond

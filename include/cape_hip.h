@@ -552,13 +552,16 @@ int cape_sumsq_ranges(const float *x, const int64_t *ranges, int32_t nranges, fl
                       void *workspace, int64_t workspace_bytes, void *stream);
 
 /*
- * VAE sampling + KL term (lib/models.py:193-196, :371-372) on contiguous [N, nz] tensors:
+ * VAE sampling + KL term (lib/models.py:193-196, :371-372); mean / logvar / eps contiguous [N, nz]:
  *   z = mean + exp(0.5*logvar) * eps ;  *kl = (-0.5/N) * sum(1 + logvar - mean^2 - exp(logvar))
- * backward: dmean = gz + (gkl/N)*mean ; dlogvar = 0.5*(gz*std*eps + (gkl/N)*(exp(logvar) - 1)).  gz / gkl may be NULL.
+ * z is written with row stride ldz; cond (NULL or [N, Cc], row stride ldc) is copied behind it, so that z IS the decoder's input
+ * [z | cond] of lib/models.py:296 (tf.concat) when ldz >= nz + Cc.
+ * backward: dmean = gz + (gkl/N)*mean ; dlogvar = 0.5*(gz*std*eps + (gkl/N)*(exp(logvar) - 1)).  gz (row stride ldgz: the first nz
+ * columns of the gradient of [z | cond]) / gkl may be NULL.
  */
-int cape_vae_sample_kl_fwd(const float *mean, const float *logvar, const float *eps, float *z, float *kl,
-                           int32_t N, int32_t nz, void *stream);
-int cape_vae_sample_kl_bwd(const float *mean, const float *logvar, const float *eps, const float *gz,
+int cape_vae_sample_kl_fwd(const float *mean, const float *logvar, const float *eps, float *z, int32_t ldz, float *kl,
+                           int32_t N, int32_t nz, const float *cond, int32_t ldc, int32_t Cc, void *stream);
+int cape_vae_sample_kl_bwd(const float *mean, const float *logvar, const float *eps, const float *gz, int32_t ldgz,
                            const float *gkl, float *dmean, float *dlogvar, int32_t N, int32_t nz, void *stream);
 
 /*
