@@ -117,8 +117,8 @@ SIGNATURES = {
     "cape_gconv_dw_workspace_bytes": (_i64, [_SRCP, _i32, _i32, _i32, _i32]),
     "cape_gconv_dw": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _p, C.c_uint32, _i32, _i32, _i32, _i32, _p, _i64, _p]),
     "cape_gconv_dw_stage": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _p, C.c_uint32, _i32, _i32, _i32, _i32, _p, _i64, _i32, _p]),
-    "cape_condnet_fwd": (C.c_int, [_p, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
-    "cape_condnet_bwd": (C.c_int, [_p, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "cape_condnet_fwd": (C.c_int, [_p, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "cape_condnet_bwd": (C.c_int, [_p, _i32, _p, _i32, _p, _p, _p, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "cape_gconv_dw_reduce_batch": (C.c_int, [C.c_void_p, _i32, _p]),
     "cape_gconv_dw_plan": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _p, C.c_uint32, _i32, _i32, _i32, C.POINTER(_i32)]),
     "cape_gconv_fwd_bf16": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p, _i32, _i32, _p,
@@ -174,8 +174,8 @@ SIGNATURES = {
     "cape_cheb_fused_bwd": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _p, _p, _i64, _i32, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                       _p, _p, _p, _p, _i32, _p, _i64, _p]),
     "cape_recon_edge_workspace_bytes": (_i64, [_i32, _i32, _i32]),
-    "cape_recon_edge_loss_fwd_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _f32,
-                                               _p, _p, _p, _f32, _p, _p, _p, _i64, _p]),
+    "cape_recon_edge_loss_fwd_bwd": (C.c_int, [_p, _i32, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f32, _f32,
+                                               _p, _p, _p, _f32, _p, _p, _i32, _p, _i64, _p]),
 }
 
 # bf16-storage variants with the argument list of their fp32 namesake (include/cape_hip.h, last section)

@@ -14,7 +14,10 @@ struct CondNetP {
     const float *W1, *b1, *W2, *b2, *Wc, *bc;
     float *h;            // [N, hid] post-activation hidden layer (saved for backward)
     float *ycat;         // [N, out1 + out2]
-    const float *dycat;  // backward: gradient w.r.t. ycat (contiguous)
+    float *ycat2;        // NULL or a second copy of ycat (a consumer of its own: its gradient then arrives separately as dycat2)
+    const float *dycat;  // backward: gradient w.r.t. ycat, rows lddy floats apart (NULL: zero)
+    const float *dycat2; // backward: NULL or the gradient w.r.t. ycat2, rows lddy2 apart; the kernel reads dycat + dycat2
+    int lddy, lddy2;
     float *gW1, *gb1, *gW2, *gb2, *gWc, *gbc;
     int N, in1, hid, out1, in2, out2;
 };
@@ -60,7 +63,11 @@ __global__ __launch_bounds__(256) void condnet_fwd_kernel(CondNetP p) {
             for (int i = part; i < p.in2; i += 4) a = fmaf(p.c2[(long long)n * p.ld2 + i], p.Wc[(long long)i * p.out2 + g], a);
         }
         a = quad_sum(red, col, part, a, 64);
-        if (part == 0 && f < oc) p.ycat[(long long)n * oc + f] = a + (f < p.out1 ? p.b2[f] : p.bc[f - p.out1]);
+        if (part == 0 && f < oc) {
+            const float v = a + (f < p.out1 ? p.b2[f] : p.bc[f - p.out1]);
+            p.ycat[(long long)n * oc + f] = v;
+            if (p.ycat2) p.ycat2[(long long)n * oc + f] = v;
+        }
     }
 }
 
@@ -72,7 +79,12 @@ __global__ __launch_bounds__(256) void condnet_bwd_kernel(CondNetP p) {
     float *sh = sm;                          // [N][hid]   h, then dh in place
     float *sd = sh + p.N * p.hid;            // [N][oc]    dycat
     for (int i = threadIdx.x; i < p.N * p.hid; i += 256) sh[i] = p.h[i];
-    for (int i = threadIdx.x; i < p.N * oc; i += 256) sd[i] = p.dycat[i];
+    for (int i = threadIdx.x; i < p.N * oc; i += 256) {
+        const int n = i / oc, f = i % oc;
+        float v = p.dycat ? p.dycat[(long long)n * p.lddy + f] : 0.f;
+        if (p.dycat2) v += p.dycat2[(long long)n * p.lddy2 + f];
+        sd[i] = v;
+    }
     __syncthreads();
     if (blockIdx.x == 0) {
         for (int o = threadIdx.x; o < (p.hid + 1) * p.out1; o += 256) {
@@ -128,10 +140,10 @@ inline int condnet_check(const CondNetP &p) {
 
 extern "C" int cape_condnet_fwd(const float *c1, int32_t ld1, const float *c2, int32_t ld2, const float *W1, const float *b1,
                                 const float *W2, const float *b2, const float *Wc, const float *bc, float *h, float *ycat,
-                                int32_t N, int32_t in1, int32_t hid, int32_t out1, int32_t in2, int32_t out2, void *stream) {
+                                float *ycat2, int32_t N, int32_t in1, int32_t hid, int32_t out1, int32_t in2, int32_t out2, void *stream) {
     CondNetP p{};
     p.c1 = c1; p.c2 = c2; p.ld1 = ld1; p.ld2 = ld2; p.W1 = W1; p.b1 = b1; p.W2 = W2; p.b2 = b2; p.Wc = Wc; p.bc = bc;
-    p.h = h; p.ycat = ycat; p.N = N; p.in1 = in1; p.hid = hid; p.out1 = out1; p.in2 = in2; p.out2 = out2;
+    p.h = h; p.ycat = ycat; p.ycat2 = ycat2; p.N = N; p.in1 = in1; p.hid = hid; p.out1 = out1; p.in2 = in2; p.out2 = out2;
     if (!ycat) return CAPE_EINVAL;
     const int rc = condnet_check(p);
     if (rc) return rc;
@@ -141,14 +153,17 @@ extern "C" int cape_condnet_fwd(const float *c1, int32_t ld1, const float *c2, i
 }
 
 extern "C" int cape_condnet_bwd(const float *c1, int32_t ld1, const float *c2, int32_t ld2, const float *W2, const float *h,
-                                const float *dycat, float *gW1, float *gb1, float *gW2, float *gb2, float *gWc, float *gbc,
+                                const float *dycat, int32_t lddy, const float *dycat2, int32_t lddy2, float *gW1, float *gb1,
+                                float *gW2, float *gb2, float *gWc, float *gbc,
                                 int32_t N, int32_t in1, int32_t hid, int32_t out1, int32_t in2, int32_t out2, void *stream) {
     CondNetP p{};
-    p.c1 = c1; p.c2 = c2; p.ld1 = ld1; p.ld2 = ld2; p.W2 = W2; p.h = const_cast<float *>(h); p.dycat = dycat;
+    p.c1 = c1; p.c2 = c2; p.ld1 = ld1; p.ld2 = ld2; p.W2 = W2; p.h = const_cast<float *>(h);
+    p.dycat = dycat; p.dycat2 = dycat2; p.lddy = lddy; p.lddy2 = lddy2;
     p.gW1 = gW1; p.gb1 = gb1; p.gW2 = gW2; p.gb2 = gb2; p.gWc = gWc; p.gbc = gbc;
     p.N = N; p.in1 = in1; p.hid = hid; p.out1 = out1; p.in2 = in2; p.out2 = out2;
     p.W1 = p.b1 = p.b2 = p.Wc = p.bc = W2;      // (unused by the backward kernel; non-null for the shared check)
-    if (!dycat || !gW1 || !gb1 || !gW2 || !gb2 || !gWc || !gbc) return CAPE_EINVAL;
+    if ((!dycat && !dycat2) || (dycat && lddy < out1 + out2) || (dycat2 && lddy2 < out1 + out2)) return CAPE_EINVAL;
+    if (!gW1 || !gb1 || !gW2 || !gb2 || !gWc || !gbc) return CAPE_EINVAL;
     const int rc = condnet_check(p);
     if (rc) return rc;
     CAPE_LAUNCH(condnet_bwd_kernel, dim3(16), dim3(256), condnet_lds(p, true), (hipStream_t)stream, p);

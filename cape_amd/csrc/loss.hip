@@ -22,7 +22,7 @@ __device__ __forceinline__ float block_sum256(float v, float *red) {
 
 // per (n, e): unit difference vector -> unit[n,e,0:3], block-partial sum of lengths
 __global__ __launch_bounds__(LB) void edge_fwd_kernel(const float *pred, const float *gt, const float *ref, const int *edges,
-                                                      int N, int M, int E, float *unit, float *part) {
+                                                      int N, int M, int E, int ldp, float *unit, float *part) {
     __shared__ float red[4];
     const long long total = (long long)N * E;
     float s = 0.f;
@@ -33,8 +33,8 @@ __global__ __launch_bounds__(LB) void edge_fwd_kernel(const float *pred, const f
         float d[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float pa = pred[(n * M + a) * 3 + k] + ref[a * 3 + k];
-            const float pb = pred[(n * M + b) * 3 + k] + ref[b * 3 + k];
+            const float pa = pred[(n * M + a) * ldp + k] + ref[a * 3 + k];
+            const float pb = pred[(n * M + b) * ldp + k] + ref[b * 3 + k];
             const float ga = gt[(n * M + a) * 3 + k] + ref[a * 3 + k];
             const float gb = gt[(n * M + b) * 3 + k] + ref[b * 3 + k];
             d[k] = (pa - pb) - (ga - gb);
@@ -54,8 +54,8 @@ __global__ __launch_bounds__(LB) void edge_fwd_kernel(const float *pred, const f
 
 // per (n, v): L1 partial sums and the combined gradient
 __global__ __launch_bounds__(LB) void vert_kernel(const float *pred, const float *gt, const float *unit, const int *vptr,
-                                                  const int *vidx, int N, int M, int E, float cr, float ce, float *dpred,
-                                                  float *part) {
+                                                  const int *vidx, int N, int M, int E, int ldp, int ldd, float cr, float ce,
+                                                  float *dpred, float *part) {
     __shared__ float red[4];
     const long long total = (long long)N * M;
     float s = 0.f;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(LB) void vert_kernel(const float *pred, const float
         float g[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float d = pred[i * 3 + k] - gt[i * 3 + k];
+            const float d = pred[i * ldp + k] - gt[i * 3 + k];
             s += fabsf(d);
             g[k] = cr * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
         }
@@ -79,9 +79,9 @@ __global__ __launch_bounds__(LB) void vert_kernel(const float *pred, const float
                 g[1] = fmaf(sg, u[1], g[1]);
                 g[2] = fmaf(sg, u[2], g[2]);
             }
-            dpred[i * 3 + 0] = g[0];
-            dpred[i * 3 + 1] = g[1];
-            dpred[i * 3 + 2] = g[2];
+            dpred[i * ldd + 0] = g[0];
+            dpred[i * ldd + 1] = g[1];
+            dpred[i * ldd + 2] = g[2];
         }
     }
     s = block_sum256(s, red);
@@ -179,23 +179,24 @@ extern "C" int64_t cape_recon_edge_workspace_bytes(int32_t N, int32_t M, int32_t
     return ((int64_t)N * E * 3 + 2048) * (int64_t)sizeof(float);
 }
 
-extern "C" int cape_recon_edge_loss_fwd_bwd(const float *pred, const float *gt, const float *verts_ref, const int32_t *edges,
+extern "C" int cape_recon_edge_loss_fwd_bwd(const float *pred, int32_t ldp, const float *gt, const float *verts_ref, const int32_t *edges,
                                             const int32_t *vert_edge_ptr, const int32_t *vert_edge_idx, int32_t N, int32_t M,
                                             int32_t E, float w_recon, float w_edge, float *loss_out, float *total_out,
-                                            const float *term_a, float w_a, const float *term_b, float *dpred, void *workspace,
-                                            int64_t workspace_bytes, void *stream) {
-    if (!pred || !gt || !verts_ref || !edges || !loss_out || !workspace || N < 1 || M < 1 || E < 1) return CAPE_EINVAL;
+                                            const float *term_a, float w_a, const float *term_b, float *dpred, int32_t ldd,
+                                            void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!pred || !gt || !verts_ref || !edges || !loss_out || !workspace || N < 1 || M < 1 || E < 1 || ldp < 3) return CAPE_EINVAL;
+    if (dpred && ldd < 3) return CAPE_EINVAL;
     if (dpred && (!vert_edge_ptr || !vert_edge_idx)) return CAPE_EINVAL;
     if (workspace_bytes < cape_recon_edge_workspace_bytes(N, M, E)) return CAPE_EWORKSPACE;
     float *ws = (float *)workspace;
     float *part_e = ws, *part_v = ws + 1024, *unit = ws + 2048;
     hipStream_t st = (hipStream_t)stream;
     const int ne = nblocks((long long)N * E), nv = nblocks((long long)N * M);
-    CAPE_LAUNCH(edge_fwd_kernel, dim3(ne), dim3(LB), 0, st, pred, gt, verts_ref, edges, N, M, E, unit, part_e);
+    CAPE_LAUNCH(edge_fwd_kernel, dim3(ne), dim3(LB), 0, st, pred, gt, verts_ref, edges, N, M, E, ldp, unit, part_e);
     CAPE_LAUNCH_CHECK();
     const float cr = w_recon / ((float)N * (float)M * 3.0f);
     const float ce = w_edge / ((float)N * (float)E);
-    CAPE_LAUNCH(vert_kernel, dim3(nv), dim3(LB), 0, st, pred, gt, unit, vert_edge_ptr, vert_edge_idx, N, M, E, cr, ce, dpred, part_v);
+    CAPE_LAUNCH(vert_kernel, dim3(nv), dim3(LB), 0, st, pred, gt, unit, vert_edge_ptr, vert_edge_idx, N, M, E, ldp, ldd, cr, ce, dpred, part_v);
     CAPE_LAUNCH_CHECK();
     CAPE_LAUNCH(loss_final_kernel, dim3(1), dim3(LB), 0, st, part_e, ne, 1.0f / ((float)N * (float)E), part_v, nv,
                        1.0f / ((float)N * (float)M * 3.0f), loss_out, w_recon, w_edge, total_out, term_a, w_a, term_b);

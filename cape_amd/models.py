@@ -494,19 +494,25 @@ class CAPE(base_model):
                 with self.variable_scope('fc1'):
                     Wc, bc, gc = self._dense_vars(int(cond2.shape[-1]), int(self.nz_cond2))
             gb = g1 + g2 + gc
-            ycat = ops.CondNetsFn.apply(cond, cond2, W1, b1, W2, b2, Wc, bc, gb if all(v is not None for v in gb) else None)
+            # under differentiation the kernel writes the embedding twice: the second buffer belongs to the decoder input
+            # [z | y | y2] alone, so that its gradient reaches the backward kernel by itself (no element-wise sum of the two)
+            two = torch.is_grad_enabled() and any(v.requires_grad for v in (W1, W2, Wc))
+            res = ops.CondNetsFn.apply(cond, cond2, W1, b1, W2, b2, Wc, bc, gb if all(v is not None for v in gb) else None,
+                                       2 if two else 1)
+            ycat, ycat_b = res if two else (res, None)
             y, y2 = ycat[:, :nzc], ycat[:, nzc:]
-            self._ycat = (y, y2, ycat)
+            self._ycat = (y, y2, ycat, ycat_b)
             return y, y2
         y = self.condition(cond, 'pose', self.nz_cond, nlayers=2)
         y2 = self.condition(cond2, 'clo_label', self.nz_cond2, nlayers=self.n_layer_cond)
         return y, y2
 
-    def _cat_cond(self, y, y2):
-        """tf.concat([y, y2], 1): the tensor the fused condition kernel already produced when y / y2 are its halves."""
+    def _cat_cond(self, y, y2, own=False):
+        """tf.concat([y, y2], 1): the tensor the fused condition kernel already produced when y / y2 are its halves
+        (``own``: the second copy, reserved for ONE consumer -- see _conditions)."""
         t = getattr(self, '_ycat', None)
         if t is not None and y is t[0] and y2 is t[1]:
-            return t[2]
+            return t[3] if own and t[3] is not None else t[2]
         return torch.cat([y, y2], 1)
 
     def res_block(self, x_in, i, name):
@@ -701,7 +707,7 @@ class CAPE(base_model):
                 eps = torch.randn((z_mean.shape[0], int(self.nz)), device=z_mean.device, dtype=torch.float32)
             # sampling (:193-196) and the KL term (:371-372) share one hand-differentiated op
             # (the op also appends the condition: [z | y | y2], the decoder's input of :296, without a concat launch)
-            z_total, self._kl_of_last_sample = ops.VaeSampleKLFn.apply(z_mean, z_logvar, eps, self._cat_cond(y, y2))
+            z_total, self._kl_of_last_sample = ops.VaeSampleKLFn.apply(z_mean, z_logvar, eps, self._cat_cond(y, y2, own=True))
             self._kl_inputs = (z_mean, z_logvar)
             x_hat = self.decoder_cond_vert(z_total, y, y2, use_res_block=self.use_res_block_dec)
         return x_hat, z_mean, z_logvar
@@ -975,7 +981,7 @@ class CAPE(base_model):
         self.prepare_pieces()                   # unconditionally: a captured step must contain the refresh of the piece planes
         y_g, y2_g = self._conditions(cond_g, cond2_g)
         # heads of the two-phase backward: the tensors the decoder / discriminator actually consume
-        self._y_pair = (self._ycat[2],) if self._ycat is not None else (y_g, y2_g)
+        self._y_pair = tuple(t for t in self._ycat[2:] if t is not None) if self._ycat is not None else (y_g, y2_g)
         x_hat, z_mean, z_logvar = self.generator(data_g, y_g, y2_g, eps=eps)
         out = self.loss_terms(x_hat, gt, z_mean, z_logvar)
         out['prediction'] = x_hat

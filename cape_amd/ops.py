@@ -1837,8 +1837,12 @@ class ReconEdgeLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, gt, verts_ref, edges, vptr, vidx, w_recon, w_edge, term_a=None, w_a=0.0, term_b=None):
         _lib.require_gpu()
-        pred, gt = pred.contiguous(), gt.contiguous()
+        gt = gt.contiguous()
         N, M, _ = pred.shape
+        # the decoder's output is a [N, M, 3] view of 16-byte rows: read it where it lies (no re-homing launch)
+        if pred.stride(2) != 1 or pred.stride(1) < 3 or (N > 1 and pred.stride(0) != M * pred.stride(1)):
+            pred = pred.contiguous()
+        ldp = int(pred.stride(1)) if M > 1 else 3
         E = edges.shape[0]
         if L1_SIGN_TRACE is not None and w_recon != 0.0:
             L1_SIGN_TRACE.append(torch.sign(pred.detach() - gt).cpu())       # the kernel takes the sign of the same fp32 difference
@@ -1846,15 +1850,17 @@ class ReconEdgeLossFn(torch.autograd.Function):
         ws = torch.empty((need + 3) // 4, device=pred.device, dtype=torch.float32)
         out = torch.empty(2, device=pred.device, dtype=torch.float32)
         total = torch.empty((), device=pred.device, dtype=torch.float32)
-        dpred = torch.empty_like(pred)
+        dpred = alloc_act(N, M, 3, pred.device, zero=False)                  # row-padded like every activation gradient
+        ldd = int(dpred.stride(1))
         for t in (term_a, term_b):
             assert t is None or (t.dim() == 0 and t.dtype == torch.float32 and t.device == pred.device)
         _log_launch("recon_edge_loss", 0, N * (E * 24 + M * 36),
-                    lambda: check(lib.cape_recon_edge_loss_fwd_bwd(_ptr(pred), _ptr(gt), _ptr(verts_ref), _ptr(edges), _ptr(vptr),
+                    lambda: check(lib.cape_recon_edge_loss_fwd_bwd(_ptr(pred), ldp, _ptr(gt), _ptr(verts_ref), _ptr(edges), _ptr(vptr),
                                                                    _ptr(vidx), N, M, E, float(w_recon), float(w_edge), _ptr(out),
                                                                    _ptr(total), _ptr(term_a), float(w_a), _ptr(term_b), _ptr(dpred),
-                                                                   _ptr(ws), need, _stream()),
+                                                                   ldd, _ptr(ws), need, _stream()),
                                   "cape_recon_edge_loss_fwd_bwd"))
+        ctx.set_materialize_grads(False)         # no zeros for the non-differentiable parts' gradient
         ctx.save_for_backward(dpred)
         ctx.w_a = float(w_a) if term_a is not None else None
         ctx.mark_non_differentiable(out)
@@ -1863,6 +1869,8 @@ class ReconEdgeLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gtotal, _gout):
         (dpred,) = ctx.saved_tensors
+        if gtotal is None:
+            return (None,) * 11
         unit = UNIT_GRAD is not None and gtotal.data_ptr() == UNIT_GRAD.data_ptr()      # d(loss)/d(total) is the caller's constant 1
         ga = None
         if ctx.w_a is not None and ctx.needs_input_grad[8]:
@@ -2024,7 +2032,9 @@ class CondNetsFn(torch.autograd.Function):
     bc) or None -- with views the backward kernel writes the bucket directly."""
 
     @staticmethod
-    def forward(ctx, c1, c2, W1, b1, W2, b2, Wc, bc, gbufs):
+    def forward(ctx, c1, c2, W1, b1, W2, b2, Wc, bc, gbufs, copies=1):
+        """``copies`` 2: returns (ycat, ycat_b), the same values in two buffers -- a consumer that reads ycat_b alone hands its
+        gradient to the backward kernel directly (which differentiates the sum) instead of through an element-wise add."""
         _lib.require_gpu()
         c1, c2 = c1.contiguous(), c2.contiguous()
         N, in1 = c1.shape
@@ -2033,19 +2043,25 @@ class CondNetsFn(torch.autograd.Function):
         assert tuple(W1.shape) == (in1, hid) and tuple(W2.shape) == (hid, out1) and tuple(Wc.shape) == (in2, out2)
         h = torch.empty((N, hid), device=c1.device, dtype=torch.float32)
         ycat = torch.empty((N, out1 + out2), device=c1.device, dtype=torch.float32)
+        ycat_b = torch.empty_like(ycat) if copies == 2 else None
         check(lib.cape_condnet_fwd(_ptr(c1), in1, _ptr(c2), in2, _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(Wc), _ptr(bc),
-                                   _ptr(h), _ptr(ycat), N, in1, hid, out1, in2, out2, _stream()), "cape_condnet_fwd")
+                                   _ptr(h), _ptr(ycat), _ptr(ycat_b), N, in1, hid, out1, in2, out2, _stream()), "cape_condnet_fwd")
         _trace_sign(h, "leaky")
         ctx.gbufs, ctx.dims = gbufs, (N, in1, hid, out1, in2, out2)
         ctx.save_for_backward(c1, c2, W2, h)
         ctx.shapes = [tuple(t.shape) for t in (W1, b1, W2, b2, Wc, bc)]
-        return ycat
+        ctx.set_materialize_grads(False)
+        return ycat if ycat_b is None else (ycat, ycat_b)
 
     @staticmethod
-    def backward(ctx, dycat):
+    def backward(ctx, dycat, dycat_b=None):
         c1, c2, W2, h = ctx.saved_tensors
         N, in1, hid, out1, in2, out2 = ctx.dims
-        dycat = dycat.contiguous()
+        if dycat is None and dycat_b is None:
+            return (None,) * 10
+        rows = lambda t: None if t is None else (t if t.stride(1) == 1 and (N == 1 or t.stride(0) >= out1 + out2) else t.contiguous())
+        dycat, dycat_b = rows(dycat), rows(dycat_b)
+        ld = lambda t: 0 if t is None else (int(t.stride(0)) if N > 1 else out1 + out2)
         outs = []
         for i, shp in enumerate(ctx.shapes):
             v = None if ctx.gbufs is None else ctx.gbufs[i]
@@ -2053,9 +2069,10 @@ class CondNetsFn(torch.autograd.Function):
                 outs.append(v.view(shp))
             else:
                 outs.append(torch.empty(shp, device=c1.device, dtype=torch.float32))
-        check(lib.cape_condnet_bwd(_ptr(c1), in1, _ptr(c2), in2, _ptr(W2), _ptr(h), _ptr(dycat), *[_ptr(t) for t in outs],
-                                   N, in1, hid, out1, in2, out2, _stream()), "cape_condnet_bwd")
-        return (None, None) + tuple(outs) + (None,)
+        check(lib.cape_condnet_bwd(_ptr(c1), in1, _ptr(c2), in2, _ptr(W2), _ptr(h), _ptr(dycat), ld(dycat), _ptr(dycat_b),
+                                   ld(dycat_b), *[_ptr(t) for t in outs], N, in1, hid, out1, in2, out2, _stream()),
+              "cape_condnet_bwd")
+        return (None, None) + tuple(outs) + (None, None)
 
 
 def poolwT(x, fwd_csr, bwd_csr):

@@ -63,16 +63,12 @@ class GraphedTrainStep(object):
         return m.forward_losses(b['data_g'], b['cond_g'], b['cond2_g'], b['gt'], eps=b['eps'], with_gan=False, reg_via_bucket=True)
 
     def _keep_losses(self, out):
-        m = self.model
-        dst, src = [], []
+        """The step's loss values stay where the loss kernels wrote them: under capture those tensors live in the graph's
+        memory pool (kept alive by these references, so nothing later in the graph reuses them) and every replay rewrites
+        them in place -- no copy launches."""
         for k in ('loss_g', 'loss_d', 'recon', 'latent', 'edge'):
             if k in out and torch.is_tensor(out[k]):
-                if k not in self.losses:
-                    self.losses[k] = torch.zeros((), device=m.device)
-                dst.append(self.losses[k])
-                src.append(out[k].detach().reshape(()))
-        if dst:
-            torch._foreach_copy_(dst, src)
+                self.losses[k] = out[k].detach().reshape(())
 
     def _fwd_bwd(self):
         """forward + the whole backward pass (single-rank path; also what bench.py's per-launch timing replays)."""

@@ -499,14 +499,16 @@ int cape_groupnorm_param_reduce_batch(const cape_gn_param_item_t *items, int32_t
  *   training loss, lib/models.py:393-394): the weighted sum of the loss is then complete after this launch
  *   dpred = w_recon * d(recon)/dpred + w_edge * d(edge)/dpred      (dpred may be NULL)
  * edges: device int32 [E,2].  workspace >= cape_recon_edge_workspace_bytes(N, M, E).
+ * pred rows are ldp floats apart and dpred rows ldd (>= 3: the layer stack's outputs are padded to 16-byte rows, ld 4;
+ * samples follow each other after M rows); gt is dense [N, M, 3].
  */
 int64_t cape_recon_edge_workspace_bytes(int32_t N, int32_t M, int32_t E);
-int cape_recon_edge_loss_fwd_bwd(const float *pred, const float *gt, const float *verts_ref,
+int cape_recon_edge_loss_fwd_bwd(const float *pred, int32_t ldp, const float *gt, const float *verts_ref,
                                  const int32_t *edges, const int32_t *vert_edge_ptr,
                                  const int32_t *vert_edge_idx, int32_t N, int32_t M, int32_t E,
                                  float w_recon, float w_edge, float *loss_out, float *total_out,
                                  const float *term_a, float w_a, const float *term_b, float *dpred,
-                                 void *workspace, int64_t workspace_bytes, void *stream);
+                                 int32_t ldd, void *workspace, int64_t workspace_bytes, void *stream);
 
 /*
  * Adversarial losses on the discriminator's logits (lib/models.py:381-390, tf.nn.sigmoid_cross_entropy_with_logits with
@@ -596,15 +598,18 @@ int cape_fc_wide_bwd(const float *x, int32_t ldx, const float *g, int32_t ldg, c
  *   h    = leaky_relu(c1 W1 + b1, 0.2)   [N, hid]     (tf.layers.dense, pose MLP layer 1)
  *   ycat = [ h W2 + b2 | c2 Wc + bc ]    [N, out1 + out2]   (pose MLP layer 2 | clothing-type layer, concatenated the
  *          way every consumer concatenates them, :533, :591, :663)
- * W* row-major [in, out]; c1 / c2 rows ld1 / ld2 apart; h and ycat contiguous; N <= 64.  Backward: dycat [N, out1 + out2]
- * contiguous -> gradients of all six variables (written, not accumulated).  Fixed summation order (deterministic).
+ * W* row-major [in, out]; c1 / c2 rows ld1 / ld2 apart; h and ycat contiguous; N <= 64.  ycat2: NULL or a second buffer that
+ * receives the same values -- a consumer of its own (the decoder input [z | ycat], :296), whose gradient then reaches the
+ * backward separately instead of through an element-wise sum.  Backward: dycat / dycat2 [N, out1 + out2], rows lddy / lddy2
+ * floats apart, either may be NULL (zero), the kernel differentiates dycat + dycat2 -> gradients of all six variables
+ * (written, not accumulated).  Fixed summation order (deterministic).
  */
 int cape_condnet_fwd(const float *c1, int32_t ld1, const float *c2, int32_t ld2, const float *W1, const float *b1,
                      const float *W2, const float *b2, const float *Wc, const float *bc, float *h, float *ycat,
-                     int32_t N, int32_t in1, int32_t hid, int32_t out1, int32_t in2, int32_t out2, void *stream);
+                     float *ycat2, int32_t N, int32_t in1, int32_t hid, int32_t out1, int32_t in2, int32_t out2, void *stream);
 int cape_condnet_bwd(const float *c1, int32_t ld1, const float *c2, int32_t ld2, const float *W2, const float *h,
-                     const float *dycat, float *gW1, float *gb1, float *gW2, float *gb2, float *gWc, float *gbc,
-                     int32_t N, int32_t in1, int32_t hid, int32_t out1, int32_t in2, int32_t out2, void *stream);
+                     const float *dycat, int32_t lddy, const float *dycat2, int32_t lddy2, float *gW1, float *gb1,
+                     float *gW2, float *gb2, float *gWc, float *gbc, int32_t N, int32_t in1, int32_t hid, int32_t out1, int32_t in2, int32_t out2, void *stream);
 
 /*
  * ---- bf16 storage variants (BASELINE configs[4]: "bf16 weights/activations", SURVEY section 8(b) "_bf16") -----------------

@@ -354,6 +354,16 @@ def test_recon_edge_loss(mesh_ops, dev):
     (2.0 * total2).backward()
     assert abs(ha.grad.item() - 0.5) < 1e-6
     assert vertex_err(hp2.grad.cpu().numpy(), 2.0 * tp.grad.numpy()) < TOL
+    # a prediction lying in 16-byte rows (the decoder's own output layout) is read in place: same numbers
+    buf = torch.zeros((3, 6890, 4), dtype=torch.float32, device=dev)
+    buf[:, :, :3] = torch.tensor(pred, dtype=torch.float32, device=dev)
+    buf[:, :, 3] = 1e9                                           # the padding must never be read
+    hp3 = buf.requires_grad_(True)
+    total3, parts3 = ops.ReconEdgeLossFn.apply(hp3[:, :, :3], d(gt, torch.float32), d(vr, torch.float32), d(edges, torch.int32),
+                                               d(vptr, torch.int32), d(vidx, torch.int32), 0.7, 1.3)
+    total3.backward()
+    assert total3.item() == total.item() and torch.equal(parts3, parts)
+    assert torch.equal(hp3.grad[:, :, :3], hp.grad) and float(hp3.grad[:, :, 3].abs().max()) == 0.0
 
 
 def test_baseline_config2_full_size(mesh_ops, dev):

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_c_abi_exports_match_header():
     hdr = open(os.path.join(ROOT, "include", "cape_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|int64_t)\s+(cape_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int32_t|int64_t)\s+(cape_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 18
     lib = ctypes.CDLL(os.path.join(ROOT, "cape_amd", "libcape_hip.so"))
     for name in declared:
