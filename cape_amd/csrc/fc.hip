@@ -4,6 +4,7 @@
 // layer, ~0.1 GFLOP): every kernel here reads or writes each weight exactly once with coalesced accesses and
 // keeps the 16 activations rows in LDS; reductions are two-stage with a fixed summation order.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -549,6 +550,8 @@ __global__ __launch_bounds__(256) void fc_wide_bwd_dx_partial_v4_kernel(const fl
     }
 }
 
+#include "fc_mfma.h"
+
 inline bool fc_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 inline int long_args(LongArgs &A, int nmat, const float *const *W, const float *const *b, const float *const *g, float *const *y,
@@ -590,7 +593,12 @@ extern "C" int cape_fc_long_fwd(const float *x, int32_t ldx, int32_t N, int32_t 
     hipStream_t st = (hipStream_t)stream;
     bool v4 = N <= 16 && (out & 3) == 0;
     for (int m = 0; m < nmat; ++m) v4 = v4 && fc_al16(A.W[m]);
-    if (v4)
+    const bool m16 = fc_m16_on && v4 && (out == 64 || out == 128) && (in & 3) == 0 && (ldx & 3) == 0 && fc_al16(x) && fc_al16(workspace);
+    if (m16 && out == 64)
+        CAPE_LAUNCH((fc_long_partial_m16_kernel<1>), dim3(nsplit, nmat), dim3(256), 0, st, A, x, ldx, N, in, nsplit, (float *)workspace);
+    else if (m16)
+        CAPE_LAUNCH((fc_long_partial_m16_kernel<2>), dim3(nsplit, nmat), dim3(256), 0, st, A, x, ldx, N, in, nsplit, (float *)workspace);
+    else if (v4)
         CAPE_LAUNCH(fc_long_partial_v4_kernel, dim3(nsplit, nmat), dim3(256), 0, st, A, x, ldx, N, in, out, nsplit, (float *)workspace);
     else
         CAPE_LAUNCH(fc_long_partial_kernel, dim3(nsplit, nmat), dim3(256), (size_t)N * FC_RS * 4, st, A, x, ldx, N, in, out, nsplit, (float *)workspace);
@@ -612,6 +620,17 @@ extern "C" int cape_fc_long_bwd(const float *x, int32_t ldx, int32_t N, int32_t 
         if (!A.g[m]) return CAPE_EINVAL;
     bool v4 = N <= 16 && (out & 3) == 0 && (size_t)(16 * 64 + nmat * 16 * out) * 4 <= 60 * 1024;
     for (int m = 0; m < nmat; ++m) v4 = v4 && fc_al16(A.W[m]) && (!A.dW[m] || fc_al16(A.dW[m]));
+    bool m16 = fc_m16_on && v4 && (out == 64 || (out == 128 && nmat == 1)) && (!dx || ((lddx & 3) == 0 && fc_al16(dx)));
+    for (int m = 0; m < nmat; ++m) m16 = m16 && fc_al16(A.g[m]);
+    if (m16) {
+        const dim3 grid((in + FC_RS - 1) / FC_RS);
+        hipStream_t st = (hipStream_t)stream;
+        if (out == 128) CAPE_LAUNCH((fc_long_bwd_m16_kernel<2, 1>), grid, dim3(256), 0, st, A, x, ldx, N, in, dx, lddx);
+        else if (nmat == 1) CAPE_LAUNCH((fc_long_bwd_m16_kernel<1, 1>), grid, dim3(256), 0, st, A, x, ldx, N, in, dx, lddx);
+        else CAPE_LAUNCH((fc_long_bwd_m16_kernel<1, 2>), grid, dim3(256), 0, st, A, x, ldx, N, in, dx, lddx);
+        CAPE_LAUNCH_CHECK();
+        return CAPE_OK;
+    }
     if (v4) {
         CAPE_LAUNCH(fc_long_bwd_v4_kernel, dim3((in + 63) / 64), dim3(256), (size_t)(16 * 64 + nmat * 16 * out) * 4, (hipStream_t)stream, A, x, ldx, N,
                     in, out, dx, lddx);
@@ -629,7 +648,15 @@ extern "C" int cape_fc_wide_fwd(const float *x, int32_t ldx, int32_t N, int32_t 
                                 const float *b, int32_t act, float *y, int32_t ldy, void *stream) {
     if (!x || !W || !y || N < 1 || N > FC_MAXN || in < 1 || out < 1 || ldx < in || ldy < out) return CAPE_EINVAL;
     if (act < CAPE_ACT_NONE || act > CAPE_ACT_TANH || (long long)N * in * 4 > 48 * 1024) return CAPE_EINVAL;
-    if (N <= 16 && (out & 3) == 0 && fc_al16(W) && (size_t)(16 * in + 4 * 16 * 128) * 4 <= 60 * 1024)
+    const bool m16 = fc_m16_on && N <= 16 && (out & 63) == 0 && (in == 64 || in == 128 || in == 256) && fc_al16(W) && fc_al16(x) &&
+                     (ldx & 3) == 0 && fc_al16(y) && (ldy & 3) == 0 && (!b || fc_al16(b));
+    if (m16 && in == 64)
+        CAPE_LAUNCH((fc_wide_fwd_m16_kernel<1>), dim3(out / 64), dim3(256), 0, (hipStream_t)stream, x, ldx, N, out, W, b, act, y, ldy);
+    else if (m16 && in == 128)
+        CAPE_LAUNCH((fc_wide_fwd_m16_kernel<2>), dim3(out / 64), dim3(256), 0, (hipStream_t)stream, x, ldx, N, out, W, b, act, y, ldy);
+    else if (m16)
+        CAPE_LAUNCH((fc_wide_fwd_m16_kernel<4>), dim3(out / 64), dim3(256), 0, (hipStream_t)stream, x, ldx, N, out, W, b, act, y, ldy);
+    else if (N <= 16 && (out & 3) == 0 && fc_al16(W) && (size_t)(16 * in + 4 * 16 * 128) * 4 <= 60 * 1024)
         CAPE_LAUNCH(fc_wide_fwd_v4_kernel, dim3((out + 127) / 128), dim3(256), (size_t)(16 * in + 4 * 16 * 128) * 4, (hipStream_t)stream, x, ldx, N,
                     in, out, W, b, act, y, ldy);
     else
@@ -654,7 +681,14 @@ extern "C" int cape_fc_wide_bwd(const float *x, int32_t ldx, const float *g, int
     if (dW || db) {
         const bool v4 = N <= 16 && (out & 3) == 0 && (ldg & 3) == 0 && fc_al16(g) && (!dW || fc_al16(dW)) && (!db || fc_al16(db)) &&
                         (act == CAPE_ACT_NONE || ((ldy & 3) == 0 && fc_al16(y)));
-        if (v4)
+        const bool m16 = fc_m16_on && v4 && (out & 63) == 0 && (in == 64 || in == 128 || in == 256) && (ldx & 3) == 0;
+        if (m16 && in == 64)
+            CAPE_LAUNCH((fc_wide_bwd_dw_m16_kernel<1>), dim3(out / 64), dim3(256), 0, st, x, ldx, g, ldg, y, ldy, act, N, out, dW, db);
+        else if (m16 && in == 128)
+            CAPE_LAUNCH((fc_wide_bwd_dw_m16_kernel<2>), dim3(out / 64), dim3(256), 0, st, x, ldx, g, ldg, y, ldy, act, N, out, dW, db);
+        else if (m16)
+            CAPE_LAUNCH((fc_wide_bwd_dw_m16_kernel<4>), dim3(out / 64), dim3(256), 0, st, x, ldx, g, ldg, y, ldy, act, N, out, dW, db);
+        else if (v4)
             CAPE_LAUNCH(fc_wide_bwd_dw_v4_kernel, dim3((out + 255) / 256, dW ? 4 : 1), dim3(256), (size_t)16 * in * 4, st, x, ldx, g, ldg, y, ldy, act, N, in, out,
                         dW, db);
         else
@@ -665,8 +699,15 @@ extern "C" int cape_fc_wide_bwd(const float *x, int32_t ldx, const float *g, int
     if (dx) {
         if (lddx < in || !workspace) return CAPE_EINVAL;
         if (workspace_bytes < cape_fc_wide_bwd_workspace_bytes(N, in, out)) return CAPE_EWORKSPACE;
-        const int chunks = (out + 63) / 64;
-        if (N <= 16 && (in & 3) == 0 && fc_al16(workspace) && ((size_t)64 * (in + 4) + 16 * 64) * 4 <= 60 * 1024)
+        int chunks = (out + 63) / 64;
+        const bool m16 = fc_m16_on && N <= 16 && (out & 63) == 0 && (in == 64 || in == 128 || in == 256) && fc_al16(W) && fc_al16(g) && (ldg & 3) == 0 &&
+                         (act == CAPE_ACT_NONE || ((ldy & 3) == 0 && fc_al16(y)));
+        if (m16) {
+            chunks = (chunks + FC_DXC - 1) / FC_DXC;             // partial slabs: one per FC_DXC chunks of 64 columns
+            if (in == 64) CAPE_LAUNCH((fc_wide_bwd_dx_m16_kernel<1>), dim3(chunks), dim3(256), 0, st, g, ldg, y, ldy, act, N, out, W, (float *)workspace);
+            else if (in == 128) CAPE_LAUNCH((fc_wide_bwd_dx_m16_kernel<2>), dim3(chunks), dim3(256), 0, st, g, ldg, y, ldy, act, N, out, W, (float *)workspace);
+            else CAPE_LAUNCH((fc_wide_bwd_dx_m16_kernel<4>), dim3(chunks), dim3(256), 0, st, g, ldg, y, ldy, act, N, out, W, (float *)workspace);
+        } else if (N <= 16 && (in & 3) == 0 && fc_al16(workspace) && ((size_t)64 * (in + 4) + 16 * 64) * 4 <= 60 * 1024)
             CAPE_LAUNCH(fc_wide_bwd_dx_partial_v4_kernel, dim3(chunks), dim3(256), ((size_t)64 * (in + 4) + 16 * 64) * 4, st, g, ldg, y, ldy, act, N, in,
                         out, W, (float *)workspace);
         else

@@ -171,7 +171,7 @@ def test_cond_coef_all_layers():
     assert rel(hc.grad.cpu().numpy(), want_dc) < TOL
 
 
-@pytest.mark.parametrize("N,kin,out", [(5, 9001, 18), (16, 8256, 64), (11, 8200, 20)])
+@pytest.mark.parametrize("N,kin,out", [(5, 9001, 18), (16, 8256, 64), (11, 8200, 20), (11, 8256, 64), (16, 55168, 64), (7, 4100, 128)])
 def test_fc_long_pair(N, kin, out):
     """Encoder fc_mean / fc_var kernels (csrc/fc.hip) against float64 numpy, ragged sizes."""
     from cape_amd import ops
@@ -196,7 +196,8 @@ def test_fc_long_pair(N, kin, out):
     assert rel(y.detach().cpu().numpy(), x @ W[0] + b[0]) < TOL
 
 
-@pytest.mark.parametrize("N,kin,out,act", [(3, 50, 9001, "leaky_relu"), (16, 128, 8256, None), (13, 132, 8448, "leaky_relu")])
+@pytest.mark.parametrize("N,kin,out,act", [(3, 50, 9001, "leaky_relu"), (16, 128, 8256, None), (13, 132, 8448, "leaky_relu"),
+                                          (7, 128, 8256, "leaky_relu"), (16, 128, 55168, "leaky_relu"), (16, 64, 8256, None), (9, 256, 8256 + 64, "leaky_relu")])
 def test_fc_wide(N, kin, out, act):
     """Decoder fc1 kernels (bias + leaky-ReLU fused) against float64 numpy."""
     from cape_amd import ops
