@@ -147,9 +147,9 @@ SIGNATURES = {
     "cape_reduce_cond": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "cape_groupnorm_workspace_bytes": (_i64, [_i32, _i32, _i32]),
     "cape_groupnorm_fwd": (C.c_int, [_p, _i64, _i32, _p, _p, _f32, _i32, _i32, _p, _i64, _i32, _p, _p,
-                                     _i32, _i32, _i32, _p, _i64, _p]),
+                                     _i32, _i32, _i32, _p, _i64, _p, _p]),
     "cape_groupnorm_bwd": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _p, _p, _p, _i32, _i32, _p, _i64, _i32,
-                                     _p, _i64, _i32, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p]),
+                                     _p, _i64, _i32, _p, _p, _p, _i32, _i32, _i32, _p, _i64, _p, _p]),
     "cape_gan_bce_fwd_bwd": (C.c_int, [_p, _i64, _i32, _p, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _p, _p, _p, _p, _p, _p]),
     "cape_groupnorm_param_reduce_batch": (C.c_int, [C.c_void_p, _i32, _p]),
     "cape_cond_coef_fwd": (C.c_int, [_p, _i32, _i32, _i32, C.POINTER(CapeCondLayer), _i32, _p]),

@@ -173,8 +173,23 @@ __global__ __launch_bounds__(256) void gn_final_kernel(const float *part, int ch
     }
 }
 
+// max |o| over the valid lanes of a quad, then over the c4 consecutive lanes that hold the row; its first lane stores it
+__device__ __forceinline__ float gn_quad_bound(const float4 &o, int left) {
+    float m = fabsf(o.x);
+    if (left > 1) m = fmaxf(m, fabsf(o.y));
+    if (left > 2) m = fmaxf(m, fabsf(o.z));
+    if (left > 3) m = fmaxf(m, fabsf(o.w));
+    return m;
+}
+__device__ __forceinline__ void gn_row_bound(float *rm, long long row, const float4 &o, int left, int c4, bool first) {
+    const float m = cape_group_max(gn_quad_bound(o, left), c4);
+    if (first) cape_store_rowmax(rm, row, m);
+}
+
+// rm (may be null): row bounds of the output, [N*V][4] = (max_c |y|, 0, 0, 0), for the fp16 two-piece contractions that read y
+// next (csrc/gemm_h2.h); passed only when a row's quads are a power-of-two lane group of one wave (gn_rm_fused)
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float *x, long long xs, int ldx, const float *coef, int relu,
-                                                       float *y, long long ys, int ldy, int N, int V, int C) {
+                                                       float *y, long long ys, int ldy, int N, int V, int C, float *rm) {
     const int Cp = (C + 3) & ~3, c4 = Cp >> 2;
     const long long total = (long long)N * V * c4;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -191,6 +206,41 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *x, long long
             o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
         }
         gn_store4(y + (long long)n * ys + (long long)v * ldy + c, o, C - c);
+        if (rm) gn_row_bound(rm, nv, o, C - c, c4, c == 0);
+    }
+}
+
+// The same pass with WHOLE ROWS per block (256 / c4 rows, thread = one quad as above): for channel counts whose quads are no
+// power-of-two lane group (the GraphCMR blocks normalise [features | condition]: 288, 544 channels) the row bound goes through
+// an LDS maximum (non-negative floats order like their bit patterns; a NaN's pattern is above every finite one).  c4 <= 256.
+__global__ __launch_bounds__(256) void gn_apply_rows_kernel(const float *x, long long xs, int ldx, const float *coef, int relu,
+                                                            float *y, long long ys, int ldy, int N, int V, int C, float *rm) {
+    __shared__ unsigned mx[64];
+    const int Cp = (C + 3) & ~3, c4 = Cp >> 2;
+    const int RB = 256 / c4, rl = threadIdx.x / c4;
+    const long long rows = (long long)N * V;
+    for (long long base = (long long)blockIdx.x * RB; base < rows; base += (long long)gridDim.x * RB) {
+        if (threadIdx.x < RB) mx[threadIdx.x] = 0u;
+        __syncthreads();
+        const long long nv = base + rl;
+        if (rl < RB && nv < rows) {
+            const int v = (int)(nv % V), n = (int)(nv / V);
+            {
+            const int c = 4 * (threadIdx.x % c4);
+            const float *cf = coef + (long long)n * 4 * Cp + c;
+            const float4 a = *reinterpret_cast<const float4 *>(cf), b = *reinterpret_cast<const float4 *>(cf + Cp);
+            const float4 xv = *reinterpret_cast<const float4 *>(x + (long long)n * xs + (long long)v * ldx + c);
+            float4 o;
+            o.x = fmaf(a.x, xv.x, b.x); o.y = fmaf(a.y, xv.y, b.y); o.z = fmaf(a.z, xv.z, b.z); o.w = fmaf(a.w, xv.w, b.w);
+            if (relu) {
+                o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+            }
+            gn_store4(y + (long long)n * ys + (long long)v * ldy + c, o, C - c);
+            atomicMax(&mx[rl], __float_as_uint(gn_quad_bound(o, C - c)));
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < RB && base + threadIdx.x < rows) cape_store_rowmax(rm, base + threadIdx.x, __uint_as_float(mx[threadIdx.x]));
     }
 }
 
@@ -246,7 +296,7 @@ __global__ __launch_bounds__(256) void gn_bwd_final_kernel(const float *part, in
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *x, long long xs, int ldx, const float *dy, long long dys,
                                                            int lddy, const float *coef, const float *bcoef, int relu, float *dx,
                                                            long long dxs, int lddx, const float *add, long long adds, int ldadd,
-                                                           int N, int V, int C) {
+                                                           int N, int V, int C, float *rm) {
     const int Cp = (C + 3) & ~3, c4 = Cp >> 2;
     const long long total = (long long)N * V * c4;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -276,6 +326,54 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *x, long 
             o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
         }
         gn_store4(dx + (long long)n * dxs + (long long)v * lddx + c, o, C - c);
+        if (rm) gn_row_bound(rm, nv, o, C - c, c4, c == 0);
+    }
+}
+
+// whole rows per block, as gn_apply_rows_kernel
+__global__ __launch_bounds__(256) void gn_bwd_apply_rows_kernel(const float *x, long long xs, int ldx, const float *dy, long long dys,
+                                                                int lddy, const float *coef, const float *bcoef, int relu, float *dx,
+                                                                long long dxs, int lddx, const float *add, long long adds, int ldadd,
+                                                                int N, int V, int C, float *rm) {
+    __shared__ unsigned mx[64];
+    const int Cp = (C + 3) & ~3, c4 = Cp >> 2;
+    const int RB = 256 / c4, rl = threadIdx.x / c4;
+    const long long rows = (long long)N * V;
+    for (long long base = (long long)blockIdx.x * RB; base < rows; base += (long long)gridDim.x * RB) {
+        if (threadIdx.x < RB) mx[threadIdx.x] = 0u;
+        __syncthreads();
+        const long long nv = base + rl;
+        if (rl < RB && nv < rows) {
+            const int v = (int)(nv % V), n = (int)(nv / V);
+            {
+            const int c = 4 * (threadIdx.x % c4);
+            const float *cf = coef + (long long)n * 4 * Cp + c;
+            const float *bc = bcoef + (long long)n * 3 * Cp + c;
+            const float4 a = *reinterpret_cast<const float4 *>(cf), b = *reinterpret_cast<const float4 *>(cf + Cp);
+            const float4 rr = *reinterpret_cast<const float4 *>(cf + 2 * Cp), mr = *reinterpret_cast<const float4 *>(cf + 3 * Cp);
+            const float4 A = *reinterpret_cast<const float4 *>(bc), B = *reinterpret_cast<const float4 *>(bc + Cp);
+            const float4 Cc = *reinterpret_cast<const float4 *>(bc + 2 * Cp);
+            const float4 xv = *reinterpret_cast<const float4 *>(x + (long long)n * xs + (long long)v * ldx + c);
+            float4 d = *reinterpret_cast<const float4 *>(dy + (long long)n * dys + (long long)v * lddy + c);
+            if (relu) {
+                d.x = fmaf(a.x, xv.x, b.x) > 0.f ? d.x : 0.f; d.y = fmaf(a.y, xv.y, b.y) > 0.f ? d.y : 0.f;
+                d.z = fmaf(a.z, xv.z, b.z) > 0.f ? d.z : 0.f; d.w = fmaf(a.w, xv.w, b.w) > 0.f ? d.w : 0.f;
+            }
+            float4 o;
+            o.x = A.x * d.x - fmaf(fmaf(xv.x, rr.x, -mr.x), Cc.x, B.x);
+            o.y = A.y * d.y - fmaf(fmaf(xv.y, rr.y, -mr.y), Cc.y, B.y);
+            o.z = A.z * d.z - fmaf(fmaf(xv.z, rr.z, -mr.z), Cc.z, B.z);
+            o.w = A.w * d.w - fmaf(fmaf(xv.w, rr.w, -mr.w), Cc.w, B.w);
+            if (add) {
+                const float4 e = *reinterpret_cast<const float4 *>(add + (long long)n * adds + (long long)v * ldadd + c);
+                o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+            }
+            gn_store4(dx + (long long)n * dxs + (long long)v * lddx + c, o, C - c);
+            atomicMax(&mx[rl], __float_as_uint(gn_quad_bound(o, C - c)));
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < RB && base + threadIdx.x < rows) cape_store_rowmax(rm, base + threadIdx.x, __uint_as_float(mx[threadIdx.x]));
     }
 }
 
@@ -312,6 +410,17 @@ inline bool gn_shape_ok(int C, int G) {
     return C / G <= 256;
 }
 
+inline int gn_rows_grid(int N, int V, int C) {
+    const int RB = 256 / ((C + 3) >> 2);
+    return grid_for(((long long)N * V + RB - 1) / RB * 256);
+}
+
+// the apply kernels can bound whole rows when a row's float4 lanes are a power-of-two group inside one wave
+inline bool gn_rm_fused(int C) {
+    const int c4 = (C + 3) >> 2;
+    return c4 <= 64 && (c4 & (c4 - 1)) == 0;
+}
+
 }  // namespace
 
 extern "C" int64_t cape_groupnorm_workspace_bytes(int32_t N, int32_t V, int32_t C) {
@@ -324,7 +433,7 @@ extern "C" int64_t cape_groupnorm_workspace_bytes(int32_t N, int32_t V, int32_t 
 extern "C" int cape_groupnorm_fwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *gamma,
                                   const float *beta, float eps, int32_t G, int32_t relu, float *y, int64_t y_sample_stride,
                                   int32_t ldy, float *stats, float *coef, int32_t N, int32_t V, int32_t C, void *workspace,
-                                  int64_t workspace_bytes, void *stream) {
+                                  int64_t workspace_bytes, float *rowmax_out, void *stream) {
     if (!x || !gamma || !beta || !y || !stats || !coef || !workspace || N < 1 || V < 1 || C < 1 || G < 1 || (C % G) != 0 ||
         ldx < C || ldy < C)
         return CAPE_EINVAL;
@@ -339,9 +448,15 @@ extern "C" int cape_groupnorm_fwd(const float *x, int64_t x_sample_stride, int32
     CAPE_LAUNCH(gn_final_kernel, dim3(N * G), dim3(256), 0, st, (const float *)workspace, chunks, x, (long long)x_sample_stride,
                 gamma, beta, eps, G, V, C, stats, coef);
     CAPE_LAUNCH_CHECK();
-    CAPE_LAUNCH(gn_apply_kernel, dim3(grid_for((long long)N * V * ((C + 3) / 4))), dim3(256), 0, st, x, (long long)x_sample_stride, ldx,
-                (const float *)coef, relu, y, (long long)y_sample_stride, ldy, N, V, C);
+    const bool rows_form = rowmax_out && !gn_rm_fused(C) && C <= 1024;
+    if (rows_form)
+        CAPE_LAUNCH(gn_apply_rows_kernel, dim3(gn_rows_grid(N, V, C)), dim3(256), 0, st, x, (long long)x_sample_stride, ldx,
+                    (const float *)coef, relu, y, (long long)y_sample_stride, ldy, N, V, C, rowmax_out);
+    else
+        CAPE_LAUNCH(gn_apply_kernel, dim3(grid_for((long long)N * V * ((C + 3) / 4))), dim3(256), 0, st, x, (long long)x_sample_stride, ldx,
+                    (const float *)coef, relu, y, (long long)y_sample_stride, ldy, N, V, C, gn_rm_fused(C) ? rowmax_out : (float *)nullptr);
     CAPE_LAUNCH_CHECK();
+    if (rowmax_out && !rows_form && !gn_rm_fused(C)) return cape_rowmax(y, y_sample_stride, ldy, N, V, C, rowmax_out, 4, stream);
     return CAPE_OK;
 }
 
@@ -350,7 +465,7 @@ extern "C" int cape_groupnorm_bwd(const float *x, int64_t x_sample_stride, int32
                                   const float *coef, int32_t G, int32_t relu, float *dx, int64_t dx_sample_stride, int32_t lddx,
                                   const float *dx_add, int64_t add_sample_stride, int32_t ldadd,
                                   float *dgamma_partial, float *dbeta_partial, float *bcoef, int32_t N, int32_t V, int32_t C,
-                                  void *workspace, int64_t workspace_bytes, void *stream) {
+                                  void *workspace, int64_t workspace_bytes, float *rowmax_out, void *stream) {
     if (!x || !dy || !gamma || !stats || !coef || !dx || !dgamma_partial || !dbeta_partial || !bcoef || !workspace || N < 1 ||
         V < 1 || C < 1 || G < 1 || (C % G) != 0 || ldx < C || lddy < C || lddx < C || (dx_add && ldadd < C))
         return CAPE_EINVAL;
@@ -367,10 +482,17 @@ extern "C" int cape_groupnorm_bwd(const float *x, int64_t x_sample_stride, int32
     CAPE_LAUNCH(gn_bwd_final_kernel, dim3(N * G), dim3(256), 0, st, (const float *)workspace, chunks, gamma, stats, G, V, C,
                 dgamma_partial, dbeta_partial, bcoef);
     CAPE_LAUNCH_CHECK();
-    CAPE_LAUNCH(gn_bwd_apply_kernel, dim3(grid_for((long long)N * V * ((C + 3) / 4))), dim3(256), 0, st, x, (long long)x_sample_stride,
-                ldx, dy, (long long)dy_sample_stride, lddy, coef, (const float *)bcoef, relu, dx, (long long)dx_sample_stride, lddx,
-                dx_add, (long long)add_sample_stride, ldadd, N, V, C);
+    const bool rows_form = rowmax_out && !gn_rm_fused(C) && C <= 1024;
+    if (rows_form)
+        CAPE_LAUNCH(gn_bwd_apply_rows_kernel, dim3(gn_rows_grid(N, V, C)), dim3(256), 0, st, x, (long long)x_sample_stride, ldx, dy,
+                    (long long)dy_sample_stride, lddy, coef, (const float *)bcoef, relu, dx, (long long)dx_sample_stride, lddx, dx_add,
+                    (long long)add_sample_stride, ldadd, N, V, C, rowmax_out);
+    else
+        CAPE_LAUNCH(gn_bwd_apply_kernel, dim3(grid_for((long long)N * V * ((C + 3) / 4))), dim3(256), 0, st, x, (long long)x_sample_stride,
+                    ldx, dy, (long long)dy_sample_stride, lddy, coef, (const float *)bcoef, relu, dx, (long long)dx_sample_stride, lddx,
+                    dx_add, (long long)add_sample_stride, ldadd, N, V, C, gn_rm_fused(C) ? rowmax_out : (float *)nullptr);
     CAPE_LAUNCH_CHECK();
+    if (rowmax_out && !rows_form && !gn_rm_fused(C)) return cape_rowmax(dx, dx_sample_stride, lddx, N, V, C, rowmax_out, 4, stream);
     return CAPE_OK;
 }
 

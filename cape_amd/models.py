@@ -1072,6 +1072,7 @@ class CAPE(base_model):
                 if not failed:
                     ops.flush_deferred()
             finally:
+                ops._join_dw_stream()                 # (a failed sweep still rejoins its side branch before buffers go)
                 ops.DEFERRED = None
                 ops.DEFERRED_DW[:] = []
                 ops.DEFERRED_GN[:] = []

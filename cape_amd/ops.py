@@ -431,11 +431,16 @@ def h2_shape_ok(ktot, F):
     return F >= 64 and (ktot >= 256 or (ktot >= 128 and F >= 128))
 
 
-def _want_rm(t, Cn=None):
+def _want_rm(t, Cn=None, any_width=False):
     """Row bounds are worth writing for an output that can be an operand of the fp16 two-piece contraction: fp32, whole
-    32-channel chunks."""
+    32-channel chunks -- and, for the streaming sparse kernels, a power-of-two channel count (a row is then a lane group):
+    with other widths (the 288 / 544 channels of [features | condition]) they would add a standalone pass for every output,
+    wanted or not, so the consumer asks for one lazily instead (``rowmax``).  ``any_width``: producers that bound any row in
+    their own launch (group norm's wave-per-row apply pass)."""
     Cn = t.shape[2] if Cn is None else Cn
-    return bool(H2) and t.dtype == torch.float32 and Cn % 32 == 0 and Cn >= 32
+    if not (bool(H2) and t.dtype == torch.float32 and Cn % 32 == 0 and Cn >= 32):
+        return False
+    return any_width or (Cn & (Cn - 1)) == 0
 
 
 def _new_rm(t):
@@ -689,7 +694,15 @@ def gconv_dw(entries, dz, accumulate=False, dz2=None, defer=False):
             plan = (C.c_int32 * 4)()
             dw_plan(plan)
             PLAN_LOG.add(("dw", plan[0], plan[1], plan[2]) + (("bf16",) if bf else ()))
-        dw_stage(1)
+        if DW_STREAM_ON:
+            global _DW_FORKED
+            side = _dw_side_stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                dw_stage(1)
+            _DW_FORKED = True
+        else:
+            dw_stage(1)
         it = _lib.CapeDwItem()
         it.srcs, it.nsrc = C.addressof(arr), len(entries)
         it.dz, it.dz_sample_stride, it.lddz = p.value, ss, ld
@@ -957,6 +970,28 @@ DEFERRED = None
 DEFERRED_DW = []          # queued weight-gradient slab reductions (gconv_dw(defer=True)), same lifetime as DEFERRED
 DEFERRED_GN = []          # queued batch sums of group-norm parameter-gradient partials (GroupNormFn.backward), likewise
 
+# Weight-gradient contractions are leaves of the backward sweep (nothing reads dW before the flush): with CAPE_DW_STREAM=1 the
+# deferred ones run on a second HIP stream, forked where their dz is ready and joined before the batched slab reduction, so a
+# captured step holds them as a parallel branch next to the data-gradient chain.  Every operand is kept alive by DEFERRED_DW
+# until the join (no allocator reuse under the branch).
+DW_STREAM_ON = _os.environ.get("CAPE_DW_STREAM", "0") == "1"
+_DW_STREAM = None
+_DW_FORKED = False
+
+
+def _dw_side_stream():
+    global _DW_STREAM
+    if _DW_STREAM is None:
+        _DW_STREAM = torch.cuda.Stream()
+    return _DW_STREAM
+
+
+def _join_dw_stream():
+    global _DW_FORKED
+    if _DW_FORKED:
+        torch.cuda.current_stream().wait_stream(_DW_STREAM)
+        _DW_FORKED = False
+
 
 def flush_deferred():
     global DEFERRED
@@ -971,6 +1006,7 @@ def flush_deferred():
                 a.dgamma, a.dbeta = dst_g.data_ptr(), dst_b.data_ptr()
                 a.N, a.C = int(dgb.shape[1]), int(dgb.shape[2])
             check(lib.cape_groupnorm_param_reduce_batch(C.addressof(arr), len(chunk), _stream()), "cape_groupnorm_param_reduce_batch")
+    _join_dw_stream()
     if DEFERRED_DW:
         queued, DEFERRED_DW[:] = list(DEFERRED_DW), []
         nmax = 12                                    # CAPE_MAX_DW_REDUCE_ITEMS
@@ -1755,10 +1791,12 @@ class GroupNormFn(torch.autograd.Function):
         ws = torch.empty((need + 3) // 4, device=x.device, dtype=torch.float32)
         xp, xs, xl = _v(x)
         yp, ys, yl = _v(y)
+        rm = _new_rm(y) if _want_rm(y, any_width=True) else None      # the apply pass bounds the rows of its output for the contraction next
         _log_launch("groupnorm_fwd", 0, 3 * 4 * N * V * Cn,
                     lambda: check(lib.cape_groupnorm_fwd(xp, xs, xl, _ptr(gamma), _ptr(beta), float(eps), int(G), int(relu), yp, ys, yl,
-                                                         _ptr(stats), _ptr(coef), N, V, Cn, _ptr(ws), need, _stream()),
+                                                         _ptr(stats), _ptr(coef), N, V, Cn, _ptr(ws), need, _ptr(rm), _stream()),
                                   "cape_groupnorm_fwd"))
+        set_rm(y, rm)
         if relu:
             _trace_sign(y, "relu")             # y = relu(fma(a, x, b)): positive exactly where the kernel's fma was
         ctx.G, ctx.relu, ctx.passthrough = G, relu, bool(passthrough)
@@ -1797,10 +1835,12 @@ class GroupNormFn(torch.autograd.Function):
             ap, as_, al = _v(g_pass)
         else:
             ap, as_, al = None, 0, 0
+        rm = _new_rm(dx) if _want_rm(dx, any_width=True) else None
         _log_launch("groupnorm_bwd", 0, (5 + (1 if g_pass is not None else 0)) * 4 * N * V * Cn,
                     lambda: check(lib.cape_groupnorm_bwd(xp, xs, xl, gp, gs, gl, _ptr(gamma), _ptr(stats), _ptr(coef), int(ctx.G),
                                                          int(ctx.relu), dp, ds, dl, ap, as_, al, _ptr(dgb[0]), _ptr(dgb[1]),
-                                                         _ptr(bcoef), N, V, Cn, _ptr(ws), need, _stream()), "cape_groupnorm_bwd"))
+                                                         _ptr(bcoef), N, V, Cn, _ptr(ws), need, _ptr(rm), _stream()), "cape_groupnorm_bwd"))
+        set_rm(dx, rm)
         gg, gb_ = ctx.g_gamma, ctx.g_beta
         if (DEFERRED is not None and LAUNCH_LOG is None and gg is not None and gb_ is not None and gg.shape == (Cn,)
                 and gb_.shape == (Cn,) and gg.is_contiguous() and gb_.is_contiguous()):

@@ -461,12 +461,15 @@ int cape_reduce_cond(const float *dy, int64_t dy_sample_stride, int32_t lddy, co
  * b = beta - mean*a, rstd, mean*rstd) per channel; the forward evaluates y = relu?(fma(a, x, b)) and the backward
  * re-derives the ReLU mask from the same fma, so it never reads y.  Statistics: one pass of pivot-shifted sums
  * (pivot = the sample's first row), combined per group in float64.  workspace >= cape_groupnorm_workspace_bytes.
+ * rowmax_out: NULL or [N*V][4] floats that receive the row bounds (max_c |y|, 0, 0, 0) of the output -- of dx in the backward
+ * -- for the fp16 two-piece contractions that read it next (cape_gconv_fwd_h2): written by the apply pass itself when a row is
+ * a power-of-two lane group (C <= 256, C/4 a power of two), by a wave-per-row form of the same pass otherwise.
  */
 int64_t cape_groupnorm_workspace_bytes(int32_t N, int32_t V, int32_t C);
 int cape_groupnorm_fwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *gamma,
                        const float *beta, float eps, int32_t G, int32_t relu, float *y,
                        int64_t y_sample_stride, int32_t ldy, float *stats, float *coef, int32_t N, int32_t V,
-                       int32_t C, void *workspace, int64_t workspace_bytes, void *stream);
+                       int32_t C, void *workspace, int64_t workspace_bytes, float *rowmax_out, void *stream);
 /* dx (+ dx_add when not NULL: a second gradient of the same input -- the residual branch of res_block_decoder,
  * lib/models.py:744-774 -- summed in the apply pass instead of by a separate element-wise launch) plus per-sample partial
  * parameter gradients dgamma_partial / dbeta_partial [N, C] (the caller sums them over N); stats / coef are the forward
@@ -476,7 +479,7 @@ int cape_groupnorm_bwd(const float *x, int64_t x_sample_stride, int32_t ldx, con
                        const float *stats, const float *coef, int32_t G, int32_t relu, float *dx,
                        int64_t dx_sample_stride, int32_t lddx, const float *dx_add, int64_t add_sample_stride,
                        int32_t ldadd, float *dgamma_partial, float *dbeta_partial, float *bcoef, int32_t N,
-                       int32_t V, int32_t C, void *workspace, int64_t workspace_bytes, void *stream);
+                       int32_t V, int32_t C, void *workspace, int64_t workspace_bytes, float *rowmax_out, void *stream);
 
 /* dgamma[c] = sum_n dgamma_partial[n, c] (likewise dbeta) for up to CAPE_MAX_GN_REDUCE_ITEMS earlier cape_groupnorm_bwd calls in
  * ONE launch, samples added in index order (the training step needs the parameter gradients only at the end of the backward

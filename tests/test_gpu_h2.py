@@ -254,6 +254,34 @@ def test_row_bounds_of_the_row_owning_producers(mesh_ops):
         assert ops.rm_of(dz2) is ops.rm_of(g) and np.all(ops.rm_of(dz2).cpu().numpy().max(-1) >= true)
 
 
+@pytest.mark.parametrize("Cn", [32, 64, 256, 96, 512])
+def test_group_norm_bounds_its_rows(Cn):
+    """The group-norm apply passes (forward output, backward dx) write the row bounds in the same launch when a row is a
+    power-of-two lane group (32 / 64 / 256 channels), through one standalone pass otherwise (96, 512): exact maxima either way."""
+    from cape_amd import ops
+    rng = np.random.default_rng(Cn)
+    N, V = 3, 131
+    x = _act((rng.standard_normal((N, V, Cn)) * _row_scales(N, V, rng)[:, :, None]).astype(np.float32)).requires_grad_(True)
+    gamma = torch.tensor(rng.standard_normal(Cn).astype(np.float32), device=DEV, requires_grad=True)
+    beta = torch.tensor(rng.standard_normal(Cn).astype(np.float32), device=DEV, requires_grad=True)
+    for relu in (0, 1):
+        y = ops.GroupNormFn.apply(x, gamma, beta, ops.group_count(N, Cn), 1e-5, relu)
+        rm = ops.rm_of(y)
+        assert rm is not None and rm.shape == (N, V, 4)
+        r = rm.cpu().numpy()
+        assert np.array_equal(r[:, :, 0], np.abs(y.detach().cpu().numpy()).max(-1)) and np.all(r[:, :, 1:] == 0)
+        g = _act((rng.standard_normal((N, V, Cn)) * _row_scales(N, V, rng)[:, :, None]).astype(np.float32))
+        seen = {}
+        h = x.register_hook(lambda t: seen.setdefault("dx", t))
+        y.backward(g)
+        h.remove()
+        dx = seen["dx"]
+        rd = ops.rm_of(dx)
+        assert rd is not None, "the gradient tensor handed to the next backward carries its bounds"
+        assert np.array_equal(rd.cpu().numpy()[:, :, 0], np.abs(dx.cpu().numpy()).max(-1))
+        x.grad = None
+
+
 DW_CASES = [(2, 203, [64], 72), (16, 862, [256, 256], 512), (5, 330, [128, 64], 132), (16, 1723, [128, 128], 128)]
 
 
