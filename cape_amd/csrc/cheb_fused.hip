@@ -683,19 +683,26 @@ extern "C" int cape_cheb_fused_bwd(const float *x, int64_t x_sample_stride, int3
     size_t lds = 0;
     const int rc = cf_fill(p, N, M, Cin, Fout, K, P, pinfo, vid, ell_col, ell_val, rmax, true, lds);
     if (rc != CAPE_OK) return rc;
-    if (!x || !dy || !W || !dx || !dW || !workspace || ldx < Cin || lddy < Fout || lddx < Cin ||
-        !cf_aligned(x, x_sample_stride, ldx) || !cf_aligned(dx, dx_sample_stride, lddx) || (reinterpret_cast<uintptr_t>(dW) & 15))
+    // dx / dW: either may be NULL -- that half of the backward pass is skipped (a data-gradient-only sweep through the layer,
+    // or a layer whose input needs no gradient)
+    if (!x || !dy || !W || (!dx && !dW) || !workspace || ldx < Cin || lddy < Fout || (dx && lddx < Cin) ||
+        !cf_aligned(x, x_sample_stride, ldx) || (dx && !cf_aligned(dx, dx_sample_stride, lddx)) || (reinterpret_cast<uintptr_t>(dW) & 15))
         return CAPE_EINVAL;
     if (workspace_bytes < cape_cheb_fused_bwd_workspace_bytes(N, Cin, Fout, K, P)) return CAPE_EWORKSPACE;
     p.x = x; p.xs = x_sample_stride; p.ldx = ldx; p.W = W;
     p.dy = dy; p.dys = dy_sample_stride; p.lddy = lddy;
     p.dx = dx; p.dxs = dx_sample_stride; p.lddx = lddx;
     p.dwpart = (float *)workspace;
-    const int rc2 = cf_dispatch<CfDw>(Cin, Fout, p, lds, (hipStream_t)stream);
-    if (rc2 != CAPE_OK) return rc2;
-    const int rc3 = cf_dispatch<CfDx>(Cin, Fout, p, (size_t)2 * rmax * (Cin + 4) * sizeof(float) + (size_t)K * Cin * Fout * sizeof(float),
-                                      (hipStream_t)stream);
-    if (rc3 != CAPE_OK) return rc3;
+    if (dW) {
+        const int rc2 = cf_dispatch<CfDw>(Cin, Fout, p, lds, (hipStream_t)stream);
+        if (rc2 != CAPE_OK) return rc2;
+    }
+    if (dx) {
+        const int rc3 = cf_dispatch<CfDx>(Cin, Fout, p, (size_t)2 * rmax * (Cin + 4) * sizeof(float) + (size_t)K * Cin * Fout * sizeof(float),
+                                          (hipStream_t)stream);
+        if (rc3 != CAPE_OK) return rc3;
+    }
+    if (!dW) return CAPE_OK;
     const long long elems = (long long)K * Cin * Fout;
     const long long nslab = (long long)N * P;
     const long long per = (nslab + CF_RED_GROUPS - 1) / CF_RED_GROUPS;

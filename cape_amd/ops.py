@@ -1614,15 +1614,20 @@ class ChebConvFusedFn(torch.autograd.Function):
             ga = alloc_act(N, M, Fout, g.device)
             ga.copy_(g)
             g = ga
-        dx = alloc_act(N, M, Cin, x.device)
-        dW = torch.empty_like(W)
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if NO_WEIGHT_GRAD and W.data_ptr() in NO_WEIGHT_GRAD:
+            need_w = False                             # data-gradient-only sweep through this layer (see NO_WEIGHT_GRAD)
+        if not (need_x or need_w):
+            return None, None, None, None
+        dx = alloc_act(N, M, Cin, x.device) if need_x else None
+        dW = torch.empty_like(W) if need_w else None
         need = int(lib.cape_cheb_fused_bwd_workspace_bytes(N, Cin, Fout, K, plan.P))
         if need < 0:
             check(need, "cape_cheb_fused_bwd_workspace_bytes")
         ws = torch.empty((need + 3) // 4, device=x.device, dtype=torch.float32)
         xp, xs, xl = _v(x)
         gp, gs, gl = _v(g)
-        dp, ds, dl = _v(dx)
+        dp, ds, dl = _v(dx) if dx is not None else (None, 0, 0)
         nnz = int(ops.host.Lt.nnz)
         flops = 2 * (2 * N * M * Cin * K * Fout + (K - 1) * 2 * nnz * Cin * N + max(K - 2, 0) * 2 * M * Cin * N)
         _log_launch("cheb_fused_dw_kernel + cheb_fused_dx_kernel", flops, 4 * (2 * N * M * Cin + N * M * Fout + 2 * Cin * K * Fout) + 8 * nnz + 4 * (M + 1),

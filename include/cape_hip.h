@@ -680,7 +680,8 @@ int cape_colsum_vertex_bf16(const void *x, int64_t x_sample_stride, int32_t ldx,
  * Supported: fp32, Cin in {8, 16, 24, 32}, Fout in {32, 64}, rows 16-byte aligned (cape_cheb_fused_supported).
  * The backward entry needs L~ symmetric (it is: lib/mesh_sampling.py:10-38 builds I - D^-1/2 A D^-1/2); it recomputes the
  * recurrence for dW = sum_n sum_k T_k(L~) x[n]^T dy[n] (per-workgroup partials in ``workspace``, reduced in a fixed order)
- * and evaluates dx[n] = sum_k T_k(L~) dy[n] W_k^T by Clenshaw's recurrence.  Deterministic, no atomics.
+ * and evaluates dx[n] = sum_k T_k(L~) dy[n] W_k^T by Clenshaw's recurrence.  Deterministic, no atomics.  Either of dx / dW
+ * may be NULL: that half is skipped (a data-gradient-only sweep through the layer; an input that needs no gradient).
  */
 int cape_cheb_fused_supported(int32_t Cin, int32_t Fout, int32_t K);
 int cape_cheb_fused_fwd(const float *x, int64_t x_sample_stride, int32_t ldx, const float *W, float *y,

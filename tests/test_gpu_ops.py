@@ -481,6 +481,15 @@ def test_cheb_fused_recurrence(case, mesh_ops, dev):
     assert vertex_err(hy.detach().cpu().numpy(), hy2.detach().cpu().numpy().astype(np.float64)) < TOL
     assert vertex_err(gx.cpu().numpy(), hx.grad.cpu().numpy().astype(np.float64)) < TOL
     assert mat_err(gW.cpu().numpy(), hW.grad.cpu().numpy().astype(np.float64)) < TOL
+    # either half alone: a data-gradient-only sweep (NO_WEIGHT_GRAD names the kernel) and an input that needs no gradient
+    ops.NO_WEIGHT_GRAD = {hW.data_ptr()}
+    try:
+        (dx_only,) = torch.autograd.grad(ops.chebyshev5(hx, hW, dops), [hx], torch.tensor(dy, dtype=torch.float32, device=dev))
+    finally:
+        ops.NO_WEIGHT_GRAD = None
+    assert torch.equal(dx_only, gx)
+    (dw_only,) = torch.autograd.grad(ops.chebyshev5(hx.detach(), hW, dops), [hW], torch.tensor(dy, dtype=torch.float32, device=dev))
+    assert torch.equal(dw_only, gW)
 
 
 def test_cheb_fused_with_bias_and_activation(mesh_ops, dev):
