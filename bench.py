@@ -229,22 +229,23 @@ def cpu_baseline(batch=16, iters=5, budget_s=150.0):
                        "median of %d timed passes (%.1f s of CPU work)" % (batch, len(times), sum(times)))
 
 
-def exact_fp32_run(args):
-    """The same step with every contraction on the exact-fp32 MFMA (CAPE_GEMM_BF16X6=0 CAPE_DW_BF16X6=0; the library reads the knobs once
-    per process, hence a child process): reported NEXT TO the headline so that both arithmetic paths are measured by the
-    same bench invocation.  Never replaces ``value``; any failure is reported as a string instead of aborting the line."""
+def exact_fp32_run(args, env_over=None, note=None):
+    """The same step with every contraction on the exact-fp32 MFMA (CAPE_H2=0 CAPE_GEMM_BF16X6=0 CAPE_DW_BF16X6=0; the library reads the
+    knobs once per process, hence a child process): reported NEXT TO the headline so that both arithmetic paths are measured by
+    the same bench invocation.  Never replaces ``value``; any failure is reported as a string instead of aborting the line.
+    ``env_over`` / ``note``: another knob setting measured the same way (the six-product bf16 split of round 3)."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(min(args.steps, 30)), '--warmup', str(min(args.warmup, 5)),
            '--batch', str(args.batch), '--config', args.config, '--no-cpu-baseline', '--no-roofline', '--no-ab', '--no-extras']
     if args.gan:
         cmd.append('--gan')
     try:
-        env = dict(os.environ, CAPE_GEMM_BF16X6='0', CAPE_DW_BF16X6='0')
+        env = dict(os.environ, **(env_over or dict(CAPE_H2='0', CAPE_GEMM_BF16X6='0', CAPE_DW_BF16X6='0')))
         out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=180, check=True)
         line = [l for l in out.stdout.decode().splitlines() if l.startswith('{')][-1]
         r = json.loads(line)
         return {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
-                "note": "same step, CAPE_GEMM_BF16X6=0 CAPE_DW_BF16X6=0: all contractions on v_mfma_f32_32x32x2_f32"}
+                "note": note or "same step, CAPE_H2=0 CAPE_GEMM_BF16X6=0 CAPE_DW_BF16X6=0: all contractions on v_mfma_f32_32x32x2_f32"}
     except Exception as e:                                  # noqa: BLE001 -- the comparison is optional
         return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
@@ -541,10 +542,13 @@ def main():
                    "arithmetic": "bf16 activation storage (BASELINE configs[4] per-GPU shard): bf16 operands, one bf16 MFMA product "
                                  "per multiply-add, fp32 accumulate, fp32 master weights / dense layers / losses / optimiser"
                    if args.dtype == 'bf16' else
-                                 "fp32 in/out/accumulate; eligible contractions (forward incl. the affine DUAL form, data "
-                                 "gradient, weight gradient) as 6 bf16 MFMA products per multiply-add on an exact 3-way "
-                                 "bf16 split of each fp32 operand (fp32 accuracy, not bit-identical to an fp32 FMA chain; "
-                                 "inf operands give NaN), exact-fp32 MFMA for odd-channel / packed launches",
+                                 "fp32 in/out/accumulate; contractions over >= 256 channels (>= 128 with F >= 128; forward incl. the "
+                                 "affine DUAL form, data gradient, weight gradient) as 3 fp16 MFMA products per multiply-add on a "
+                                 "two-piece fp16 split (hi + lo, 22 significand bits) of each operand, scaled by a power of two per "
+                                 "activation row / weight column (fp32-class accuracy: rms error ~0.7x that of an fp32 FMA chain, "
+                                 "tests/test_h2_numerics.py; not bit-identical; inf / NaN operands stay in their rows); shorter "
+                                 "contractions as 6 bf16 products on an exact 3-way bf16 split; exact-fp32 MFMA for odd-channel / "
+                                 "packed launches and the dense layers",
                    "final_loss_g": loss},
         "roofline": roof,
         "step_roofline": step_roofline(ms, args.batch, args.gan, args.dtype == 'bf16', cmr=args.config.startswith("CAPE_nz18"))
@@ -558,6 +562,9 @@ def main():
         result["cpu_baseline"] = None
     if world == 1 and not args.no_ab and not args.host_inputs and args.dtype == 'fp32' and os.environ.get("CAPE_GEMM_BF16X6", "1") != "0":
         result["exact_fp32_mfma"] = exact_fp32_run(args)
+        if os.environ.get("CAPE_H2", "1") != "0":
+            result["bf16x6_split"] = exact_fp32_run(args, dict(CAPE_H2='0'),
+                                                    "same step, CAPE_H2=0: every eligible contraction as 6 bf16 products (the arithmetic of round 3)")
     if (world == 1 and not args.no_extras and not args.host_inputs and args.dtype == 'fp32' and not args.global_batch
             and args.config.startswith("CAPE-affineconv_nz64") and not args.no_graph):
         result["extra_configs"], result["scaling_model"] = extra_measurements(args, ms, model)

@@ -104,13 +104,14 @@ __global__ __launch_bounds__(256) void cond_coef_dw_kernel(CondLayers L, const f
     }
 }
 
-// dcond[n, c] = sum_l sum_r sum_f dcoef_l[n, r, f] * Wrow_l(c, r)[f]: block = (n, group of 16 c), 16 lanes per c,
-// each lane strides the f range in float4 steps with four independent accumulators.
+// dcond[n, c] = sum_l sum_r sum_f dcoef_l[n, r, f] * Wrow_l(c, r)[f]: block = (n, group of 4 c), one WAVE per c, each lane
+// strides the f range in float4 steps with four independent accumulators.  (16 lanes per c and 16 c per block left 64 blocks
+// with ~100 dependent loads per lane: 21 us for 1.5 MB of weights; a wave per c: 256 blocks, a quarter of the chain.)
 __global__ __launch_bounds__(256) void cond_coef_dcond_kernel(CondLayers L, float *dcond, int ldd, int N, int Cc, int accumulate) {
-    const int cgroups = (Cc + 15) / 16;
+    const int cgroups = (Cc + 3) / 4;
     const int n = blockIdx.x / cgroups;
-    const int c = (blockIdx.x % cgroups) * 16 + (threadIdx.x >> 4);
-    const int lane = threadIdx.x & 15;
+    const int c = (blockIdx.x % cgroups) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < Cc) {
         for (int li = 0; li < L.nlayers; ++li) {
@@ -125,20 +126,20 @@ __global__ __launch_bounds__(256) void cond_coef_dcond_kernel(CondLayers L, floa
                     const int F4 = Y.F >> 2;
                     const float4 *w4 = reinterpret_cast<const float4 *>(w), *d4 = reinterpret_cast<const float4 *>(d);
 #pragma unroll 4
-                    for (int q = lane; q < F4; q += 16) {
+                    for (int q = lane; q < F4; q += 64) {
                         const float4 a = d4[q], b = w4[q];
                         s0 = fmaf(a.x, b.x, s0); s1 = fmaf(a.y, b.y, s1); s2 = fmaf(a.z, b.z, s2); s3 = fmaf(a.w, b.w, s3);
                     }
                 } else {
-                    for (int f = lane; f < Y.F; f += 16) s0 = fmaf(d[f], w[f], s0);
+                    for (int f = lane; f < Y.F; f += 64) s0 = fmaf(d[f], w[f], s0);
                 }
             }
         }
     }
     float s = (s0 + s1) + (s2 + s3);
-    // fixed-order reduction over the 16 lanes of this c (lanes of one c are contiguous within a wave)
+    // fixed-order reduction over the wave of this c
 #pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) s += __shfl_down(s, off, 16);
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0 && c < Cc) {
         float *dst = dcond + (long long)n * ldd + c;
         *dst = accumulate ? (*dst + s) : s;
@@ -192,7 +193,7 @@ extern "C" int cape_cond_coef_bwd(const float *cond, int32_t ldc, int32_t N, int
         CAPE_LAUNCH_CHECK();
     }
     if (dcond) {
-        CAPE_LAUNCH(cond_coef_dcond_kernel, dim3(N * ((Cc + 15) / 16)), dim3(256), 0, st, L, dcond, ldd, N, Cc, accumulate);
+        CAPE_LAUNCH(cond_coef_dcond_kernel, dim3(N * ((Cc + 3) / 4)), dim3(256), 0, st, L, dcond, ldd, N, Cc, accumulate);
         CAPE_LAUNCH_CHECK();
     }
     return CAPE_OK;

@@ -38,11 +38,13 @@ make -C $R/tools/ubench > /dev/null 2>&1
 (cd $R/tools/ubench && ./mfma_peak) > $O/${TAG}_ubench_mfma_peak.txt 2>&1
 # split data-parallel step with the real collective backend (one-rank RCCL group, collectives forced on)
 python $R/tools/dp_selftest.py 2>&1 | grep -v "UserWarning\|run_backward\|amdgpu.ids\|socket.cpp\|^$" > $O/${TAG}_dp_selftest.txt
-# round 3: split-GEMM structure experiments (interleaved fragment reads = what the library runs; ping-pong; producer/consumer),
-# phase stamps of the on-chip Chebyshev kernel, error decomposition of the bf16-storage model
-(cd $R/tools/ubench && timeout 120 ./gemm_bf16x3 ilv) > $O/${TAG}_ubench_split_interleave.txt 2>&1
-(cd $R/tools/ubench && timeout 120 ./gemm_bf16x3 v4) > $O/${TAG}_ubench_split_pingpong.txt 2>&1
-(cd $R/tools/ubench && timeout 120 ./gemm_bf16x3 v5) > $O/${TAG}_ubench_split_producer_consumer.txt 2>&1
+# round 4: the fp16 two-piece kernels -- standalone pipeline experiment (accuracy vs float64 + phase timings) and the library's
+# h2 / six-product kernels side by side over the layer shapes of the benchmarked model
+(cd $R/tools/ubench && timeout 120 ./gemm_h2) > $O/${TAG}_ubench_h2_final.txt 2>&1
+(cd $R/tools/ubench && timeout 180 ./h2_bench) > $O/${TAG}_h2_bench_final.txt 2>&1
+# same-box A/B of this round's switches on the replayed step
+for kv in "CAPE_H2=1" "CAPE_H2=0" "CAPE_FUSE_ACT_GRAD=0" "CAPE_FC_MFMA=0" "CAPE_DW_STREAM=1"; do
+  echo "$kv $(env $kv python $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-extras --no-ab --no-roofline 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"], "ms/step")')"
+done > $O/${TAG}_switch_ab.txt
 cd $R && timeout 120 python tools/cheb_fused_phases.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_cheb_fused_phases.txt
-cd $R && timeout 400 python tools/diag_bf16_error.py 2 2>&1 | grep -v amdgpu.ids > $O/${TAG}_diag_bf16_error.txt
 ls $O | grep "^${TAG}_" | wc -l
