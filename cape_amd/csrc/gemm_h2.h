@@ -132,8 +132,14 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GconvParams p) {
     struct Cur { int si, c0; };
     Cur cb = {0, 0}, ca = {0, 0};
     unsigned bvoff[BPW], bvoff2[DUAL ? BPW : 1];
+    // the fields of the current source live in registers between source changes: a scalar load of p.s[si] inside the chunk
+    // loop shares its wait counter (lgkmcnt) with the LDS fragment reads and would drain them once per chunk
+    const unsigned short *b_wh = nullptr, *b_wl = nullptr, *b_wh2 = nullptr, *b_wl2 = nullptr;
+    int b_C = 0, a_C = 0;
     auto open_b = [&]() {
         const SrcDev &S = p.s[cb.si];
+        b_wh = S.wh; b_wl = S.wl; b_C = S.C;
+        if constexpr (DUAL) { b_wh2 = S.wh2; b_wl2 = S.wl2; }
 #pragma unroll
         for (int j = 0; j < BPW; ++j) {
             bvoff[j] = (unsigned)(((long long)bcol[j] * S.wp + 8 * dseg) * 2);
@@ -144,28 +150,28 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GconvParams p) {
     __amdgpu_buffer_rsrc_t arsrc;
     auto open_a = [&]() {
         const SrcDev &S = p.s[ca.si];
+        a_C = S.C;
         arsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(S.x + (long long)n * S.xs), 0, 0x7FFFFFFC, 0x00020000);
 #pragma unroll
         for (int i = 0; i < PA; ++i) avoff[i] = (rc[i] * S.ldx + 8 * q) * 4;
     };
     unsigned has2 = 0;                                   // (DUAL) bit b: the chunk staged in LDS buffer b carries a second weight set
     auto dma = [&](int buf) {
-        const SrcDev &S = p.s[cb.si];
         const unsigned dst = lds0 + buf * STAGE;
 #pragma unroll
         for (int j = 0; j < BPW; ++j)
-            h2_glds16((bplane[j] ? S.wl : S.wh) + cb.c0, bvoff[j], dst + bdst[j]);
+            h2_glds16((bplane[j] ? b_wl : b_wh) + cb.c0, bvoff[j], dst + bdst[j]);
         if constexpr (DUAL) {
-            const bool two = S.wh2 != nullptr;
+            const bool two = b_wh2 != nullptr;
             has2 = (has2 & ~(1u << buf)) | ((two ? 1u : 0u) << buf);
             if (two) {
 #pragma unroll
                 for (int j = 0; j < BPW; ++j)
-                    h2_glds16((bplane[j] ? S.wl2 : S.wh2) + cb.c0, bvoff2[j], dst + bdst[j] + 2 * BPL);
+                    h2_glds16((bplane[j] ? b_wl2 : b_wh2) + cb.c0, bvoff2[j], dst + bdst[j] + 2 * BPL);
             }
         }
         cb.c0 += H2_KC;
-        if (cb.c0 >= S.C) {
+        if (cb.c0 >= b_C) {
             cb.c0 = 0;
             ++cb.si;
             if (cb.si < p.nsrc) open_b();
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GconvParams p) {
             ra[i][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, avoff[i] + 16, so, 0));
         }
         ca.c0 += H2_KC;
-        if (ca.c0 >= p.s[ca.si].C) {
+        if (ca.c0 >= a_C) {
             ca.c0 = 0;
             ++ca.si;
             if (ca.si < p.nsrc) open_a();
