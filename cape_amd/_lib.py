@@ -98,6 +98,7 @@ _SRCP = C.POINTER(CapeSrc)
 
 SIGNATURES = {
     "cape_abi_version": (C.c_int, []),
+    "cape_spin_us": (C.c_int, [_i32, _p]),
     "cape_csr_validate": (C.c_int, [_i32, _i32, _i64, _p, _p]),
     "cape_gconv_fwd": (C.c_int, [_SRCP, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p, _i32, _i32, _p,
                                  C.POINTER(CapeRank), _i32, _p]),

@@ -367,7 +367,9 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? 2 : 3) void dw_h2_ker
     constexpr int RK = 32, PITCH = 80;                // bytes per LDS row of one piece plane: 32 halfs + 16 B pad
     constexpr int WTM = CT / 2, WTN = FT / 2;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int CPA = CT / 64, CPB = FT / 64;       // channels per thread (8 rows each)
+    constexpr int CPA = CT / 64, CPB = FT / 64;       // channels per thread (8 rows each): lane, lane + 64 -- consecutive lanes write
+                                                      // LDS rows PITCH = 80 B apart (16 lanes = 16 different 16-byte bank groups);
+                                                      // with channels 2 lane, 2 lane + 1 the 160 B stride cost 24-33 % of the LDS cycles
     constexpr int APLANE = CT * PITCH, BPLANE = FT * PITCH;
     static_assert(TM >= 1 && TN >= 1 && (CT == 64 || CT == 128) && (FT == 64 || FT == 128), "tile");
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (APLANE + BPLANE)];
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? 2 : 3) void dw_h2_ker
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
     const int rg = tid >> 6;
-    const int ca = (tid & 63) * CPA, fb = (tid & 63) * CPB;
+    const int ca = tid & 63, fb = tid & 63;
 
     const int ntiles = p.tile_off[p.nsrc];
     int tile, split;
@@ -435,8 +437,11 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? 2 : 3) void dw_h2_ker
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
 
-    const int a_col = (c0 + ca < S.C) ? c0 + ca : 0;
-    const int b_col = (f0 + fb < p.F) ? f0 + fb : 0;
+    int a_col[CPA], b_col[CPB];
+#pragma unroll
+    for (int ch = 0; ch < CPA; ++ch) a_col[ch] = (c0 + ca + 64 * ch < S.C) ? c0 + ca + 64 * ch : 0;
+#pragma unroll
+    for (int ch = 0; ch < CPB; ++ch) b_col[ch] = (f0 + fb + 64 * ch < p.F) ? f0 + fb + 64 * ch : 0;
     const int chunks = (rb - ra + RK - 1) / RK;
     const int total = (n_end - n_begin) * chunks;
     int l_n = n_begin, l_r = ra;
@@ -444,26 +449,18 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? 2 : 3) void dw_h2_ker
     unsigned ok = 0;
 
     auto load_regs = [&]() {
-        const float *xb = S.x + (long long)l_n * S.xs + a_col;
-        const float *zb = dz0 + (long long)l_n * p.dzs + b_col;
+        const float *xb = S.x + (long long)l_n * S.xs;
+        const float *zb = dz0 + (long long)l_n * p.dzs;
         ok = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int r = l_r + 8 * rg + j;
             ok |= (r < rb ? 1u : 0u) << j;
             const int rr = min(r, rb - 1);
-            if constexpr (CPA == 2) {
-                const float2 v = cape_ld2(xb + (long long)rr * S.ldx);
-                xa[0][j] = v.x; xa[1][j] = v.y;
-            } else {
-                xa[0][j] = cape_ld(xb + (long long)rr * S.ldx);
-            }
-            if constexpr (CPB == 2) {
-                const float2 v = cape_ld2(zb + (long long)rr * p.lddz);
-                xz[0][j] = v.x; xz[1][j] = v.y;
-            } else {
-                xz[0][j] = cape_ld(zb + (long long)rr * p.lddz);
-            }
+#pragma unroll
+            for (int ch = 0; ch < CPA; ++ch) xa[ch][j] = cape_ld(xb + (long long)rr * S.ldx + a_col[ch]);
+#pragma unroll
+            for (int ch = 0; ch < CPB; ++ch) xz[ch][j] = cape_ld(zb + (long long)rr * p.lddz + b_col[ch]);
         }
         l_r += RK;
         if (l_r >= rb) { l_r = ra; ++l_n; }
@@ -479,9 +476,9 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? 2 : 3) void dw_h2_ker
     };
     auto store_regs = [&]() {
 #pragma unroll
-        for (int ch = 0; ch < CPA; ++ch) store8(sA + (ca + ch) * PITCH + 16 * rg, APLANE, xa[ch], sx);
+        for (int ch = 0; ch < CPA; ++ch) store8(sA + (ca + 64 * ch) * PITCH + 16 * rg, APLANE, xa[ch], sx);
 #pragma unroll
-        for (int ch = 0; ch < CPB; ++ch) store8(sB + (fb + ch) * PITCH + 16 * rg, BPLANE, xz[ch], sz);
+        for (int ch = 0; ch < CPB; ++ch) store8(sB + (fb + 64 * ch) * PITCH + 16 * rg, BPLANE, xz[ch], sz);
     };
     auto compute = [&]() {
         const unsigned char *pa = sA + (wm * WTM + li) * PITCH;

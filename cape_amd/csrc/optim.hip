@@ -163,6 +163,19 @@ extern "C" int cape_flat_gradnorm(const float *g, const float *w, int64_t n, con
     return CAPE_OK;
 }
 
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+extern "C" int cape_spin_us(int32_t us, void *stream) {
+    if (us < 0 || us > 100000) return CAPE_EINVAL;
+    if (us == 0) return CAPE_OK;
+    CAPE_LAUNCH(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)us * 100);        // s_memrealtime: 100 MHz
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}
+
 extern "C" int cape_sumsq_ranges(const float *x, const int64_t *ranges, int32_t nranges, float scale, float *out,
                                  void *workspace, int64_t workspace_bytes, void *stream) {
     if (!x || !out || !workspace || nranges < 1 || !al16(x)) return CAPE_EINVAL;

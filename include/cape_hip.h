@@ -130,6 +130,11 @@ typedef struct cape_cond_layer {
 
 int cape_abi_version(void);
 
+/* Measurement utility: keep the stream busy for about ``us`` microseconds (one wave spinning on the 100 MHz wall clock, no
+ * memory traffic).  bench.py's per-launch timing enqueues it in front of every bracketed launch, so that the start event, the
+ * launch and the stop event are all queued while it runs and the bracket measures the kernel, not the host's launch path. */
+int cape_spin_us(int32_t us, void *stream);
+
 /* Host-side structural check of a CSR operator (host pointers). */
 int cape_csr_validate(int32_t rows, int32_t cols, int64_t nnz, const int32_t *rowptr,
                       const int32_t *colidx);
