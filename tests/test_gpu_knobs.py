@@ -20,6 +20,11 @@ KNOBS = [
     dict(CAPE_GEMM_PLAIN="0", CAPE_DW_PLAIN="0"),              # generic gather kernels for every launch
     dict(CAPE_SPMM_UNROLL="0"),                                # sparse kernels: plain entry loop
     dict(CAPE_SPMM_UNROLL="8"),                                # sparse kernels: entries in unrolled groups of 8
+    dict(CAPE_H2="0"),                                         # no piece planes / row bounds: the six-product kernels of round 3
+                                                               # (what bench.py reports as ``bf16x6_split``)
+    dict(CAPE_GEMM_H2="0", CAPE_DW_H2="0"),                    # operands attached, the library ignores them
+    dict(CAPE_H2_TILE="128x128"),                              # forced tiles of the two-piece forward kernel
+    dict(CAPE_H2_TILE="64x64"),
 ]
 
 
@@ -33,3 +38,24 @@ def test_operator_parity_under_knob(knobs):
     tail = r.stdout.decode()[-1500:]
     assert r.returncode == 0, tail
     assert " passed" in tail and "failed" not in tail, tail
+
+
+def test_dense_layers_on_the_register_tiled_kernels():
+    """CAPE_FC_MFMA=0: the long dense layers on the kernels of csrc/fc.hip instead of csrc/fc_mfma.h, same parity cases."""
+    env = dict(os.environ, CAPE_FC_MFMA="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_ragged.py"), "-x", "-q", "-m", "gpu", "-k", "fc_"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    tail = r.stdout.decode()[-1500:]
+    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, tail
+
+
+def test_step_without_the_fused_activation_gradient_and_with_the_side_stream():
+    """CAPE_FUSE_ACT_GRAD=0 (op-by-op backward-prep in the encoder) and CAPE_DW_STREAM=1 (deferred weight-gradient contractions
+    as a parallel branch of the captured step) both have to reproduce the reference golden at batch 16 and the twin's gradients."""
+    for knobs in (dict(CAPE_FUSE_ACT_GRAD="0"), dict(CAPE_DW_STREAM="1")):
+        env = dict(os.environ, **knobs)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_model.py"), "-x", "-q", "-m", "gpu",
+                            "-k", "test_batch16_parity_covers_every_bench_kernel or test_train_step_matches_manual_update"],
+                           env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        tail = r.stdout.decode()[-1500:]
+        assert r.returncode == 0 and " passed" in tail and "failed" not in tail, (knobs, tail)

@@ -54,6 +54,8 @@ int main(int argc, char **argv) {
         {16, 3445, 2, 64, 64, 1},
         {16, 6890, 2, 64, 64, 0}, {16, 6890, 1, 64, 128, 0}, {16, 6890, 1, 64, 64, 0}, {16, 6890, 1, 32, 64, 0},
     };
+    if (argc > 2)                                    // batch override: how do the short launches behave over more rounds of workgroups?
+        for (Shape &s : shapes) s.N = atoi(argv[2]);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     double tot[2] = {0, 0};
     for (const Shape &s : shapes) {
