@@ -104,45 +104,48 @@ __global__ __launch_bounds__(256) void cond_coef_dw_kernel(CondLayers L, const f
     }
 }
 
-// dcond[n, c] = sum_l sum_r sum_f dcoef_l[n, r, f] * Wrow_l(c, r)[f]: block = (n, group of 4 c), one WAVE per c, each lane
-// strides the f range in float4 steps with four independent accumulators.  (16 lanes per c and 16 c per block left 64 blocks
-// with ~100 dependent loads per lane: 21 us for 1.5 MB of weights; a wave per c: 256 blocks, a quarter of the chain.)
+// dcond[n, c] = sum_l sum_r sum_f dcoef_l[n, r, f] * Wrow_l(c, r)[f]: block = (n, c); the (layer, r) pairs are dealt round robin to
+// the four waves, each lane strides the f range in float4 steps with four independent accumulators.  The pairs are a chain
+// of dependent accesses (layer descriptor -> row pointers -> data: ~0.8 us each, 24 of them in the benchmarked model); one
+// wave per c walked the whole chain (19-21 us for 1.5 MB of weights), four waves a quarter of it.
 __global__ __launch_bounds__(256) void cond_coef_dcond_kernel(CondLayers L, float *dcond, int ldd, int N, int Cc, int accumulate) {
-    const int cgroups = (Cc + 3) / 4;
-    const int n = blockIdx.x / cgroups;
-    const int c = (blockIdx.x % cgroups) * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+    __shared__ float red[4];
+    const int n = blockIdx.x / Cc, c = blockIdx.x % Cc;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (c < Cc) {
-        for (int li = 0; li < L.nlayers; ++li) {
-            const cape_cond_layer_t &Y = L.l[li];
-            const int R = Y.K + (Y.w_aff ? 1 : 0);
-            const bool v4 = (Y.F & 3) == 0 && ((reinterpret_cast<uintptr_t>(Y.w) | reinterpret_cast<uintptr_t>(Y.dcoef) |
-                                                 reinterpret_cast<uintptr_t>(Y.w_aff)) & 15) == 0;
-            for (int r = 0; r < R; ++r) {
-                const float *w = (r < Y.K) ? Y.w + ((long long)c * Y.K + r) * Y.F : Y.w_aff + (long long)c * Y.F;
-                const float *d = Y.dcoef + ((long long)n * R + r) * Y.F;
-                if (v4) {
-                    const int F4 = Y.F >> 2;
-                    const float4 *w4 = reinterpret_cast<const float4 *>(w), *d4 = reinterpret_cast<const float4 *>(d);
-#pragma unroll 4
-                    for (int q = lane; q < F4; q += 64) {
-                        const float4 a = d4[q], b = w4[q];
-                        s0 = fmaf(a.x, b.x, s0); s1 = fmaf(a.y, b.y, s1); s2 = fmaf(a.z, b.z, s2); s3 = fmaf(a.w, b.w, s3);
-                    }
-                } else {
-                    for (int f = lane; f < Y.F; f += 64) s0 = fmaf(d[f], w[f], s0);
+    int pair = 0;
+    for (int li = 0; li < L.nlayers; ++li) {
+        const cape_cond_layer_t &Y = L.l[li];
+        const int R = Y.K + (Y.w_aff ? 1 : 0);
+        const bool v4 = (Y.F & 3) == 0 && ((reinterpret_cast<uintptr_t>(Y.w) | reinterpret_cast<uintptr_t>(Y.dcoef) |
+                                             reinterpret_cast<uintptr_t>(Y.w_aff)) & 15) == 0;
+        for (int r = 0; r < R; ++r, ++pair) {
+            if ((pair & 3) != wave) continue;
+            const float *w = (r < Y.K) ? Y.w + ((long long)c * Y.K + r) * Y.F : Y.w_aff + (long long)c * Y.F;
+            const float *d = Y.dcoef + ((long long)n * R + r) * Y.F;
+            if (v4) {
+                const int F4 = Y.F >> 2;
+                const float4 *w4 = reinterpret_cast<const float4 *>(w), *d4 = reinterpret_cast<const float4 *>(d);
+#pragma unroll 2
+                for (int q = lane; q < F4; q += 64) {
+                    const float4 a = d4[q], b = w4[q];
+                    s0 = fmaf(a.x, b.x, s0); s1 = fmaf(a.y, b.y, s1); s2 = fmaf(a.z, b.z, s2); s3 = fmaf(a.w, b.w, s3);
                 }
+            } else {
+                for (int f = lane; f < Y.F; f += 64) s0 = fmaf(d[f], w[f], s0);
             }
         }
     }
     float s = (s0 + s1) + (s2 + s3);
-    // fixed-order reduction over the wave of this c
+    // fixed-order reduction: the lanes of a wave, then the four waves
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0 && c < Cc) {
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (red[0] + red[1]) + (red[2] + red[3]);
         float *dst = dcond + (long long)n * ldd + c;
-        *dst = accumulate ? (*dst + s) : s;
+        *dst = accumulate ? (*dst + t) : t;
     }
 }
 
@@ -193,7 +196,7 @@ extern "C" int cape_cond_coef_bwd(const float *cond, int32_t ldc, int32_t N, int
         CAPE_LAUNCH_CHECK();
     }
     if (dcond) {
-        CAPE_LAUNCH(cond_coef_dcond_kernel, dim3(N * ((Cc + 3) / 4)), dim3(256), 0, st, L, dcond, ldd, N, Cc, accumulate);
+        CAPE_LAUNCH(cond_coef_dcond_kernel, dim3(N * Cc), dim3(256), 0, st, L, dcond, ldd, N, Cc, accumulate);
         CAPE_LAUNCH_CHECK();
     }
     return CAPE_OK;

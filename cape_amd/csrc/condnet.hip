@@ -41,8 +41,11 @@ __global__ __launch_bounds__(256) void condnet_fwd_kernel(CondNetP p) {
     for (int j0 = 0; j0 < p.hid; j0 += 64) {               // hidden layer, 64 columns at a time
         const int j = j0 + col;
         float a = 0.f;
-        if (j < p.hid)
+        if (j < p.hid) {
+            // (the weight loads are independent: eight in flight -- a rolled loop waits ~0.5 us for every one of its ~32)
+#pragma unroll 8
             for (int i = part; i < p.in1; i += 4) a = fmaf(s1[i], p.W1[(long long)i * p.hid + j], a);
+        }
         a = quad_sum(red, col, part, a, 64);
         if (part == 0 && j < p.hid) {
             a += p.b1[j];
@@ -57,9 +60,11 @@ __global__ __launch_bounds__(256) void condnet_fwd_kernel(CondNetP p) {
         const int f = f0 + col;
         float a = 0.f;
         if (f < p.out1) {
+#pragma unroll 8
             for (int j = part; j < p.hid; j += 4) a = fmaf(sh[j], p.W2[(long long)j * p.out1 + f], a);
         } else if (f < oc) {
             const int g = f - p.out1;
+#pragma unroll 4
             for (int i = part; i < p.in2; i += 4) a = fmaf(p.c2[(long long)n * p.ld2 + i], p.Wc[(long long)i * p.out2 + g], a);
         }
         a = quad_sum(red, col, part, a, 64);
@@ -97,6 +102,7 @@ __global__ __launch_bounds__(256) void condnet_bwd_kernel(CondNetP p) {
         for (int o = threadIdx.x; o < (p.in2 + 1) * p.out2; o += 256) {
             const int i = o / p.out2, g = o % p.out2;
             float a = 0.f;
+#pragma unroll 8
             for (int n = 0; n < p.N; ++n) a = fmaf(i < p.in2 ? p.c2[(long long)n * p.ld2 + i] : 1.f, sd[n * oc + p.out1 + g], a);
             if (i < p.in2) p.gWc[o] = a;
             else p.gbc[g] = a;
@@ -106,6 +112,7 @@ __global__ __launch_bounds__(256) void condnet_bwd_kernel(CondNetP p) {
     for (int o = threadIdx.x; o < p.N * p.hid; o += 256) {
         const int n = o / p.hid, j = o % p.hid;
         float a = 0.f;
+#pragma unroll 8
         for (int f = 0; f < p.out1; ++f) a = fmaf(sd[n * oc + f], p.W2[(long long)j * p.out1 + f], a);
         const float hv = sh[o];                            // own element only: the in-place update needs no barrier
         sh[o] = hv > 0.f ? a : 0.2f * a;
@@ -118,6 +125,7 @@ __global__ __launch_bounds__(256) void condnet_bwd_kernel(CondNetP p) {
     for (int o = threadIdx.x; o < (i1 - i0) * p.hid; o += 256) {
         const int i = i0 + o / p.hid, j = o % p.hid;
         float a = 0.f;
+#pragma unroll 8
         for (int n = 0; n < p.N; ++n) a = fmaf(i < p.in1 ? p.c1[(long long)n * p.ld1 + i] : 1.f, sh[n * p.hid + j], a);
         if (i < p.in1) p.gW1[(long long)i * p.hid + j] = a;
         else p.gb1[j] = a;
