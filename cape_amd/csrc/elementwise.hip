@@ -731,6 +731,67 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(CViewT<AT> g, CViewT<AT> 
     }
 }
 
+// narrow variant (F <= 4: the 3-channel output layer): thread = ROW, its F columns in registers.  The column-lane mapping
+// above keeps 3 of 64 lanes busy there, each walking its rows one dependent access at a time (24 us for 2 MB).
+template <typename AT = float>
+__global__ __launch_bounds__(256) void bwd_prep_narrow_kernel(CViewT<AT> g, CViewT<AT> y, int act, const unsigned *mask, ViewT<AT> dz,
+                                                              const float *rowscale, int R, int rg, int want_bias, int want_g,
+                                                              int N, int Mo, int F, float *part, int chunks, int RB) {
+    __shared__ float red[4][BP_MAXT * 4];
+    const int n = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+    const int ra = ch * RB, rb = min(Mo, ra + RB);
+    const int T = R + 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[BP_MAXT][4];
+#pragma unroll
+    for (int j = 0; j < BP_MAXT; ++j)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[j][f] = 0.f;
+    for (int r = ra + (int)threadIdx.x; r < rb; r += 256) {
+        float gv[4], rs[RSR_MAXR], rsg = 0.f;
+        const unsigned mw = mask ? mask[(long long)n * Mo + r] : 0u;            // F <= 4: one sign word per row
+#pragma unroll
+        for (int f = 0; f < 4; ++f) gv[f] = f < F ? cape_ld(g.p + (long long)n * g.ss + (long long)r * g.ld + f) : 0.f;
+#pragma unroll
+        for (int j = 0; j < RSR_MAXR; ++j) rs[j] = j < R ? rowscale[(long long)j * Mo + r] : 0.f;
+        if (want_g) rsg = rowscale[(long long)rg * Mo + r];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            if (f >= F) continue;
+            float d;
+            if (mask) d = ((mw >> f) & 1u) ? gv[f] : 0.f;
+            else if (act != CAPE_ACT_NONE) d = gv[f] * cape_act_grad_from_out(cape_ld(y.p + (long long)n * y.ss + (long long)r * y.ld + f), act);
+            else d = gv[f];
+            cape_st(dz.p + (long long)n * dz.ss + (long long)r * dz.ld + f, d);
+            acc[0][f] += d;
+#pragma unroll
+            for (int j = 0; j < RSR_MAXR; ++j) acc[1 + j][f] = fmaf(rs[j], d, acc[1 + j][f]);
+            acc[BP_MAXT - 1][f] = fmaf(rsg, gv[f], acc[BP_MAXT - 1][f]);
+        }
+    }
+    // fixed-order sums: the lanes of a wave (xor butterflies), then the four waves
+#pragma unroll
+    for (int j = 0; j < BP_MAXT; ++j)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            float v = acc[j][f];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0) red[wave][j * 4 + f] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < BP_MAXT * 4) {
+        const int j = threadIdx.x >> 2, f = threadIdx.x & 3;
+        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        float *pp = part + ((long long)n * chunks + ch) * T * F;
+        if (f < F) {
+            if (j == 0) { if (want_bias) pp[f] = t; }
+            else if (j == BP_MAXT - 1) { if (want_g) pp[(R + 1) * F + f] = t; }
+            else if (j - 1 < R) pp[j * F + f] = t;
+        }
+    }
+}
+
 // vector variant (F % VW == 0, aligned views): thread = (column group of VW channels, row lane).  The rows of a lane are
 // taken UR at a time: the UR gradient rows (and their sign words / outputs) are all loaded before the first is used, so a
 // thread waits for one memory round trip per UR rows instead of one per row.
@@ -1356,6 +1417,9 @@ int bwd_prep_impl(const T *g, int64_t g_sample_stride, int32_t ldg, const T *y, 
         else CAPE_BP_LAUNCH(4, 1);
     }
 #undef CAPE_BP_LAUNCH
+    else if (F <= 4)
+        CAPE_LAUNCH((bwd_prep_narrow_kernel<T>), dim3(N * chunks), dim3(256), 0, st, gv, yv, act, mask, zv, rowscale, R, rg, dbias ? 1 : 0,
+                    dcoef_g ? 1 : 0, N, Mo, F, (float *)workspace, chunks, RB);
     else
         CAPE_LAUNCH((bwd_prep_kernel<T>), dim3(N * chunks), dim3(256), 0, st, gv, yv, act, mask, zv, rowscale, R, rg, dbias ? 1 : 0,
                     dcoef_g ? 1 : 0, N, Mo, F, (float *)workspace, chunks, RB);
