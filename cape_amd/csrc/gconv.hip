@@ -15,6 +15,7 @@
 #include "gemm_plain.h"
 #include "gemm_split.h"
 #include "gemm_h2.h"
+#include "narrow.h"
 #include <stdlib.h>
 
 namespace {
@@ -1012,6 +1013,10 @@ int gconv_dw_plan_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz, in
         fill_h2_dw(p, h2);
         if (h2_dw_eligible(p)) plan[0] = 4;
     }
+    {
+        const int nm = dw_narrow_mode(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, F, plan[0], bf16);
+        if (nm) plan[0] = nm;
+    }
     plan[1] = pl.ct; plan[2] = pl.ft; plan[3] = pl.ngroups * pl.rsplit;
     return CAPE_OK;
 }
@@ -1127,8 +1132,13 @@ int gconv_dw_stage_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz,
     fill_h2_dw(p, bf16 ? nullptr : h2);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(pl.ntiles * ((pl.ngroups * pl.rsplit + 7) / 8) * 8)), block(256);     // cape_map_dw_block
+    const int narrow = dw_narrow_mode(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, F, fam, bf16);
     if (stage >= 2) {
         // reduction only: the partial slabs of an earlier stage-1 call with the same arguments are in the workspace
+    } else if (narrow == 6) {                                   // narrow.h: same splits and slabs, tile 0's workgroups do all sources
+        int sumC = 0;
+        for (int i = 0; i < nsrc; ++i) sumC += srcs[i].C;
+        CAPE_LAUNCH(dw_narrow_out_kernel, grid, block, 16384, st, p, narrow_lpr(sumC / 4), pl.ntiles);
     } else if (!bf16 && dw_split && h2_dw_eligible(p)) {
         h2_dw_launch(p, pl.ct, pl.ft, grid, st);                // fp16 two-piece operands: same tiles, splits and slabs
     } else if (bf16 && dw_split) {

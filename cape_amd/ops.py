@@ -343,7 +343,8 @@ def _log_launch(name, flops, byts, fn):
 
 
 _FWD_FAMILY = {0: "gconv_fwd_kernel", 1: "gemm_plain_kernel", 2: "gemm_split_kernel", 3: "gemm_h2_kernel"}
-_DW_FAMILY = {0: "gconv_dw_kernel", 1: "dw_plain_kernel", 2: "dw_packed_kernel", 3: "dw_split_kernel", 4: "dw_h2_kernel"}
+_DW_FAMILY = {0: "gconv_dw_kernel", 1: "dw_plain_kernel", 2: "dw_packed_kernel", 3: "dw_split_kernel", 4: "dw_h2_kernel",
+              6: "dw_narrow_out_kernel"}
 
 
 def fwd_kernel_name(fam, bm, bn, layout, dual, bf16=False):
@@ -361,6 +362,8 @@ def fwd_kernel_name(fam, bm, bn, layout, dual, bf16=False):
 
 
 def dw_kernel_name(fam, ct, ft, bf16=False):
+    if fam == 6:
+        return _DW_FAMILY[fam]
     if fam == 4:
         return "dw_h2_kernel<%d, %d>" % (ct, ft)
     if fam == 3 or fam == 0:

@@ -25,6 +25,7 @@ KNOBS = [
     dict(CAPE_GEMM_H2="0", CAPE_DW_H2="0"),                    # operands attached, the library ignores them
     dict(CAPE_H2_TILE="128x128"),                              # forced tiles of the two-piece forward kernel
     dict(CAPE_H2_TILE="64x64"),
+    dict(CAPE_NARROW="0"),                                     # weight gradient of the 3-channel output layer on the tile kernels
 ]
 
 
