@@ -788,7 +788,8 @@ inline int choose_dw(const cape_src_t *srcs, int nsrc, const float *dz, int64_t 
 
 // Kernel choice of one forward launch (pure function of the arguments).
 struct FwdPlan {
-    int family;   // 0: gather-GEMM (gconv_fwd_kernel), 1: pipelined plain GEMM (gemm_plain_kernel),
+    int family;   // 4: plain sources with <= 8 input channels in total (fwd_narrow_in_kernel; plain epilogue only, else family 1)
+                  // 0: gather-GEMM (gconv_fwd_kernel), 1: pipelined plain GEMM (gemm_plain_kernel),
                   // 2: plain GEMM on the bf16 matrix pipe with exact three-way operand split (gemm_split_kernel)
                   // 3: plain GEMM as three fp16 products on two-piece operands (gemm_h2_kernel; needs cape_h2_t operands)
     int BM, BN;
@@ -834,6 +835,16 @@ inline FwdPlan plan_fwd(const GconvParams &p, const cape_src_t *srcs, bool dual,
         if (gs_on && gs_eligible(p, dual)) {
             pl.family = 2;
             gs_tile(dual, p.N, p.Mo, p.F, pl.BM, pl.BN);
+            return pl;
+        }
+        // at most 8 input channels over all sources (the 3-channel network inputs): the narrow side in registers (narrow.h)
+        static const int narrow_on = getenv("CAPE_NARROW") ? atoi(getenv("CAPE_NARROW")) : 1;
+        int sumC = 0;
+        for (int i = 0; i < p.nsrc; ++i) sumC += p.s[i].C;
+        if (narrow_on && !dual && sumC <= NARROW_MAXC && (p.F & 3) == 0 && p.F >= 16 && p.F <= 256 &&
+            (long long)p.N * p.Mo < (1LL << 31)) {
+            pl.family = 4;
+            pl.BM = 256 / narrow_lpr(p.F / 4); pl.BN = p.F;
             return pl;
         }
         pl.family = 1;
@@ -926,7 +937,23 @@ int gconv_fwd_impl(const cape_src_t *srcs, int32_t nsrc, float *y, int64_t y_sam
     }
     rc = fill_h2(p, h2, dual, dK);
     if (rc) return rc;
-    const FwdPlan pl = plan_fwd(p, srcs, dual, bf16);
+    FwdPlan pl = plan_fwd(p, srcs, dual, bf16);
+    if (pl.family == 4) {
+        // the narrow kernel has the plain epilogue (bias + activation, float4 stores); anything else takes the tile kernel
+        const bool ok = !p.rankR && !p.mask && dK == 1 && !p.rm_out && (ldy & 3) == 0 && (y_sample_stride & 3) == 0 &&
+                        (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0);
+        if (ok) {
+            const int lpr = narrow_lpr(F / 4), RL = 256 / lpr;
+            long long blocks = ((long long)N * Mo + 4 * RL - 1) / (4 * RL);       // four rows per thread and pass
+            if (blocks > 1024) blocks = 1024;                                     // (per-block set-up: weights into LDS, pointer table)
+            CAPE_LAUNCH(fwd_narrow_in_kernel, dim3((unsigned)blocks), dim3(256), (size_t)NARROW_MAXC * 4 * lpr * sizeof(float),
+                        (hipStream_t)stream, p, lpr);
+            CAPE_LAUNCH_CHECK();
+            return CAPE_OK;
+        }
+        pl.family = 1;
+        gp_tile(dual, p.F, pl.BM, pl.BN);
+    }
     p.row_tiles = (Mo + pl.BM - 1) / pl.BM;
     p.col_tiles = (F + pl.BN - 1) / pl.BN;
     dim3 grid((unsigned)(N * p.row_tiles * p.col_tiles));
@@ -1135,7 +1162,9 @@ int gconv_dw_stage_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz,
     const int narrow = dw_narrow_mode(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, F, fam, bf16);
     if (stage >= 2) {
         // reduction only: the partial slabs of an earlier stage-1 call with the same arguments are in the workspace
-    } else if (narrow == 6) {                                   // narrow.h: same splits and slabs, tile 0's workgroups do all sources
+    } else if (narrow == 5) {                                   // narrow.h: same splits and slabs, tile 0's workgroups do all sources
+        CAPE_LAUNCH(dw_narrow_in_kernel, grid, block, 32768, st, p, narrow_lpr(F / 4), pl.ntiles);
+    } else if (narrow == 6) {
         int sumC = 0;
         for (int i = 0; i < nsrc; ++i) sumC += srcs[i].C;
         CAPE_LAUNCH(dw_narrow_out_kernel, grid, block, 16384, st, p, narrow_lpr(sumC / 4), pl.ntiles);

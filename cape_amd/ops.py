@@ -342,9 +342,9 @@ def _log_launch(name, flops, byts, fn):
     return out
 
 
-_FWD_FAMILY = {0: "gconv_fwd_kernel", 1: "gemm_plain_kernel", 2: "gemm_split_kernel", 3: "gemm_h2_kernel"}
+_FWD_FAMILY = {0: "gconv_fwd_kernel", 1: "gemm_plain_kernel", 2: "gemm_split_kernel", 3: "gemm_h2_kernel", 4: "fwd_narrow_in_kernel"}
 _DW_FAMILY = {0: "gconv_dw_kernel", 1: "dw_plain_kernel", 2: "dw_packed_kernel", 3: "dw_split_kernel", 4: "dw_h2_kernel",
-              6: "dw_narrow_out_kernel"}
+              5: "dw_narrow_in_kernel", 6: "dw_narrow_out_kernel"}
 
 
 def fwd_kernel_name(fam, bm, bn, layout, dual, bf16=False):
@@ -352,6 +352,8 @@ def fwd_kernel_name(fam, bm, bn, layout, dual, bf16=False):
     waves = "2, 2" if (bm, bn) in ((64, 128), (128, 128), (64, 64)) else "4, 1"
     tf = lambda b: "true" if b else "false"
     at = ", unsigned short" if bf16 else ", float"
+    if fam == 4:
+        return "fwd_narrow_in_kernel"
     if fam == 3:
         return "gemm_h2_kernel<%d, %d, %s>" % (bm, bn, tf(dual))
     if fam == 2:
@@ -362,7 +364,7 @@ def fwd_kernel_name(fam, bm, bn, layout, dual, bf16=False):
 
 
 def dw_kernel_name(fam, ct, ft, bf16=False):
-    if fam == 6:
+    if fam in (5, 6):
         return _DW_FAMILY[fam]
     if fam == 4:
         return "dw_h2_kernel<%d, %d>" % (ct, ft)
