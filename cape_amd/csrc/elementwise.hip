@@ -928,19 +928,23 @@ __device__ __forceinline__ void bwd_prep_final_block(int bid, const float *part,
     float *dst = nullptr;
     if (b == 0) {            // bias
         if (dbias && f < F) {
-            // four independent partial sums: the chain of dependent L2 loads, not bandwidth, bounds this loop
+            // sixteen independent partial sums: the chain of dependent L2 loads, not bandwidth, bounds this loop (the fused
+            // activation-gradient form leaves one partial per spmm_multi workgroup: 16 x 216 per column in the benchmarked model,
+            // 54 round trips with four sums)
             const long long total = (long long)N * chunks;
             const long long TF = (long long)T * F;
-            float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            constexpr int NS = 16;
+            float ps[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) ps[k] = 0.f;
             long long i = ln;
-            for (; i + 48 < total; i += 64) {
-                s += part[i * TF + f];
-                s1 += part[(i + 16) * TF + f];
-                s2 += part[(i + 32) * TF + f];
-                s3 += part[(i + 48) * TF + f];
+            for (; i + 16 * (NS - 1) < total; i += 16 * NS) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) ps[k] += part[(i + 16 * k) * TF + f];
             }
             for (; i < total; i += 16) s += part[i * TF + f];
-            s = (s + s1) + (s2 + s3);
+#pragma unroll
+            for (int k = 0; k < NS; k += 4) s += (ps[k] + ps[k + 1]) + (ps[k + 2] + ps[k + 3]);
             dst = dbias + f;
         }
     } else {
