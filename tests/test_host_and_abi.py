@@ -2,6 +2,7 @@
 host-side operator algebra, loaders, config assembly, and the loud-failure rule (no CPU fallback)."""
 import ctypes
 import os
+import sys
 import re
 
 import numpy as np
@@ -321,3 +322,17 @@ def test_deferred_sweep_flushes_inside_a_callers_except_block(monkeypatch):
             ops.DEFERRED.append("abandoned")
             raise ValueError("the sweep failed")
     assert len(calls) == 1 and ops.DEFERRED is None and ops.DEFERRED_DW == [] and ops.DEFERRED_GN == []
+
+
+def test_committed_pmc_summary_belongs_to_the_committed_kernel_sources():
+    """bench.py attaches `roofline.traffic` only while profiles/pmc_summary.json carries the fingerprint of cape_amd/csrc: a kernel
+    edit after the last evidence collection would silently turn the driver's line into `traffic: null`."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    meta = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))["_meta"]
+    assert meta["csrc_sha"] == bench._csrc_fingerprint(), "re-collect the PMC passes (tools/collect_profiles.sh) after kernel changes"
+    # and the summary covers the kernel the headline line names as dominant
+    line = [l for l in open(os.path.join(ROOT, "profiles", "r04_bench.json")).read().splitlines() if l.startswith("{")][-1]
+    roof = json.loads(line)["roofline"]
+    assert roof["traffic"] and roof["traffic"] > roof["alg_bytes_per_launch"] * 0.5
