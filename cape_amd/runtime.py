@@ -205,4 +205,8 @@ class GraphedTrainStep(object):
             if self._gB is not None:
                 self._exchange()
                 self._gB.replay()
+        # a replay rewrites the variables without Python seeing it (no version bump, no apply_updates call): the piece planes
+        # of the fp16 two-piece contractions, refreshed at the START of the captured step, are one update behind afterwards --
+        # the next pass outside the graph (validation inside fit(), predict, encode) must rebuild them
+        m._pieces_dirty = True
         m.global_step += len(self._groups())

@@ -456,6 +456,35 @@ def test_training_step_is_bitwise_reproducible(cfg, gan, mesh_ops):
     assert moved                                         # the steps did update something
 
 
+def test_piece_planes_follow_the_weights_through_graph_replays(mesh_ops):
+    """A replayed step rewrites the variables without Python noticing (no version bump, no apply_updates call), and the piece
+    planes of the fp16 two-piece contractions are refreshed at the START of the captured step: after a replay they are one
+    update behind.  Every pass outside the graph -- also the SECOND evaluation between replays, when no flag is left over from
+    the capture -- must see planes of the current weights: the generator's output has to equal that of the same weights with
+    freshly built planes."""
+    from cape_amd.runtime import GraphedTrainStep
+    N = 2
+    P, twin, model = _build("affine_nz64", mesh_ops, N, dict(regularization=0.5, lr_warmup=False, decay_steps=1000))
+    x, gt, xd, cond, cond_d, clo, clo_d, eps = _inputs(N, P["nz"])
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=model.device)
+    runner = GraphedTrainStep(model, with_gan=False)
+    runner.load_batch(data_g=x, cond_g=cond, cond2_g=clo, gt=gt, data_d=xd, cond_d=cond_d, cond2_d=clo_d, eps=eps)
+    runner.capture(preserve_state=True)
+
+    def evaluate():
+        with torch.no_grad():
+            y, y2 = model._conditions(t(cond), t(clo))
+            return model.generator(t(x), y, y2, eps=t(eps))[0].float().clone()
+
+    for rep in range(2):                                  # replay, evaluate, replay, evaluate
+        runner.step()
+        runner.step()
+        got = evaluate()
+        model._pieces_dirty = True                        # the reference: planes rebuilt from the weights as they are now
+        want = evaluate()
+        assert torch.equal(got, want), (rep, float((got - want).abs().max()))
+
+
 def test_merged_discriminator_pass_equals_two_passes(mesh_ops):
     """D(generated) and D(real) as one pass over the concatenated batch (ops.MERGED_D_PASS, the default up to 16 + 16 meshes)
     against the two passes the reference builds (lib/models.py:299-302): same losses, same gradients of both groups."""
