@@ -13,6 +13,7 @@ autograd / optimizer shell.  There is no CPU fallback.
 """
 import collections
 import contextlib
+import weakref
 import glob
 import os
 import shutil
@@ -220,7 +221,21 @@ class base_model(object):
                 fpair = (self._vars[fn].detach(), self._conv_meta[fn][0] * self._conv_meta[fn][1])
             specs.append(dict(W=W.detach(), Ch=Ch, K=K, pair=pair, fpair=fpair))
         self._piece_plan_key = tuple(sorted(self._conv_meta.items()))
+        old = getattr(self, '_piece_finalizer', None)
+        if old is not None:
+            old()                                       # the registry entries of the plan this one replaces
         self._piece_plan = ops.PiecePlan(specs, self.device) if specs else None
+        # the registry (ops.PIECES, keyed by the weights' addresses) keeps weights and planes alive: drop this model's entries
+        # when the model goes (a process that builds many models -- the test suite -- would otherwise accumulate them)
+        self._piece_finalizer = weakref.finalize(self, ops.drop_pieces, [sp_["W"].data_ptr() for sp_ in specs]) if specs else None
+
+    def _weights_version(self):
+        """Version counters of everything the piece planes are computed from: the flat buckets (training: the variables are
+        views of them) and the conv weights themselves (a model without optimiser state holds them as separate tensors).
+        In-place edits through torch bump them; kernels that write through raw pointers and graph replays do not -- those
+        paths set ``_pieces_dirty``."""
+        v = tuple(int(st['flat']._version) for st in self._opt_state.values()) if getattr(self, '_opt_state', None) else ()
+        return v + tuple(int(self._vars[n]._version) for n in sorted(self._conv_meta) if n in self._vars)
 
     def prepare_pieces(self):
         """(Re)write the piece planes of all conv weights from their CURRENT values: two launches.  Runs at the start of
@@ -228,21 +243,21 @@ class base_model(object):
         any other pass once the weights may have changed (``_pieces_dirty``: optimiser step, restore, in-place edits)."""
         if not ops.H2 or self.act_dtype != torch.float32 or not self._conv_meta:
             return
-        if self._piece_plan is None or getattr(self, '_piece_plan_key', None) != tuple(sorted(self._conv_meta.items())):
-            self._build_piece_plan()
+        if getattr(self, '_piece_plan_key', None) != tuple(sorted(self._conv_meta.items())):
+            self._build_piece_plan()                    # (also when no layer qualified last time: the key says so)
         if self._piece_plan is None:
             return
         for wp in self._piece_plan.run():
             ops.PIECES[wp.W.data_ptr()] = wp
         self._pieces_dirty = False
-        self._pieces_versions = tuple(int(st['flat']._version) for st in self._opt_state.values()) if getattr(self, '_opt_state', None) else None
+        self._pieces_versions = self._weights_version()
 
     def _ensure_pieces(self):
-        if self._piece_plan is None:
-            return                      # first trace: the layers prepare their planes on demand
-        vers = tuple(int(st['flat']._version) for st in self._opt_state.values()) if getattr(self, '_opt_state', None) else None
-        if self._pieces_dirty or vers != getattr(self, '_pieces_versions', None):
-            self.prepare_pieces()
+        if self._piece_plan is None and not getattr(self, '_traced', False):
+            return                      # first trace (build_graph): the layers prepare their planes on demand
+        if self._piece_plan is None or self._pieces_dirty or self._weights_version() != getattr(self, '_pieces_versions', None):
+            self.prepare_pieces()       # (a traced model without a plan yet -- inference only -- gets one here: two launches per
+                                        # pass instead of two per layer)
 
     # ---- the reference's named operators (plug-points) --------------------------------------------
     def chebyshev5(self, x, L, Fout, K, activation=None, bias=None, pool=None, unpool=None, cond=None,
@@ -402,6 +417,7 @@ class base_model(object):
                         raise ValueError("shape mismatch for %s: %s vs %s" % (k, a.shape, tuple(v.shape)))
                     v.copy_(torch.from_numpy(a).to(v.device))
         self._weights_loaded = True
+        self._pieces_dirty = True
 
 
 class CAPE(base_model):
@@ -837,6 +853,7 @@ class CAPE(base_model):
         self._d_names = [n for n in self._vars if n.startswith('discriminator')]
         if phase == 'train':
             self._init_optimizer()
+        self._traced = True
         return self
 
     # ======================= optimiser shell (reference :419-474) ===================================

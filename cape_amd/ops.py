@@ -557,6 +557,12 @@ class PiecePlan(object):
 PIECES = {}
 
 
+def drop_pieces(ptrs):
+    """Remove registry entries (a model's finaliser: the entries hold its weights and planes)."""
+    for q in ptrs:
+        PIECES.pop(q, None)
+
+
 def pieces_for(W, Ch, K, pair=None, fpair=None):
     """Piece planes of W for ``Ch`` feature channels at order K, or None when the layer does not qualify."""
     if not H2 or not W.is_cuda or W.dtype != torch.float32 or Ch % 8 or W.shape[1] % 8 or not W.is_contiguous():
