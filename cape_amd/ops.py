@@ -423,6 +423,7 @@ def set_rm(t, rm):
     views are new objects and do not inherit it, and every in-place writer of ``t`` must drop it (``drop_rm``)."""
     if rm is not None:
         t._cape_rm = rm
+        t._cape_rm_version = t._version           # (see rm_of)
     return t
 
 
@@ -434,6 +435,12 @@ def drop_rm(t):
 def rm_of(t):
     rm = getattr(t, "_cape_rm", None)
     if rm is None or rm.shape[0] != t.shape[0] or rm.shape[1] != t.shape[1] or rm.device != t.device:
+        return None
+    # the bounds describe the contents at attach time: an in-place torch write since then -- e.g. the autograd engine summing a
+    # second gradient INTO this tensor (it accumulates in place when it holds the only reference) -- bumps the version counter
+    # and voids them (a bound that is too small overflows fp16).  Kernels of this library that write through raw pointers do not
+    # bump it: those call sites use drop_rm.
+    if getattr(t, "_cape_rm_version", None) != t._version:
         return None
     return rm
 
