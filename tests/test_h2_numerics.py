@@ -124,3 +124,28 @@ def test_inf_and_nan_stay_in_their_rows():
     assert np.all(~np.isfinite(got[2])) and np.all(np.isnan(got[6]))
     e = np.abs(got[ok] - ref[ok]).max() / np.abs(ref[ok]).max()
     assert e < 2e-6
+
+
+def test_row_bounds_are_voided_by_in_place_writes():
+    """The bounds attached to an activation tensor describe its contents at that moment (cape_amd.ops.set_rm / rm_of): any
+    in-place torch write afterwards -- e.g. the autograd engine accumulating a second gradient into the tensor -- must void
+    them (a stale, too small bound overflows fp16), views do not inherit them, an explicit drop removes them."""
+    import torch
+    from cape_amd import ops
+    t = torch.zeros(2, 5, 32)
+    rm = torch.ones(2, 5, 4)
+    assert ops.rm_of(t) is None
+    assert ops.set_rm(t, rm) is t and ops.rm_of(t) is rm
+    assert ops.rm_of(t[:, :, :16]) is None                    # a view is a new object
+    u = t.detach()                                            # shares storage and version counter, but not the attribute
+    assert ops.rm_of(u) is None
+    t.add_(1.0)                                               # what the engine's in-place accumulation does
+    assert ops.rm_of(t) is None
+    ops.set_rm(t, rm)
+    assert ops.rm_of(t) is rm
+    u.mul_(2.0)                                               # a write through an alias bumps the shared counter too
+    assert ops.rm_of(t) is None
+    ops.set_rm(t, rm)
+    ops.drop_rm(t)
+    assert ops.rm_of(t) is None
+    assert ops.rm_of(ops.set_rm(torch.zeros(2, 6, 32), rm)) is None      # bounds of another row count never apply
