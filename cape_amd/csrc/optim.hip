@@ -101,6 +101,56 @@ __global__ __launch_bounds__(256) void momentum_update_kernel(float *w, const fl
     }
 }
 
+
+// tf.train.AdamOptimizer (reference lib/models.py:447-449; beta1 0.9, beta2 0.999, epsilon 1e-8 are TensorFlow's defaults) on the
+// same flat buckets, behind the same global-norm clip and with the same folded regulariser gradient as the momentum form:
+//     t = step + 1;  lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
+//     m = beta1 m + (1 - beta1) g';  v = beta2 v + (1 - beta2) g'^2;  w -= lr_t * m / (sqrt(v) + eps)       (g' = clipped g + reg)
+// The step count lives on the device (state[0]; state[1] = finished-workgroup counter): every workgroup reads state[0] when it
+// starts, and the LAST one to finish -- by then every workgroup has read it -- advances it, so a captured graph replays the
+// right bias correction without any host-side counter.  (An integer ticket: no floating-point result depends on arrival order.)
+__global__ __launch_bounds__(256) void adam_update_kernel(float *w, const float *g, float *m, float *v, long long n4, float beta1, float beta2,
+                                                          float eps, float clip, const float *sumsq, const float *neg_lr, int *state, Ranges R) {
+    __shared__ float s_nlr;
+    if (threadIdx.x == 0) {
+        const double t = (double)(state[0] + 1);
+        s_nlr = (float)((double)*neg_lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
+    }
+    __syncthreads();
+    const float nlr = s_nlr;
+    const float norm = sqrtf(*sumsq);
+    const float scale = clip / fmaxf(norm, clip);       // tf.clip_by_global_norm
+    const float c1 = 1.f - beta1, c2 = 1.f - beta2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 gv = reinterpret_cast<const float4 *>(g)[i];
+        float4 wv = reinterpret_cast<float4 *>(w)[i];
+        float4 mv = reinterpret_cast<float4 *>(m)[i];
+        float4 vv = reinterpret_cast<float4 *>(v)[i];
+        const float c = R.n ? reg_coef_at(R, 4 * i) : 0.f;
+        if (c != 0.f) {
+            gv.x = fmaf(c, wv.x, gv.x); gv.y = fmaf(c, wv.y, gv.y); gv.z = fmaf(c, wv.z, gv.z); gv.w = fmaf(c, wv.w, gv.w);
+        }
+        gv.x *= scale; gv.y *= scale; gv.z *= scale; gv.w *= scale;
+        mv.x = fmaf(beta1, mv.x, c1 * gv.x); mv.y = fmaf(beta1, mv.y, c1 * gv.y);
+        mv.z = fmaf(beta1, mv.z, c1 * gv.z); mv.w = fmaf(beta1, mv.w, c1 * gv.w);
+        vv.x = fmaf(beta2, vv.x, c2 * gv.x * gv.x); vv.y = fmaf(beta2, vv.y, c2 * gv.y * gv.y);
+        vv.z = fmaf(beta2, vv.z, c2 * gv.z * gv.z); vv.w = fmaf(beta2, vv.w, c2 * gv.w * gv.w);
+        wv.x = fmaf(nlr, mv.x / (sqrtf(vv.x) + eps), wv.x); wv.y = fmaf(nlr, mv.y / (sqrtf(vv.y) + eps), wv.y);
+        wv.z = fmaf(nlr, mv.z / (sqrtf(vv.z) + eps), wv.z); wv.w = fmaf(nlr, mv.w / (sqrtf(vv.w) + eps), wv.w);
+        reinterpret_cast<float4 *>(m)[i] = mv;
+        reinterpret_cast<float4 *>(v)[i] = vv;
+        reinterpret_cast<float4 *>(w)[i] = wv;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&state[1], 1) == (int)gridDim.x - 1) {
+            state[1] = 0;
+            atomicAdd(&state[0], 1);
+        }
+    }
+}
+
 inline int fill_ranges(Ranges &R, const int64_t *ranges, int nr, float coef) {
     if (nr < 0 || nr > MAX_RANGES || (nr > 0 && !ranges)) return CAPE_EINVAL;
     R.n = nr; R.coef = coef;
@@ -203,6 +253,24 @@ extern "C" int cape_flat_momentum_update(float *w, const float *g, float *m, int
     if (blocks > 4096) blocks = 4096;
     CAPE_LAUNCH(momentum_update_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, g, m, n4, momentum, clip, sumsq,
                 neg_lr, R);
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}
+
+extern "C" int cape_flat_adam_update(float *w, const float *g, float *m, float *v, int64_t n, float beta1, float beta2, float eps,
+                                     float clip, const float *sumsq, const float *neg_lr, int32_t *state,
+                                     const int64_t *reg_ranges, int32_t nranges, float reg_coef, void *stream) {
+    if (!w || !g || !m || !v || n < 4 || (n & 3) || !sumsq || !neg_lr || !state || !al16(w) || !al16(g) || !al16(m) || !al16(v) || clip <= 0.f)
+        return CAPE_EINVAL;
+    if (!(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps > 0.f)) return CAPE_EINVAL;
+    Ranges R;
+    int rc = fill_ranges(R, reg_ranges, nranges, reg_coef);
+    if (rc) return rc;
+    const long long n4 = n >> 2;
+    long long blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    CAPE_LAUNCH(adam_update_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n4, beta1, beta2, eps, clip,
+                sumsq, neg_lr, (int *)state, R);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }

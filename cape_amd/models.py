@@ -805,8 +805,8 @@ class CAPE(base_model):
     def _fc_regulariser(self):
         """l2_regularizer(scale)(w) = scale*sum(w^2)/2 on dense kernels under 'generator', multiplied by
         `regularization` once more (reference :40, :378-379; quirk C6).  Its VALUE is reported here from
-        detached kernels; its GRADIENT (regularization^2 * w) is added to the flat gradient bucket by
-        backward_to_flat -- identical numbers, without recording 7M-element tape nodes for three kernels."""
+        detached kernels; its GRADIENT (regularization^2 * w) is folded into the optimiser's norm and update
+        kernels on the flat bucket (apply_updates, Momentum and Adam alike) -- identical numbers, without recording 7M-element tape nodes for three kernels."""
         reg = 0.0
         self._reg_names = []
         if self.regularization:
@@ -900,7 +900,8 @@ class CAPE(base_model):
                   'neg_lr': torch.zeros((), device=self.device, dtype=torch.float32)}
             if self.optimizer == 'adam':
                 st['v'] = torch.zeros_like(flat)
-                st['t'] = 0
+                # device-resident step count of cape_flat_adam_update ([count, workgroup ticket]): graph replays advance it
+                st['t'] = torch.zeros(2, device=self.device, dtype=torch.int32)
             self._opt_state[grp] = st
         self.global_step = 0
 
@@ -928,23 +929,19 @@ class CAPE(base_model):
                 st['neg_lr_host'] = -lr
         return lr_g, lr_d
 
+    def adam_steps(self, grp):
+        """Number of Adam updates applied to a group so far (TF keeps it as beta1_power / beta2_power, :447-449)."""
+        return int(self._opt_state[grp]['t'][0].item())
+
+    def _set_adam_steps(self, grp, t):
+        with torch.no_grad():
+            self._opt_state[grp]['t'].copy_(torch.tensor([int(t), 0], dtype=torch.int32))
+
     def _reg_ranges(self):
         """Element ranges (padded to the 256-byte variable alignment; the padding holds zeros) of the generator's
         regularised dense kernels inside the G bucket."""
         off = self._opt_state['g']['offsets']
         return [(off[n][0], off[n][0] + off[n][1]) for n in getattr(self, '_reg_names', [])]
-
-    def _add_reg_grads(self):
-        """d/dw [regularization^2 * sum(w^2)/2] = regularization^2 * w for the generator's dense kernels.  The
-        momentum path folds this into the fused update kernels (apply_updates); Adam adds it to the bucket here."""
-        if not getattr(self, '_reg_in_bucket', False) or self.optimizer != 'adam':
-            return
-        coef = self.regularization * self.regularization
-        st = self._opt_state['g']
-        with torch.no_grad():
-            for n in self._reg_names:
-                i = self._g_names.index(n)
-                st['grad_views'][i].add_(self._vars[n], alpha=coef)
 
     def store_grads(self, grp, grads, lo=0, hi=None):
         """Put the gradients of variables [lo, hi) of a group into its flat gradient bucket."""
@@ -962,28 +959,21 @@ class CAPE(base_model):
 
     def apply_updates(self, grp, clip=5.0):
         """clip_by_global_norm(5.0) (:461) + Momentum (non-Nesterov, TF semantics: accum = m*accum + g;
-        var -= lr*accum) or Adam, on the flat buffers.  Capturable: no host reads."""
+        var -= lr*accum) or Adam (:447-449), on the flat buffers.  Capturable: no host reads, no host-side counters."""
         st = self._opt_state[grp]
         g, flat, m = st['flat_grad'], st['flat'], st['m']
         with torch.no_grad():
-            if self.optimizer == 'adam':
-                gnorm = torch.linalg.vector_norm(g)
-                scale = clip / torch.clamp(gnorm, min=clip)
-                st['t'] += 1
-                b1, b2, eps = 0.9, 0.999, 1e-8
-                corr = float(np.sqrt(1 - b2 ** st['t']) / (1 - b1 ** st['t']))
-                gs = g * scale
-                m.mul_(b1).add_(gs, alpha=1 - b1)
-                st['v'].mul_(b2).addcmul_(gs, gs, value=1 - b2)
-                flat.add_(st['neg_lr'] * corr * m / (st['v'].sqrt() + eps))
-                return gnorm
-            # momentum: 3 launches on the flat buckets (csrc/optim.hip); the dense kernels' regulariser gradient
-            # regularization^2 * w is part of the effective gradient (norm AND update) on its ranges
+            # 3 launches on the flat buckets (csrc/optim.hip), Momentum and Adam alike; the dense kernels' regulariser
+            # gradient regularization^2 * w is part of the effective gradient (norm AND update) on its ranges
             ranges, coef = [], 0.0
             if grp == 'g' and getattr(self, '_reg_in_bucket', False):
                 ranges, coef = self._reg_ranges(), self.regularization * self.regularization
             ops.flat_gradnorm(g, flat, ranges, coef, st['sumsq'], st['ws'])
-            ops.flat_momentum_update(flat, g, m, self.momentum, clip, st['sumsq'], st['neg_lr'], ranges, coef)
+            if self.optimizer == 'adam':
+                # tf.train.AdamOptimizer(learning_rate) with TensorFlow's defaults (:447-449); the step count is on the device
+                ops.flat_adam_update(flat, g, m, st['v'], 0.9, 0.999, 1e-8, clip, st['sumsq'], st['neg_lr'], st['t'], ranges, coef)
+            else:
+                ops.flat_momentum_update(flat, g, m, self.momentum, clip, st['sumsq'], st['neg_lr'], ranges, coef)
             self._pieces_dirty = True           # (the kernel writes through raw pointers: no version bump to detect)
         return st['sumsq']
 
@@ -1124,10 +1114,6 @@ class CAPE(base_model):
                 grads_d = torch.autograd.grad(out['loss_d'], self._opt_state['d']['params'], grad_outputs=one, retain_graph=True,
                                               allow_unused=True)
                 self.store_grads('d', grads_d)
-        # Adam path: the regularised dense kernels are all EARLY variables, so their regulariser gradient must be in
-        # the bucket before the early range is handed to the asynchronous all-reduce (adding it in phase 2 would race
-        # with the collective that reduces the same range in place)
-        self._add_reg_grads()
 
     def backward_phase2(self):
         """Second half: from the cut (and the condition embeddings) through the encoder convolutions and the
@@ -1165,7 +1151,6 @@ class CAPE(base_model):
         if 'loss_d' not in out:
             grads_g = torch.autograd.grad(out['loss_g'], g_params, grad_outputs=one, allow_unused=True)
             self.store_grads('g', grads_g)
-            self._add_reg_grads()
             return
         if self.bug_compat:
             grads_g = torch.autograd.grad(out['loss_g'], g_params, allow_unused=True)
@@ -1177,7 +1162,6 @@ class CAPE(base_model):
                 grads_g = torch.autograd.grad(out['loss_g'], g_params, grad_outputs=one, retain_graph=True, allow_unused=True)
             grads_d = torch.autograd.grad(out['loss_d'], d_params, grad_outputs=one, allow_unused=True)
         self.store_grads('g', grads_g)
-        self._add_reg_grads()
         self.store_grads('d', grads_d)
 
     def train_step(self, data_g, cond_g, cond2_g, gt, data_d, cond_d, cond2_d, eps=None, grad_hook=None):
@@ -1205,7 +1189,7 @@ class CAPE(base_model):
                 arrays['training/momentum_' + grp] = st['m'].detach().cpu().numpy()
                 if 'v' in st:                        # Adam: second moment and step count (bias correction)
                     arrays['training/adam_v_' + grp] = st['v'].detach().cpu().numpy()
-                    arrays['training/adam_t_' + grp] = np.asarray(st['t'], dtype=np.int64)
+                    arrays['training/adam_t_' + grp] = np.asarray(self.adam_steps(grp), dtype=np.int64)
         fn = os.path.join(path, 'model-%d.npz' % step)
         np.savez(fn, **arrays)
         keep = sorted(glob.glob(os.path.join(path, 'model-*.npz')), key=os.path.getmtime)
@@ -1257,13 +1241,13 @@ class CAPE(base_model):
                         kv, kt = 'training/adam_v_' + grp, 'training/adam_t_' + grp
                         if kv in arrays and kt in arrays and arrays[kv].shape == tuple(st['v'].shape):
                             st['v'].copy_(torch.from_numpy(arrays[kv]).to(self.device))
-                            st['t'] = int(arrays[kt])
+                            self._set_adam_steps(grp, int(arrays[kt]))
                         else:
                             # first moment without second moment / step count: restart Adam's statistics instead of
                             # applying the t = 1 bias correction to a warm m (a 10x first step)
                             st['m'].zero_()
                             st['v'].zero_()
-                            st['t'] = 0
+                            self._set_adam_steps(grp, 0)
                     continue
                 for buf in ('m', 'v'):                     # per-variable TF slots -> flat bucket
                     suffix = self._slot_suffix(buf)
@@ -1276,8 +1260,8 @@ class CAPE(base_model):
                                 torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32).reshape(-1)).to(self.device))
                 if 't' in st:
                     b1p = arrays.get('training/beta1_power' if grp == 'g' else 'training/beta1_power_1')
-                    st['t'] = int(round(np.log(float(b1p)) / np.log(0.9))) if b1p is not None and 0 < float(b1p) < 1 \
-                        else self.global_step // 2
+                    self._set_adam_steps(grp, int(round(np.log(float(b1p)) / np.log(0.9))) if b1p is not None and 0 < float(b1p) < 1
+                                         else self.global_step // 2)
 
     def export_tf_checkpoint(self, prefix=None, with_slots=True):
         """Write the variables as a TensorFlow V2 checkpoint the reference's ``tf.train.Saver`` can restore
@@ -1300,8 +1284,8 @@ class CAPE(base_model):
                         arrays[name + suffix] = flat[off:off + v.numel()].reshape(tuple(v.shape)).copy()
                 if 't' in st:
                     tag = '' if grp == 'g' else '_1'
-                    arrays['training/beta1_power' + tag] = np.asarray(0.9 ** st['t'], dtype=np.float32)
-                    arrays['training/beta2_power' + tag] = np.asarray(0.999 ** st['t'], dtype=np.float32)
+                    arrays['training/beta1_power' + tag] = np.asarray(0.9 ** self.adam_steps(grp), dtype=np.float32)
+                    arrays['training/beta2_power' + tag] = np.asarray(0.999 ** self.adam_steps(grp), dtype=np.float32)
         tf_checkpoint.write_bundle(prefix, arrays)
         tf_checkpoint.update_checkpoint_state(os.path.dirname(os.path.abspath(prefix)), os.path.abspath(prefix))
         return prefix
@@ -1377,7 +1361,7 @@ class CAPE(base_model):
             for _ in range(2 if self.bug_compat else 1):   # quirk C1: two sess.run, each applies both updates
                 runner.buf['eps'].normal_()                # tf.random_normal inside the graph (:194): fresh per run
                 if not captured:
-                    runner.capture(preserve_state=True)    # (no-op for Adam: host-side step counter -> eager runner)
+                    runner.capture(preserve_state=True)
                     captured = True
                 runner.step()
                 torch.stack([runner.losses['loss_g'], runner.losses['loss_d']], out=cur)

@@ -1019,6 +1019,18 @@ def _join_dw_stream():
         _DW_FORKED = False
 
 
+def _flush_dw():
+    """The queued fixed-order slab reductions of the weight gradient, as batched launches."""
+    _join_dw_stream()
+    if DEFERRED_DW:
+        queued, DEFERRED_DW[:] = list(DEFERRED_DW), []
+        nmax = 12                                    # CAPE_MAX_DW_REDUCE_ITEMS
+        for i0 in range(0, len(queued), nmax):
+            chunk = queued[i0:i0 + nmax]
+            arr = (_lib.CapeDwItem * len(chunk))(*[q[0] for q in chunk])
+            check(lib.cape_gconv_dw_reduce_batch(C.addressof(arr), len(chunk), _stream()), "cape_gconv_dw_reduce_batch")
+
+
 def flush_deferred():
     global DEFERRED
     if DEFERRED_GN:
@@ -1032,14 +1044,7 @@ def flush_deferred():
                 a.dgamma, a.dbeta = dst_g.data_ptr(), dst_b.data_ptr()
                 a.N, a.C = int(dgb.shape[1]), int(dgb.shape[2])
             check(lib.cape_groupnorm_param_reduce_batch(C.addressof(arr), len(chunk), _stream()), "cape_groupnorm_param_reduce_batch")
-    _join_dw_stream()
-    if DEFERRED_DW:
-        queued, DEFERRED_DW[:] = list(DEFERRED_DW), []
-        nmax = 12                                    # CAPE_MAX_DW_REDUCE_ITEMS
-        for i0 in range(0, len(queued), nmax):
-            chunk = queued[i0:i0 + nmax]
-            arr = (_lib.CapeDwItem * len(chunk))(*[q[0] for q in chunk])
-            check(lib.cape_gconv_dw_reduce_batch(C.addressof(arr), len(chunk), _stream()), "cape_gconv_dw_reduce_batch")
+    _flush_dw()
     if not DEFERRED:
         return
     items, DEFERRED[:] = list(DEFERRED), []
@@ -2340,6 +2345,20 @@ def flat_momentum_update(w, g, m, momentum, clip, sumsq, neg_lr, ranges, coef):
                                                             w.numel(), float(momentum), float(clip), C.c_void_p(sumsq.data_ptr()),
                                                             C.c_void_p(neg_lr.data_ptr()), arr, nr, float(coef), _stream()),
                               "cape_flat_momentum_update"))
+
+
+def flat_adam_update(w, g, m, v, beta1, beta2, eps, clip, sumsq, neg_lr, state, ranges, coef):
+    """clip-by-global-norm + Adam update of a flat bucket in one launch (csrc/optim.hip; reference lib/models.py:447-449);
+    ``state``: int32[2] device tensor {number of updates so far, 0}, advanced by the launch."""
+    _lib.require_gpu()
+    assert state.dtype == torch.int32 and state.numel() >= 2 and v.shape == w.shape
+    arr, nr = _ranges_arg(ranges)
+    _log_launch("flat_adam_update", 0, 7 * 4 * w.numel(),
+                lambda: check(lib.cape_flat_adam_update(C.c_void_p(w.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
+                                                        C.c_void_p(v.data_ptr()), w.numel(), float(beta1), float(beta2), float(eps),
+                                                        float(clip), C.c_void_p(sumsq.data_ptr()), C.c_void_p(neg_lr.data_ptr()),
+                                                        C.c_void_p(state.data_ptr()), arr, nr, float(coef), _stream()),
+                              "cape_flat_adam_update"))
 
 
 def sumsq_ranges(x, ranges, scale, ws):

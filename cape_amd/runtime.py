@@ -37,7 +37,7 @@ class GraphedTrainStep(object):
             split = env == "1" or (grad_hook is not None and env != "0")
         self.split = bool(split) and not model.bug_compat
         model.split_backward = self.split
-        self.use_graph = use_graph and model.optimizer != "adam"   # Adam keeps a host-side step counter
+        self.use_graph = use_graph          # (Adam's step count is a device counter advanced by the update kernel: capturable)
         B, d = model.batch_size, model.device
         M, Cn = model.input_num_verts, model.nn_input_channel
         z = lambda *s: torch.zeros(s, device=d, dtype=torch.float32)
@@ -141,7 +141,7 @@ class GraphedTrainStep(object):
             return self
         saved = None
         if preserve_state and warmup > 0:
-            saved = {grp: {k: st[k].detach().clone() for k in ('flat', 'm', 'v') if k in st}
+            saved = {grp: {k: st[k].detach().clone() for k in ('flat', 'm', 'v', 't') if k in st}
                      for grp, st in self.model._opt_state.items()}
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())

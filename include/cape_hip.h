@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define CAPE_ABI_VERSION 11
+#define CAPE_ABI_VERSION 12
 #define CAPE_MAX_SRC 8
 
 /* error codes (negative = argument error; positive values are hipError_t) */
@@ -549,6 +549,11 @@ int cape_cond_coef_bwd(const float *cond, int32_t ldc, int32_t N, int32_t Cc,
  * ranges (multiples of 4) on which the effective gradient is g + reg_coef * w.
  *   cape_flat_gradnorm:        *sumsq_out = sum (g + reg)^2            (two deterministic launches)
  *   cape_flat_momentum_update: s = clip / max(sqrt(*sumsq), clip);  m = momentum*m + s*(g + reg);  w += (*neg_lr)*m
+ *   cape_flat_adam_update:     tf.train.AdamOptimizer (lib/models.py:447-449) behind the same clip and regulariser:
+ *                              t = state[0] + 1;  lr_t = -(*neg_lr) * sqrt(1 - beta2^t) / (1 - beta1^t);  g' = s*(g + reg);
+ *                              m = beta1*m + (1-beta1)*g';  v = beta2*v + (1-beta2)*g'^2;  w -= lr_t * m / (sqrt(v) + eps).
+ *                              state: two DEVICE int32 {step count, 0}; the call advances state[0] by one (TF's beta powers
+ *                              as a counter), so replays of a captured graph apply the right bias correction.
  *   cape_sumsq_ranges:         *out = scale * sum over the ranges of x^2  (the regulariser's VALUE)
  * sumsq / neg_lr / out are DEVICE scalars (nothing is read back: the sequence is graph-capturable).
  */
@@ -558,6 +563,9 @@ int cape_flat_gradnorm(const float *g, const float *w, int64_t n, const int64_t 
 int cape_flat_momentum_update(float *w, const float *g, float *m, int64_t n, float momentum, float clip,
                               const float *sumsq, const float *neg_lr, const int64_t *reg_ranges,
                               int32_t nranges, float reg_coef, void *stream);
+int cape_flat_adam_update(float *w, const float *g, float *m, float *v, int64_t n, float beta1, float beta2, float eps,
+                          float clip, const float *sumsq, const float *neg_lr, int32_t *state,
+                          const int64_t *reg_ranges, int32_t nranges, float reg_coef, void *stream);
 int cape_sumsq_ranges(const float *x, const int64_t *ranges, int32_t nranges, float scale, float *out,
                       void *workspace, int64_t workspace_bytes, void *stream);
 
