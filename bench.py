@@ -85,18 +85,32 @@ def _csrc_fingerprint():
     return h.hexdigest()[:16]
 
 
-def _pmc_traffic(kernel):
-    """HBM bytes per launch of ``kernel`` from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    separate passes, tools/collect_profiles.sh; counters cannot be read from inside this process), or None when the
-    summary was collected from different kernel code."""
+def _pmc_entry(kernel):
+    """The committed PMC summary's record of ``kernel`` (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ counters in separate
+    passes, tools/collect_profiles.sh; counters cannot be read from inside this process), or {} when the summary was
+    collected from different kernel code."""
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
         if pmc.get("_meta", {}).get("csrc_sha") != _csrc_fingerprint():
-            return None
+            return {}
         key = next((k for k in pmc if k.replace(" ", "") == kernel.replace(" ", "")), None)
-        return None if key is None else pmc[key].get("hbm_bytes_per_dispatch")
+        return {} if key is None else pmc[key]
     except Exception:
-        return None
+        return {}
+
+
+def _pmc_traffic(kernel):
+    """HBM bytes per launch (1024 * (2 * FETCH_SIZE + WRITE_SIZE): the guide's gfx950 correction) or None."""
+    return _pmc_entry(kernel).get("hbm_bytes_per_dispatch")
+
+
+def _mfma_products(kernel):
+    """MFMA products the kernel executes per algorithmic multiply-add, and the dense peak of the pipe it runs them on."""
+    if kernel.startswith(("gemm_h2_kernel", "dw_h2_kernel")):
+        return 3, BF16_MFMA_PEAK_TFLOPS
+    if kernel.startswith(("gemm_split_kernel", "dw_split_kernel")):
+        return (2 if "unsigned short" in kernel else 6), BF16_MFMA_PEAK_TFLOPS
+    return 1, FP32_MFMA_PEAK_TFLOPS
 
 
 def kernel_roofline(runner):
@@ -136,6 +150,17 @@ def kernel_roofline(runner):
     n, t, fl, by = agg[dom]
     table = {k: dict(launches=v[0] // reps, avg_us=1e6 * v[1] / v[0], total_us=1e6 * v[1] / reps, tflops=v[2] / v[1] / 1e12,
                      alg_gbs=v[3] / v[1] / 1e9) for k, v in agg.items()}
+    for k, row in table.items():
+        # MFMA utilisation, two ways: executed matrix-pipe flops (algorithmic x products per multiply-add) over the dense peak
+        # of that pipe at the maximum clock -- live, from this run's timing -- and, when the committed counter summary belongs
+        # to these kernel sources, SQ_VALU_MFMA_BUSY_CYCLES over SIMD-cycles (tools/pmc_merge.py), i.e. against the clock the
+        # kernel actually ran at
+        if row["tflops"] > 0.5:
+            prod, pipe_peak = _mfma_products(k)
+            row["mfma_util_of_dense_peak"] = row["tflops"] * prod / pipe_peak
+            pm = _pmc_entry(k).get("mfma_util")
+            if pm is not None:
+                row["mfma_util_pmc"] = pm
     split = dom.startswith(("gemm_split_kernel", "dw_split_kernel"))
     h2 = dom.startswith(("gemm_h2_kernel", "dw_h2_kernel"))   # fp16 two-piece operands: three fp16 MFMA products per multiply-add
     one_product = split and "unsigned short" in dom          # bf16 storage: one bf16 MFMA product per multiply-add
@@ -162,6 +187,12 @@ def kernel_roofline(runner):
                 tflops=round(fl / t / 1e12, 2), frac_of_fp32_mfma_peak=round(fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                 hbm_alg_gbs=round(by / t / 1e9, 1), hbm_frac=round(by / t / 1e9 / HBM_PEAK_GBS, 4),
                 share_of_logged_time=round(t / sum(v[1] for v in agg.values()), 4))
+    prod, pipe_peak = _mfma_products(dom)
+    roof["mfma_util"] = dict(of_dense_peak=round(fl / t / 1e12 * prod / pipe_peak, 4), products_per_multiply_add=prod,
+                             pipe_peak_tflops=pipe_peak, pmc_busy_over_simd_cycles=_pmc_entry(dom).get("mfma_util"),
+                             note="of_dense_peak: executed MFMA flops / dense peak of the pipe at the maximum clock (live timing); "
+                                  "pmc: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) from the committed "
+                                  "counter pass of the same kernel sources (null otherwise)")
     return roof, table
 
 
@@ -485,10 +516,24 @@ def main():
         args.batch = args.global_batch // world
     model = build_model(args.batch, local, args.config, act_dtype=args.dtype)
     hook = None
+    dp = dict(world=world, backend=(tdist.get_backend() if world > 1 else None), ranks=cdist.rank_inventory(model.device))
     if world > 1:
         for grp in ('g', 'd'):
             cdist.broadcast_flat(model._opt_state[grp]['flat'])
         hook = cdist.GradAverager()
+        st_g = model._opt_state['g']
+        nelem = int(st_g['flat_grad'].numel())
+        dp.update(bucket_mb=round(4 * nelem / 1e6, 2), early_fraction=round(float(st_g['split_off']) / nelem, 4),
+                  mean="folded into the optimiser kernels (grad_scale = 1/world): the exchange leaves the SUM")
+        if os.environ.get("CAPE_DP_PROBE", "1") != "0":
+            # every form of the exchange timed on the real bucket (standalone: nothing to hide behind), MAX over ranks; the
+            # fastest one that worked carries the timed steps unless CAPE_DP_COLLECTIVE pins the choice
+            probe = cdist.probe_collectives(hook, nelem, model.device)
+            dp["collective_probe_ms"] = probe
+            ok = {k: v for k, v in probe.items() if isinstance(v, float)}
+            if ok and "CAPE_DP_COLLECTIVE" not in os.environ:
+                hook.mode = min(ok, key=ok.get)
+        dp["collective"] = hook.mode
     runner = GraphedTrainStep(model, with_gan=args.gan, grad_hook=hook, use_graph=not args.no_graph)
     runner.load_batch(**synthetic_batch(model, seed=1234 + rank))
     torch.cuda.synchronize()
@@ -520,6 +565,23 @@ def main():
     elapsed = cdist.max_over_ranks(time.perf_counter() - t0, model.device)
 
     loss = float(runner.losses['loss_g']) if 'loss_g' in runner.losses else float('nan')
+    if world > 1:
+        # what the exchange costs the step: the same split step (graphs A1 / A2 / B) with the collectives switched off, AFTER the
+        # timed region (the replicas drift apart from here on; nothing below reads the variables)
+        hook.enabled = False
+        torch.cuda.synchronize()
+        tdist.barrier()
+        t1 = time.perf_counter()
+        for i in range(min(args.steps, 20)):
+            one_step(i)
+        torch.cuda.synchronize()
+        t_off = cdist.max_over_ranks((time.perf_counter() - t1) / min(args.steps, 20), model.device)
+        hook.enabled = True
+        dp["ms_per_step_exchange_off"] = round(1e3 * t_off, 4)
+        dp["exposed_exchange_ms"] = round(1e3 * (elapsed / args.steps - t_off), 4)
+        probe_ms = dp.get("collective_probe_ms", {}).get(dp["collective"])
+        if isinstance(probe_ms, float):
+            dp["hidden_exchange_ms"] = round(max(0.0, probe_ms - dp["exposed_exchange_ms"]), 4)
     roof, table = (None, {})
     if not args.no_roofline:
         roof, table = kernel_roofline(runner)
@@ -549,7 +611,7 @@ def main():
                                  "tests/test_h2_numerics.py; not bit-identical; inf / NaN operands stay in their rows); shorter "
                                  "contractions as 6 bf16 products on an exact 3-way bf16 split; exact-fp32 MFMA for odd-channel / "
                                  "packed launches and the dense layers",
-                   "final_loss_g": loss},
+                   "final_loss_g": loss, "dp": dp},
         "roofline": roof,
         "step_roofline": step_roofline(ms, args.batch, args.gan, args.dtype == 'bf16', cmr=args.config.startswith("CAPE_nz18"))
         if args.config.startswith(("CAPE-affineconv_nz64", "CAPE_nz18")) else None,
@@ -562,6 +624,11 @@ def main():
         result["cpu_baseline"] = None
     if world == 1 and not args.no_ab and not args.host_inputs and args.dtype == 'fp32' and os.environ.get("CAPE_GEMM_BF16X6", "1") != "0":
         result["exact_fp32_mfma"] = exact_fp32_run(args)
+        # the strict-fp32 figure next to the headline, where a parser of `config` sees it: `value` runs long contractions on a
+        # 22-bit two-piece fp16 split (fp32-class accuracy, see `arithmetic`), this is the same step with nothing narrower than
+        # the reference's fp32 multiplier anywhere
+        result["config"]["exact_fp32_mfma_meshes_per_s"] = result["exact_fp32_mfma"].get("value")
+        result["config"]["exact_fp32_mfma_ms_per_step"] = result["exact_fp32_mfma"].get("ms_per_step")
         if os.environ.get("CAPE_H2", "1") != "0":
             result["bf16x6_split"] = exact_fp32_run(args, dict(CAPE_H2='0'),
                                                     "same step, CAPE_H2=0: every eligible contraction as 6 bf16 products (the arithmetic of round 3)")

@@ -156,9 +156,9 @@ SIGNATURES = {
     "cape_cond_coef_fwd": (C.c_int, [_p, _i32, _i32, _i32, C.POINTER(CapeCondLayer), _i32, _p]),
     "cape_cond_coef_bwd": (C.c_int, [_p, _i32, _i32, _i32, C.POINTER(CapeCondLayer), _i32, _p, _i32, _i32, _p]),
     "cape_flat_workspace_bytes": (_i64, []),
-    "cape_flat_gradnorm": (C.c_int, [_p, _p, _i64, C.POINTER(_i64), _i32, _f32, _p, _p, _i64, _p]),
-    "cape_flat_momentum_update": (C.c_int, [_p, _p, _p, _i64, _f32, _f32, _p, _p, C.POINTER(_i64), _i32, _f32, _p]),
-    "cape_flat_adam_update": (C.c_int, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _p, _p, _p, C.POINTER(_i64), _i32, _f32, _p]),
+    "cape_flat_gradnorm": (C.c_int, [_p, _p, _i64, C.POINTER(_i64), _i32, _f32, _f32, _p, _p, _i64, _p]),
+    "cape_flat_momentum_update": (C.c_int, [_p, _p, _p, _i64, _f32, _f32, _p, _p, C.POINTER(_i64), _i32, _f32, _f32, _p]),
+    "cape_flat_adam_update": (C.c_int, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _p, _p, _p, C.POINTER(_i64), _i32, _f32, _f32, _p]),
     "cape_sumsq_ranges": (C.c_int, [_p, C.POINTER(_i64), _i32, _f32, _p, _p, _i64, _p]),
     "cape_vae_sample_kl_fwd": (C.c_int, [_p, _p, _p, _p, _i32, _p, _i32, _i32, _p, _i32, _i32, _p]),
     "cape_vae_sample_kl_bwd": (C.c_int, [_p, _p, _p, _p, _i32, _p, _p, _p, _i32, _i32, _p]),

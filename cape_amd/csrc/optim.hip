@@ -41,11 +41,13 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
 }
 
 // partial[b] = sum over this block's grid-stride elements of (g + coef*w)^2      (n % 4 == 0, 16-byte aligned)
-__global__ __launch_bounds__(256) void gradnorm_partial_kernel(const float *g, const float *w, long long n4, Ranges R, float *partial) {
+// (gs: factor on the raw gradient -- 1 / world when the bucket holds the SUM over data-parallel ranks, so the mean needs no launch)
+__global__ __launch_bounds__(256) void gradnorm_partial_kernel(const float *g, const float *w, long long n4, Ranges R, float gs, float *partial) {
     __shared__ float red[256];
     float s = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)FLAT_BLOCKS * 256) {
         float4 gv = reinterpret_cast<const float4 *>(g)[i];
+        gv.x *= gs; gv.y *= gs; gv.z *= gs; gv.w *= gs;
         const float c = R.n ? reg_coef_at(R, 4 * i) : 0.f;     // ranges are multiples of 4 long and 4-aligned
         if (c != 0.f) {
             const float4 wv = reinterpret_cast<const float4 *>(w)[i];
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void flat_final_kernel(const float *partial, f
 }
 
 __global__ __launch_bounds__(256) void momentum_update_kernel(float *w, const float *g, float *m, long long n4, float momentum, float clip,
-                                                              const float *sumsq, const float *neg_lr, Ranges R) {
+                                                              const float *sumsq, const float *neg_lr, Ranges R, float gs) {
     const float norm = sqrtf(*sumsq);
     const float scale = clip / fmaxf(norm, clip);       // tf.clip_by_global_norm
     const float nlr = *neg_lr;
@@ -89,6 +91,7 @@ __global__ __launch_bounds__(256) void momentum_update_kernel(float *w, const fl
         float4 gv = reinterpret_cast<const float4 *>(g)[i];
         float4 wv = reinterpret_cast<float4 *>(w)[i];
         float4 mv = reinterpret_cast<float4 *>(m)[i];
+        gv.x *= gs; gv.y *= gs; gv.z *= gs; gv.w *= gs;
         const float c = R.n ? reg_coef_at(R, 4 * i) : 0.f;
         if (c != 0.f) {
             gv.x = fmaf(c, wv.x, gv.x); gv.y = fmaf(c, wv.y, gv.y); gv.z = fmaf(c, wv.z, gv.z); gv.w = fmaf(c, wv.w, gv.w);
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256) void momentum_update_kernel(float *w, const fl
 // starts, and the LAST one to finish -- by then every workgroup has read it -- advances it, so a captured graph replays the
 // right bias correction without any host-side counter.  (An integer ticket: no floating-point result depends on arrival order.)
 __global__ __launch_bounds__(256) void adam_update_kernel(float *w, const float *g, float *m, float *v, long long n4, float beta1, float beta2,
-                                                          float eps, float clip, const float *sumsq, const float *neg_lr, int *state, Ranges R) {
+                                                          float eps, float clip, const float *sumsq, const float *neg_lr, int *state, Ranges R, float gs) {
     __shared__ float s_nlr;
     if (threadIdx.x == 0) {
         const double t = (double)(state[0] + 1);
@@ -126,6 +129,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float *w, const float 
         float4 wv = reinterpret_cast<float4 *>(w)[i];
         float4 mv = reinterpret_cast<float4 *>(m)[i];
         float4 vv = reinterpret_cast<float4 *>(v)[i];
+        gv.x *= gs; gv.y *= gs; gv.z *= gs; gv.w *= gs;
         const float c = R.n ? reg_coef_at(R, 4 * i) : 0.f;
         if (c != 0.f) {
             gv.x = fmaf(c, wv.x, gv.x); gv.y = fmaf(c, wv.y, gv.y); gv.z = fmaf(c, wv.z, gv.z); gv.w = fmaf(c, wv.w, gv.w);
@@ -199,14 +203,15 @@ __global__ __launch_bounds__(256) void vae_bwd_kernel(const float *mean, const f
 extern "C" int64_t cape_flat_workspace_bytes(void) { return (int64_t)FLAT_BLOCKS * sizeof(float); }
 
 extern "C" int cape_flat_gradnorm(const float *g, const float *w, int64_t n, const int64_t *reg_ranges, int32_t nranges,
-                                  float reg_coef, float *sumsq_out, void *workspace, int64_t workspace_bytes, void *stream) {
+                                  float reg_coef, float grad_scale, float *sumsq_out, void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!(grad_scale > 0.f)) return CAPE_EINVAL;
     if (!g || n < 4 || (n & 3) || !sumsq_out || !workspace || !al16(g) || (nranges > 0 && (!w || !al16(w)))) return CAPE_EINVAL;
     if (workspace_bytes < cape_flat_workspace_bytes()) return CAPE_EWORKSPACE;
     Ranges R;
     int rc = fill_ranges(R, reg_ranges, nranges, reg_coef);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    CAPE_LAUNCH(gradnorm_partial_kernel, dim3(FLAT_BLOCKS), dim3(256), 0, st, g, w, (long long)(n >> 2), R, (float *)workspace);
+    CAPE_LAUNCH(gradnorm_partial_kernel, dim3(FLAT_BLOCKS), dim3(256), 0, st, g, w, (long long)(n >> 2), R, grad_scale, (float *)workspace);
     CAPE_LAUNCH_CHECK();
     CAPE_LAUNCH(flat_final_kernel, dim3(1), dim3(256), 0, st, (const float *)workspace, 1.0f, sumsq_out);
     CAPE_LAUNCH_CHECK();
@@ -243,7 +248,8 @@ extern "C" int cape_sumsq_ranges(const float *x, const int64_t *ranges, int32_t 
 
 extern "C" int cape_flat_momentum_update(float *w, const float *g, float *m, int64_t n, float momentum, float clip,
                                          const float *sumsq, const float *neg_lr, const int64_t *reg_ranges,
-                                         int32_t nranges, float reg_coef, void *stream) {
+                                         int32_t nranges, float reg_coef, float grad_scale, void *stream) {
+    if (!(grad_scale > 0.f)) return CAPE_EINVAL;
     if (!w || !g || !m || n < 4 || (n & 3) || !sumsq || !neg_lr || !al16(w) || !al16(g) || !al16(m) || clip <= 0.f) return CAPE_EINVAL;
     Ranges R;
     int rc = fill_ranges(R, reg_ranges, nranges, reg_coef);
@@ -252,14 +258,15 @@ extern "C" int cape_flat_momentum_update(float *w, const float *g, float *m, int
     long long blocks = (n4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     CAPE_LAUNCH(momentum_update_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, g, m, n4, momentum, clip, sumsq,
-                neg_lr, R);
+                neg_lr, R, grad_scale);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }
 
 extern "C" int cape_flat_adam_update(float *w, const float *g, float *m, float *v, int64_t n, float beta1, float beta2, float eps,
                                      float clip, const float *sumsq, const float *neg_lr, int32_t *state,
-                                     const int64_t *reg_ranges, int32_t nranges, float reg_coef, void *stream) {
+                                     const int64_t *reg_ranges, int32_t nranges, float reg_coef, float grad_scale, void *stream) {
+    if (!(grad_scale > 0.f)) return CAPE_EINVAL;
     if (!w || !g || !m || !v || n < 4 || (n & 3) || !sumsq || !neg_lr || !state || !al16(w) || !al16(g) || !al16(m) || !al16(v) || clip <= 0.f)
         return CAPE_EINVAL;
     if (!(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps > 0.f)) return CAPE_EINVAL;
@@ -270,7 +277,7 @@ extern "C" int cape_flat_adam_update(float *w, const float *g, float *m, float *
     long long blocks = (n4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     CAPE_LAUNCH(adam_update_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n4, beta1, beta2, eps, clip,
-                sumsq, neg_lr, (int *)state, R);
+                sumsq, neg_lr, (int *)state, R, grad_scale);
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }

@@ -968,12 +968,16 @@ class CAPE(base_model):
             ranges, coef = [], 0.0
             if grp == 'g' and getattr(self, '_reg_in_bucket', False):
                 ranges, coef = self._reg_ranges(), self.regularization * self.regularization
-            ops.flat_gradnorm(g, flat, ranges, coef, st['sumsq'], st['ws'])
+            # data parallel: the bucket holds the SUM over the ranks (cape_amd.dist.GradAverager, defer_mean) and the kernels
+            # apply 1 / world themselves; bug-compat D "gradients" are the (replicated) weights and are never exchanged
+            gs = 1.0 if (grp == 'd' and self.bug_compat) else float(getattr(self, 'grad_scale', 1.0))
+            ops.flat_gradnorm(g, flat, ranges, coef, st['sumsq'], st['ws'], grad_scale=gs)
             if self.optimizer == 'adam':
                 # tf.train.AdamOptimizer(learning_rate) with TensorFlow's defaults (:447-449); the step count is on the device
-                ops.flat_adam_update(flat, g, m, st['v'], 0.9, 0.999, 1e-8, clip, st['sumsq'], st['neg_lr'], st['t'], ranges, coef)
+                ops.flat_adam_update(flat, g, m, st['v'], 0.9, 0.999, 1e-8, clip, st['sumsq'], st['neg_lr'], st['t'], ranges, coef,
+                                     grad_scale=gs)
             else:
-                ops.flat_momentum_update(flat, g, m, self.momentum, clip, st['sumsq'], st['neg_lr'], ranges, coef)
+                ops.flat_momentum_update(flat, g, m, self.momentum, clip, st['sumsq'], st['neg_lr'], ranges, coef, grad_scale=gs)
             self._pieces_dirty = True           # (the kernel writes through raw pointers: no version bump to detect)
         return st['sumsq']
 

@@ -2325,29 +2325,29 @@ def flat_workspace(device):
     return torch.empty(int(lib.cape_flat_workspace_bytes()) // 4, device=device, dtype=torch.float32)
 
 
-def flat_gradnorm(g, w, ranges, coef, sumsq_out, ws):
-    """sumsq_out <- sum (g + coef*w on ``ranges``)^2 over a flat bucket (two deterministic launches)."""
+def flat_gradnorm(g, w, ranges, coef, sumsq_out, ws, grad_scale=1.0):
+    """sumsq_out <- sum (grad_scale*g + coef*w on ``ranges``)^2 over a flat bucket (two deterministic launches)."""
     _lib.require_gpu()
     arr, nr = _ranges_arg(ranges)
     _log_launch("flat_gradnorm", 0, 4 * g.numel(),
-                lambda: check(lib.cape_flat_gradnorm(C.c_void_p(g.data_ptr()), _ptr(w), g.numel(), arr, nr, float(coef),
+                lambda: check(lib.cape_flat_gradnorm(C.c_void_p(g.data_ptr()), _ptr(w), g.numel(), arr, nr, float(coef), float(grad_scale),
                                                      C.c_void_p(sumsq_out.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel() * 4,
                                                      _stream()), "cape_flat_gradnorm"))
     return sumsq_out
 
 
-def flat_momentum_update(w, g, m, momentum, clip, sumsq, neg_lr, ranges, coef):
+def flat_momentum_update(w, g, m, momentum, clip, sumsq, neg_lr, ranges, coef, grad_scale=1.0):
     """clip-by-global-norm + momentum update of a flat bucket in one launch (csrc/optim.hip)."""
     _lib.require_gpu()
     arr, nr = _ranges_arg(ranges)
     _log_launch("flat_momentum_update", 0, 5 * 4 * w.numel(),
                 lambda: check(lib.cape_flat_momentum_update(C.c_void_p(w.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
                                                             w.numel(), float(momentum), float(clip), C.c_void_p(sumsq.data_ptr()),
-                                                            C.c_void_p(neg_lr.data_ptr()), arr, nr, float(coef), _stream()),
+                                                            C.c_void_p(neg_lr.data_ptr()), arr, nr, float(coef), float(grad_scale), _stream()),
                               "cape_flat_momentum_update"))
 
 
-def flat_adam_update(w, g, m, v, beta1, beta2, eps, clip, sumsq, neg_lr, state, ranges, coef):
+def flat_adam_update(w, g, m, v, beta1, beta2, eps, clip, sumsq, neg_lr, state, ranges, coef, grad_scale=1.0):
     """clip-by-global-norm + Adam update of a flat bucket in one launch (csrc/optim.hip; reference lib/models.py:447-449);
     ``state``: int32[2] device tensor {number of updates so far, 0}, advanced by the launch."""
     _lib.require_gpu()
@@ -2357,7 +2357,7 @@ def flat_adam_update(w, g, m, v, beta1, beta2, eps, clip, sumsq, neg_lr, state, 
                 lambda: check(lib.cape_flat_adam_update(C.c_void_p(w.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()),
                                                         C.c_void_p(v.data_ptr()), w.numel(), float(beta1), float(beta2), float(eps),
                                                         float(clip), C.c_void_p(sumsq.data_ptr()), C.c_void_p(neg_lr.data_ptr()),
-                                                        C.c_void_p(state.data_ptr()), arr, nr, float(coef), _stream()),
+                                                        C.c_void_p(state.data_ptr()), arr, nr, float(coef), float(grad_scale), _stream()),
                               "cape_flat_adam_update"))
 
 

@@ -37,6 +37,12 @@ class GraphedTrainStep(object):
             split = env == "1" or (grad_hook is not None and env != "0")
         self.split = bool(split) and not model.bug_compat
         model.split_backward = self.split
+        # the exchange leaves the SUM of the ranks' gradients in the bucket; the optimiser kernels apply 1 / world (one bucket-sized
+        # launch less per exchanged bucket, and clipping still sees the mean)
+        model.grad_scale = 1.0
+        if grad_hook is not None and hasattr(grad_hook, "defer_mean"):
+            grad_hook.defer_mean = True
+            model.grad_scale = grad_hook.grad_scale
         self.use_graph = use_graph          # (Adam's step count is a device counter advanced by the update kernel: capturable)
         B, d = model.batch_size, model.device
         M, Cn = model.input_num_verts, model.nn_input_channel

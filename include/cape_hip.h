@@ -546,7 +546,9 @@ int cape_cond_coef_bwd(const float *cond, int32_t ldc, int32_t N, int32_t Cc,
  * Optimiser step on flat fp32 buckets (parameters w, gradients g, momentum m; n % 4 == 0, 16-byte aligned):
  * tf.clip_by_global_norm(5.0) + tf.train.MomentumOptimizer (lib/models.py:448-461) with the dense kernels' L2
  * regulariser gradient (:40, :378-379) folded in.  reg_ranges: HOST array of nranges [begin, end) element
- * ranges (multiples of 4) on which the effective gradient is g + reg_coef * w.
+ * ranges (multiples of 4) on which the effective gradient is g + reg_coef * w.  grad_scale (> 0) multiplies the raw bucket
+ * first, everywhere "g" appears below: 1 for a single process, 1 / world when the bucket holds the SUM of the data-parallel
+ * ranks' gradients after the all-reduce (the mean then costs no launch of its own; clipping sees the mean, as it must).
  *   cape_flat_gradnorm:        *sumsq_out = sum (g + reg)^2            (two deterministic launches)
  *   cape_flat_momentum_update: s = clip / max(sqrt(*sumsq), clip);  m = momentum*m + s*(g + reg);  w += (*neg_lr)*m
  *   cape_flat_adam_update:     tf.train.AdamOptimizer (lib/models.py:447-449) behind the same clip and regulariser:
@@ -559,13 +561,13 @@ int cape_cond_coef_bwd(const float *cond, int32_t ldc, int32_t N, int32_t Cc,
  */
 int64_t cape_flat_workspace_bytes(void);
 int cape_flat_gradnorm(const float *g, const float *w, int64_t n, const int64_t *reg_ranges, int32_t nranges,
-                       float reg_coef, float *sumsq_out, void *workspace, int64_t workspace_bytes, void *stream);
+                       float reg_coef, float grad_scale, float *sumsq_out, void *workspace, int64_t workspace_bytes, void *stream);
 int cape_flat_momentum_update(float *w, const float *g, float *m, int64_t n, float momentum, float clip,
                               const float *sumsq, const float *neg_lr, const int64_t *reg_ranges,
-                              int32_t nranges, float reg_coef, void *stream);
+                              int32_t nranges, float reg_coef, float grad_scale, void *stream);
 int cape_flat_adam_update(float *w, const float *g, float *m, float *v, int64_t n, float beta1, float beta2, float eps,
                           float clip, const float *sumsq, const float *neg_lr, int32_t *state,
-                          const int64_t *reg_ranges, int32_t nranges, float reg_coef, void *stream);
+                          const int64_t *reg_ranges, int32_t nranges, float reg_coef, float grad_scale, void *stream);
 int cape_sumsq_ranges(const float *x, const int64_t *ranges, int32_t nranges, float scale, float *out,
                       void *workspace, int64_t workspace_bytes, void *stream);
 

@@ -30,10 +30,23 @@ from oracle.configs import cape_params     # noqa: E402
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 
 
-def inputs(N, nz, seed):
+def range_setup():
+    """(input field, decoder field) of the "range" profile from the reference's own template and row selections."""
+    from oracle.golden_inputs import range_fields
+    verts = np.array([[float(t) for t in l.split()[1:4]] for l in open(os.path.join(REF, "data", "template_mesh.obj")) if l.startswith("v ")])
+    _np_load = np.load
+    np.load = lambda *a, **k: _np_load(*a, **dict(k, allow_pickle=True))
+    try:
+        D = load_graph_mtx(REF, load_for_demo=True)[1]
+    finally:
+        np.load = _np_load
+    return range_fields(verts, D)
+
+
+def inputs(N, nz, seed, in_field=None):
     from oracle.golden_inputs import golden_inputs
     rot = np.load(os.path.join(REF, "data", "demo_data", "demo_pose_params.npz"))["rot"]
-    d = golden_inputs(N, nz, seed, rot)
+    d = golden_inputs(N, nz, seed, rot, in_field=in_field)
     # cross-check our filter_cloth_pose restatement against the reference's (lib/utils.py:38-62)
     assert np.array_equal(d["cond"], np.tile(filter_cloth_pose(rot), (N // 6 + 1, 1))[:N].astype(np.float32))
     return d
@@ -72,7 +85,16 @@ def run_chunked(tag, cfg, overrides, N, seed, chunk):
           float(np.abs(out["out_op_prediction"]).mean()))
 
 
-def run(tag, cfg, overrides, N, seed, given=None):
+def run(tag, cfg, overrides, N, seed, given=None, profile=None):
+    if profile is not None:
+        # operand-range cases (oracle/weights.py "range" profile): zero conv biases, decoder dense kernel scaled per vertex,
+        # displacements scaled per vertex over 22 binades with an exactly-zero region
+        from oracle import weights
+        assert profile == "range" and given is None
+        f_in, f_dec = range_setup()
+        nz = dict(cape_params(cfg, N), **(overrides or {}))["nz"]
+        with weights.profile("range", f_dec):
+            return run(tag, cfg, overrides, N, seed, given=inputs(N, nz, seed, in_field=f_in), profile=None)
     tf.shim_reset()
     # the reference targets numpy < 1.16.3 where np.load unpickled object arrays by default
     _np_load = np.load
@@ -120,7 +142,11 @@ def run(tag, cfg, overrides, N, seed, given=None):
     out["var_shapes"] = np.array([",".join(str(s) for s in var[n].shape) for n in vn])
     out["var_sums"] = np.array([float(np.asarray(var[n], np.float64).sum()) for n in vn])
     out["var_crc"] = np.array([zlib.crc32(np.ascontiguousarray(var[n], dtype=np.float32).tobytes()) for n in vn], dtype=np.int64)
-    out["config"] = np.array(repr(dict(cfg=cfg, overrides=overrides, N=N, seed=seed)))
+    from oracle import weights as _w
+    meta = dict(cfg=cfg, overrides=overrides, N=N, seed=seed)
+    if _w.PROFILE is not None:
+        meta["profile"] = _w.PROFILE["kind"]
+    out["config"] = np.array(repr(meta))
     if tag is None:
         return out
     fn = os.path.join(OUT, "ref_%s.npz" % tag)
@@ -168,11 +194,23 @@ CASES = [
                                     F=[16, 16, 32, 32, 32, 32, 64, 64], reduce_dim=16), 2, 14),
 ]
 
+# operand-range cases of the fp16 two-piece contractions at model level (see run(profile=...)): rows spanning 20+ binades, zero
+# rows; the second one with tanh activations, which saturate on the large rows and are linear on the small ones
+RANGE_CASES = [
+    ("range_affine", "affine_nz64", None, 2, 51),
+    ("range_tanh", "affine_nz18", dict(use_res_block=True, use_res_block_dec=False, cond_encoder=True, activation='b1tanh',
+                                       F=[16, 16, 32, 32, 64, 64, 128, 128], reduce_dim=32, loss='l2'), 2, 52),
+]
+
+
 def main():
     only = set(sys.argv[1:])               # optional: tags to (re)generate
     for case in CASES:
         if not only or case[0] in only:
             (run_chunked if len(case) == 6 else run)(*case)
+    for case in RANGE_CASES:
+        if not only or case[0] in only:
+            run(*case, profile="range")
 
 
 if __name__ == "__main__":

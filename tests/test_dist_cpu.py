@@ -27,7 +27,7 @@ def _flat_sgd_step(flat, flat_grad, m, lr=0.1, mom=0.9, clip=5.0):
     return gnorm
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, mode="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     from cape_amd import dist as cdist
@@ -39,7 +39,17 @@ def _worker(rank, world, port, out_dir):
     flat = W0.clone() + rank                 # deliberately different start; rank 0 wins after broadcast
     cdist.broadcast_flat(flat)
     b, e = cdist.shard_range(8, world, rank)
-    hook = cdist.GradAverager()
+    hook = cdist.GradAverager(mode=mode)
+    # deferred mean (what the step runner uses): the SUM stays in the bucket, grad_scale = 1 / world goes to the optimiser kernels
+    probe = torch.arange(12, dtype=torch.float32) * (rank + 1)
+    hook.defer_mean = True
+    hook(probe)
+    assert hook.grad_scale == 1.0 / world and torch.equal(probe, torch.arange(12, dtype=torch.float32) * sum(range(1, world + 1)))
+    hook.defer_mean = False
+    assert hook.grad_scale == 1.0
+    odd = torch.ones(7) * (rank + 1)               # a length the ranks cannot split evenly: falls back to the all-reduce
+    hook(odd)
+    assert torch.allclose(odd, torch.full((7,), sum(range(1, world + 1)) / world))
     m = torch.zeros_like(flat)
     for _ in range(3):
         p = flat.clone().requires_grad_(True)
@@ -61,11 +71,15 @@ def _worker(rank, world, port, out_dir):
     tdist.destroy_process_group()
 
 
-def test_two_rank_dp_matches_single_process(tmp_path):
+@pytest.mark.parametrize("mode", ["allreduce", "rsag", "direct"])
+def test_two_rank_dp_matches_single_process(tmp_path, mode):
+    """Every form of the exchange (one all-reduce; reduce-scatter + all-gather; all-to-all + fixed-order local sum + all-gather,
+    the direct form SURVEY 8(e) sized for the point-to-point xGMI links) gives bit-identical replicas and the single-process
+    result."""
     from cape_amd import dist as cdist
     assert cdist.shard_range(10, 4, 0) == (0, 3) and cdist.shard_range(10, 4, 3) == (8, 10)
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
     flats = [np.load(os.path.join(str(tmp_path), "flat_%d.npy" % r)) for r in range(world)]
     assert np.array_equal(flats[0], flats[1])                # replicas stay bit-identical
     # single-process reference on the full batch (mean of per-shard means == full mean for equal shards)

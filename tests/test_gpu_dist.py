@@ -19,17 +19,13 @@ def _env(**extra):
     return env
 
 
-@pytest.mark.parametrize("gan", [False, True], ids=["cvae", "adversarial"])
-def test_two_rank_step_equals_global_batch_step(gan, tmp_path):
-    """2 ranks x B meshes (mean of the rank gradients, clip after the reduce, replicas bit-identical) must reproduce the
-    single-process step on the 2B-mesh global batch: every loss term is a batch mean, so the averaged gradient IS the
-    global gradient.  Tolerance: fp32 summation order only (kernel tile selection differs between batch B and 2B)."""
+def _two_rank_equals_global(gan, tmp_path, backend, env, port):
     B, steps = 2, 2
     out = str(tmp_path / "dp.npz")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "tools", "dp_equiv_worker.py"), out, str(B), str(steps), "1" if gan else "0",
-           "gloo"]
-    r = subprocess.run(cmd, env=_env(CAPE_FORCE_DEVICE="0"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+           "--master-port", str(port), os.path.join(ROOT, "tools", "dp_equiv_worker.py"), out, str(B), str(steps), "1" if gan else "0",
+           backend]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
     dp = np.load(out)
     assert int(dp["split"]) == 1                       # the two-phase backward was the path taken
@@ -45,6 +41,25 @@ def test_two_rank_step_equals_global_batch_step(gan, tmp_path):
         err = np.abs(got - ref).max()
         print(grp, "largest update %.3e, dp-vs-global difference %.3e" % (moved, err))
         assert moved > 0 and err <= 2e-3 * moved + 1e-7, (grp, err, moved)
+
+
+@pytest.mark.parametrize("gan", [False, True], ids=["cvae", "adversarial"])
+def test_two_rank_step_equals_global_batch_step(gan, tmp_path):
+    """2 ranks x B meshes (sum of the rank gradients, 1 / world and the clip inside the optimiser kernels, replicas
+    bit-identical) must reproduce the single-process step on the 2B-mesh global batch: every loss term is a batch mean, so the
+    averaged gradient IS the global gradient.  Tolerance: fp32 summation order only (kernel tile selection differs between
+    batch B and 2B).  Two ranks on device 0 over gloo."""
+    _two_rank_equals_global(gan, tmp_path, "gloo", _env(CAPE_FORCE_DEVICE="0"), 29533)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two HIP devices: RCCL over xGMI between them")
+@pytest.mark.parametrize("mode", ["allreduce", "rsag", "direct"])
+def test_two_rank_rccl_step_equals_global_batch_step(mode, tmp_path):
+    """The same equivalence over the real transport -- one process per GPU, backend "nccl" (RCCL), every form of the exchange
+    (cape_amd.dist.MODES) -- wherever two devices are visible; skipped on the one-GPU boxes of the test tier."""
+    env = _env(CAPE_DP_COLLECTIVE=mode)
+    env.pop("CAPE_FORCE_DEVICE", None)
+    _two_rank_equals_global(False, tmp_path, "nccl", env, 29541)
 
 
 def test_split_step_with_one_rank_rccl_group():
@@ -71,6 +86,13 @@ def test_bench_gpus2_without_torchrun_launches_two_ranks():
     assert len(lines) == 1, r.stdout.decode()[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 4
+    # the line proves what ran: both ranks with their device and backend, every exchange form timed (or its refusal named),
+    # the form used, and what the exchange cost the step
+    dp = out["config"]["dp"]
+    assert dp["world"] == 2 and dp["backend"] == "gloo" and sorted(r["rank"] for r in dp["ranks"]) == [0, 1]
+    assert all(r["device"] == 0 and r["backend"] == "gloo" for r in dp["ranks"]) and len({r["pid"] for r in dp["ranks"]}) == 2
+    assert set(dp["collective_probe_ms"]) == {"allreduce", "rsag", "direct"} and isinstance(dp["collective_probe_ms"]["allreduce"], float)
+    assert dp["collective"] in dp["collective_probe_ms"] and "exposed_exchange_ms" in dp and dp["bucket_mb"] > 60
 
 
 def test_bench_gpus_refuses_more_ranks_than_devices():

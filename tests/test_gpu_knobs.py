@@ -60,3 +60,22 @@ def test_step_without_the_fused_activation_gradient_and_with_the_side_stream():
                            env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
         tail = r.stdout.decode()[-1500:]
         assert r.returncode == 0 and " passed" in tail and "failed" not in tail, (knobs, tail)
+
+
+ARITHMETIC_LEGS = [
+    ("six_product_bf16", dict(CAPE_H2="0")),                                                 # round 3's arithmetic
+    ("exact_fp32_mfma", dict(CAPE_H2="0", CAPE_GEMM_BF16X6="0", CAPE_DW_BF16X6="0")),        # v_mfma_f32_32x32x2_f32 everywhere
+]
+
+
+@pytest.mark.parametrize("leg,knobs", ARITHMETIC_LEGS, ids=[l for l, _ in ARITHMETIC_LEGS])
+def test_reference_goldens_under_each_arithmetic(leg, knobs):
+    """The whole reference-golden suite (thirteen network configurations incl. the two operand-range cases, SURVEY 8(c)'s 4x bar
+    and the 1e-4 absolute bar) on the library's two other arithmetics; the default (fp16 two-piece) leg is the plain run of
+    tests/test_gpu_model.py.  Margins of every leg go to CAPE_PARITY_MARGINS when set."""
+    env = dict(os.environ, CAPE_PARITY_LEG=leg, **knobs)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_model.py"), "-q", "-m", "gpu",
+                        "-k", "test_model_matches_reference_golden"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
+    tail = r.stdout.decode()[-2500:]
+    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, tail

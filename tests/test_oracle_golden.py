@@ -4,6 +4,7 @@ code executed on the numpy TF1 shim -- same variable names and shapes, same weig
 initialisers), same forward values.  This is what pins the oracle; the HIP path is then compared with
 the oracle (tests/test_gpu_*.py) and with these vectors directly."""
 import ast
+import contextlib
 import os
 import zlib
 
@@ -11,13 +12,30 @@ import numpy as np
 import pytest
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["affine_nz64", "cmr_nz18", "resblock_udn_tanh", "affine_nz64_b16", "cmr_nz18_b32", "cheb_k6", "switches_relu", "affine_mixed_k", "huber_res_affine", "cmr_k3_res", "reduce0", "b2relu_udn", "cond3"]
+CASES = ["affine_nz64", "cmr_nz18", "resblock_udn_tanh", "affine_nz64_b16", "cmr_nz18_b32", "cheb_k6", "switches_relu", "affine_mixed_k", "huber_res_affine", "cmr_k3_res", "reduce0", "b2relu_udn", "cond3",
+         # operand-range cases (oracle/weights.py "range" profile): rows spanning 20+ binades, exactly-zero rows, saturating tanh
+         "range_affine", "range_tanh"]
 
 
 def load_case(tag):
     g = np.load(os.path.join(GOLD, "ref_%s.npz" % tag))
     meta = ast.literal_eval(str(g["config"]))
     return g, meta
+
+
+@contextlib.contextmanager
+def case_profile(meta, mesh_ops):
+    """The weight profile a golden case was recorded under (must stay active while the oracle / twin materialises its
+    variables, i.e. around the forward pass); yields the per-vertex input field for golden_inputs (None: plain case)."""
+    if meta.get("profile") == "range":
+        from oracle import weights
+        from oracle.golden_inputs import range_fields
+        f_in, f_dec = range_fields(mesh_ops["pack"]["template_verts"], mesh_ops["D"])
+        with weights.profile("range", f_dec):
+            yield f_in
+    else:
+        assert meta.get("profile") is None, meta
+        yield None
 
 
 def build_oracle(meta, mesh_ops, dtype=np.float64):
@@ -34,13 +52,14 @@ def build_oracle(meta, mesh_ops, dtype=np.float64):
 def test_oracle_reproduces_reference_graph(tag, mesh_ops):
     from oracle.golden_inputs import golden_inputs
     g, meta = load_case(tag)
-    P, orc = build_oracle(meta, mesh_ops)
-    inp = golden_inputs(meta["N"], P["nz"], meta["seed"], mesh_ops["pack"]["demo_rot"])
-    y, y2 = orc.cond_embeddings(inp["cond"], inp["clo"])
-    xh, zm, zl = orc.generator(inp["x"], y, y2, inp["eps"])
-    yd, y2d = orc.cond_embeddings(inp["cond_d"], inp["clo_d"])
-    d_fake = orc.discriminator(xh, y, y2)
-    d_real = orc.discriminator(inp["xd"], yd, y2d)
+    with case_profile(meta, mesh_ops) as in_field:
+        P, orc = build_oracle(meta, mesh_ops)
+        inp = golden_inputs(meta["N"], P["nz"], meta["seed"], mesh_ops["pack"]["demo_rot"], in_field=in_field)
+        y, y2 = orc.cond_embeddings(inp["cond"], inp["clo"])
+        xh, zm, zl = orc.generator(inp["x"], y, y2, inp["eps"])
+        yd, y2d = orc.cond_embeddings(inp["cond_d"], inp["clo_d"])
+        d_fake = orc.discriminator(xh, y, y2)
+        d_real = orc.discriminator(inp["xd"], yd, y2d)
     ls = orc.losses(xh, inp["gt"], zm, zl, d_real, d_fake)
 
     # identical variable inventory (names, shapes, values) to what the reference graph created

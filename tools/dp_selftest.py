@@ -39,6 +39,9 @@ for name, hook in (("single_graph", None), ("split_rccl_1rank", cdist.GradAverag
     torch.cuda.synchronize()
     res[name] = round((time.perf_counter() - t0) / 30 * 1e3, 4)
     finals[name] = model._opt_state['g']['flat'].detach().clone()
+# every form of the exchange against the real backend (one rank: each is a device copy, the point is that RCCL accepts the calls)
+res["collective_probe_ms"] = cdist.probe_collectives(cdist.GradAverager(always=True), int(finals["single_graph"].numel()), torch.device("cuda:0"))
+assert all(isinstance(v, float) for v in res["collective_probe_ms"].values()), res["collective_probe_ms"]
 d = (finals["single_graph"] - finals["split_rccl_1rank"]).abs().max().item()
 res["max_abs_param_diff"] = d
 res["split"] = bool(runner.split)

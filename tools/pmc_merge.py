@@ -9,6 +9,8 @@ taken as reported (uncalibrated there).  Both counters are in KiB.
 import json
 import sys
 
+N_XCD, N_CU, N_SIMD = 8, 256, 1024      # MI355X: 8 XCDs x 32 CUs x 4 SIMDs
+
 
 def main(fetch, write, sq, out):
     F, W, S = (json.load(open(p)) for p in (fetch, write, sq))
@@ -35,10 +37,19 @@ def main(fetch, write, sq, out):
             e["lds_bank_conflict_frac"] = round(bc / la, 4)
         mb, gui = g(S, "SQ_VALU_MFMA_BUSY_CYCLES"), g(S, "GRBM_GUI_ACTIVE")
         if mb is not None and gui:
-            # raw ratio of the two counters as rocprofv3 aggregates them.  Reading it as a pipe-busy fraction needs the
-            # aggregation widths: with GUI_ACTIVE summed over the 8 XCDs and MFMA_BUSY over the 1024 SIMDs,
-            # busy fraction = ratio * 8 / 1024 (0.48 for a ratio of 61) -- an assumption, stated in DESIGN.md.
-            e["mfma_busy_cycles_over_gui_active"] = round(mb / gui, 2)
+            # MFMA utilisation = matrix-pipe busy cycles / (SIMDs x kernel cycles).  rocprofv3 reports SQ_VALU_MFMA_BUSY_CYCLES
+            # summed over the chip's 1024 SIMDs (checked on dw_h2_kernel<128,128>: 17 104 896 = 32 cycles x 534 528
+            # v_mfma_f32_32x32x16_f16, exactly the instruction count of the launch) and GRBM_GUI_ACTIVE summed over the 8 XCDs
+            # (816 525 / 8 = 102 k cycles = the launch's duration under the counter run), so
+            #     mfma_util = MFMA_BUSY / (1024 * GUI_ACTIVE / 8)
+            # -- the fraction of SIMD-cycles in which the matrix pipe is executing, against the clock the kernel actually
+            # ran at (a fraction of the DVFS-limited pipe rate, not of the quoted 2.5 PFLOP/s at the maximum clock).
+            e["mfma_busy_cycles"] = int(mb)
+            e["kernel_cycles"] = int(gui / N_XCD)
+            e["mfma_util"] = round(mb / (N_SIMD * gui / N_XCD), 4)
+            la2 = g(S, "SQ_LDS_IDX_ACTIVE")
+            if la2 is not None:
+                e["lds_active_frac"] = round(la2 / (N_CU * gui / N_XCD), 4)       # LDS-array cycles per CU-cycle
         res[k] = e
     # stamp: bench.py attaches these figures to its roofline object only while the kernel sources are the ones measured
     import os, sys as _sys
