@@ -518,8 +518,7 @@ def main():
     hook = None
     dp = dict(world=world, backend=(tdist.get_backend() if world > 1 else None), ranks=cdist.rank_inventory(model.device))
     if world > 1:
-        for grp in ('g', 'd'):
-            cdist.broadcast_flat(model._opt_state[grp]['flat'])
+        model.sync_variables(src=0)
         hook = cdist.GradAverager()
         st_g = model._opt_state['g']
         nelem = int(st_g['flat_grad'].numel())

@@ -672,14 +672,13 @@ constexpr int BP_RB_MAX = 128;              // rows per block (upper bound; halv
 #define CAPE_BP_BLOCKS_DEFAULT 448
 #endif
 #ifndef CAPE_BP_UNROLL_DEFAULT
-#define CAPE_BP_UNROLL_DEFAULT 2           // rows loaded ahead per thread in bwd_prep_vec_kernel (CAPE_BP_UNROLL = 1, 2, 4)
+#define CAPE_BP_UNROLL_DEFAULT 2           // rows loaded ahead per thread in bwd_prep_vec_kernel (compile-time: 1, 2, 4)
 #endif
 #ifndef CAPE_BP_RB_MIN_DEFAULT
 #define CAPE_BP_RB_MIN_DEFAULT 16
 #endif
 inline int bp_rows(int N, int Mo) {
-    static const int want = getenv("CAPE_BP_BLOCKS") ? atoi(getenv("CAPE_BP_BLOCKS")) : CAPE_BP_BLOCKS_DEFAULT;
-    static const int rbmin = getenv("CAPE_BP_RB_MIN") ? atoi(getenv("CAPE_BP_RB_MIN")) : CAPE_BP_RB_MIN_DEFAULT;
+    constexpr int want = CAPE_BP_BLOCKS_DEFAULT, rbmin = CAPE_BP_RB_MIN_DEFAULT;      // (measured in round 2; no run-time knob)
     int rb = BP_RB_MAX;
     while (rb > rbmin && (long long)N * ((Mo + rb - 1) / rb) < want) rb >>= 1;
     return rb;
@@ -1406,8 +1405,7 @@ int bwd_prep_impl(const T *g, int64_t g_sample_stride, int32_t ldg, const T *y, 
     // measured (tools/bench_sparse.py, profiles/r02_ubench_sparse_bwd_prep.txt): two rows ahead is the best depth for the 4-wide
     // kernel; the 8-wide one pays only from 256 channels (fewer row lanes per column group below that), fp32 without
     // read-ahead (167 registers at depth 4, 129 at 2)
-    static const int bp_ur_env = getenv("CAPE_BP_UNROLL") ? atoi(getenv("CAPE_BP_UNROLL")) : 0;
-    const int bp_ur = bp_ur_env ? bp_ur_env : (wide && es == 4) ? 1 : CAPE_BP_UNROLL_DEFAULT;
+    const int bp_ur = (wide && es == 4) ? 1 : CAPE_BP_UNROLL_DEFAULT;
 #define CAPE_BP_LAUNCH(VW_, UR_)                                                                                                    \
     CAPE_LAUNCH((bwd_prep_vec_kernel<T, VW_, UR_>), dim3(N * chunks), dim3(256), 0, st, gv, yv, act, mask, zv, rowscale, R, rg,     \
                 dbias ? 1 : 0, dcoef_g ? 1 : 0, N, Mo, F, (float *)workspace, chunks, RB, rowmax_out)

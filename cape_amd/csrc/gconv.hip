@@ -856,7 +856,7 @@ inline FwdPlan plan_fwd(const GconvParams &p, const cape_src_t *srcs, bool dual,
     pl.BM = 128;
     // small meshes: 128-row tiles leave <= 2 workgroups per CU (no overlap partner while staging);
     // 64-row tiles double the resident workgroups at the price of re-reading the weight tile
-    static const int bm64_below = getenv("CAPE_BM64_BELOW") ? atoi(getenv("CAPE_BM64_BELOW")) : 640;
+    constexpr int bm64_below = 640;
     if (pl.BN == 128 && (long long)p.N * ((p.Mo + 127) / 128) * ((p.F + 127) / 128) < bm64_below) pl.BM = 64;
     return pl;
 }

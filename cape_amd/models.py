@@ -235,7 +235,10 @@ class base_model(object):
         In-place edits through torch bump them; kernels that write through raw pointers and graph replays do not -- those
         paths set ``_pieces_dirty``."""
         v = tuple(int(st['flat']._version) for st in self._opt_state.values()) if getattr(self, '_opt_state', None) else ()
-        return v + tuple(int(self._vars[n]._version) for n in sorted(self._conv_meta) if n in self._vars)
+        names = getattr(self, '_conv_names_sorted', None)
+        if names is None or len(names) != len(self._conv_meta):             # (the layer list only grows, during the first trace)
+            names = self._conv_names_sorted = [n for n in sorted(self._conv_meta) if n in self._vars]
+        return v + tuple(int(self._vars[n]._version) for n in names)
 
     def prepare_pieces(self):
         """(Re)write the piece planes of all conv weights from their CURRENT values: two launches.  Runs at the start of
@@ -251,6 +254,19 @@ class base_model(object):
             ops.PIECES[wp.W.data_ptr()] = wp
         self._pieces_dirty = False
         self._pieces_versions = self._weights_version()
+
+    def _begin_pass(self):
+        """Entry of every top-level pass (forward_losses, encode, encode_only_condition, predict / evaluate, decode): the piece
+        planes are rewritten from the current weights UNCONDITIONALLY -- two small launches -- instead of trusting that every
+        writer of the variables (optimiser kernels, graph replays, collectives, raw-pointer writers) was seen."""
+        self.prepare_pieces()
+
+    def sync_variables(self, src=0):
+        """Data parallel: every rank starts from rank ``src``'s variables (cape_amd.dist.broadcast_flat on the flat buckets)."""
+        from . import dist as cdist
+        for st in self._opt_state.values():
+            cdist.broadcast_flat(st['flat'], src=src)
+        self._pieces_dirty = True               # (a collective writes the bucket without a version bump)
 
     def _ensure_pieces(self):
         if self._piece_plan is None and not getattr(self, '_traced', False):
@@ -989,7 +1005,7 @@ class CAPE(base_model):
         regularisation gradient to the flat bucket itself (the loss then carries only its value)."""
         self._reg_via_bucket = reg_via_bucket
         self._reg_in_bucket = False
-        self.prepare_pieces()                   # unconditionally: a captured step must contain the refresh of the piece planes
+        self._begin_pass()                      # unconditionally: a captured step must contain the refresh of the piece planes
         y_g, y2_g = self._conditions(cond_g, cond2_g)
         # heads of the two-phase backward: the tensors the decoder / discriminator actually consume
         self._y_pair = tuple(t for t in self._ycat[2:] if t is not None) if self._ycat is not None else (y_g, y2_g)
@@ -1083,7 +1099,6 @@ class CAPE(base_model):
                 if not failed:
                     ops.flush_deferred()
             finally:
-                ops._join_dw_stream()                 # (a failed sweep still rejoins its side branch before buffers go)
                 ops.DEFERRED = None
                 ops.DEFERRED_DW[:] = []
                 ops.DEFERRED_GN[:] = []
@@ -1396,6 +1411,7 @@ class CAPE(base_model):
     def encode(self, data=None, cond=None, cond2=None):
         size = data.shape[0]
         self._get_session()
+        self._begin_pass()
         zs = [[], [], [], []]
         with torch.no_grad():
             for begin in range(0, size, self.batch_size):
@@ -1413,6 +1429,7 @@ class CAPE(base_model):
     def encode_only_condition(self, cond=None, cond2=None):
         size = cond.shape[0]
         self._get_session()
+        self._begin_pass()
         zc, zc2 = [], []
         with torch.no_grad():
             for begin in range(0, size, self.batch_size):
@@ -1430,6 +1447,7 @@ class CAPE(base_model):
         # float division, as in the reference (:1039; quirk C8)
         num_zero_phs = self.batch_size * (size / self.batch_size + 1) - size
         self._get_session(sess)
+        self._begin_pass()
         preds = []
         with torch.no_grad():
             for begin in range(0, size, self.batch_size):
@@ -1471,6 +1489,7 @@ class CAPE(base_model):
     def decode(self, data, cond=None, cond2=None):
         size = data.shape[0]
         self._get_session()
+        self._begin_pass()
         recs = []
         with torch.no_grad():
             for begin in range(0, size, self.batch_size):

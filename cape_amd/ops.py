@@ -386,6 +386,19 @@ FUSE_ACT_GRAD = int(_os.environ.get("CAPE_FUSE_ACT_GRAD", "1"))
 _CHAIN = [False]
 
 
+class _ActOffer(object):
+    """What a layer attaches to its output (``_cape_act_out``) when its consumer may differentiate its bias + activation
+    epilogue for it.  The hand-over travels on Python attributes of autograd tensors, so both ends check it: the consumer's
+    backward marks ``fused`` (it multiplied by act' and queued the bias partials) and tags the gradient with the version
+    counter it had then (``_cape_is_dz``); the offering layer's backward refuses a tagged gradient that was written since (the
+    autograd engine sums a second gradient INTO a tensor it owns) and a fused hand-over whose tag did not arrive (a hook or a
+    copy dropped it: act' would be applied twice and the bias partials queued twice)."""
+    __slots__ = ("act", "gB", "fused")
+
+    def __init__(self, act, gB):
+        self.act, self.gB, self.fused = act, gB, False
+
+
 class sole_consumer_chain(object):
     def __init__(self, on=True):
         self.on = bool(on)
@@ -720,15 +733,7 @@ def gconv_dw(entries, dz, accumulate=False, dz2=None, defer=False):
             plan = (C.c_int32 * 4)()
             dw_plan(plan)
             PLAN_LOG.add(("dw", plan[0], plan[1], plan[2]) + (("bf16",) if bf else ()))
-        if DW_STREAM_ON:
-            global _DW_FORKED
-            side = _dw_side_stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                dw_stage(1)
-            _DW_FORKED = True
-        else:
-            dw_stage(1)
+        dw_stage(1)
         it = _lib.CapeDwItem()
         it.srcs, it.nsrc = C.addressof(arr), len(entries)
         it.dz, it.dz_sample_stride, it.lddz = p.value, ss, ld
@@ -852,7 +857,7 @@ def spmm_multi(xs, csrs, sum=False, scales=None, act_x=None, act=None):
 def actgrad_fusable(xs, act_x, Cn):
     """The fused activation-gradient form of spmm_multi needs the 8-wide vector kernel with the lanes of a row forming one
     power-of-two group of at most 64: 64..512 channels in powers of two, every operand 32-byte aligned (fresh outputs are)."""
-    if not (FUSE_ACT_GRAD and H2 is not None and Cn in (64, 128, 256, 512)) or _os.environ.get("CAPE_SPMM_WIDE", "1") == "0":
+    if not (FUSE_ACT_GRAD and Cn in (64, 128, 256, 512)) or _os.environ.get("CAPE_SPMM_WIDE", "1") == "0":
         return False
     for t in list(xs) + [act_x]:
         p, ss, ld = _v(t)
@@ -996,32 +1001,8 @@ DEFERRED = None
 DEFERRED_DW = []          # queued weight-gradient slab reductions (gconv_dw(defer=True)), same lifetime as DEFERRED
 DEFERRED_GN = []          # queued batch sums of group-norm parameter-gradient partials (GroupNormFn.backward), likewise
 
-# Weight-gradient contractions are leaves of the backward sweep (nothing reads dW before the flush): with CAPE_DW_STREAM=1 the
-# deferred ones run on a second HIP stream, forked where their dz is ready and joined before the batched slab reduction, so a
-# captured step holds them as a parallel branch next to the data-gradient chain.  Every operand is kept alive by DEFERRED_DW
-# until the join (no allocator reuse under the branch).
-DW_STREAM_ON = _os.environ.get("CAPE_DW_STREAM", "0") == "1"
-_DW_STREAM = None
-_DW_FORKED = False
-
-
-def _dw_side_stream():
-    global _DW_STREAM
-    if _DW_STREAM is None:
-        _DW_STREAM = torch.cuda.Stream()
-    return _DW_STREAM
-
-
-def _join_dw_stream():
-    global _DW_FORKED
-    if _DW_FORKED:
-        torch.cuda.current_stream().wait_stream(_DW_STREAM)
-        _DW_FORKED = False
-
-
 def _flush_dw():
     """The queued fixed-order slab reductions of the weight gradient, as batched launches."""
-    _join_dw_stream()
     if DEFERRED_DW:
         queued, DEFERRED_DW[:] = list(DEFERRED_DW), []
         nmax = 12                                    # CAPE_MAX_DW_REDUCE_ITEMS
@@ -1259,8 +1240,9 @@ class ChebConvFn(torch.autograd.Function):
         ctx.prev_act = getattr(x, "_cape_act_out", None) if (_CHAIN[0] and FUSE_ACT_GRAD and twopass) else None
         ctx.offers_dz = bool(W_aff is None and Co == 0 and Cc == 0 and bias is not None and bias_mode == _lib.BIAS_CHANNEL
                              and act in ("leaky", "relu") and y.dtype == torch.float32 and gB is not None)
+        ctx.offer = None
         if ctx.offers_dz:
-            yfull._cape_act_out = (act, gB)
+            ctx.offer = yfull._cape_act_out = _ActOffer(act, gB)
         # up-sampling layers (Mo > Mi): the data gradient needs T_k = S_k^T dz at the Mi input rows anyway, and
         # dW_k = X_k^T dz = x^T T_k -- the weight gradient contracts over the COARSE rows (half the flops) and the
         # fine-level X_k need not be kept for the backward pass at all
@@ -1368,6 +1350,15 @@ class ChebConvFn(torch.autograd.Function):
         tag = getattr(gfull, "_cape_is_dz", None)
         if tag is not None and not getattr(ctx, "offers_dz", False):
             raise RuntimeError("a pre-activated gradient reached a layer that did not offer it (sole_consumer_chain misuse)")
+        offer = getattr(ctx, "offer", None)
+        if tag is not None and (tag["offer"] is not offer or gfull._version != tag["version"]):
+            raise RuntimeError("a pre-activated gradient was written after its producer tagged it, or belongs to another layer "
+                               "(sole_consumer_chain: the tensor has a second consumer whose gradient the engine summed in)")
+        if offer is not None:
+            if offer.fused and tag is None:
+                raise RuntimeError("the consumer of this layer's output differentiated its activation (sole_consumer_chain) but "
+                                   "the gradient arrived without its tag: it would be multiplied by act' twice")
+            offer.fused = False
         if plain:
             dz, dbv, dcoef, dca = g, None, None, None
         elif tag is not None:
@@ -1468,18 +1459,19 @@ class ChebConvFn(torch.autograd.Function):
                     Gs = [Gall[:, :, k * ChP:k * ChP + Ch] for k in range(K)]
                     fused = None
                     if act_x is not None and actgrad_fusable(Gs, act_x, Ch) and tuple(act_x.shape) == (N, Mi, Ch):
-                        fused = spmm_multi(Gs, [ops.bwd[k] for k in range(K)], sum=True, act_x=act_x, act=ctx.prev_act[0])
+                        fused = spmm_multi(Gs, [ops.bwd[k] for k in range(K)], sum=True, act_x=act_x, act=ctx.prev_act.act)
                     if fused is not None:
                         dx, part, chunks = fused
-                        gB_prev = ctx.prev_act[1]
+                        gB_prev = ctx.prev_act.gB
+                        ctx.prev_act.fused = True
                         item = dict(ws=part, N=N, Mo=Mi, F=Ch, R=0, dbias=gB_prev.view(Ch), dcoef=None, dcoef_g=None, cstride=0, chunks=chunks)
                         if DEFERRED is not None:
                             DEFERRED.append(item)
-                            dx._cape_is_dz = dict(dbias=None)
+                            dx._cape_is_dz = dict(dbias=None, offer=ctx.prev_act, version=dx._version)
                         else:
                             db = torch.empty(Ch, device=dev, dtype=torch.float32)
                             _finalize_bwd_prep([dict(item, dbias=db)])
-                            dx._cape_is_dz = dict(dbias=db)
+                            dx._cape_is_dz = dict(dbias=db, offer=ctx.prev_act, version=dx._version)
                     else:
                         dx = spmm_multi(Gs, [ops.bwd[k] for k in range(K)], sum=True)
                 elif contract_first:

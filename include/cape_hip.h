@@ -3,10 +3,17 @@
  * Chebyshev mesh-convolution hot path.
  *
  * Every entry point is extern "C", takes caller-owned DEVICE pointers + explicit sizes +
- * a hipStream_t (passed as void*), performs no allocation and no synchronisation, keeps
- * no global mutable state and returns 0 on success, a negative CAPE_E* code for argument
- * errors or a positive hipError_t for launch errors.  Results are deterministic (no
- * floating-point atomics).  Tensors are fp32, row-major [N, M, ld] with channels
+ * a hipStream_t (passed as void*), performs no allocation and no synchronisation, and
+ * returns 0 on success, a negative CAPE_E* code for argument errors or a positive
+ * hipError_t for launch errors.  Process-wide state: no buffers, no caches, nothing a caller
+ * can change through the ABI -- but the library does latch a set of kernel-SELECTION
+ * switches from the environment on first use (CAPE_GEMM_H2, CAPE_DW_H2, CAPE_H2_TILE,
+ * CAPE_GEMM_BF16X6[_DUAL], CAPE_DW_BF16X6, CAPE_GEMM_PLAIN, CAPE_DW_PLAIN, CAPE_NARROW,
+ * CAPE_FC_MFMA, CAPE_SPMM_UNROLL, CAPE_SPMM_WIDE; INTEGRATION.md lists them): they choose
+ * among kernel families that compute the same function and are all held to the same parity
+ * tests; with none of them set (the default every test and bench line runs) behaviour
+ * depends on the arguments alone.  Results are deterministic (no floating-point atomics; the
+ * one integer ticket, in cape_flat_adam_update, orders no floating-point operation).  Tensors are fp32, row-major [N, M, ld] with channels
  * contiguous (ld >= C is the row stride in elements), i.e. the reference's [N, M, F]
  * placeholder layout (reference lib/models.py:272-282) without its [M, F*N] shuffles
  * (lib/models.py:81-83, 97-99, 147-151).

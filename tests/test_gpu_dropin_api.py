@@ -198,3 +198,62 @@ def test_fit_runs_the_graph_runner_and_matches_eager_train_steps(tmp_path, mesh_
         assert d <= 1e-6 * max(fb.abs().max().item(), 1.0), (grp, d)
     # and the weights did move (the comparison is not vacuous)
     assert any(not np.array_equal(init[k], v) for k, v in b.variables().items())
+
+
+def test_reference_demo_trace_on_device(tmp_path, mesh_ops):
+    """The device half of tests/test_reference_entry_script.py: the call trace that the reference's UNMODIFIED
+    run_simple_demo.py produced against cape_amd (constructor keywords, build_graph / encode_only_condition / decode calls and
+    every array the script handed over; committed as tests/golden/run_simple_demo_trace.npz) replayed on the real model, followed
+    by the demo's own post-processing (demos.py:397-407) down to the .obj files."""
+    import json
+    from cape_amd import models
+    from cape_amd.load_data import load_graph_mtx
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "run_simple_demo_trace.npz"))
+    meta = json.loads(str(g["meta"]))
+    L, D, U, p, L_ds2, D_ds2, U_ds2 = load_graph_mtx(None, load_for_demo=True)
+    ops_ = dict(L=L, D=D, U=U, L_d=L_ds2, D_d=D_ds2)
+    # the operators the reference's own loader handed the constructor are the ones of our pack
+    for k, mats in ops_.items():
+        assert [list(m.shape) for m in mats] == meta["operator_shapes"][k] and [int(m.nnz) for m in mats] == meta["operator_nnz"][k], k
+    ctor = dict(meta["ctor"], project_dir=str(tmp_path))
+    assert ctor["p"] == list(p)
+    # the demo restores a trained checkpoint (lib/models.py:209-215): give the experiment one (reference initialisers)
+    trainer = models.CAPE(**ops_, **ctor)
+    trainer.build_graph(trainer.input_num_verts, trainer.nn_input_channel, phase='train')
+    trainer.save_checkpoint(0)
+
+    model = models.CAPE(**ops_, **ctor)                                               # run_simple_demo.py:45
+    outs = []
+    for call in meta["calls"]:
+        name, args = call[0], call[1:]
+        if name == "build_graph":
+            model.build_graph(args[0], args[1], phase=args[2])                        # run_simple_demo.py:47
+        elif name == "encode_only_condition":
+            pose_emb, clo_emb = model.encode_only_condition(g[args[0]], g[args[1]])     # demos.py:376
+            assert pose_emb.shape == (4, model.nz_cond) and clo_emb.shape == (4, model.nz_cond2)
+            assert np.isfinite(pose_emb).all() and np.isfinite(clo_emb).all()
+            assert np.abs(pose_emb - pose_emb[0]).max() == 0                          # the script repeats ONE pose four times
+        elif name == "decode":
+            pred = model.decode(g[args[0]], cond=g[args[1]], cond2=g[args[2]])         # demos.py:395
+            assert pred.shape == (3, 6890, 3) and pred.dtype == np.float32 and np.isfinite(pred).all()
+            outs.append(pred)
+        else:
+            raise AssertionError(name)
+    assert len(outs) == 4
+    # demos.py:397-407: de-normalise, mask to the clothing vertices, add the minimal shape, export
+    out_dir = tmp_path / "results" / "demo_results"
+    os.makedirs(out_dir)
+    verts = mesh_ops["pack"]["template_verts"]
+    faces = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "template_faces.npy"))
+    for i, pred in enumerate(outs):
+        full = pred * g["train_std"] + g["train_mean"] + verts
+        assert np.isfinite(full).all()
+        for j in range(len(full)):
+            with open(out_dir / ("clo%d_%04d.obj" % (i, j)), "w") as f:
+                f.writelines("v %.8f %.8f %.8f\n" % tuple(v) for v in full[j])
+                f.writelines("f %d %d %d\n" % tuple(t + 1) for t in faces)
+    assert len(os.listdir(out_dir)) == 12
+    # decoding the same z under another clothing type gives another mesh; the same call twice gives the same one
+    assert np.abs(outs[0] - outs[1]).max() > 0
+    again = model.decode(g["dec0_z"], cond=g["dec0_cond"], cond2=g["dec0_cond2"])
+    assert np.array_equal(again, outs[0])

@@ -357,3 +357,31 @@ def test_fused_activation_gradient_chain_equals_op_by_op(mesh_ops):
     assert names_ref.count("bwd_prep") == 3 and names.count("bwd_prep") == 1, (names_ref.count("bwd_prep"), names.count("bwd_prep"))
     for a, b_ in zip(got, ref):
         assert np.abs(a - b_).max() <= 2e-6 * np.abs(b_).max()
+
+
+@pytest.mark.parametrize("tamper", ["second_gradient_summed_in", "tag_dropped"])
+def test_fused_activation_gradient_hand_over_is_guarded(tamper, mesh_ops):
+    """The pre-activated gradient travels between two layers as a Python attribute on an autograd tensor.  If the tagged tensor
+    is written afterwards (the engine sums a second consumer's gradient into it) or arrives without its tag (a hook returned a
+    copy), the result would be silently wrong -- act' applied to a mixed sum, or applied twice with the bias partials queued
+    twice.  Both must raise."""
+    from cape_amd import ops
+    from cape_amd.graph import ConvOperators
+    dev = torch.device(DEV)
+    L = mesh_ops["L"]
+    rng = np.random.default_rng(12)
+    dops = [ops.DeviceConvOps(ConvOperators(L[4], 2), dev) for _ in range(2)]
+    x = torch.tensor(rng.standard_normal((2, 1723, 64)), dtype=torch.float32, device=dev, requires_grad=True)
+    W = [torch.tensor(rng.standard_normal((128, 64)) * 0.1, dtype=torch.float32, device=dev, requires_grad=True) for _ in range(2)]
+    b = [torch.tensor(rng.standard_normal((1, 1, 64)) * 0.1, dtype=torch.float32, device=dev, requires_grad=True) for _ in range(2)]
+    gB = [torch.zeros_like(t) for t in b]
+    with ops.sole_consumer_chain(True):
+        h1 = ops.chebyshev5(x, W[0], dops[0], bias=b[0], activation="b1leakyrelu", bias_grad_buf=gB[0])
+        if tamper == "second_gradient_summed_in":
+            h1.register_hook(lambda g: g.add_(1.0))            # in place: the tag stays on the object, the version moves
+        else:
+            h1.register_hook(lambda g: g.clone())              # a copy: the contents are pre-activated, the tag is gone
+        h2 = ops.chebyshev5(h1, W[1], dops[1], bias=b[1], activation="b1leakyrelu", bias_grad_buf=gB[1])
+    with pytest.raises(RuntimeError, match="sole_consumer_chain"):
+        torch.autograd.grad(h2.sum(), [x] + W + b)
+    torch.cuda.synchronize()

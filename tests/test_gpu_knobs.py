@@ -50,10 +50,10 @@ def test_dense_layers_on_the_register_tiled_kernels():
     assert r.returncode == 0 and " passed" in tail and "failed" not in tail, tail
 
 
-def test_step_without_the_fused_activation_gradient_and_with_the_side_stream():
-    """CAPE_FUSE_ACT_GRAD=0 (op-by-op backward-prep in the encoder) and CAPE_DW_STREAM=1 (deferred weight-gradient contractions
-    as a parallel branch of the captured step) both have to reproduce the reference golden at batch 16 and the twin's gradients."""
-    for knobs in (dict(CAPE_FUSE_ACT_GRAD="0"), dict(CAPE_DW_STREAM="1")):
+def test_step_without_the_fused_activation_gradient():
+    """CAPE_FUSE_ACT_GRAD=0 (op-by-op backward-prep in the encoder), alone and on round 3's arithmetic (CAPE_H2=0: the pure
+    six-product reference leg), has to reproduce the reference golden at batch 16 and the twin's gradients."""
+    for knobs in (dict(CAPE_FUSE_ACT_GRAD="0"), dict(CAPE_FUSE_ACT_GRAD="0", CAPE_H2="0")):
         env = dict(os.environ, **knobs)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_model.py"), "-x", "-q", "-m", "gpu",
                             "-k", "test_batch16_parity_covers_every_bench_kernel or test_train_step_matches_manual_update"],

@@ -43,7 +43,7 @@ python $R/tools/dp_selftest.py 2>&1 | grep -v "UserWarning\|run_backward\|amdgpu
 (cd $R/tools/ubench && timeout 120 ./gemm_h2) > $O/${TAG}_ubench_h2_final.txt 2>&1
 (cd $R/tools/ubench && timeout 180 ./h2_bench) > $O/${TAG}_h2_bench_final.txt 2>&1
 # same-box A/B of this round's switches on the replayed step
-for kv in "CAPE_H2=1" "CAPE_H2=0" "CAPE_FUSE_ACT_GRAD=0" "CAPE_FC_MFMA=0" "CAPE_DW_STREAM=1"; do
+for kv in "CAPE_H2=1" "CAPE_H2=0" "CAPE_FUSE_ACT_GRAD=0" "CAPE_FC_MFMA=0"; do
   echo "$kv $(env $kv python $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-extras --no-ab --no-roofline 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"], "ms/step")')"
 done > $O/${TAG}_switch_ab.txt
 cd $R && timeout 120 python tools/cheb_fused_phases.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_cheb_fused_phases.txt

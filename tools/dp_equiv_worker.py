@@ -54,8 +54,7 @@ def main():
     dev = int(os.environ.get("CAPE_FORCE_DEVICE", local))
     torch.cuda.set_device(dev)
     model = build(B, 'cuda:%d' % dev)
-    for grp in ('g', 'd'):
-        cdist.broadcast_flat(model._opt_state[grp]['flat'])
+    model.sync_variables(src=0)
     gb = global_batch(B * world, int(model.nz))
     shard = {k: v[rank * B:(rank + 1) * B] for k, v in gb.items()}
     runner = run(model, shard, steps, gan, cdist.GradAverager() if world > 1 else None)
