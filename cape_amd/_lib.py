@@ -55,7 +55,7 @@ class CapeDwItem(C.Structure):
     _fields_ = [("srcs", C.c_void_p), ("nsrc", C.c_int32), ("dz", C.c_void_p), ("dz_sample_stride", C.c_int64),
                 ("lddz", C.c_int32), ("dz2", C.c_void_p), ("dz2_mask", C.c_uint32), ("N", C.c_int32), ("Mo", C.c_int32),
                 ("F", C.c_int32), ("accumulate", C.c_int32), ("bf16", C.c_int32), ("workspace", C.c_void_p),
-                ("workspace_bytes", C.c_int64)]
+                ("workspace_bytes", C.c_int64), ("h2", C.c_void_p)]
 
 
 class CapeH2Src(C.Structure):

@@ -651,12 +651,17 @@ struct DwPlan {
     long long slab;
 };
 
-inline void plan_dw_splits(int N, int Mo, DwPlan &pl) {
+// slots: workgroups the launch aims at.  512 = two per CU for the serial kernels (dw_split / dw_plain / dw_packed / gather: a
+// second workgroup hides their staging phase); 256 = one per CU for the pipelined dw_h2_kernel, which overlaps its phases
+// inside each wave -- half the partial slabs to write and to reduce: step 2.697 -> 2.670 ms in three alternating A/B pairs on one
+// box, the kernel itself 33 -> 37 us (profiles/r05_exp_dw_slots.txt); the same setting costs the serial bf16 kernels 5 %.
+constexpr int DW_SLOTS_SERIAL = 512, DW_SLOTS_PIPELINED = 256;
+inline void plan_dw_splits(int N, int Mo, DwPlan &pl, int slots = DW_SLOTS_SERIAL) {
     // ONE round of workgroups (two per CU = 512 slots) with equal contraction lengths: split over the samples first
     // (the largest divisor of N that fits: every group gets the same number of samples), then the vertex range into
     // equal row blocks.  (An older rule rounded the split count UP, so the widest layers ran 672 workgroups of 24 chunks
     // on 512 slots -- one and a third rounds, groups of 6 / 6 / 4 samples -- where 512 of 27 chunks do: 50.7 -> 43.8 us.)
-    int S = 512 / pl.ntiles;              // (768 / 1024 slots for the smaller tiles measured slower)
+    int S = slots / pl.ntiles;            // (768 / 1024 slots for the smaller tiles measured slower)
     if (S < 1) S = 1;
     int ngroups = 1;
     for (int d = 1; d <= N && d <= S; ++d)
@@ -1027,18 +1032,27 @@ extern "C" int64_t cape_gconv_dw_workspace_bytes(const cape_src_t *srcs, int32_t
 }
 
 namespace {
+// does this launch run as dw_h2_kernel (fp16 two-piece operands)?  Decided from the arguments alone, identically by the plan
+// query, the contraction stage and the reduction stages (they must agree on the number of partial slabs)
+inline bool dw_takes_h2(const cape_src_t *srcs, int nsrc, const float *dz2, uint32_t dz2_mask, int Mo, int lddz, const cape_h2_dw_t *h2) {
+    if (!h2) return false;
+    DwParams p;
+    p.nsrc = nsrc;
+    p.dz2_mask = dz2 ? dz2_mask : 0u;
+    p.Mo = Mo; p.lddz = lddz;                                     // (what h2_dw_eligible reads besides the row bounds)
+    for (int i = 0; i < nsrc; ++i) p.s[i].ldx = srcs[i].ldx;
+    fill_h2_dw(p, h2);
+    return h2_dw_eligible(p);
+}
 int gconv_dw_plan_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz, int64_t dz_sample_stride,
                        int32_t lddz, const float *dz2, uint32_t dz2_mask, int32_t N, int32_t Mo, int32_t F,
                        int32_t plan[4], bool bf16, const cape_h2_dw_t *h2 = nullptr) {
     if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || !dz || N < 1 || Mo < 1 || F < 1 || lddz < F || !plan) return CAPE_EINVAL;
     DwPlan pl;
     plan[0] = choose_dw(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, N, Mo, F, pl, bf16);
-    if (plan[0] == 3 && !bf16 && h2) {
-        DwParams p;
-        p.nsrc = nsrc;
-        p.dz2_mask = dz2 ? dz2_mask : 0u;
-        fill_h2_dw(p, h2);
-        if (h2_dw_eligible(p)) plan[0] = 4;
+    if (plan[0] == 3 && !bf16 && dw_takes_h2(srcs, nsrc, dz2, dz2_mask, Mo, lddz, h2)) {
+        plan[0] = 4;
+        plan_dw_splits(N, Mo, pl, DW_SLOTS_PIPELINED);
     }
     {
         const int nm = dw_narrow_mode(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, F, plan[0], bf16);
@@ -1130,6 +1144,8 @@ int gconv_dw_stage_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz,
     DwPlan pl;
     const int fam = choose_dw(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, N, Mo, F, pl, bf16);
     const bool packed = fam == 2, plain = fam != 0, dw_split = fam == 3;
+    const bool use_h2 = !bf16 && dw_split && dw_takes_h2(srcs, nsrc, dz2, dz2_mask, Mo, lddz, h2);
+    if (use_h2) plan_dw_splits(N, Mo, pl, DW_SLOTS_PIPELINED);
     const bool dzvec = dw_dz_vec(dz, dz_sample_stride, lddz, dz2, bf16 ? 2 : 4);
     const long long need = pl.slab * pl.ngroups * pl.rsplit * (long long)sizeof(float);
     if (workspace_bytes < need) return CAPE_EWORKSPACE;
@@ -1168,7 +1184,7 @@ int gconv_dw_stage_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz,
         int sumC = 0;
         for (int i = 0; i < nsrc; ++i) sumC += srcs[i].C;
         CAPE_LAUNCH(dw_narrow_out_kernel, grid, block, 16384, st, p, narrow_lpr(sumC / 4), pl.ntiles);
-    } else if (!bf16 && dw_split && h2_dw_eligible(p)) {
+    } else if (use_h2) {
         h2_dw_launch(p, pl.ct, pl.ft, grid, st);                // fp16 two-piece operands: same tiles, splits and slabs
     } else if (bf16 && dw_split) {
         if (pl.ct == 64 && pl.ft == 64) CAPE_LAUNCH((dw_split_kernel<64, 64, cape_bf16>), grid, block, 0, st, p);
@@ -1246,7 +1262,7 @@ extern "C" int cape_gconv_dw_reduce_batch(const cape_dw_item_t *items, int32_t n
         int blocks = 0;
         const int rc = gconv_dw_stage_impl(t.srcs, t.nsrc, (const float *)t.dz, t.dz_sample_stride, t.lddz, (const float *)t.dz2,
                                            t.dz2_mask, t.N, t.Mo, t.F, t.accumulate, t.workspace, t.workspace_bytes, 3, stream,
-                                           t.bf16 != 0, &B.it[i], &B.vec[i], &blocks);
+                                           t.bf16 != 0, &B.it[i], &B.vec[i], &blocks, t.h2);
         if (rc) return rc;
         B.blk_off[i] = off;
         off += blocks;

@@ -364,17 +364,17 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GconvParams p) {
 // =============================================================================================================
 template <int CT, int FT>
 __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? 2 : 3) void dw_h2_kernel(DwParams p) {
-    constexpr int RK = 32, PITCH = 80;                // bytes per LDS row of one piece plane: 32 halfs + 16 B pad
+    constexpr int RK = 32;
     constexpr int WTM = CT / 2, WTN = FT / 2;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int CPA = CT / 64, CPB = FT / 64;       // channels per thread (8 rows each): lane, lane + 64 -- consecutive lanes write
-                                                      // LDS rows PITCH = 80 B apart (16 lanes = 16 different 16-byte bank groups);
-                                                      // with channels 2 lane, 2 lane + 1 the 160 B stride cost 24-33 % of the LDS cycles
-    constexpr int APLANE = CT * PITCH, BPLANE = FT * PITCH;
+    constexpr int CPA = CT / 64, CPB = FT / 64;       // channels per thread (8 rows each): lane, lane + 64
     static_assert(TM >= 1 && TN >= 1 && (CT == 64 || CT == 128) && (FT == 64 || FT == 128), "tile");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (APLANE + BPLANE)];
+    // TWO stages of unpadded 64-byte rows, 16-byte segments XOR-swizzled by (row >> 2) & 3 (the
+    // fragment-read pattern of gemm_h2_kernel: conflict-free ds_read_b128; the staging writes are 2-way, inside the
+    // instruction's own issue time)
+    constexpr int ROW = 64, APL2 = CT * ROW, BPL2 = FT * ROW, STAGE2 = 2 * (APL2 + BPL2);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE2];
     __shared__ float red[2][4];
-    unsigned char *sA = smem, *sB = smem + 2 * APLANE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
@@ -437,98 +437,170 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? 2 : 3) void dw_h2_ker
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
 
-    int a_col[CPA], b_col[CPB];
-#pragma unroll
-    for (int ch = 0; ch < CPA; ++ch) a_col[ch] = (c0 + ca + 64 * ch < S.C) ? c0 + ca + 64 * ch : 0;
-#pragma unroll
-    for (int ch = 0; ch < CPB; ++ch) b_col[ch] = (f0 + fb + 64 * ch < p.F) ? f0 + fb + 64 * ch : 0;
     const int chunks = (rb - ra + RK - 1) / RK;
     const int total = (n_end - n_begin) * chunks;
     int l_n = n_begin, l_r = ra;
     float xa[CPA][8], xz[CPB][8];
-    unsigned ok = 0;
 
-    auto load_regs = [&]() {
-        const float *xb = S.x + (long long)l_n * S.xs;
-        const float *zb = dz0 + (long long)l_n * p.dzs;
-        ok = 0;
+    // ---- operand streams through buffer resources (one per operand and sample: base = the sample, num_records = the bytes
+    //      below row rb).  Round 5: the loop used to form a 64-bit address per element (v_mad_i64_i32 + v_lshl_add_u64 + moves:
+    //      ~160 of its ~460 VALU instructions per chunk) and to mask the rows past rb with selects that also kept hipcc from
+    //      fusing the scale, the conversion and the subtraction of the split (v_fma_mixlo_f16) -- with 24 MFMAs per chunk the
+    //      kernel was bound by VALU issue (3.7 cycles per VALU instruction over the whole launch), not by the matrix pipe.
+    //      A buffer load takes a 32-bit per-lane byte offset against a scalar base and returns 0 past num_records, so rows
+    //      >= rb read as zeros without a select and an address costs one v_add per row and chunk.  Channel columns past
+    //      S.C / p.F (edge tiles) read whatever lies there inside the row range: they only reach accumulator rows / columns
+    //      the store below drops (an MFMA output element depends on its own operand row and column alone).
+    int xoff[8], zoff[8];                            // byte offset of this thread's row j, first channel, inside a chunk
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = l_r + 8 * rg + j;
-            ok |= (r < rb ? 1u : 0u) << j;
-            const int rr = min(r, rb - 1);
+    for (int j = 0; j < 8; ++j) {
+        xoff[j] = ((8 * rg + j) * S.ldx + c0 + ca) * 4;
+        zoff[j] = ((8 * rg + j) * p.lddz + f0 + fb) * 4;
+    }
+    __amdgpu_buffer_rsrc_t rx, rz;
+    auto open_sample = [&]() {
+        rx = __builtin_amdgcn_make_buffer_rsrc((void *)(S.x + (long long)l_n * S.xs), 0, rb * S.ldx * 4, 0x00020000);
+        rz = __builtin_amdgcn_make_buffer_rsrc((void *)(dz0 + (long long)l_n * p.dzs), 0, rb * p.lddz * 4, 0x00020000);
+    };
+    // (the row advance goes into the per-lane offset, which IS range-checked; a scalar offset operand would not be)
+    auto load_a = [&]() {
+        const int bx = l_r * S.ldx * 4;
 #pragma unroll
-            for (int ch = 0; ch < CPA; ++ch) xa[ch][j] = cape_ld(xb + (long long)rr * S.ldx + a_col[ch]);
+        for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int ch = 0; ch < CPB; ++ch) xz[ch][j] = cape_ld(zb + (long long)rr * p.lddz + b_col[ch]);
-        }
+            for (int ch = 0; ch < CPA; ++ch)
+                xa[ch][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff[j] + bx + 256 * ch, 0, 0));
+    };
+    auto load_b = [&]() {                            // ... and advances the chunk cursor: call after load_a
+        const int bz = l_r * p.lddz * 4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int ch = 0; ch < CPB; ++ch)
+                xz[ch][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, zoff[j] + bz + 256 * ch, 0, 0));
         l_r += RK;
-        if (l_r >= rb) { l_r = ra; ++l_n; }
+        if (l_r >= rb) {
+            l_r = ra;
+            ++l_n;
+            if (l_n < n_end) open_sample();
+        }
     };
     auto store8 = [&](unsigned char *dst, int plane, const float (&v)[8], float s) {
         uint4 hi, lo;
-        h2_split2(((ok >> 0) & 1u) ? v[0] * s : 0.f, ((ok >> 1) & 1u) ? v[1] * s : 0.f, hi.x, lo.x);
-        h2_split2(((ok >> 2) & 1u) ? v[2] * s : 0.f, ((ok >> 3) & 1u) ? v[3] * s : 0.f, hi.y, lo.y);
-        h2_split2(((ok >> 4) & 1u) ? v[4] * s : 0.f, ((ok >> 5) & 1u) ? v[5] * s : 0.f, hi.z, lo.z);
-        h2_split2(((ok >> 6) & 1u) ? v[6] * s : 0.f, ((ok >> 7) & 1u) ? v[7] * s : 0.f, hi.w, lo.w);
+        h2_split2(v[0] * s, v[1] * s, hi.x, lo.x);
+        h2_split2(v[2] * s, v[3] * s, hi.y, lo.y);
+        h2_split2(v[4] * s, v[5] * s, hi.z, lo.z);
+        h2_split2(v[6] * s, v[7] * s, hi.w, lo.w);
         *reinterpret_cast<uint4 *>(dst) = hi;
         *reinterpret_cast<uint4 *>(dst + plane) = lo;
     };
-    auto store_regs = [&]() {
+    // ---- software-pipelined chunk loop (round 5).  Measured on the serial loop this replaces (load chunk it + 1 -> multiply
+    //      chunk it -> barrier -> split + store chunk it + 1 -> barrier) with phases knocked out (profiles/
+    //      r05_exp_dw_h2_phases.txt; average of the nine 128 x 128 launches of the step): everything 33 us; prologue + barriers +
+    //      slab store alone 11; on top of that floor the global loads +14, the LDS reads + MFMAs +13, the split + LDS stores +10
+    //      -- 47 us if nothing overlapped, i.e. two workgroups per CU hid only a third of it, and neither four times fewer VALU
+    //      instructions nor a longer load lead moved the total (profiles/r05_exp_dw_h2_load_lead.txt).  Now the three run inside
+    //      ONE instruction stream per wave: the MFMAs of chunk it with the fragment reads of their second k16 step AND the
+    //      split + LDS stores of chunk it + 1 (into the other stage) placed between them (sched_group_barrier: the matrix pipe
+    //      takes 32 cycles per MFMA, an MFMA issues in 4-8), each operand's loads of chunk it + 2 issued as soon as its registers
+    //      are staged, one barrier per chunk.
+    unsigned char *st0 = smem, *st1 = smem + STAGE2;
+    const int fsw = (li >> 2) & 3;
+    auto stage_a = [&](unsigned char *st) {
 #pragma unroll
-        for (int ch = 0; ch < CPA; ++ch) store8(sA + (ca + 64 * ch) * PITCH + 16 * rg, APLANE, xa[ch], sx);
-#pragma unroll
-        for (int ch = 0; ch < CPB; ++ch) store8(sB + (fb + 64 * ch) * PITCH + 16 * rg, BPLANE, xz[ch], sz);
+        for (int ch = 0; ch < CPA; ++ch) {
+            const int row = ca + 64 * ch;
+            store8(st + row * ROW + 16 * (rg ^ ((row >> 2) & 3)), APL2, xa[ch], sx);
+        }
     };
-    auto compute = [&]() {
-        const unsigned char *pa = sA + (wm * WTM + li) * PITCH;
-        const unsigned char *pb = sB + (wn * WTN + li) * PITCH;
-        h2_half8 af[2][TM][2], bf[2][TN][2];
-        auto rd = [&](int ks) {
-            const int so = 16 * (lh + 2 * ks);
+    auto stage_b = [&](unsigned char *st) {
+#pragma unroll
+        for (int ch = 0; ch < CPB; ++ch) {
+            const int row = fb + 64 * ch;
+            store8(st + 2 * APL2 + row * ROW + 16 * (rg ^ ((row >> 2) & 3)), BPL2, xz[ch], sz);
+        }
+    };
+    h2_half8 af[2][TM][2], bf[2][TN][2];
+    auto rd = [&](const unsigned char *st, int ks) {
+        const unsigned char *pa = st + (wm * WTM + li) * ROW, *pb = st + 2 * APL2 + (wn * WTN + li) * ROW;
+        const int so = 16 * ((2 * ks + lh) ^ fsw);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) af[ks][a][pc] = *reinterpret_cast<const h2_half8 *>(pa + pc * APL2 + a * 32 * ROW + so);
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) bf[ks][b][pc] = *reinterpret_cast<const h2_half8 *>(pb + pc * BPL2 + b * 32 * ROW + so);
+    };
+    auto mm = [&](int ks) {
+#pragma unroll
+        for (int term = 0; term < 3; ++term)         // lo*hi, hi*lo, hi*hi: small products first
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int pc = 0; pc < 2; ++pc) af[ks][a][pc] = *reinterpret_cast<const h2_half8 *>(pa + pc * APLANE + a * 32 * PITCH + so);
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-#pragma unroll
-                for (int pc = 0; pc < 2; ++pc) bf[ks][b][pc] = *reinterpret_cast<const h2_half8 *>(pb + pc * BPLANE + b * 32 * PITCH + so);
-        };
-        auto mm = [&](int ks) {
-#pragma unroll
-            for (int term = 0; term < 3; ++term)
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][a][term == 0 ? 1 : 0], bf[ks][b][term == 1 ? 1 : 0],
-                                                                           acc[a][b], 0, 0, 0);
-        };
-        constexpr int NM = 3 * TM * TN, NR = 2 * (TM + TN);
-        rd(0);
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][a][term == 0 ? 1 : 0], bf[ks][b][term == 1 ? 1 : 0],
+                                                                       acc[a][b], 0, 0, 0);
+    };
+    constexpr int NM = 3 * TM * TN, NR = 2 * (TM + TN);
+    // VALU instructions of one operand's split as hipcc emits it (per four values: v_pk_mul, v_cvt_pk_f16 x 2, v_cvt_f32_f16 x 2,
+    // v_pk_fma): 12 per channel of 8 rows, plus the row offsets of the loads that follow; dealt over the MFMAs of a k16 step
+    constexpr int VA = (12 * CPA + 8 + NM - 1) / NM, VB = (12 * CPB + 8 + NM - 1) / NM;
+    // one chunk: stage `cur` holds chunk it, the registers chunk it + 1 (NEXT), stage `nxt` is free; MORE: chunk it + 2 exists
+    auto chunk = [&](const unsigned char *cur, unsigned char *nxt, auto next, auto more) {
+        constexpr bool NX = decltype(next)::value, MO = decltype(more)::value;
+        rd(cur, 0);
         __builtin_amdgcn_sched_barrier(0);
-        rd(1);
+        rd(cur, 1);
         mm(0);
+        if constexpr (NX) stage_a(nxt);
+        if constexpr (MO) load_a();
 #pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, NM / NR > 0 ? NM / NR : 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        for (int i = 0; i < NM; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if constexpr (NX) {
+                __builtin_amdgcn_sched_group_barrier(0x002, VA, 0);
+                if (i >= NM - 2 * CPA) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         mm(1);
+        if constexpr (NX) stage_b(nxt);
+        if constexpr (MO) load_b();
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (NX) {
+                __builtin_amdgcn_sched_group_barrier(0x002, VB, 0);
+                if (i >= NM - 2 * CPB) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     };
-
     if (total > 0) {
-        load_regs();
-        store_regs();
+        open_sample();
+        load_a();
+        load_b();
+        stage_a(st0);
+        stage_b(st0);
+        if (total > 1) { load_a(); load_b(); }
         __syncthreads();
-        for (int it = 0; it < total; ++it) {
-            const bool more = it + 1 < total;
-            if (more) load_regs();
-            compute();
+        int it = 0;
+        // steady state: chunks it + 1, it + 2, it + 3 exist -- no branches inside, so hipcc's own vmcnt bookkeeping stays exact
+        for (; it + 3 < total; it += 2) {
+            chunk(st0, st1, std::true_type{}, std::true_type{});      // multiply chunk it, stage it + 1, load it + 2
             __syncthreads();
-            if (more) store_regs();
+            chunk(st1, st0, std::true_type{}, std::true_type{});
+            __syncthreads();
+        }
+        for (; it < total; ++it) {
+            const unsigned char *cur = (it & 1) ? st1 : st0;
+            unsigned char *nxt = (it & 1) ? st0 : st1;
+            if (it + 2 < total) chunk(cur, nxt, std::true_type{}, std::true_type{});
+            else if (it + 1 < total) chunk(cur, nxt, std::true_type{}, std::false_type{});
+            else chunk(cur, nxt, std::false_type{}, std::false_type{});
             __syncthreads();
         }
     }
@@ -593,8 +665,12 @@ inline void h2_tile(bool dual, int N, int Mo, int F, int Ktot, int &BM, int &BN)
 inline bool h2_dw_eligible(const DwParams &p) {
     static const int on = getenv("CAPE_DW_H2") ? atoi(getenv("CAPE_DW_H2")) : 1;          // 0: A/B against dw_split_kernel
     if (!on || !p.dzrm || p.dzrmw < 4 || (p.dzrmw & 3) || (p.dz2_mask && (!p.dz2rm || p.dz2rmw < 4 || (p.dz2rmw & 3)))) return false;
-    for (int i = 0; i < p.nsrc; ++i)
+    // (the operands are read through 32-bit buffer offsets: a sample's rows, plus an edge tile's overhang, within 2^31 bytes)
+    if (((long long)p.Mo * p.lddz + 512) * 4 >= (1LL << 31)) return false;
+    for (int i = 0; i < p.nsrc; ++i) {
         if (!p.s[i].rm || p.s[i].rmw < 4 || (p.s[i].rmw & 3)) return false;
+        if (((long long)p.Mo * p.s[i].ldx + 512) * 4 >= (1LL << 31)) return false;
+    }
     return true;
 }
 

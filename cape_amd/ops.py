@@ -740,7 +740,8 @@ def gconv_dw(entries, dz, accumulate=False, dz2=None, defer=False):
         it.dz2, it.dz2_mask = (p2.value if p2 is not None else None), mask
         it.N, it.Mo, it.F, it.accumulate, it.bf16 = N, Mo, F, 1 if accumulate else 0, 1 if bf else 0
         it.workspace, it.workspace_bytes = ws.data_ptr(), need
-        DEFERRED_DW.append((it, arr, ws, dz, dz2, [e["x"] for e in entries]))       # keep every buffer alive until the flush
+        it.h2 = C.addressof(h2) if h2 is not None else None        # (the reduction counts the slabs the two-piece kernel wrote)
+        DEFERRED_DW.append((it, arr, ws, dz, dz2, [e["x"] for e in entries], h2))   # keep every buffer alive until the flush
         return
     if LAUNCH_LOG is None and PLAN_LOG is None:
         launch()

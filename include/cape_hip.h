@@ -282,8 +282,10 @@ int cape_gconv_dw_stage(const cape_src_t *srcs, int32_t nsrc, const float *dz,
                         int64_t workspace_bytes, int32_t stage, void *stream);
 
 /* The weight gradient with fp16 two-piece operands (see cape_h2_t): row bounds of every source and of dz / dz2; launches that
- * would take dw_split_kernel (plan family 3) then run dw_h2_kernel (family 4) on the same tiles, splits and slabs -- the
- * reduction stage and cape_gconv_dw_reduce_batch are unchanged.  h2 == NULL: identical to cape_gconv_dw_stage / _plan. */
+ * would take dw_split_kernel (plan family 3) then run dw_h2_kernel (family 4) on the same tiles with HALF the contraction
+ * splits (one workgroup per CU: the kernel overlaps loads, operand split and MFMAs inside each wave; half the partial slabs).
+ * The reduction must count the same slabs: stage 2 through cape_gconv_dw_stage_h2 with the same h2, batched reductions with
+ * cape_dw_item_t::h2 set.  h2 == NULL: identical to cape_gconv_dw_stage / _plan. */
 typedef struct cape_h2_dw {
     const float *src_rowmax[CAPE_MAX_SRC];
     int32_t src_rowmax_w[CAPE_MAX_SRC];
@@ -315,6 +317,9 @@ typedef struct cape_dw_item {
     int32_t N, Mo, F, accumulate, bf16;
     void *workspace;
     int64_t workspace_bytes;
+    const struct cape_h2_dw *h2;      /* the operands' row bounds when the contraction went through cape_gconv_dw_stage_h2 (NULL
+                                         otherwise): the two-piece kernel writes fewer, fatter partial slabs, and the reduction
+                                         has to count the same ones */
 } cape_dw_item_t;
 int cape_gconv_dw_reduce_batch(const cape_dw_item_t *items, int32_t nitems, void *stream);
 
