@@ -362,9 +362,15 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GconvParams p) {
 // maximum loses relative precision, but its contribution to the sum is smaller by the same factor: the error of an element
 // is <= 2^-22 |x| + 2^-40 max|x|, against fp32's own 2^-24 |x z| per term.
 // =============================================================================================================
+// Round 5: a workgroup is TWO groups of four waves (KG = 2, 512 threads).  Each group runs the pipeline above on its own half
+// of the workgroup's row range with its own LDS stages -- the two groups share a CU the way two workgroups used to -- and the
+// halves' accumulators are added through LDS before ONE partial slab is written: half the slabs to write and to reduce
+// (the slab store of 512 workgroups was most of the launch's 11 us floor, profiles/r05_exp_dw_h2_phases.txt) at the
+// per-CU concurrency of the two-workgroup form.  Fixed order (group 0 + group 1): bit-reproducible.
+constexpr int H2_DW_KG = 2;
 template <int CT, int FT>
-__global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? 2 : 3) void dw_h2_kernel(DwParams p) {
-    constexpr int RK = 32;
+__global__ __launch_bounds__(256 * H2_DW_KG, 1) void dw_h2_kernel(DwParams p) {
+    constexpr int RK = 32, KG = H2_DW_KG;
     constexpr int WTM = CT / 2, WTN = FT / 2;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int CPA = CT / 64, CPB = FT / 64;       // channels per thread (8 rows each): lane, lane + 64
@@ -373,10 +379,13 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? 2 : 3) void dw_h2_ker
     // fragment-read pattern of gemm_h2_kernel: conflict-free ds_read_b128; the staging writes are 2-way, inside the
     // instruction's own issue time)
     constexpr int ROW = 64, APL2 = CT * ROW, BPL2 = FT * ROW, STAGE2 = 2 * (APL2 + BPL2);
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE2];
-    __shared__ float red[2][4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem_all[KG * 2 * STAGE2];
+    __shared__ float red[2][4 * KG];
+    static_assert(2 * STAGE2 >= TM * TN * 16 * 256 * 4, "a group's stages hold its accumulator for the final sum");
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kg = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);      // contraction half of this wave's group
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;       // everything below is per GROUP of four waves
+    unsigned char *smem = smem_all + kg * 2 * STAGE2;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
     const int rg = tid >> 6;
     const int ca = tid & 63, fb = tid & 63;
@@ -394,35 +403,40 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? 2 : 3) void dw_h2_ker
     const int lt = tile - p.tile_off[si];
     const int c0 = (lt / p.ftiles) * CT;
     const int f0 = (lt % p.ftiles) * FT;
-    const int ra = rs * p.rows_per_split;
-    const int rb = min(p.Mo, ra + p.rows_per_split);
+    const int wra = rs * p.rows_per_split;                        // the WORKGROUP's row range ...
+    const int rb = min(p.Mo, wra + p.rows_per_split);
+    // ... and this group's part of it: whole chunks, the same number for every group (a part that reaches past rb reads zeros
+    // there -- the buffer resources end at row rb -- so the groups run the same trip count and share their barriers)
+    const int chunks = ((rb - wra + RK - 1) / RK + KG - 1) / KG;
+    const int ra = wra + kg * chunks * RK;
     const bool two = ((p.dz2_mask >> si) & 1u) != 0;
     const float *dz0 = two ? p.dz2 : p.dz;
 
-    // ---- scales of this workgroup's range
+    // ---- scales of the workgroup's range (one pair for both groups: their accumulators are added unscaled)
     float sx, sz, inv;
     {
         const float *rmz = two ? p.dz2rm : p.dzrm;
         const int wz = two ? p.dz2rmw : p.dzrmw;
         float mx = 0.f, mz = 0.f;
         for (int n = n_begin; n < n_end; ++n) {
-            const float *px = S.rm + ((long long)n * p.Mo + ra) * S.rmw;
-            const float *pz = rmz + ((long long)n * p.Mo + ra) * wz;
+            const float *px = S.rm + ((long long)n * p.Mo + wra) * S.rmw;
+            const float *pz = rmz + ((long long)n * p.Mo + wra) * wz;
             // (row widths are multiples of 4 and the arrays 16-byte aligned: float4 loads, four in flight per thread)
             const float4 *px4 = reinterpret_cast<const float4 *>(px), *pz4 = reinterpret_cast<const float4 *>(pz);
-            const int nx = (rb - ra) * (S.rmw >> 2), nz = (rb - ra) * (wz >> 2);
+            const int nx = (rb - wra) * (S.rmw >> 2), nz = (rb - wra) * (wz >> 2);
 #pragma unroll 4
-            for (int i = tid; i < nx; i += 256) { const float4 v = px4[i]; mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w))); }
+            for (int i = (int)threadIdx.x; i < nx; i += 256 * KG) { const float4 v = px4[i]; mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w))); }
 #pragma unroll 4
-            for (int i = tid; i < nz; i += 256) { const float4 v = pz4[i]; mz = fmaxf(mz, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w))); }
+            for (int i = (int)threadIdx.x; i < nz; i += 256 * KG) { const float4 v = pz4[i]; mz = fmaxf(mz, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w))); }
         }
         mx = h2_max_ror(mx); mz = h2_max_ror(mz);
         mx = fmaxf(mx, __shfl_xor(mx, 16)); mz = fmaxf(mz, __shfl_xor(mz, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32)); mz = fmaxf(mz, __shfl_xor(mz, 32));
-        if (lane == 0) { red[0][wave] = mx; red[1][wave] = mz; }
+        if (lane == 0) { red[0][kg * 4 + wave] = mx; red[1][kg * 4 + wave] = mz; }
         __syncthreads();
-        mx = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
-        mz = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+        mx = mz = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4 * KG; ++w) { mx = fmaxf(mx, red[0][w]); mz = fmaxf(mz, red[1][w]); }
         float ix, iz;
         h2_scale_of(mx, sx, ix);
         h2_scale_of(mz, sz, iz);
@@ -437,8 +451,8 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? 2 : 3) void dw_h2_ker
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[a][b][g] = 0.f;
 
-    const int chunks = (rb - ra + RK - 1) / RK;
     const int total = (n_end - n_begin) * chunks;
+    const int rend = ra + chunks * RK;               // end of this group's part (the cursor wraps here; rows >= rb read zeros)
     int l_n = n_begin, l_r = ra;
     float xa[CPA][8], xz[CPB][8];
 
@@ -479,7 +493,7 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? 2 : 3) void dw_h2_ker
             for (int ch = 0; ch < CPB; ++ch)
                 xz[ch][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, zoff[j] + bz + 256 * ch, 0, 0));
         l_r += RK;
-        if (l_r >= rb) {
+        if (l_r >= rend) {
             l_r = ra;
             ++l_n;
             if (l_n < n_end) open_sample();
@@ -605,6 +619,27 @@ __global__ __launch_bounds__(256, (CT * FT >= 128 * 128) ? 2 : 3) void dw_h2_ker
         }
     }
 
+    // ---- the halves' sum, in a fixed order: group 1 parks its accumulator in its own (now idle) stages, group 0 adds it
+    //      (element k of thread t at [k][t]: consecutive lanes, consecutive words)
+    if constexpr (KG == 2) {
+        float *park = reinterpret_cast<float *>(smem_all + 2 * STAGE2);
+        if (kg == 1) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) park[((a * TN + b) * 16 + g) * 256 + tid] = acc[a][b][g];
+        }
+        __syncthreads();
+        if (kg == 1) return;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[a][b][g] += park[((a * TN + b) * 16 + g) * 256 + tid];
+    }
     float *out = p.ws + (long long)split * p.slab + p.part_off[si];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -675,10 +710,11 @@ inline bool h2_dw_eligible(const DwParams &p) {
 }
 
 inline void h2_dw_launch(const DwParams &p, int ct, int ft, dim3 grid, hipStream_t st) {
-    if (ct == 64 && ft == 64) CAPE_LAUNCH((dw_h2_kernel<64, 64>), grid, dim3(256), 0, st, p);
-    else if (ct == 64) CAPE_LAUNCH((dw_h2_kernel<64, 128>), grid, dim3(256), 0, st, p);
-    else if (ft == 64) CAPE_LAUNCH((dw_h2_kernel<128, 64>), grid, dim3(256), 0, st, p);
-    else CAPE_LAUNCH((dw_h2_kernel<128, 128>), grid, dim3(256), 0, st, p);
+    const dim3 block(256 * H2_DW_KG);
+    if (ct == 64 && ft == 64) CAPE_LAUNCH((dw_h2_kernel<64, 64>), grid, block, 0, st, p);
+    else if (ct == 64) CAPE_LAUNCH((dw_h2_kernel<64, 128>), grid, block, 0, st, p);
+    else if (ft == 64) CAPE_LAUNCH((dw_h2_kernel<128, 64>), grid, block, 0, st, p);
+    else CAPE_LAUNCH((dw_h2_kernel<128, 128>), grid, block, 0, st, p);
 }
 
 inline void h2_launch(const GconvParams &p, bool dual, int BM, int BN, dim3 grid, hipStream_t st) {

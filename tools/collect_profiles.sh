@@ -38,9 +38,7 @@ make -C $R/tools/ubench > /dev/null 2>&1
 (cd $R/tools/ubench && ./mfma_peak) > $O/${TAG}_ubench_mfma_peak.txt 2>&1
 # split data-parallel step with the real collective backend (one-rank RCCL group, collectives forced on)
 python $R/tools/dp_selftest.py 2>&1 | grep -v "UserWarning\|run_backward\|amdgpu.ids\|socket.cpp\|^$" > $O/${TAG}_dp_selftest.txt
-# round 4: the fp16 two-piece kernels -- standalone pipeline experiment (accuracy vs float64 + phase timings) and the library's
-# h2 / six-product kernels side by side over the layer shapes of the benchmarked model
-(cd $R/tools/ubench && timeout 120 ./gemm_h2) > $O/${TAG}_ubench_h2_final.txt 2>&1
+# the library's two-piece / six-product forward kernels side by side over the layer shapes of the benchmarked model
 (cd $R/tools/ubench && timeout 180 ./h2_bench) > $O/${TAG}_h2_bench_final.txt 2>&1
 # same-box A/B of this round's switches on the replayed step
 for kv in "CAPE_H2=1" "CAPE_H2=0" "CAPE_FUSE_ACT_GRAD=0" "CAPE_FC_MFMA=0"; do
