@@ -134,16 +134,18 @@ def probe_collectives(hook, nelem, device, iters=5, modes=MODES):
     refuses is reported and left out."""
     import time
     out = {}
+    device = torch.device(device)
+    sync = (lambda: torch.cuda.synchronize(device)) if device.type == "cuda" else (lambda: None)
     buf = torch.ones(nelem, device=device, dtype=torch.float32)
     for mode in modes:
         try:
             hook.exchange_sum(buf, mode)                # warm-up (communicator set-up, scratch allocation)
-            torch.cuda.synchronize(device)
+            sync()
             dist.barrier(group=hook.group)
             t0 = time.perf_counter()
             for _ in range(iters):
                 hook.exchange_sum(buf, mode)
-            torch.cuda.synchronize(device)
+            sync()
             out[mode] = round(max_over_ranks(1e3 * (time.perf_counter() - t0) / iters, device), 4)
             buf.fill_(1.0)
         except Exception as e:                          # noqa: BLE001 -- report, do not lose the run
@@ -153,8 +155,9 @@ def probe_collectives(hook, nelem, device, iters=5, modes=MODES):
 
 def rank_inventory(device):
     """What every rank actually runs on: [(rank, local device index, device name, backend)] gathered to all ranks."""
-    me = dict(rank=dist.get_rank() if dist.is_initialized() else 0, device=int(torch.cuda.current_device()),
-              name=torch.cuda.get_device_name(torch.cuda.current_device()), pid=os.getpid(),
+    on_gpu = torch.device(device).type == "cuda"
+    me = dict(rank=dist.get_rank() if dist.is_initialized() else 0, device=int(torch.cuda.current_device()) if on_gpu else -1,
+              name=torch.cuda.get_device_name(torch.cuda.current_device()) if on_gpu else "cpu", pid=os.getpid(),
               backend=dist.get_backend() if dist.is_initialized() else None)
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [me]

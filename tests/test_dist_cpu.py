@@ -66,6 +66,12 @@ def _worker(rank, world, port, out_dir, mode="allreduce"):
         else:
             hook(flat_grad)
         _flat_sgd_step(flat, flat_grad, m)
+    # what `bench.py --gpus N` reports before its timed steps: every exchange form timed on a bucket (MAX over ranks; a form
+    # the backend refuses is named instead of raising) and who runs where
+    probe = cdist.probe_collectives(hook, 64, torch.device("cpu"), iters=2)
+    assert set(probe) == set(cdist.MODES) and all(isinstance(v, float) and v >= 0 for v in probe.values()), probe
+    inv = cdist.rank_inventory(torch.device("cpu"))
+    assert sorted(r["rank"] for r in inv) == list(range(world)) and all(r["backend"] == "gloo" for r in inv)
     np.save(os.path.join(out_dir, "flat_%d.npy" % rank), flat.numpy())
     assert cdist.max_over_ranks(rank + 1.0, torch.device("cpu")) == float(world)
     tdist.destroy_process_group()
