@@ -54,8 +54,13 @@ int main(int argc, char **argv) {
         {16, 3445, 2, 64, 64, 1},
         {16, 6890, 2, 64, 64, 0}, {16, 6890, 1, 64, 128, 0}, {16, 6890, 1, 64, 64, 0}, {16, 6890, 1, 32, 64, 0},
     };
-    if (argc > 2)                                    // batch override: how do the short launches behave over more rounds of workgroups?
+    if (argc > 2 && atoi(argv[2]) > 0)               // batch override: how do the short launches behave over more rounds of workgroups?
         for (Shape &s : shapes) s.N = atoi(argv[2]);
+    if (argc > 3) {                                  // shape filter: comma-separated indices into the list above (counter passes)
+        std::vector<Shape> keep;
+        for (char *t = strtok(argv[3], ","); t; t = strtok(nullptr, ",")) keep.push_back(shapes.at(atoi(t)));
+        shapes = keep;
+    }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     double tot[2] = {0, 0};
     for (const Shape &s : shapes) {
