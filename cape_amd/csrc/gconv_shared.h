@@ -191,10 +191,10 @@ __device__ __forceinline__ void gconv_epilogue(const GconvParams &p,
 // Short epilogue for the common launches of the pipelined kernels (no rank-1 terms; channel bias or none; identity / ReLU /
 // leaky ReLU as one negative-side slope).  With two workgroups per CU all tiles of a launch finish together, so the epilogue
 // is not hidden behind other workgroups' multiplies: the general one (uniform branches per element) cost ~10 us there.
-template <int BM, int BN, typename AT = float>
-__device__ __forceinline__ void gconv_epilogue_short(const GconvParams &p, f32x16 (&acc)[BM / 64][BN / 64], int n, int r0, int f0,
-                                                     int wm, int wn, int li, int lh) {
-    constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32;
+template <int BM, int BN, typename AT = float, int WAVES_M = 2, int WAVES_N = 2>
+__device__ __forceinline__ void gconv_epilogue_short(const GconvParams &p, f32x16 (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32], int n, int r0,
+                                                     int f0, int wm, int wn, int li, int lh) {
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N, TM = WTM / 32, TN = WTN / 32;
     const float slope = p.act == CAPE_ACT_LEAKY ? 0.2f : 1.f;
     const bool relu = p.act == CAPE_ACT_RELU;
     AT *yb = reinterpret_cast<AT *>(p.y) + (long long)n * p.ys;

@@ -680,7 +680,9 @@ inline bool h2_eligible(const GconvParams &p, bool dual) {
     return true;
 }
 
+inline bool h2x_wanted(bool dual, int N, int Mo, int F, int Ktot);        // gemm_h2x.h: the wide tile, 128 x 256
 inline void h2_tile(bool dual, int N, int Mo, int F, int Ktot, int &BM, int &BN) {
+    if (h2x_wanted(dual, N, Mo, F, Ktot)) { BM = 128; BN = 256; return; }
     if (dual) { BM = 128; BN = 64; return; }
     // CAPE_H2_TILE=BMxBN (experiments, tools/ubench/h2_bench.cpp): force one of the four single-accumulator tiles
     static const char *force = getenv("CAPE_H2_TILE");
@@ -717,8 +719,10 @@ inline void h2_dw_launch(const DwParams &p, int ct, int ft, dim3 grid, hipStream
     else CAPE_LAUNCH((dw_h2_kernel<128, 128>), grid, block, 0, st, p);
 }
 
+inline void h2x_launch(const GconvParams &p, dim3 grid, hipStream_t st);
 inline void h2_launch(const GconvParams &p, bool dual, int BM, int BN, dim3 grid, hipStream_t st) {
-    if (dual) CAPE_LAUNCH((gemm_h2_kernel<128, 64, true>), grid, dim3(256), 0, st, p);
+    if (!dual && BM == 128 && BN == 256) h2x_launch(p, grid, st);
+    else if (dual) CAPE_LAUNCH((gemm_h2_kernel<128, 64, true>), grid, dim3(256), 0, st, p);
     else if (BM == 128 && BN == 128) CAPE_LAUNCH((gemm_h2_kernel<128, 128, false>), grid, dim3(256), 0, st, p);
     else if (BM == 128) CAPE_LAUNCH((gemm_h2_kernel<128, 64, false>), grid, dim3(256), 0, st, p);
     else if (BN == 128) CAPE_LAUNCH((gemm_h2_kernel<64, 128, false>), grid, dim3(256), 0, st, p);
@@ -726,3 +730,5 @@ inline void h2_launch(const GconvParams &p, bool dual, int BM, int BN, dim3 grid
 }
 
 }  // namespace
+
+#include "gemm_h2x.h"
