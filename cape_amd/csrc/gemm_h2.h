@@ -23,6 +23,7 @@
 // fine ones (profiles/r04_ubench_h2_pf2.txt); the loads alone (448 MB through L2 for the widest layer) take 39 us of its
 // 57 -- the 128 x 128 tile's L2 traffic, not the matrix pipe, is the next bound.
 #pragma once
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -48,6 +49,22 @@ __device__ __forceinline__ void h2_split2(float x0, float x1, unsigned &hi, unsi
     const h2_half2 H = {h0, h1}, L = {l0, l1};
     hi = __builtin_bit_cast(unsigned, H);
     lo = __builtin_bit_cast(unsigned, L);
+}
+
+// The same split of two values TIMES a power of two in four instructions: both conversions fold the multiplication (the product
+// is exact in fp32, so rounding x * s to fp16 once equals rounding the fp32 product) and the residual x * s - hi is formed in
+// fp32 inside the fused op before it is rounded -- bit-identical to h2_split2(x0 * s, x1 * s, ...).  hipcc's own selection for
+// that expression is seven instructions per pair (v_mul x2, v_fma_mixlo x3, v_fma_mixhi, v_cvt_pk): it packs hi from the
+// products instead of writing both halves of one register.  (Not volatile: the scheduler may place it.)
+__device__ __forceinline__ void h2_split2s(float x0, float x1, float s, unsigned &hi, unsigned &lo) {
+    unsigned h, l;
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(h), "=&v"(l) : "v"(x0), "v"(x1), "v"(s));
+    hi = h;
+    lo = l;
 }
 
 // power of two that puts a bound m of the absolute maximum into [2^13, 2^14), and its reciprocal.  Zero / denormal bounds
@@ -197,10 +214,10 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GconvParams p) {
             const int row = r + 64 * i;
             const float s = sa[i];
             uint4 hi, lo;
-            h2_split2(ra[i][0].x * s, ra[i][0].y * s, hi.x, lo.x);
-            h2_split2(ra[i][0].z * s, ra[i][0].w * s, hi.y, lo.y);
-            h2_split2(ra[i][1].x * s, ra[i][1].y * s, hi.z, lo.z);
-            h2_split2(ra[i][1].z * s, ra[i][1].w * s, hi.w, lo.w);
+            h2_split2s(ra[i][0].x, ra[i][0].y, s, hi.x, lo.x);
+            h2_split2s(ra[i][0].z, ra[i][0].w, s, hi.y, lo.y);
+            h2_split2s(ra[i][1].x, ra[i][1].y, s, hi.z, lo.z);
+            h2_split2s(ra[i][1].z, ra[i][1].w, s, hi.w, lo.w);
             unsigned char *d = smem + buf * STAGE + row * H2_ROW + 16 * (q ^ ((row >> 2) & 3));
             *reinterpret_cast<uint4 *>(d) = hi;
             *reinterpret_cast<uint4 *>(d + APL) = lo;
@@ -368,7 +385,14 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(GconvParams p) {
 // (the slab store of 512 workgroups was most of the launch's 11 us floor, profiles/r05_exp_dw_h2_phases.txt) at the
 // per-CU concurrency of the two-workgroup form.  Fixed order (group 0 + group 1): bit-reproducible.
 constexpr int H2_DW_KG = 2;
-template <int CT, int FT>
+// V4 (round 6): the operands are read with 16-byte loads -- a thread takes FOUR consecutive channels of 8 (4 for a 64-wide
+// operand) consecutive rows, waves 0-1 of a group the source tile, waves 2-3 the gradient tile -- instead of one channel of
+// eight rows with 4-byte loads: a quarter of the load instructions (32 -> 8 per thread and chunk) and of their address
+// arithmetic.  For the LDS stores of that pattern to spread over the banks (lanes = channel quads: with the channels of a quad
+// in consecutive 64-byte rows every store of a wave would fall on four 16-byte slots) the rows of a quad are ROTATED by
+// (quad >> 2) & 3 inside the stage; the accumulator rows / columns come out in the same rotated order and the slab store
+// undoes it.  CAPE_DW_V4=0 keeps the 4-byte form (A/B).
+template <int CT, int FT, bool V4 = true>
 __global__ __launch_bounds__(256 * H2_DW_KG, 1) void dw_h2_kernel(DwParams p) {
     constexpr int RK = 32, KG = H2_DW_KG;
     constexpr int WTM = CT / 2, WTN = FT / 2;
@@ -399,7 +423,12 @@ __global__ __launch_bounds__(256 * H2_DW_KG, 1) void dw_h2_kernel(DwParams p) {
     const int n_end = min(p.N, n_begin + p.samples_per_group);
     int si = 0;
     while (si + 1 < p.nsrc && tile >= p.tile_off[si + 1]) ++si;
-    const SrcDev &S = p.s[si];
+    // (the source is indexed at run time: its fields are read through the kernel-argument segment -- scalar loads with a register
+    // offset -- and copied; a reference into the by-value parameter can make hipcc copy the whole block to scratch memory)
+    typedef const __attribute__((address_space(4))) SrcDev *SrcTab;
+    const SrcTab src_tab = (SrcTab)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(DwParams, s));
+    struct { const float *x, *rm; long long xs; int ldx, C, rmw; } S;
+    S.x = src_tab[si].x; S.rm = src_tab[si].rm; S.xs = src_tab[si].xs; S.ldx = src_tab[si].ldx; S.C = src_tab[si].C; S.rmw = src_tab[si].rmw;
     const int lt = tile - p.tile_off[si];
     const int c0 = (lt / p.ftiles) * CT;
     const int f0 = (lt % p.ftiles) * FT;
@@ -454,7 +483,17 @@ __global__ __launch_bounds__(256 * H2_DW_KG, 1) void dw_h2_kernel(DwParams p) {
     const int total = (n_end - n_begin) * chunks;
     const int rend = ra + chunks * RK;               // end of this group's part (the cursor wraps here; rows >= rb read zeros)
     int l_n = n_begin, l_r = ra;
-    float xa[CPA][8], xz[CPB][8];
+    float xa[V4 ? 1 : CPA][8], xz[V4 ? 1 : CPB][8];
+    // ---- V4: this thread's operand (waves 0-1: x, waves 2-3: dz), channel quad and row group
+    constexpr int QA = CT / 4, QB = FT / 4;                                // channel quads of a tile
+    constexpr int RPA = QA / 4, RPB = QB / 4;                              // rows per thread: 32 rows / (128 threads / quads)
+    constexpr int RPM = RPA > RPB ? RPA : RPB;
+    const bool is_b = V4 && __builtin_amdgcn_readfirstlane(tid >> 6) >= 2;   // (wave-uniform)
+    const int t_op = tid & 127;
+    const int qn = is_b ? QB : QA;
+    const int cq = t_op % qn, rgi = t_op / qn;
+    float v4[V4 ? RPM : 1][4];
+    int voff4 = 0;
 
     // ---- operand streams through buffer resources (one per operand and sample: base = the sample, num_records = the bytes
     //      below row rb).  Round 5: the loop used to form a 64-bit address per element (v_mad_i64_i32 + v_lshl_add_u64 + moves:
@@ -473,10 +512,37 @@ __global__ __launch_bounds__(256 * H2_DW_KG, 1) void dw_h2_kernel(DwParams p) {
     }
     __amdgpu_buffer_rsrc_t rx, rz;
     auto open_sample = [&]() {
-        rx = __builtin_amdgcn_make_buffer_rsrc((void *)(S.x + (long long)l_n * S.xs), 0, rb * S.ldx * 4, 0x00020000);
-        rz = __builtin_amdgcn_make_buffer_rsrc((void *)(dz0 + (long long)l_n * p.dzs), 0, rb * p.lddz * 4, 0x00020000);
+        // (bounded at the last row's last channel, not at the end of its padded pitch: the overhang of an edge tile reads 0)
+        rx = __builtin_amdgcn_make_buffer_rsrc((void *)(S.x + (long long)l_n * S.xs), 0, ((rb - 1) * S.ldx + S.C) * 4, 0x00020000);
+        rz = __builtin_amdgcn_make_buffer_rsrc((void *)(dz0 + (long long)l_n * p.dzs), 0, ((rb - 1) * p.lddz + p.F) * 4, 0x00020000);
     };
     // (the row advance goes into the per-lane offset, which IS range-checked; a scalar offset operand would not be)
+    // (operand-dependent values are chosen by masks on VALUES: a select between two kernel-argument addresses makes hipcc copy
+    // the whole parameter block to scratch memory)
+    const int mb = -(int)is_b;
+    const int ld_x = S.ldx, ld_z = p.lddz;
+    if constexpr (V4) voff4 = ((((rgi * RPB) * ld_z + f0 + 4 * cq) * 4) & mb) | ((((rgi * RPA) * ld_x + c0 + 4 * cq) * 4) & ~mb);
+    auto load4 = [&]() __attribute__((always_inline)) {      // ... and advances the chunk cursor
+        auto ld = [&](__amdgpu_buffer_rsrc_t rs, int base, int pitch, int j) __attribute__((always_inline)) {
+            const float4 t = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, base + j * pitch, 0, 0));
+            v4[j][0] = t.x; v4[j][1] = t.y; v4[j][2] = t.z; v4[j][3] = t.w;
+        };
+        if (!is_b) {
+            const int bx = l_r * ld_x * 4 + voff4, pitch = ld_x * 4;
+#pragma unroll
+            for (int j = 0; j < RPA; ++j) ld(rx, bx, pitch, j);
+        } else {
+            const int bz = l_r * ld_z * 4 + voff4, pitch = ld_z * 4;
+#pragma unroll
+            for (int j = 0; j < RPB; ++j) ld(rz, bz, pitch, j);
+        }
+        l_r += RK;
+        if (l_r >= rend) {
+            l_r = ra;
+            ++l_n;
+            if (l_n < n_end) open_sample();
+        }
+    };
     auto load_a = [&]() {
         const int bx = l_r * S.ldx * 4;
 #pragma unroll
@@ -501,10 +567,10 @@ __global__ __launch_bounds__(256 * H2_DW_KG, 1) void dw_h2_kernel(DwParams p) {
     };
     auto store8 = [&](unsigned char *dst, int plane, const float (&v)[8], float s) {
         uint4 hi, lo;
-        h2_split2(v[0] * s, v[1] * s, hi.x, lo.x);
-        h2_split2(v[2] * s, v[3] * s, hi.y, lo.y);
-        h2_split2(v[4] * s, v[5] * s, hi.z, lo.z);
-        h2_split2(v[6] * s, v[7] * s, hi.w, lo.w);
+        h2_split2s(v[0], v[1], s, hi.x, lo.x);
+        h2_split2s(v[2], v[3], s, hi.y, lo.y);
+        h2_split2s(v[4], v[5], s, hi.z, lo.z);
+        h2_split2s(v[6], v[7], s, hi.w, lo.w);
         *reinterpret_cast<uint4 *>(dst) = hi;
         *reinterpret_cast<uint4 *>(dst + plane) = lo;
     };
@@ -534,8 +600,39 @@ __global__ __launch_bounds__(256 * H2_DW_KG, 1) void dw_h2_kernel(DwParams p) {
             store8(st + 2 * APL2 + row * ROW + 16 * (rg ^ ((row >> 2) & 3)), BPL2, xz[ch], sz);
         }
     };
+    // V4: channel i of the thread's quad, rows rgi * RP .. + RP - 1 -> one 16-byte (RP = 8) or 8-byte (RP = 4) piece per plane at
+    // LDS row 4 cq + ((i + (cq >> 2)) & 3) (the rotation), segment (rows / 8) ^ (cq & 3)
+    auto stage4 = [&](unsigned char *st) __attribute__((always_inline)) {
+        const int rot = cq >> 2, swz = cq & 3;
+        auto put = [&](unsigned char *base, int plane, float s, auto RP_) __attribute__((always_inline)) {
+            constexpr int RP = decltype(RP_)::value;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 4 * cq + ((i + rot) & 3);
+                if constexpr (RP == 8) {
+                    uint4 hi, lo;
+                    h2_split2s(v4[0][i], v4[1][i], s, hi.x, lo.x);
+                    h2_split2s(v4[2][i], v4[3][i], s, hi.y, lo.y);
+                    h2_split2s(v4[4][i], v4[5][i], s, hi.z, lo.z);
+                    h2_split2s(v4[6][i], v4[7][i], s, hi.w, lo.w);
+                    unsigned char *d = base + row * ROW + 16 * (rgi ^ swz);
+                    *reinterpret_cast<uint4 *>(d) = hi;
+                    *reinterpret_cast<uint4 *>(d + plane) = lo;
+                } else {
+                    uint2 hi, lo;
+                    h2_split2s(v4[0][i], v4[1][i], s, hi.x, lo.x);
+                    h2_split2s(v4[2][i], v4[3][i], s, hi.y, lo.y);
+                    unsigned char *d = base + row * ROW + 16 * ((rgi >> 1) ^ swz) + 8 * (rgi & 1);
+                    *reinterpret_cast<uint2 *>(d) = hi;
+                    *reinterpret_cast<uint2 *>(d + plane) = lo;
+                }
+            }
+        };
+        if (!is_b) put(st, APL2, sx, std::integral_constant<int, RPA>{});
+        else put(st + 2 * APL2, BPL2, sz, std::integral_constant<int, RPB>{});
+    };
     h2_half8 af[2][TM][2], bf[2][TN][2];
-    auto rd = [&](const unsigned char *st, int ks) {
+    auto rd = [&](const unsigned char *st, int ks) __attribute__((always_inline)) {
         const unsigned char *pa = st + (wm * WTM + li) * ROW, *pb = st + 2 * APL2 + (wn * WTN + li) * ROW;
         const int so = 16 * ((2 * ks + lh) ^ fsw);
 #pragma unroll
@@ -547,7 +644,7 @@ __global__ __launch_bounds__(256 * H2_DW_KG, 1) void dw_h2_kernel(DwParams p) {
 #pragma unroll
             for (int pc = 0; pc < 2; ++pc) bf[ks][b][pc] = *reinterpret_cast<const h2_half8 *>(pb + pc * BPL2 + b * 32 * ROW + so);
     };
-    auto mm = [&](int ks) {
+    auto mm = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
         for (int term = 0; term < 3; ++term)         // lo*hi, hi*lo, hi*hi: small products first
 #pragma unroll
@@ -560,10 +657,39 @@ __global__ __launch_bounds__(256 * H2_DW_KG, 1) void dw_h2_kernel(DwParams p) {
     constexpr int NM = 3 * TM * TN, NR = 2 * (TM + TN);
     // VALU instructions of one operand's split as hipcc emits it (per four values: v_pk_mul, v_cvt_pk_f16 x 2, v_cvt_f32_f16 x 2,
     // v_pk_fma): 12 per channel of 8 rows, plus the row offsets of the loads that follow; dealt over the MFMAs of a k16 step
-    constexpr int VA = (12 * CPA + 8 + NM - 1) / NM, VB = (12 * CPB + 8 + NM - 1) / NM;
+    constexpr int VA = (8 * CPA + 8 + NM - 1) / NM, VB = (8 * CPB + 8 + NM - 1) / NM;     // (h2_split2s: 16 per channel of 8 rows... 8 per 4 values)
     // one chunk: stage `cur` holds chunk it, the registers chunk it + 1 (NEXT), stage `nxt` is free; MORE: chunk it + 2 exists
-    auto chunk = [&](const unsigned char *cur, unsigned char *nxt, auto next, auto more) {
+    // V4: one operand per thread -- its split + stores of chunk it + 1 ride behind the second k16 step's MFMAs (the first step
+    // carries the fragment reads), its loads of chunk it + 2 follow
+    constexpr int V4S = 8 * RPM + 8;                     // VALU instructions of stage4 (per thread), dealt over NM MFMAs
+    auto chunk4 = [&](const unsigned char *cur, unsigned char *nxt, auto next, auto more) __attribute__((always_inline)) {
         constexpr bool NX = decltype(next)::value, MO = decltype(more)::value;
+        rd(cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(cur, 1);
+        mm(0);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mm(1);
+        if constexpr (NX) stage4(nxt);
+        if constexpr (MO) load4();
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (NX) {
+                __builtin_amdgcn_sched_group_barrier(0x002, (V4S + NM - 1) / NM, 0);
+                if (i >= NM - 8) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto chunk = [&](const unsigned char *cur, unsigned char *nxt, auto next, auto more) __attribute__((always_inline)) {
+        constexpr bool NX = decltype(next)::value, MO = decltype(more)::value;
+        if constexpr (V4) { chunk4(cur, nxt, next, more); return; }
         rd(cur, 0);
         __builtin_amdgcn_sched_barrier(0);
         rd(cur, 1);
@@ -595,11 +721,17 @@ __global__ __launch_bounds__(256 * H2_DW_KG, 1) void dw_h2_kernel(DwParams p) {
     };
     if (total > 0) {
         open_sample();
-        load_a();
-        load_b();
-        stage_a(st0);
-        stage_b(st0);
-        if (total > 1) { load_a(); load_b(); }
+        if constexpr (V4) {
+            load4();
+            stage4(st0);
+            if (total > 1) load4();
+        } else {
+            load_a();
+            load_b();
+            stage_a(st0);
+            stage_b(st0);
+            if (total > 1) { load_a(); load_b(); }
+        }
         __syncthreads();
         int it = 0;
         // steady state: chunks it + 1, it + 2, it + 3 exist -- no branches inside, so hipcc's own vmcnt bookkeeping stays exact
@@ -641,14 +773,16 @@ __global__ __launch_bounds__(256 * H2_DW_KG, 1) void dw_h2_kernel(DwParams p) {
                 for (int g = 0; g < 16; ++g) acc[a][b][g] += park[((a * TN + b) * 16 + g) * 256 + tid];
     }
     float *out = p.ws + (long long)split * p.slab + p.part_off[si];
+    // V4: stage row R holds channel 4 q + ((R & 3) - (q >> 2) & 3), q = R >> 2 (accumulator rows and columns alike)
+    auto unrot = [](int R) { return V4 ? (R & ~3) | (((R & 3) - (R >> 4)) & 3) : R; };
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-            const int f = f0 + wn * WTN + b * 32 + li;
+            const int f = f0 + unrot(wn * WTN + b * 32 + li);
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const int c = c0 + wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh;
+                const int c = c0 + unrot(wm * WTM + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * lh);
                 if (c < S.C && f < p.F) out[(long long)c * p.F + f] = acc[a][b][g] * inv;
             }
         }
@@ -713,10 +847,22 @@ inline bool h2_dw_eligible(const DwParams &p) {
 
 inline void h2_dw_launch(const DwParams &p, int ct, int ft, dim3 grid, hipStream_t st) {
     const dim3 block(256 * H2_DW_KG);
-    if (ct == 64 && ft == 64) CAPE_LAUNCH((dw_h2_kernel<64, 64>), grid, block, 0, st, p);
-    else if (ct == 64) CAPE_LAUNCH((dw_h2_kernel<64, 128>), grid, block, 0, st, p);
-    else if (ft == 64) CAPE_LAUNCH((dw_h2_kernel<128, 64>), grid, block, 0, st, p);
-    else CAPE_LAUNCH((dw_h2_kernel<128, 128>), grid, block, 0, st, p);
+    static const int v4 = getenv("CAPE_DW_V4") ? atoi(getenv("CAPE_DW_V4")) : 1;
+    // (16-byte loads: every operand with 16-byte aligned rows)
+    bool ok = v4 && (p.lddz & 3) == 0 && (p.dzs & 3) == 0 && (reinterpret_cast<uintptr_t>(p.dz) & 15) == 0 &&
+              (!p.dz2 || (reinterpret_cast<uintptr_t>(p.dz2) & 15) == 0);
+    for (int i = 0; i < p.nsrc && ok; ++i)
+        ok = (p.s[i].ldx & 3) == 0 && (p.s[i].xs & 3) == 0 && (reinterpret_cast<uintptr_t>(p.s[i].x) & 15) == 0;
+    // (128 x 128 tiles only: with a 64-wide operand the two wave pairs of a group get unequal shares -- measured 12.8 -> 18.4 us on
+    // 128 x 64, 17.3 -> 26.2 on 64 x 128 -- and 64 x 64 gains nothing; 128 x 128: 64.1 -> 62.6, 37.1 -> 36.3, 34.3 -> 33.6 us)
+    if (ok && ct == 128 && ft == 128) {
+        CAPE_LAUNCH((dw_h2_kernel<128, 128, true>), grid, block, 0, st, p);
+        return;
+    }
+    if (ct == 64 && ft == 64) CAPE_LAUNCH((dw_h2_kernel<64, 64, false>), grid, block, 0, st, p);
+    else if (ct == 64) CAPE_LAUNCH((dw_h2_kernel<64, 128, false>), grid, block, 0, st, p);
+    else if (ft == 64) CAPE_LAUNCH((dw_h2_kernel<128, 64, false>), grid, block, 0, st, p);
+    else CAPE_LAUNCH((dw_h2_kernel<128, 128, false>), grid, block, 0, st, p);
 }
 
 inline void h2x_launch(const GconvParams &p, dim3 grid, hipStream_t st);

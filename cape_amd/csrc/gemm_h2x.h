@@ -48,19 +48,6 @@ __device__ __forceinline__ void h2x_glds4(const void *sbase, unsigned v0, unsign
                  : "=&s"(keep) : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
-// two values times a power of two -> their fp16 pieces, packed pairwise.  Written so that hipcc emits mostly plain single-pass
-// VALU (v_mul_f32, v_cvt_f32_f16, v_sub_f32, v_cvt_pk_f16_f32) instead of the fused v_fma_mixlo / mixhi_f16 forms.  Same values
-// either way: x * s and x * s - hi are exact in fp32.
-__device__ __forceinline__ void h2x_split2(float x0, float x1, float s, unsigned &hi, unsigned &lo) {
-#pragma clang fp contract(off)
-    const float t0 = x0 * s, t1 = x1 * s;
-    const _Float16 h0 = (_Float16)t0, h1 = (_Float16)t1;
-    const _Float16 l0 = (_Float16)(t0 - (float)h0), l1 = (_Float16)(t1 - (float)h1);
-    const h2_half2 H = {h0, h1}, L = {l0, l1};
-    hi = __builtin_bit_cast(unsigned, H);
-    lo = __builtin_bit_cast(unsigned, L);
-}
-
 // KO: phase knock-outs for tools/ubench/h2x_probe.hip (0 in the library): 1 no MFMAs, 2 no weight DMA, 4 no activation loads,
 // 8 no split + LDS stores, 16 no fragment reads, 32 no barriers, 64 no epilogue.  The results are then meaningless; only the
 // time is read.  EXP: scheduling experiment of the probe (bit 1: the loads and their bookkeeping in one block behind the
@@ -172,11 +159,11 @@ __global__ __launch_bounds__(512, 2) void gemm_h2x_kernel(GconvParams p) {
     auto split_a = [&](const f32x4 (&ra)[2], int half) {  // half 0: floats 0..3 of the row segment, 1: floats 4..7
         if constexpr (KO & 8) return;
         if (half == 0) {
-            h2x_split2(ra[0][0], ra[0][1], sa, sp_hi.x, sp_lo.x);
-            h2x_split2(ra[0][2], ra[0][3], sa, sp_hi.y, sp_lo.y);
+            h2_split2s(ra[0][0], ra[0][1], sa, sp_hi.x, sp_lo.x);
+            h2_split2s(ra[0][2], ra[0][3], sa, sp_hi.y, sp_lo.y);
         } else {
-            h2x_split2(ra[1][0], ra[1][1], sa, sp_hi.z, sp_lo.z);
-            h2x_split2(ra[1][2], ra[1][3], sa, sp_hi.w, sp_lo.w);
+            h2_split2s(ra[1][0], ra[1][1], sa, sp_hi.z, sp_lo.z);
+            h2_split2s(ra[1][2], ra[1][3], sa, sp_hi.w, sp_lo.w);
         }
     };
     unsigned char *const a_dst = smem + r * H2_ROW + 16 * (q ^ ((r >> 2) & 3));
