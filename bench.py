@@ -106,7 +106,7 @@ def _pmc_traffic(kernel):
 
 def _mfma_products(kernel):
     """MFMA products the kernel executes per algorithmic multiply-add, and the dense peak of the pipe it runs them on."""
-    if kernel.startswith(("gemm_h2_kernel", "dw_h2_kernel")):
+    if kernel.startswith(("gemm_h2_kernel", "gemm_h2x_kernel", "dw_h2_kernel")):
         return 3, BF16_MFMA_PEAK_TFLOPS
     if kernel.startswith(("gemm_split_kernel", "dw_split_kernel")):
         return (2 if "unsigned short" in kernel else 6), BF16_MFMA_PEAK_TFLOPS
@@ -162,7 +162,7 @@ def kernel_roofline(runner):
             if pm is not None:
                 row["mfma_util_pmc"] = pm
     split = dom.startswith(("gemm_split_kernel", "dw_split_kernel"))
-    h2 = dom.startswith(("gemm_h2_kernel", "dw_h2_kernel"))   # fp16 two-piece operands: three fp16 MFMA products per multiply-add
+    h2 = dom.startswith(("gemm_h2_kernel", "gemm_h2x_kernel", "dw_h2_kernel"))   # fp16 two-piece operands: three fp16 MFMA products per multiply-add
     one_product = split and "unsigned short" in dom          # bf16 storage: one bf16 MFMA product per multiply-add
     mfma_peak = BF16_MFMA_PEAK_TFLOPS if one_product else BF16X6_PEAK_TFLOPS if split else F16X3_PEAK_TFLOPS if h2 else \
         FP32_MFMA_PEAK_TFLOPS
@@ -184,15 +184,21 @@ def kernel_roofline(runner):
                 frac=round(achieved / peak, 4), traffic=_pmc_traffic(dom), peak_basis=basis,
                 launches_per_step=n // reps, avg_launch_us=round(1e6 * t / n, 2),
                 alg_flop_per_launch=fl / n, alg_bytes_per_launch=by / n,
-                tflops=round(fl / t / 1e12, 2), frac_of_fp32_mfma_peak=round(fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                tflops=round(fl / t / 1e12, 2),
                 hbm_alg_gbs=round(by / t / 1e9, 1), hbm_frac=round(by / t / 1e9 / HBM_PEAK_GBS, 4),
                 share_of_logged_time=round(t / sum(v[1] for v in agg.values()), 4))
     prod, pipe_peak = _mfma_products(dom)
-    roof["mfma_util"] = dict(of_dense_peak=round(fl / t / 1e12 * prod / pipe_peak, 4), products_per_multiply_add=prod,
-                             pipe_peak_tflops=pipe_peak, pmc_busy_over_simd_cycles=_pmc_entry(dom).get("mfma_util"),
-                             note="of_dense_peak: executed MFMA flops / dense peak of the pipe at the maximum clock (live timing); "
-                                  "pmc: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) from the committed "
-                                  "counter pass of the same kernel sources (null otherwise)")
+    # scalars at the top level of the object (a parser that drops nested dicts still sees them):
+    #   mfma_util            = executed MFMA flops (algorithmic x products per multiply-add) / dense peak of the pipe at the maximum
+    #                          clock, from this run's live timing
+    #   mfma_util_pmc        = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) from the committed counter pass of the
+    #                          same kernel sources (null otherwise): against the clock the kernel actually ran at
+    #   frac_of_pipe_ceiling = algorithmic flops / (dense peak / products per multiply-add): 2500 / 3 = 833 TFLOP/s for the
+    #                          two-piece kernels -- the ceiling of THIS arithmetic on its pipe (equals `frac` when the bound is mfma)
+    roof["mfma_util"] = round(fl / t / 1e12 * prod / pipe_peak, 4)
+    roof["mfma_util_pmc"] = _pmc_entry(dom).get("mfma_util")
+    roof["frac_of_pipe_ceiling"] = round(fl / t / 1e12 / (pipe_peak / prod), 4)
+    roof["products_per_multiply_add"], roof["pipe_peak_tflops"] = prod, pipe_peak
     return roof, table
 
 
@@ -617,6 +623,18 @@ def main():
     }
     if table:
         result["kernels"] = {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in table.items()}
+        # HBM bytes the step moves according to the committed counter pass (per kernel: bytes per dispatch x launches per step),
+        # next to the algorithmic bytes of SURVEY 8(d); null while the counter summary belongs to other kernel sources
+        cb = [(_pmc_traffic(k), v["launches"]) for k, v in table.items()]
+        if cb and all(b is not None for b, _ in cb):
+            result["counter_bytes_per_step"] = int(sum(b * n for b, n in cb))
+        else:
+            have = [(b, n) for b, n in cb if b is not None]
+            result["counter_bytes_per_step"] = None
+            result["counter_bytes_per_step_partial"] = dict(bytes=int(sum(b * n for b, n in have)), kernels_with_counters=len(have),
+                                                            kernels=len(cb)) if have else None
+        if result.get("step_roofline"):
+            result["step_roofline"]["counter_bytes_per_step"] = result["counter_bytes_per_step"]
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(batch=args.batch)
     else:
@@ -628,6 +646,8 @@ def main():
         # the reference's fp32 multiplier anywhere
         result["config"]["exact_fp32_mfma_meshes_per_s"] = result["exact_fp32_mfma"].get("value")
         result["config"]["exact_fp32_mfma_ms_per_step"] = result["exact_fp32_mfma"].get("ms_per_step")
+        if result["exact_fp32_mfma"].get("ms_per_step"):
+            result["exact_fp32_mfma"]["step_roofline"] = step_roofline(result["exact_fp32_mfma"]["ms_per_step"], args.batch, args.gan)
         if os.environ.get("CAPE_H2", "1") != "0":
             result["bf16x6_split"] = exact_fp32_run(args, dict(CAPE_H2='0'),
                                                     "same step, CAPE_H2=0: every eligible contraction as 6 bf16 products (the arithmetic of round 3)")

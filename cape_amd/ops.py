@@ -16,10 +16,12 @@ from . import _lib
 from ._lib import lib, CapeSrc, check
 from .graph import ConvOperators, HostCSR
 
-# "twopass": sparse operators applied by the streaming spmm kernel, dense contraction as a plain GEMM
-# "fused":   sparse operators gathered inside the GEMM kernel's A-tile staging (one launch per layer)
+# One evaluation form per layer: sparse operators applied by the streaming spmm kernels, dense contraction as a plain GEMM
+# ("two-pass").  The single-launch form of rounds 1-5 (operators gathered inside the GEMM's A-tile staging for WHOLE layers,
+# CAPE_MODE=fused) was slower at every mesh level and reached only 8 x the fp32 restatement's error on one data gradient where
+# the contract is 4 x (one fp32 MFMA chain per output element); it is gone.  The gather-form kernels themselves remain what the
+# library launches for sources that cannot be staged plainly (the 3-channel output layer), through the same C entry point.
 import os as _os
-MODE = _os.environ.get("CAPE_MODE", "twopass")
 # polynomial orders above the precomposed-operator limit: 1 = recurrence on chip where the layer qualifies
 # (csrc/cheb_fused.hip), 0 = always the materialised K-stack (ChebConvRecurrenceFn; the A/B reference)
 FUSED_RECURRENCE = int(_os.environ.get("CAPE_FUSED_RECURRENCE", "1"))
@@ -355,6 +357,8 @@ def fwd_kernel_name(fam, bm, bn, layout, dual, bf16=False):
     if fam == 4:
         return "fwd_narrow_in_kernel"
     if fam == 3:
+        if (bm, bn) == (128, 256) and not dual:
+            return "gemm_h2x_kernel<0, 0>"                  # the wide tile (csrc/gemm_h2x.h)
         return "gemm_h2_kernel<%d, %d, %s>" % (bm, bn, tf(dual))
     if fam == 2:
         return "gemm_split_kernel<%d, %d, %s, %s%s>" % (bm, bn, tf(layout), tf(dual), at)
@@ -367,7 +371,7 @@ def dw_kernel_name(fam, ct, ft, bf16=False):
     if fam in (5, 6):
         return _DW_FAMILY[fam]
     if fam == 4:
-        return "dw_h2_kernel<%d, %d>" % (ct, ft)
+        return "dw_h2_kernel<%d, %d, %s>" % (ct, ft, "true" if (DW_V4 and (ct, ft) == (128, 128)) else "false")
     if fam == 3 or fam == 0:
         return "%s<%d, %d, %s>" % (_DW_FAMILY[fam], ct, ft, "unsigned short" if bf16 else "float")
     waves = "4, 1" if (fam == 2 and ft == 32) else "2, 2"
@@ -383,6 +387,7 @@ def dw_kernel_name(fam, ct, ft, bf16=False):
 # FUSE_ACT_GRAD = 0 keeps the op-by-op form (the A/B reference).
 # --------------------------------------------------------------------------------------------
 FUSE_ACT_GRAD = int(_os.environ.get("CAPE_FUSE_ACT_GRAD", "1"))
+DW_V4 = int(_os.environ.get("CAPE_DW_V4", "1"))        # mirror of the library's switch (csrc/gemm_h2.h h2_dw_launch): kernel NAMES only
 _CHAIN = [False]
 
 
@@ -1143,8 +1148,7 @@ class ChebConvFn(torch.autograd.Function):
     contribution is the rank-1 update (S_k 1)(cond_in W_k[cond rows]) added in the GEMM epilogue.
     ``cond_out`` [N, Cc'] is appended to the OUTPUT as materialised channels (only where a consumer
     needs the concatenated tensor, e.g. group-norm blocks).
-    ``mode``: "fused"  = S_k gathered inside the GEMM kernel's A-tile staging (one launch);
-              "twopass" = X_k = S_k x by the streaming spmm kernel, then a plain multi-source GEMM.
+    ``mode``: "twopass" (the only form: X_k = S_k x by the streaming spmm kernels, then a plain multi-source GEMM).
     """
 
     @staticmethod
@@ -1169,7 +1173,8 @@ class ChebConvFn(torch.autograd.Function):
         Co = 0 if cond_out is None else cond_out.shape[1]
         yfull = alloc_act(N, ops.Mo, Fout + Co, x.device, dtype=x.dtype)
         y = yfull[:, :, :Fout]
-        twopass = (mode == "twopass")
+        assert mode == "twopass"
+        twopass = True
         # up-sampling layer in two-pass mode: contract on the coarse rows, apply the operators to the products
         # (only when backward will not ask for the fine-level X_k: inference, or the coarse weight-gradient form)
         any_grad = any(ctx.needs_input_grad[i] for i in (0, 1, 2, 3, 4))
@@ -1190,7 +1195,7 @@ class ChebConvFn(torch.autograd.Function):
         fw_ok = P is not None and Ch % 32 == 0 and h2_shape_ok(Ch * K, Fout)      # (forward planes: whole 32-channel chunks)
         entries = []
         for k in range(K):
-            e = dict(x=xs[k], csr=None if twopass else ops.fwd[k], w=(W, k * Fout, K * Fout, 1))
+            e = dict(x=xs[k], csr=None, w=(W, k * Fout, K * Fout, 1))
             if W_aff is not None and k == 0:
                 e["w2"] = (W_aff, 0, Fout, 1)
             if fw_ok:
@@ -1382,7 +1387,7 @@ class ChebConvFn(torch.autograd.Function):
                 dB = dbv.view(1, 1, Fout)
         if H2 and twopass and dz.dtype == torch.float32 and rm_of(dz) is None and Fout % 32 == 0 and Fout >= 64 and (need_w or need_x):
             rowmax(dz)      # (a gradient without bounds, e.g. from a group norm: one pass now serves the weight AND the data gradient)
-        csr_of = (lambda k: None) if twopass else (lambda k: ops.fwd[k])
+        csr_of = lambda k: None
         if need_w:
             dW = _grad_buffer(W, ctx.gW)
         if W_aff is not None and need_wa:
@@ -1421,114 +1426,107 @@ class ChebConvFn(torch.autograd.Function):
                     dci = dci + torch.mm(dca, W_aff[Ch:].t())
         if need_x:
             dx = alloc_act(N, Mi, Ch, dev, dtype=gfull.dtype)
-            if not twopass:
-                entries = [dict(x=dz, csr=ops.bwd[k], w=(W, k * Fout, 1, K * Fout), C=Fout) for k in range(K)]
-                # only the first Ch "output" columns (x channels) of W^T are produced: F of this launch = Ch
-                if W_aff is not None:
-                    entries.append(dict(x=g, csr=ops.bwd[0], w=(W_aff, 0, 1, Fout)))
-                gconv_fwd(entries, dx)
-            else:
-                # W^T blocks read in place, contraction index (f) contiguous: B_k[f, c] = W[c*K + k, f]  (the
-                # pipelined plain GEMM stages either weight layout at the same speed, so no transposed copy)
-                wT = lambda k: (W, k * Fout, 1, K * Fout)
-                waT = (W_aff, 0, 1, Fout) if W_aff is not None else None
-                # (a tie goes to the form whose summed operator application can carry the activation gradient of the layer below)
-                contract_first = (Mo < Mi) or (Mo == Mi and (Ch < Fout or (Ch == Fout and act_x is not None and W_aff is None and K > 1)))
-                # fp16 two-piece operands of the data gradient: contraction over the Fout columns (backward planes)
-                P, Pa = ctx.pieces
-                # contraction length of the shortest launch of the branch taken: one order per launch (contract_first) or all
-                # orders (+ the affine term) as sources of one launch
-                ktot_bw = Fout if contract_first else Fout * (K + (1 if W_aff is not None else 0))
-                bw_ok = P is not None and Fout % 32 == 0 and Ch >= 64 and dz.dtype == torch.float32 and h2_shape_ok(ktot_bw, Ch)
+            # W^T blocks read in place, contraction index (f) contiguous: B_k[f, c] = W[c*K + k, f]  (the
+            # pipelined plain GEMM stages either weight layout at the same speed, so no transposed copy)
+            wT = lambda k: (W, k * Fout, 1, K * Fout)
+            waT = (W_aff, 0, 1, Fout) if W_aff is not None else None
+            # (a tie goes to the form whose summed operator application can carry the activation gradient of the layer below)
+            contract_first = (Mo < Mi) or (Mo == Mi and (Ch < Fout or (Ch == Fout and act_x is not None and W_aff is None and K > 1)))
+            # fp16 two-piece operands of the data gradient: contraction over the Fout columns (backward planes)
+            P, Pa = ctx.pieces
+            # contraction length of the shortest launch of the branch taken: one order per launch (contract_first) or all
+            # orders (+ the affine term) as sources of one launch
+            ktot_bw = Fout if contract_first else Fout * (K + (1 if W_aff is not None else 0))
+            bw_ok = P is not None and Fout % 32 == 0 and Ch >= 64 and dz.dtype == torch.float32 and h2_shape_ok(ktot_bw, Ch)
 
-                def src(xk, k, aff=False):
-                    e = dict(x=xk, csr=None, w=waT if aff else wT(k))
-                    if bw_ok:
-                        e["p"], e["rm"] = (Pa.bwd(0) if aff else P.bwd(k)), rowmax(xk)
-                    return e
-                bkw = dict(wsi=_ptr(P.bsc)) if bw_ok else {}
-                if contract_first and W_aff is None and K > 1:
-                    # all K orders in ONE launch: G = dz W[:Ch*K]^T has column c*K + k; the epilogue stores it as K
-                    # channel blocks G_k (de-interleave), then dx = sum_k S_k^T G_k
-                    ChP = _pad4(Ch)
-                    Gall = alloc_act(N, Mo, K * ChP, dev, dtype=gfull.dtype)
-                    if bw_ok:
-                        gconv_fwd([dict(x=dz, csr=None, w=(W, 0, 1, Fout), p=(P.b_hi.data_ptr(), P.b_lo.data_ptr(), Fout), rm=rowmax(dz))],
-                                  Gall, deinterleave=K, F=K * Ch, wsi=_ptr(P.bsi))
-                    else:
-                        gconv_fwd([dict(x=dz, csr=None, w=(W, 0, 1, Fout))], Gall, deinterleave=K, F=K * Ch)
-                    Gs = [Gall[:, :, k * ChP:k * ChP + Ch] for k in range(K)]
-                    fused = None
-                    if act_x is not None and actgrad_fusable(Gs, act_x, Ch) and tuple(act_x.shape) == (N, Mi, Ch):
-                        fused = spmm_multi(Gs, [ops.bwd[k] for k in range(K)], sum=True, act_x=act_x, act=ctx.prev_act.act)
-                    if fused is not None:
-                        dx, part, chunks = fused
-                        gB_prev = ctx.prev_act.gB
-                        ctx.prev_act.fused = True
-                        item = dict(ws=part, N=N, Mo=Mi, F=Ch, R=0, dbias=gB_prev.view(Ch), dcoef=None, dcoef_g=None, cstride=0, chunks=chunks)
-                        if DEFERRED is not None:
-                            DEFERRED.append(item)
-                            dx._cape_is_dz = dict(dbias=None, offer=ctx.prev_act, version=dx._version)
-                        else:
-                            db = torch.empty(Ch, device=dev, dtype=torch.float32)
-                            _finalize_bwd_prep([dict(item, dbias=db)])
-                            dx._cape_is_dz = dict(dbias=db, offer=ctx.prev_act, version=dx._version)
-                    else:
-                        dx = spmm_multi(Gs, [ops.bwd[k] for k in range(K)], sum=True)
-                elif contract_first:
-                    # G_k = dz W_k^T at the Mo output rows, then dx = sum_k S_k^T G_k
-                    first = True
-                    for k in range(K):
-                        ent = [src(dz, k)]
-                        if W_aff is not None and k == 0:
-                            ent.append(src(g, 0, aff=True))
-                        if ops.bwd[k].identity and first:
-                            gconv_fwd(ent, dx, **bkw)
-                        else:
-                            Gk = alloc_act(N, Mo, Ch, dev, dtype=gfull.dtype)
-                            gconv_fwd(ent, Gk, **bkw)
-                            if ops.bwd[k].identity:
-                                dx.add_(Gk)
-                            elif first:
-                                spmm(Gk, ops.bwd[k], y=dx)
-                            else:
-                                spmm(Gk, ops.bwd[k], z=dx, beta=1.0, y=dx)
-                        first = False
+            def src(xk, k, aff=False):
+                e = dict(x=xk, csr=None, w=waT if aff else wT(k))
+                if bw_ok:
+                    e["p"], e["rm"] = (Pa.bwd(0) if aff else P.bwd(k)), rowmax(xk)
+                return e
+            bkw = dict(wsi=_ptr(P.bsc)) if bw_ok else {}
+            if contract_first and W_aff is None and K > 1:
+                # all K orders in ONE launch: G = dz W[:Ch*K]^T has column c*K + k; the epilogue stores it as K
+                # channel blocks G_k (de-interleave), then dx = sum_k S_k^T G_k
+                ChP = _pad4(Ch)
+                Gall = alloc_act(N, Mo, K * ChP, dev, dtype=gfull.dtype)
+                if bw_ok:
+                    gconv_fwd([dict(x=dz, csr=None, w=(W, 0, 1, Fout), p=(P.b_hi.data_ptr(), P.b_lo.data_ptr(), Fout), rm=rowmax(dz))],
+                              Gall, deinterleave=K, F=K * Ch, wsi=_ptr(P.bsi))
                 else:
-                    # T_k = S_k^T dz at the Mi input rows, then one GEMM over all sources
-                    srcs = [(dz, ops.bwd[k]) for k in range(K)] + ([(g, ops.bwd[0])] if W_aff is not None else [])
-                    todo = [i for i, (_, c) in enumerate(srcs) if not c.identity]
-                    Ts = [t for t, _ in srcs]
-                    if len(todo) == 1:
-                        Ts[todo[0]] = spmm(srcs[todo[0]][0], srcs[todo[0]][1])
-                    elif todo:                         # every S^T application of this layer in one launch
-                        for i, ti in zip(todo, spmm_multi([srcs[i][0] for i in todo], [srcs[i][1] for i in todo])):
-                            Ts[i] = ti
-                    if Fout == 1 and W_aff is None and Cc == 0 and dz.dtype == torch.float32 and W.shape[0] == Ch * K:
-                        # one output channel (the discriminator's prediction map): dx[n, r, c] = sum_k T_k[n, r] W[c*K + k]
-                        # is a rank-K outer product -- K broadcast multiply-adds instead of a GEMM launch whose
-                        # contraction has length 1 (38 us in the generic kernel, three times per adversarial step)
-                        Wm = W.detach().view(Ch, K)
-                        dxv = dx[:, :, :Ch]
-                        torch.mul(Ts[0][:, :, :1], Wm[:, 0], out=dxv)
-                        for k in range(1, K):
-                            dxv.addcmul_(Ts[k][:, :, :1], Wm[:, k])
+                    gconv_fwd([dict(x=dz, csr=None, w=(W, 0, 1, Fout))], Gall, deinterleave=K, F=K * Ch)
+                Gs = [Gall[:, :, k * ChP:k * ChP + Ch] for k in range(K)]
+                fused = None
+                if act_x is not None and actgrad_fusable(Gs, act_x, Ch) and tuple(act_x.shape) == (N, Mi, Ch):
+                    fused = spmm_multi(Gs, [ops.bwd[k] for k in range(K)], sum=True, act_x=act_x, act=ctx.prev_act.act)
+                if fused is not None:
+                    dx, part, chunks = fused
+                    gB_prev = ctx.prev_act.gB
+                    ctx.prev_act.fused = True
+                    item = dict(ws=part, N=N, Mo=Mi, F=Ch, R=0, dbias=gB_prev.view(Ch), dcoef=None, dcoef_g=None, cstride=0, chunks=chunks)
+                    if DEFERRED is not None:
+                        DEFERRED.append(item)
+                        dx._cape_is_dz = dict(dbias=None, offer=ctx.prev_act, version=dx._version)
                     else:
-                        ent = [src(Ts[k], k) for k in range(K)]
-                        if W_aff is not None:
-                            ent.append(src(Ts[K], 0, aff=True))
-                        rm_dx = alloc_rm(dx) if (H2 and dx.dtype == torch.float32 and Ch >= 128) else None
-                        gconv_fwd(ent, dx, rm_out=rm_dx, **bkw)
-                        set_rm(dx, rm_dx)
-                    if ctx.coarse_dw:
-                        # dW_k^T[f, c] = sum_{n, r} T_k[n, r, f] x[n, r, c]: the T_k are the sources, x the gradient operand
-                        wen = []
-                        if need_w:
-                            wen += [dict(x=Ts[k], csr=None, w=(dW, k * Fout, 1, K * Fout)) for k in range(K)]
-                        if W_aff is not None and need_wa:
-                            wen.append(dict(x=Ts[K], csr=None, w=(dWa, 0, 1, Fout)))
-                        if wen:
-                            gconv_dw(wen, xs[0], defer=dw_defer)
+                        db = torch.empty(Ch, device=dev, dtype=torch.float32)
+                        _finalize_bwd_prep([dict(item, dbias=db)])
+                        dx._cape_is_dz = dict(dbias=db, offer=ctx.prev_act, version=dx._version)
+                else:
+                    dx = spmm_multi(Gs, [ops.bwd[k] for k in range(K)], sum=True)
+            elif contract_first:
+                # G_k = dz W_k^T at the Mo output rows, then dx = sum_k S_k^T G_k
+                first = True
+                for k in range(K):
+                    ent = [src(dz, k)]
+                    if W_aff is not None and k == 0:
+                        ent.append(src(g, 0, aff=True))
+                    if ops.bwd[k].identity and first:
+                        gconv_fwd(ent, dx, **bkw)
+                    else:
+                        Gk = alloc_act(N, Mo, Ch, dev, dtype=gfull.dtype)
+                        gconv_fwd(ent, Gk, **bkw)
+                        if ops.bwd[k].identity:
+                            dx.add_(Gk)
+                        elif first:
+                            spmm(Gk, ops.bwd[k], y=dx)
+                        else:
+                            spmm(Gk, ops.bwd[k], z=dx, beta=1.0, y=dx)
+                    first = False
+            else:
+                # T_k = S_k^T dz at the Mi input rows, then one GEMM over all sources
+                srcs = [(dz, ops.bwd[k]) for k in range(K)] + ([(g, ops.bwd[0])] if W_aff is not None else [])
+                todo = [i for i, (_, c) in enumerate(srcs) if not c.identity]
+                Ts = [t for t, _ in srcs]
+                if len(todo) == 1:
+                    Ts[todo[0]] = spmm(srcs[todo[0]][0], srcs[todo[0]][1])
+                elif todo:                         # every S^T application of this layer in one launch
+                    for i, ti in zip(todo, spmm_multi([srcs[i][0] for i in todo], [srcs[i][1] for i in todo])):
+                        Ts[i] = ti
+                if Fout == 1 and W_aff is None and Cc == 0 and dz.dtype == torch.float32 and W.shape[0] == Ch * K:
+                    # one output channel (the discriminator's prediction map): dx[n, r, c] = sum_k T_k[n, r] W[c*K + k]
+                    # is a rank-K outer product -- K broadcast multiply-adds instead of a GEMM launch whose
+                    # contraction has length 1 (38 us in the generic kernel, three times per adversarial step)
+                    Wm = W.detach().view(Ch, K)
+                    dxv = dx[:, :, :Ch]
+                    torch.mul(Ts[0][:, :, :1], Wm[:, 0], out=dxv)
+                    for k in range(1, K):
+                        dxv.addcmul_(Ts[k][:, :, :1], Wm[:, k])
+                else:
+                    ent = [src(Ts[k], k) for k in range(K)]
+                    if W_aff is not None:
+                        ent.append(src(Ts[K], 0, aff=True))
+                    rm_dx = alloc_rm(dx) if (H2 and dx.dtype == torch.float32 and Ch >= 128) else None
+                    gconv_fwd(ent, dx, rm_out=rm_dx, **bkw)
+                    set_rm(dx, rm_dx)
+                if ctx.coarse_dw:
+                    # dW_k^T[f, c] = sum_{n, r} T_k[n, r, f] x[n, r, c]: the T_k are the sources, x the gradient operand
+                    wen = []
+                    if need_w:
+                        wen += [dict(x=Ts[k], csr=None, w=(dW, k * Fout, 1, K * Fout)) for k in range(K)]
+                    if W_aff is not None and need_wa:
+                        wen.append(dict(x=Ts[K], csr=None, w=(dWa, 0, 1, Fout)))
+                    if wen:
+                        gconv_dw(wen, xs[0], defer=dw_defer)
         if Co and need_co:
             dco = reduce_cond(gfull[:, :, Fout:])
         return dx, dW, dB, dWa, dci, dco, None, None, None, None, None, None, None, dcoef_out
@@ -2015,7 +2013,7 @@ def chebyshev5(x, W, ops, bias=None, activation=None, cond=None, W_affine=None, 
     else:
         act, bmode = _ACT_OF[activation]
     if ops.fused:
-        return ChebConvFn.apply(x, W, bias, W_affine, cond_in, cond, ops, act, bmode, MODE, grad_bufs[0], grad_bufs[1],
+        return ChebConvFn.apply(x, W, bias, W_affine, cond_in, cond, ops, act, bmode, "twopass", grad_bufs[0], grad_bufs[1],
                                 bias_grad_buf, coef)
     assert W_affine is None and coef is None
     if cond_in is not None:

@@ -14,6 +14,7 @@ unit took (cape_amd.ops.ACT_TRACE) and the twin replays it (oracle.torch_twin.fo
 same piecewise-linear function: every variable's gradient must then agree to GRAD_TOL in relative L2 and the bucket as a
 whole likewise (no flip-noise allowance; the count of replayed flips is printed).
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -272,12 +273,13 @@ def test_batch16_parity_covers_every_bench_kernel(mesh_ops):
     bench_plans = _bench_step_plans(model, inputs, (False, True))
     missing = bench_plans - parity_plans
     assert not missing, "kernels launched by the benchmarked step without a parity case: %s" % _plan_names(missing)
-    # the instantiations the headline rests on: the fp16 two-piece contraction in all three tile forms (family 3: 128 x 128,
-    # 64 x 64, the DUAL 128 x 64 of the affine blocks; one weight layout -- the piece planes are contraction-contiguous),
-    # the 128 x 128 weight-gradient kernel on the same arithmetic (family 4: dw_h2_kernel)
+    # the instantiations the headline rests on: the fp16 two-piece contraction in its tile forms (family 3: the wide 128 x 256
+    # tile of round 6 -- gemm_h2x_kernel --, 64 x 64, the DUAL 128 x 64 of the affine blocks; one weight layout -- the piece planes
+    # are contraction-contiguous), the 128 x 128 weight-gradient kernel on the same arithmetic (family 4: dw_h2_kernel)
     from cape_amd import ops as _ops
     if _ops.H2:                             # (CAPE_H2=0, the six-product reference leg of tests/test_gpu_knobs.py, has no such launches)
-        for need in (("fwd", 3, 128, 128, 1, 0), ("fwd", 3, 64, 64, 1, 0), ("fwd", 3, 128, 64, 1, 1), ("dw", 4, 128, 128)):
+        wide = os.environ.get("CAPE_H2X", "1") != "0"
+        for need in (("fwd", 3, 128, 256 if wide else 128, 1, 0), ("fwd", 3, 64, 64, 1, 0), ("fwd", 3, 128, 64, 1, 1), ("dw", 4, 128, 128)):
             assert need in bench_plans, (need, sorted(bench_plans))
     print("kernel instantiations of the benchmarked step, all covered at batch 16:", _plan_names(bench_plans))
 
