@@ -1050,13 +1050,13 @@ int gconv_dw_plan_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz, in
     if (!srcs || nsrc < 1 || nsrc > CAPE_MAX_SRC || !dz || N < 1 || Mo < 1 || F < 1 || lddz < F || !plan) return CAPE_EINVAL;
     DwPlan pl;
     plan[0] = choose_dw(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, N, Mo, F, pl, bf16);
-    if (plan[0] == 3 && !bf16 && dw_takes_h2(srcs, nsrc, dz2, dz2_mask, Mo, lddz, h2)) {
+    // (the narrow kernels are serial kernels: they keep the 512-slot plan even when the launch carries row bounds -- ADVICE r05)
+    const int nm = dw_narrow_mode(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, F, plan[0], bf16);
+    if (nm) {
+        plan[0] = nm;
+    } else if (plan[0] == 3 && !bf16 && dw_takes_h2(srcs, nsrc, dz2, dz2_mask, Mo, lddz, h2)) {
         plan[0] = 4;
         plan_dw_splits(N, Mo, pl, DW_SLOTS_PIPELINED);
-    }
-    {
-        const int nm = dw_narrow_mode(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, F, plan[0], bf16);
-        if (nm) plan[0] = nm;
     }
     plan[1] = pl.ct; plan[2] = pl.ft; plan[3] = pl.ngroups * pl.rsplit;
     return CAPE_OK;
@@ -1144,7 +1144,10 @@ int gconv_dw_stage_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz,
     DwPlan pl;
     const int fam = choose_dw(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, N, Mo, F, pl, bf16);
     const bool packed = fam == 2, plain = fam != 0, dw_split = fam == 3;
-    const bool use_h2 = !bf16 && dw_split && dw_takes_h2(srcs, nsrc, dz2, dz2_mask, Mo, lddz, h2);
+    const int narrow = dw_narrow_mode(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, F, fam, bf16);
+    // one workgroup per CU (256 slots) for the pipelined two-piece kernel ONLY: the narrow kernels are serial ones and keep the
+    // 512-slot plan whether or not the launch carries row bounds (every stage and the plan query decide this identically)
+    const bool use_h2 = !narrow && !bf16 && dw_split && dw_takes_h2(srcs, nsrc, dz2, dz2_mask, Mo, lddz, h2);
     if (use_h2) plan_dw_splits(N, Mo, pl, DW_SLOTS_PIPELINED);
     const bool dzvec = dw_dz_vec(dz, dz_sample_stride, lddz, dz2, bf16 ? 2 : 4);
     const long long need = pl.slab * pl.ngroups * pl.rsplit * (long long)sizeof(float);
@@ -1175,7 +1178,6 @@ int gconv_dw_stage_impl(const cape_src_t *srcs, int32_t nsrc, const float *dz,
     fill_h2_dw(p, bf16 ? nullptr : h2);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(pl.ntiles * ((pl.ngroups * pl.rsplit + 7) / 8) * 8)), block(256);     // cape_map_dw_block
-    const int narrow = dw_narrow_mode(srcs, nsrc, dz, dz_sample_stride, lddz, dz2, dz2_mask, F, fam, bf16);
     if (stage >= 2) {
         // reduction only: the partial slabs of an earlier stage-1 call with the same arguments are in the workspace
     } else if (narrow == 5) {                                   // narrow.h: same splits and slabs, tile 0's workgroups do all sources

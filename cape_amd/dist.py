@@ -67,6 +67,7 @@ class GradAverager(object):
         self.defer_mean = False
         self.enabled = True               # bench.py switches the exchange off for its exposed-time measurement
         self._scratch = {}
+        self._parked = []                 # outgrown scratch buffers, kept alive (see _buf)
         self._side = None
 
     @property
@@ -77,9 +78,16 @@ class GradAverager(object):
         return self.enabled and (self.world > 1 or self.always)
 
     def _buf(self, key, n, like):
-        b = self._scratch.get(key)
+        # one buffer per (name, STREAM): the synchronous path (current stream) and the asynchronous one (side stream) never share
+        # scratch, and a buffer that has to grow is parked instead of released -- work queued on its stream may still use it
+        # (the caching allocator would hand the block to another stream's allocation) -- ADVICE r05
+        sid = torch.cuda.current_stream(like.device).cuda_stream if like.is_cuda else 0
+        k = (key, sid)
+        b = self._scratch.get(k)
         if b is None or b.numel() < n or b.device != like.device:
-            b = self._scratch[key] = torch.empty(n, device=like.device, dtype=like.dtype)
+            if b is not None:
+                self._parked.append(b)
+            b = self._scratch[k] = torch.empty(n, device=like.device, dtype=like.dtype)
         return b[:n]
 
     def exchange_sum(self, t, mode=None):

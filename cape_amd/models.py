@@ -973,7 +973,7 @@ class CAPE(base_model):
             if dst:
                 torch._foreach_copy_(dst, src)             # one multi-tensor launch for the small variables
 
-    def apply_updates(self, grp, clip=5.0):
+    def apply_updates(self, grp, clip=5.0, grad_scale=None):
         """clip_by_global_norm(5.0) (:461) + Momentum (non-Nesterov, TF semantics: accum = m*accum + g;
         var -= lr*accum) or Adam (:447-449), on the flat buffers.  Capturable: no host reads, no host-side counters."""
         st = self._opt_state[grp]
@@ -986,7 +986,9 @@ class CAPE(base_model):
                 ranges, coef = self._reg_ranges(), self.regularization * self.regularization
             # data parallel: the bucket holds the SUM over the ranks (cape_amd.dist.GradAverager, defer_mean) and the kernels
             # apply 1 / world themselves; bug-compat D "gradients" are the (replicated) weights and are never exchanged
-            gs = 1.0 if (grp == 'd' and self.bug_compat) else float(getattr(self, 'grad_scale', 1.0))
+            # (``grad_scale`` is the CALLER's: the step runner that arranged the deferred mean passes its own value, so that a
+            # second runner or a bare train_step on the same model cannot inherit it -- ADVICE r05)
+            gs = 1.0 if (grp == 'd' and self.bug_compat) else float(1.0 if grad_scale is None else grad_scale)
             ops.flat_gradnorm(g, flat, ranges, coef, st['sumsq'], st['ws'], grad_scale=gs)
             if self.optimizer == 'adam':
                 # tf.train.AdamOptimizer(learning_rate) with TensorFlow's defaults (:447-449); the step count is on the device

@@ -39,10 +39,12 @@ class GraphedTrainStep(object):
         model.split_backward = self.split
         # the exchange leaves the SUM of the ranks' gradients in the bucket; the optimiser kernels apply 1 / world (one bucket-sized
         # launch less per exchanged bucket, and clipping still sees the mean)
-        model.grad_scale = 1.0
+        # (kept on the RUNNER and handed to apply_updates explicitly -- it is baked by value into the captured update graph; step()
+        # checks that the hook still is in the state this runner captured)
+        self.grad_scale = 1.0
         if grad_hook is not None and hasattr(grad_hook, "defer_mean"):
             grad_hook.defer_mean = True
-            model.grad_scale = grad_hook.grad_scale
+            self.grad_scale = grad_hook.grad_scale
         self.use_graph = use_graph          # (Adam's step count is a device counter advanced by the update kernel: capturable)
         B, d = model.batch_size, model.device
         M, Cn = model.input_num_verts, model.nn_input_channel
@@ -95,7 +97,7 @@ class GraphedTrainStep(object):
 
     def _update(self):
         for grp in self._groups():
-            self.model.apply_updates(grp)
+            self.model.apply_updates(grp, grad_scale=self.grad_scale)
 
     def _exchange(self):
         """Synchronous exchange of every bucket (unsplit path)."""
@@ -191,6 +193,12 @@ class GraphedTrainStep(object):
 
     def step(self):
         m = self.model
+        h = self.grad_hook
+        if h is not None and hasattr(h, "defer_mean"):
+            # the captured update divides by what the hook left undone at capture time: both must still agree
+            if not h.defer_mean or abs(h.grad_scale - self.grad_scale) > 0:
+                raise RuntimeError("the gradient hook's state changed since this runner was built (defer_mean / world size): the "
+                                   "captured update would scale the gradients by %g where the hook now expects %g" % (self.grad_scale, h.grad_scale))
         m.set_learning_rates(self._groups())
         if self._gA is None:
             if self.split:

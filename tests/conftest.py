@@ -17,3 +17,14 @@ def mesh_ops():
     from cape_amd.load_data import load_graph_mtx, load_pack
     L, D, U, p, L_d, D_d, U_d = load_graph_mtx(None, load_for_demo=True)
     return dict(L=L, D=D, U=U, p=p, L_d=L_d, D_d=D_d, U_d=U_d, pack=load_pack())
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """CAPE_PARITY_COLLECT=1 turns every parity assertion into a recording (tools/parity_margins.py): such a session proves
+    nothing and must not pass silently.  Outside the margin-collection tool the run is failed here."""
+    pb = sys.modules.get("parity_bar")
+    n = getattr(pb, "COLLECTED", 0) if pb is not None else 0
+    if n and os.environ.get("CAPE_PARITY_COLLECT_OK") != "1":
+        sys.stderr.write("\nERROR: CAPE_PARITY_COLLECT=1 was set: %d parity comparisons were RECORDED, NOT ASSERTED -- this session is "
+                         "no parity evidence (set CAPE_PARITY_COLLECT_OK=1 only in tools/parity_margins.py runs)\n" % n)
+        session.exitstatus = 1

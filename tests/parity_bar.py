@@ -17,6 +17,7 @@ FACTOR = float(os.environ.get("CAPE_PARITY_FACTOR", "4.0"))
 FLOOR = 4.0 * 2.0 ** -24
 
 RECORDS = []
+COLLECTED = 0        # comparisons that were recorded WITHOUT being asserted (CAPE_PARITY_COLLECT=1)
 
 
 def check(test, quantity, err_hip, err_f32, also_below=None, factor=FACTOR):
@@ -29,6 +30,8 @@ def check(test, quantity, err_hip, err_f32, also_below=None, factor=FACTOR):
         with open(path, "a") as f:
             f.write("%s\t%s\t%s\t%.4e\t%.4e\t%.3f\n" % (leg, test, quantity, err_hip, err_f32, ratio))
     if os.environ.get("CAPE_PARITY_COLLECT") == "1":                 # measurement runs: record every margin, judge afterwards
+        global COLLECTED                                             # (tests/conftest.py fails the SESSION loudly when this happened)
+        COLLECTED += 1
         return ratio
     bar = max(factor * err_f32, FLOOR)
     assert err_hip <= bar, "%s / %s: HIP error %.3e vs float64 exceeds %g x the fp32 restatement's %.3e" % (test, quantity, err_hip, factor, err_f32)
