@@ -257,3 +257,77 @@ def test_reference_demo_trace_on_device(tmp_path, mesh_ops):
     assert np.abs(outs[0] - outs[1]).max() > 0
     again = model.decode(g["dec0_z"], cond=g["dec0_cond"], cond2=g["dec0_cond2"])
     assert np.array_equal(again, outs[0])
+
+
+def test_reference_main_train_trace_on_device(tmp_path, mesh_ops):
+    """The device half of tests/test_reference_entry_script.py::test_main_train_unmodified: the call trace the reference's
+    UNMODIFIED ``main.py --mode train`` produced against cape_amd (committed as tests/golden/main_train_trace.npz) replayed on
+    the real model -- constructor keywords, build_graph('train'), a REAL fit over the same synthetic BodyData (one epoch: the
+    adversarial step through the captured HIP graph, validation, checkpoint), build_graph('demo') restoring that checkpoint,
+    predict over the test split, then the two sampling demos' encode_only_condition / decode calls with the arrays the script
+    passed, and demo_full.test_model's own error statistics (demos.py:68-80)."""
+    import json
+    import sys
+    from cape_amd import models
+    from cape_amd.load_data import load_graph_mtx
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    try:
+        import entry_synth
+    finally:
+        sys.path.pop(0)
+    g = np.load(os.path.join(here, "golden", "main_train_trace.npz"))
+    meta = json.loads(str(g["meta"]))
+    L, D, U, p, L_ds2, D_ds2, U_ds2 = load_graph_mtx(None, load_for_demo=True)
+    ops_ = dict(L=L, D=D, U=U, L_d=L_ds2, D_d=D_ds2)
+    for k, mats in ops_.items():
+        assert [list(m.shape) for m in mats] == meta["operator_shapes"][k] and [int(m.nnz) for m in mats] == meta["operator_nnz"][k], k
+    # the BodyData the script built from its dataset files, rebuilt from the same seeded generator
+    bodydata = entry_synth.Wrapper()
+    for k in entry_synth.Wrapper.FIELDS:
+        assert entry_synth.summaries_match(entry_synth.summary(getattr(bodydata, k)), meta["summaries"]["bodydata." + k]), k
+    np.random.seed(meta["ctor"]["seed"])                                              # main.py:11
+    model = models.CAPE(**ops_, **dict(meta["ctor"], project_dir=str(tmp_path)))       # main.py:87
+    first = {}
+    outs, embs = [], []
+    for call in meta["calls"]:
+        name, args = call[0], call[1:]
+        if name == "build_graph":
+            model.build_graph(args[0], args[1], phase=args[2])                        # main.py:91,95
+        elif name == "fit":
+            first = {k: v.copy() for k, v in model.variables().items()}
+            losses, t_step = model.fit(bodydata)                                      # main.py:92
+            assert len(losses) == meta["ctor"]["num_epochs"] and np.isfinite(losses).all() and t_step > 0
+            assert model.global_step == 2 * 2 * (entry_synth.N_TRAIN // 16)           # 2 steps/epoch, two updates per step (C1)
+            moved = [k for k, v in model.variables().items() if not np.array_equal(first[k], v)]
+            assert len(moved) > 0.9 * len(first)
+            assert os.listdir(os.path.join(str(tmp_path), "checkpoints", meta["ctor"]["name"]))
+        elif name == "predict":
+            for tag, arr in zip(args[:3], (bodydata.vertices_test, bodydata.cond1_test, bodydata.cond2_test)):
+                assert entry_synth.summaries_match(entry_synth.summary(arr), meta["summaries"][tag]), tag
+            pred, recon, latent, edge = model.predict(data=bodydata.vertices_test, cond=bodydata.cond1_test,
+                                                      cond2=bodydata.cond2_test, labels=bodydata.vertices_test, phase=args[3])
+            assert pred.shape == bodydata.vertices_test.shape and np.isfinite(pred).all()
+            assert all(np.isfinite(v) and v >= 0 for v in (recon, latent, edge))
+            # demos.py:68-80: de-normalise and measure the per-vertex error; an untrained net on unit-variance data is O(1 sigma)
+            diff = (pred - bodydata.vertices_test) * bodydata.std
+            err = np.sqrt((diff ** 2).sum(axis=2))
+            assert np.isfinite(err).all() and err.mean() < 10 * np.linalg.norm(bodydata.std, axis=1).mean()
+        elif name == "encode_only_condition":
+            pose_emb, clo_emb = model.encode_only_condition(g[args[0]], g[args[1]])     # demos.py:136,186
+            assert pose_emb.shape == (len(g[args[0]]), model.nz_cond) and clo_emb.shape == (len(g[args[1]]), model.nz_cond2)
+            assert np.isfinite(pose_emb).all() and np.isfinite(clo_emb).all()
+            embs.append((pose_emb, clo_emb))
+        elif name == "decode":
+            pred = model.decode(g[args[0]], cond=g[args[1]], cond2=g[args[2]])         # demos.py:152,205
+            assert pred.shape == (2, 6890, 3) and pred.dtype == np.float32 and np.isfinite(pred).all()
+            outs.append(pred)
+        else:
+            raise AssertionError(name)
+    assert len(embs) == 2 and len(outs) == meta["n_pose"] + 4
+    # sample_vary_pose encodes n_pose different poses under one clothing type; sample_vary_clotype one pose under four types
+    assert np.abs(embs[0][0] - embs[0][0][0]).max() > 0 and np.abs(embs[0][1] - embs[0][1][0]).max() == 0
+    assert np.abs(embs[1][0] - embs[1][0][0]).max() == 0 and np.abs(embs[1][1] - embs[1][1][0]).max() > 0
+    # the demo graph restored what fit saved (lib/models.py:209-215): its weights are the trained ones, not fresh initialisers
+    trained = model.variables()
+    assert any(not np.array_equal(first[k], v) for k, v in trained.items())
