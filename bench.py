@@ -99,6 +99,23 @@ def _pmc_entry(kernel):
         return {}
 
 
+def _pmc_step_bytes(kernel, launches_per_step):
+    """HBM bytes of ONE step according to the committed counter pass: sum over every kernel of that run of bytes per dispatch x
+    dispatches, divided by the number of steps the run made (= dispatches of ``kernel`` / its launches per step; the run's few
+    set-up dispatches -- fills, initialisers -- are included, < 1 %).  None when the summary belongs to other kernel sources."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+        if pmc.get("_meta", {}).get("csrc_sha") != _csrc_fingerprint():
+            return None
+        key = next((k for k in pmc if k.replace(" ", "") == kernel.replace(" ", "")), None)
+        steps = pmc[key]["dispatches"] / float(launches_per_step)
+        if steps < 1 or abs(steps - round(steps)) > 1e-6:
+            return None
+        return int(sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for k, v in pmc.items() if k != "_meta" and v.get("hbm_bytes_per_dispatch")) / steps)
+    except Exception:
+        return None
+
+
 def _pmc_traffic(kernel):
     """HBM bytes per launch (1024 * (2 * FETCH_SIZE + WRITE_SIZE): the guide's gfx950 correction) or None."""
     return _pmc_entry(kernel).get("hbm_bytes_per_dispatch")
@@ -625,14 +642,13 @@ def main():
         result["kernels"] = {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in table.items()}
         # HBM bytes the step moves according to the committed counter pass (per kernel: bytes per dispatch x launches per step),
         # next to the algorithmic bytes of SURVEY 8(d); null while the counter summary belongs to other kernel sources
+        # (the launch log names sparse / dense / optimiser launches by operation, the counter summary by kernel symbol: the
+        # step total is taken over the counter run's own dispatches, the per-kernel match below is reported beside it)
         cb = [(_pmc_traffic(k), v["launches"]) for k, v in table.items()]
-        if cb and all(b is not None for b, _ in cb):
-            result["counter_bytes_per_step"] = int(sum(b * n for b, n in cb))
-        else:
-            have = [(b, n) for b, n in cb if b is not None]
-            result["counter_bytes_per_step"] = None
-            result["counter_bytes_per_step_partial"] = dict(bytes=int(sum(b * n for b, n in have)), kernels_with_counters=len(have),
-                                                            kernels=len(cb)) if have else None
+        have = [(b, n) for b, n in cb if b is not None]
+        result["counter_bytes_per_step"] = _pmc_step_bytes(roof["kernel"], roof["launches_per_step"]) if roof else None
+        result["counter_bytes_per_step_matched"] = dict(bytes=int(sum(b * n for b, n in have)), kernels_with_counters=len(have),
+                                                        kernels=len(cb)) if have else None
         if result.get("step_roofline"):
             result["step_roofline"]["counter_bytes_per_step"] = result["counter_bytes_per_step"]
     if world == 1 and not args.no_cpu_baseline:

@@ -7,7 +7,7 @@
  * returns 0 on success, a negative CAPE_E* code for argument errors or a positive
  * hipError_t for launch errors.  Process-wide state: no buffers, no caches, nothing a caller
  * can change through the ABI -- but the library does latch a set of kernel-SELECTION
- * switches from the environment on first use (CAPE_GEMM_H2, CAPE_DW_H2, CAPE_H2_TILE,
+ * switches from the environment on first use (CAPE_GEMM_H2, CAPE_DW_H2, CAPE_H2_TILE, CAPE_H2X, CAPE_DW_V4,
  * CAPE_GEMM_BF16X6[_DUAL], CAPE_DW_BF16X6, CAPE_GEMM_PLAIN, CAPE_DW_PLAIN, CAPE_NARROW,
  * CAPE_FC_MFMA, CAPE_SPMM_UNROLL, CAPE_SPMM_WIDE; INTEGRATION.md lists them): they choose
  * among kernel families that compute the same function and are all held to the same parity

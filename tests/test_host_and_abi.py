@@ -333,7 +333,7 @@ def test_committed_pmc_summary_belongs_to_the_committed_kernel_sources():
     meta = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))["_meta"]
     assert meta["csrc_sha"] == bench._csrc_fingerprint(), "re-collect the PMC passes (tools/collect_profiles.sh) after kernel changes"
     # and the summary covers the kernel the headline line names as dominant
-    line = [l for l in open(os.path.join(ROOT, "profiles", "r05_bench.json")).read().splitlines() if l.startswith("{")][-1]
+    line = [l for l in open(os.path.join(ROOT, "profiles", "r06_bench.json")).read().splitlines() if l.startswith("{")][-1]
     roof = json.loads(line)["roofline"]
     assert roof["traffic"] and roof["traffic"] > roof["alg_bytes_per_launch"] * 0.5
     # ... and carries the normalised MFMA utilisation of that kernel (SQ_VALU_MFMA_BUSY_CYCLES over SIMD-cycles)
