@@ -301,6 +301,180 @@ __global__ __launch_bounds__(256) void spmm_multi_kernel(SpmmTerms P, int sum, V
     }
 }
 
+// ---- backward-prep of an affine block fused with the operator application of its data gradient ----------------------------
+// res_block_affine at one resolution (reference lib/models.py:776-793: y = relu(conv_K(x)) + conv_1(x), K = 2), differentiated by
+// tf.gradients (:460): the incoming gradient g feeds the 1x1 branch as it is and the K-branch as dz = g * [conv_K(x) > 0] (the
+// sign bits the forward launch wrote); the data gradient then needs T_1 = L~^T dz next to dz itself, and the rank-1 condition
+// terms need sum_r rowscale_j[r] dz[n,r,:] (j < R) and sum_r rowscale_rg[r] g[n,r,:].  cape_bwd_prep + cape_spmm did that in
+// two launches and two more tensor passes; here one work item (sample, row, VW channels) writes dz of its row, gathers the
+// MASKED neighbour rows of g for T_1 (x_masked = bit ? x : 0, then the same fma chain as cape_spmm: T_1 is bit-identical to
+// the two-launch form), and the block reduces the weighted sums of its 256 / cq rows into the partial layout
+// cape_bwd_prep_finalize reads ([sample][block][R + 2][C]; slot 0, the bias sum, is not written -- these blocks have no bias).
+struct PrepSpmmP {
+    const float *g; long long gs; int ldg;
+    const unsigned *mask; int words;
+    const int *rp; const int *ci; const float *va; int ew;
+    float *dz; long long dzs; int lddz;
+    float *t1; long long t1s; int ldt1;
+    const float *rowscale; int R, rg;               // rg < 0: no g-weighted sum
+    float *part;
+    float *rm_g, *rm_t1;
+};
+
+template <int VW>
+__device__ __forceinline__ void cape_mask_row(float (&x)[VW], unsigned bits) {
+#pragma unroll
+    for (int u = 0; u < VW; ++u) x[u] = ((bits >> u) & 1u) ? x[u] : 0.f;
+}
+
+// masked forms of cape_gather_row / cape_gather_row_ell: every gathered row is multiplied by its own sign bits first
+template <int VW, int U>
+__device__ __forceinline__ void cape_gather_row_masked(const float *xb, long long ldx, const unsigned *mb, int words, int sh, const int *rp,
+                                                       const int *ci, const float *va, int r, float (&acc)[VW]) {
+#pragma unroll
+    for (int u = 0; u < VW; ++u) acc[u] = 0.f;
+    int e = rp[r];
+    const int e1 = rp[r + 1];
+    constexpr int G = U > 0 ? U : 1;
+    for (; e < e1; e += G) {
+        int cols[G];
+        float vals[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const bool ok = e + j < e1;
+            const int ee = ok ? e + j : e;
+            cols[j] = ci[ee];
+            vals[j] = ok ? va[ee] : 0.f;
+        }
+        float xv[G][VW];
+        unsigned mk[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            cape_ldv<VW>(xb + (long long)cols[j] * ldx, xv[j]);
+            mk[j] = mb[(long long)cols[j] * words] >> sh;
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            cape_mask_row<VW>(xv[j], mk[j]);
+#pragma unroll
+            for (int u = 0; u < VW; ++u) acc[u] = fmaf(vals[j], xv[j][u], acc[u]);
+        }
+    }
+}
+
+template <int VW>
+__device__ __forceinline__ void cape_gather_row_ell_masked(const float *xb, long long ldx, const unsigned *mb, int words, int sh,
+                                                           const int *ec, const float *ev, int ew, int r, float (&acc)[VW]) {
+#pragma unroll
+    for (int u = 0; u < VW; ++u) acc[u] = 0.f;
+    const int4 *c4 = reinterpret_cast<const int4 *>(ec + (long long)r * ew);
+    const float4 *v4 = reinterpret_cast<const float4 *>(ev + (long long)r * ew);
+    int4 c0 = c4[0], c1 = c0, c2 = c0;
+    float4 v0 = v4[0], v1 = make_float4(0.f, 0.f, 0.f, 0.f), v2 = v1;
+    if (ew > 4) { c1 = c4[1]; v1 = v4[1]; }
+    if (ew > 8) { c2 = c4[2]; v2 = v4[2]; }
+    auto live = [](const float4 &v) { return v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f; };
+    auto gather4 = [&](const int4 &c, float (&xv)[4][VW], unsigned (&mk)[4]) __attribute__((always_inline)) {
+        cape_ldv<VW>(xb + (long long)c.x * ldx, xv[0]); cape_ldv<VW>(xb + (long long)c.y * ldx, xv[1]);
+        cape_ldv<VW>(xb + (long long)c.z * ldx, xv[2]); cape_ldv<VW>(xb + (long long)c.w * ldx, xv[3]);
+        mk[0] = mb[(long long)c.x * words] >> sh; mk[1] = mb[(long long)c.y * words] >> sh;
+        mk[2] = mb[(long long)c.z * words] >> sh; mk[3] = mb[(long long)c.w * words] >> sh;
+    };
+    auto fma4 = [&](const float4 &v, float (&xv)[4][VW], const unsigned (&mk)[4]) __attribute__((always_inline)) {
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cape_mask_row<VW>(xv[j], mk[j]);
+#pragma unroll
+            for (int u = 0; u < VW; ++u) acc[u] = fmaf(vv[j], xv[j][u], acc[u]);
+        }
+    };
+    float xa[4][VW], xb2[4][VW];
+    unsigned ma[4], mb2[4];
+    const bool g1 = live(v1);
+    gather4(c0, xa, ma);
+    if (g1) gather4(c1, xb2, mb2);                // both groups in flight together
+    fma4(v0, xa, ma);
+    if (g1) {
+        fma4(v1, xb2, mb2);
+        if (live(v2)) {
+            gather4(c2, xa, ma);
+            fma4(v2, xa, ma);
+        }
+    }
+}
+
+template <int VW, int U>
+__global__ __launch_bounds__(256) void bwd_prep_spmm_kernel(PrepSpmmP P, int N, int Mo, int C) {
+    __shared__ float cs[4][64 * VW];
+    const int cq = C / VW;                                   // a power of two <= 64 (host check): the lanes of a row are one aligned group
+    const int bps = spmm_bps(Mo, cq);
+    int n, t;
+    cape_map_block(blockIdx.x, N, bps, n, t);                // see spmm_kernel
+    const int i = t * 256 + (int)threadIdx.x;
+    const bool live = i < Mo * cq;                           // (whole blocks stay alive for the reductions)
+    const int ii = live ? i : Mo * cq - 1;
+    const int r = ii / cq;
+    const int c = (ii - r * cq) * VW;
+    const float *gb = P.g + (long long)n * P.gs + c;
+    const unsigned *mb = P.mask + (long long)n * Mo * P.words + (c >> 5);
+    const int sh = c & 31;
+    float gv[VW], d[VW], acc[VW];
+    cape_ldv<VW>(gb + (long long)r * P.ldg, gv);
+    const unsigned mw = mb[(long long)r * P.words] >> sh;
+    if (P.ew) cape_gather_row_ell_masked<VW>(gb, P.ldg, mb, P.words, sh, P.ci, P.va, P.ew, r, acc);
+    else cape_gather_row_masked<VW, U>(gb, P.ldg, mb, P.words, sh, P.rp, P.ci, P.va, r, acc);
+#pragma unroll
+    for (int u = 0; u < VW; ++u) d[u] = gv[u];
+    cape_mask_row<VW>(d, mw);
+    if (live) {
+        cape_stv<VW>(P.dz + (long long)n * P.dzs + (long long)r * P.lddz + c, d);
+        cape_stv<VW>(P.t1 + (long long)n * P.t1s + (long long)r * P.ldt1 + c, acc);
+    }
+    if (P.rm_t1) {
+        float m = 0.f;
+#pragma unroll
+        for (int u = 0; u < VW; ++u) m = fmaxf(m, fabsf(acc[u]));
+        m = cape_group_max(m, cq);
+        if (live && c == 0) cape_store_rowmax(P.rm_t1, (long long)n * Mo + r, m);
+    }
+    if (P.rm_g) {                                            // bounds g, and therefore dz
+        float m = 0.f;
+#pragma unroll
+        for (int u = 0; u < VW; ++u) m = fmaxf(m, fabsf(gv[u]));
+        m = cape_group_max(m, cq);
+        if (live && c == 0) cape_store_rowmax(P.rm_g, (long long)n * Mo + r, m);
+    }
+    // weighted column sums over the block's 256 / cq rows, term by term: inside each wave over the lanes that hold the same
+    // column group (xor strides cq .. 32), then the four waves through LDS in a fixed order
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int T = P.R + 2;
+    float *pp = P.part + ((long long)n * bps + t) * T * C;
+    const int nterm = P.R + (P.rg >= 0 ? 1 : 0);
+    for (int j = 0; j < nterm; ++j) {
+        const bool gterm = j == P.R;
+        const float sv = live ? P.rowscale[(long long)(gterm ? P.rg : j) * Mo + r] : 0.f;
+        float v[VW];
+#pragma unroll
+        for (int u = 0; u < VW; ++u) v[u] = sv * (gterm ? gv[u] : d[u]);
+        for (int s = cq; s < 64; s <<= 1)
+#pragma unroll
+            for (int u = 0; u < VW; ++u) v[u] += __shfl_xor(v[u], s);
+        if (lane < cq)
+#pragma unroll
+            for (int u = 0; u < VW; ++u) cs[wave][lane * VW + u] = v[u];
+        __syncthreads();
+        if ((int)threadIdx.x < cq) {
+            float s4[VW];
+#pragma unroll
+            for (int u = 0; u < VW; ++u)
+                s4[u] = ((cs[0][threadIdx.x * VW + u] + cs[1][threadIdx.x * VW + u]) + cs[2][threadIdx.x * VW + u]) + cs[3][threadIdx.x * VW + u];
+            cape_stv<VW>(pp + (long long)(gterm ? P.R + 1 : 1 + j) * C + (int)threadIdx.x * VW, s4);
+        }
+        __syncthreads();
+    }
+}
+
 // ---- operator applications AFTER the dense contraction (up-sampling layers) ----------------------------------
 // (S_k x) W_k = S_k (x W_k): on an up-sampling layer the contraction runs on the coarse input rows (half the
 // GEMM work) and this kernel applies the operators to the F-channel products Z_k, adds the rank-1 condition terms
@@ -1460,6 +1634,63 @@ extern "C" int cape_bwd_prep_bf16(const void *g, int64_t g_sample_stride, int32_
     return bwd_prep_impl<cape_bf16>((const cape_bf16 *)g, g_sample_stride, ldg, (const cape_bf16 *)y, y_sample_stride, ldy, act, mask,
                                     (cape_bf16 *)dz, dz_sample_stride, lddz, dbias, rowscale, R, dcoef, rg, dcoef_g,
                                     dcoef_sample_stride, finalize, N, Mo, F, workspace, workspace_bytes, rowmax_out, stream);
+}
+
+// work items per row of the fused backward-prep + operator application: 8 channels each where every view allows it, else 4;
+// 0 = the arguments do not allow the fused form at all
+static int prep_spmm_cq(const float *g, int64_t gs, int32_t ldg, const float *dz, int64_t dzs, int32_t lddz, const float *t1,
+                        int64_t t1s, int32_t ldt1, int32_t F) {
+    if ((F & 31) || !aligned4(g, gs, ldg, F, 4) || !aligned4(dz, dzs, lddz, F, 4) || !aligned4(t1, t1s, ldt1, F, 4)) return 0;
+    const bool wide = spmm_wide() && aligned8(g, gs, ldg, F, 4) && aligned8(dz, dzs, lddz, F, 4) && aligned8(t1, t1s, ldt1, F, 4);
+    const int cq = F / (wide ? 8 : 4);
+    return rm_fused(cq) ? cq : 0;
+}
+
+extern "C" int32_t cape_bwd_prep_spmm_chunks(const float *g, int64_t g_sample_stride, int32_t ldg, const float *dz,
+                                             int64_t dz_sample_stride, int32_t lddz, const float *t1, int64_t t1_sample_stride,
+                                             int32_t ldt1, int32_t Mo, int32_t F) {
+    const int cq = prep_spmm_cq(g, g_sample_stride, ldg, dz, dz_sample_stride, lddz, t1, t1_sample_stride, ldt1, F);
+    return (cq && Mo > 0) ? spmm_bps(Mo, cq) : 0;
+}
+
+extern "C" int cape_bwd_prep_spmm(const float *g, int64_t g_sample_stride, int32_t ldg, const uint32_t *mask, const int32_t *rowptr,
+                                  const int32_t *colidx, const float *vals, int32_t ell_width, float *dz, int64_t dz_sample_stride,
+                                  int32_t lddz, float *t1, int64_t t1_sample_stride, int32_t ldt1, const float *rowscale, int32_t R,
+                                  int32_t rg, int32_t N, int32_t Mo, int32_t F, float *partials, int64_t partials_bytes,
+                                  float *rowmax_g_out, float *rowmax_t1_out, void *stream) {
+    if (!g || !mask || !rowptr || !colidx || !vals || !dz || !t1 || N < 1 || Mo < 1 || F < 1 || ldg < F || lddz < F || ldt1 < F)
+        return CAPE_EINVAL;
+    if (R < 0 || R > RSR_MAXR || ((R > 0 || rg >= 0) && (!rowscale || !partials))) return CAPE_EINVAL;
+    if (!ell_ok(ell_width, colidx, vals)) return CAPE_EINVAL;
+    if ((long long)Mo * F >= (1LL << 31)) return CAPE_EINVAL;
+    const int cq = prep_spmm_cq(g, g_sample_stride, ldg, dz, dz_sample_stride, lddz, t1, t1_sample_stride, ldt1, F);
+    if (!cq) return CAPE_EINVAL;
+    const int bps = spmm_bps(Mo, cq);
+    if ((R > 0 || rg >= 0) && partials_bytes < (int64_t)N * bps * (R + 2) * F * (int64_t)sizeof(float)) return CAPE_EWORKSPACE;
+    PrepSpmmP P;
+    P.g = g; P.gs = g_sample_stride; P.ldg = ldg;
+    P.mask = mask; P.words = (F + 31) / 32;
+    P.rp = rowptr; P.ci = colidx; P.va = vals; P.ew = ell_width;
+    P.dz = dz; P.dzs = dz_sample_stride; P.lddz = lddz;
+    P.t1 = t1; P.t1s = t1_sample_stride; P.ldt1 = ldt1;
+    P.rowscale = rowscale; P.R = R; P.rg = rg < 0 ? -1 : rg;
+    P.part = partials;
+    P.rm_g = rowmax_g_out; P.rm_t1 = rowmax_t1_out;
+    const bool wide = cq * 8 == F;
+    const dim3 grid((unsigned)(N * bps));
+    hipStream_t st = (hipStream_t)stream;
+    const int u = spmm_unroll();
+    if (wide) {
+        if (u == 8) CAPE_LAUNCH((bwd_prep_spmm_kernel<8, 8>), grid, dim3(256), 0, st, P, N, Mo, F);
+        else if (u == 4) CAPE_LAUNCH((bwd_prep_spmm_kernel<8, 4>), grid, dim3(256), 0, st, P, N, Mo, F);
+        else CAPE_LAUNCH((bwd_prep_spmm_kernel<8, 0>), grid, dim3(256), 0, st, P, N, Mo, F);
+    } else {
+        if (u == 8) CAPE_LAUNCH((bwd_prep_spmm_kernel<4, 8>), grid, dim3(256), 0, st, P, N, Mo, F);
+        else if (u == 4) CAPE_LAUNCH((bwd_prep_spmm_kernel<4, 4>), grid, dim3(256), 0, st, P, N, Mo, F);
+        else CAPE_LAUNCH((bwd_prep_spmm_kernel<4, 0>), grid, dim3(256), 0, st, P, N, Mo, F);
+    }
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
 }
 
 extern "C" int cape_bwd_prep_finalize(const cape_bwd_prep_item_t *items, int32_t nitems, void *stream) {

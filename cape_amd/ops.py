@@ -387,6 +387,8 @@ def dw_kernel_name(fam, ct, ft, bf16=False):
 # FUSE_ACT_GRAD = 0 keeps the op-by-op form (the A/B reference).
 # --------------------------------------------------------------------------------------------
 FUSE_ACT_GRAD = int(_os.environ.get("CAPE_FUSE_ACT_GRAD", "1"))
+# FUSE_PREP_SPMM = 0: the affine blocks at one resolution run cape_bwd_prep and cape_spmm instead of cape_bwd_prep_spmm (the A/B form)
+FUSE_PREP_SPMM = int(_os.environ.get("CAPE_FUSE_PREP_SPMM", "1"))
 DW_V4 = int(_os.environ.get("CAPE_DW_V4", "1"))        # mirror of the library's switch (csrc/gemm_h2.h h2_dw_launch): kernel NAMES only
 _CHAIN = [False]
 
@@ -1112,6 +1114,62 @@ def bwd_prep(g, y=None, act="none", mask=None, want_bias=False, rowscale=None, R
     return dz, dbias, dcoef, dcoef_g
 
 
+def bwd_prep_spmm(g, mask, csr, rowscale=None, R=0, rg=None, joint=False, defer=False):
+    """``bwd_prep(g, mask=mask, ...)`` and ``spmm(dz, csr)`` of an affine block at one resolution in ONE launch
+    (cape_bwd_prep_spmm): returns (dz, T1, dcoef, dcoef_g) -- T1 = csr @ dz bit-identical to the two-launch form -- or None when
+    the arguments do not allow the fused form (the caller then takes the two launches)."""
+    _lib.require_gpu()
+    N, Mo, F = g.shape
+    if not (FUSE_PREP_SPMM and g.dtype == torch.float32 and mask is not None and F % 32 == 0 and csr.shape[0] == Mo and csr.shape[1] == Mo):
+        return None
+    dev = g.device
+    dz = alloc_act(N, Mo, F, dev)
+    t1 = alloc_act(N, Mo, F, dev)
+    gp, gs, gl = _v(g)
+    zp, zs, zl = _v(dz)
+    tp, ts, tl = _v(t1)
+    chunks = int(lib.cape_bwd_prep_spmm_chunks(gp, gs, gl, zp, zs, zl, tp, ts, tl, Mo, F))
+    if chunks <= 0:
+        return None
+    cstride = 0
+    if joint and R and rg is not None:
+        dcoef = torch.empty((N, R + 1, F), device=dev, dtype=torch.float32)
+        dcoef_g = dcoef[:, R]
+        cstride = (R + 1) * F
+    else:
+        dcoef = torch.empty((N, R, F), device=dev, dtype=torch.float32) if R else None
+        dcoef_g = torch.empty((N, F), device=dev, dtype=torch.float32) if rg is not None else None
+    need_part = bool(R) or rg is not None
+    part = torch.empty((N, chunks, R + 2, F), device=dev, dtype=torch.float32) if need_part else None
+    rp_, ci_, va_, ew_ = csr.operands()
+    # row bounds: g's own (from its producer) serve dz as well (|dz| <= |g|); else the kernel bounds g.  T1's come with it.
+    rm_g_new, rm_g = None, rm_of(g)
+    if rm_g is not None:
+        set_rm(dz, rm_g)
+    elif _want_rm(dz):
+        rm_g_new = _new_rm(dz)
+        set_rm(dz, rm_g_new)
+        set_rm(g, rm_g_new)
+    rm_t1 = _new_rm(t1) if _want_rm(t1) else None
+
+    def launch():
+        rc = lib.cape_bwd_prep_spmm(gp, gs, gl, _ptr(mask), C.c_void_p(rp_), C.c_void_p(ci_), C.c_void_p(va_), ew_, zp, zs, zl, tp, ts, tl,
+                                    _ptr(rowscale), R, -1 if rg is None else int(rg), N, Mo, F, _ptr(part),
+                                    0 if part is None else part.numel() * 4, _ptr(rm_g_new), _ptr(rm_t1), _stream())
+        check(rc, "cape_bwd_prep_spmm")
+
+    # one pass: read g (+ sign words, + the gathered neighbour rows: cache hits), write dz and T1
+    _log_launch("bwd_prep_spmm", 2 * N * csr.nnz * F, 4 * N * Mo * F * 3 + N * Mo * (F // 32) * 4 + 8 * csr.nnz, launch)
+    set_rm(t1, rm_t1)
+    if need_part:
+        item = dict(ws=part, N=N, Mo=Mo, F=F, R=R, dbias=None, dcoef=dcoef, dcoef_g=dcoef_g, cstride=cstride, chunks=chunks)
+        if defer and DEFERRED is not None:
+            DEFERRED.append(item)
+        else:
+            _finalize_bwd_prep([item])
+    return dz, t1, dcoef, dcoef_g
+
+
 def rowscale_reduce(dz, rowscale, R):
     """out[n, j, f] = sum_r rowscale[j, r] * dz[n, r, f]  for j < R."""
     _lib.require_gpu()
@@ -1349,6 +1407,7 @@ class ChebConvFn(torch.autograd.Function):
         if NO_WEIGHT_GRAD and W.data_ptr() in NO_WEIGHT_GRAD:
             need_w = need_b = need_wa = False       # data-gradient-only sweep through this layer (see NO_WEIGHT_GRAD)
         dW = dB = dWa = dci = dco = dx = dcoef_out = None
+        T1_pre = None                      # T_1 = S_1^T dz when the backward-prep launch already produced it (bwd_prep_spmm)
         # one pass over g: dz (activation / ReLU-mask gradient), channel-bias gradient and the rank-1
         # condition-term gradients
         chan_bias = need_b and ctx.has_bias and ctx.bias_mode != _lib.BIAS_VERTEX
@@ -1371,12 +1430,21 @@ class ChebConvFn(torch.autograd.Function):
             # the layer above already multiplied by act'(y) and left the bias sums with the deferred reductions (or in ``dbias``)
             dz, dbv, dcoef, dca = g, (tag["dbias"] if tag["dbias"] is not None else ctx.gB), None, None
         else:
-            dz, dbv, dcoef, dca = bwd_prep(g, y=None if ysaved is None else ysaved[:, :, :Fout], act=act, mask=mask,
-                                           want_bias=chan_bias, rowscale=ops.rowscale if Cc else None,
-                                           R=K if Cc else 0, rg=(K if (Cc and W_aff is not None) else None),
-                                           dbias_out=ctx.gB, joint=ctx.banked,
-                                           # results read only at the end of the backward pass (bucket view / CondCoefFn)
-                                           defer=(not chan_bias or ctx.gB is not None) and (not Cc or ctx.banked))
+            bp_kw = dict(rowscale=ops.rowscale if Cc else None, R=K if Cc else 0, rg=(K if (Cc and W_aff is not None) else None),
+                         joint=ctx.banked,
+                         # results read only at the end of the backward pass (bucket view / CondCoefFn)
+                         defer=(not chan_bias or ctx.gB is not None) and (not Cc or ctx.banked))
+            fused_t1 = None
+            if (W_aff is not None and mask is not None and not chan_bias and need_x and K == 2 and Mo == Mi and Ch >= Fout and twopass
+                    and ops.bwd[0].identity and not ops.bwd[1].identity and not ctx.coarse_dw):
+                # affine block at one resolution: dz, T_1 = L~^T dz and the condition sums in one launch
+                fused_t1 = bwd_prep_spmm(g, mask, ops.bwd[1], **bp_kw)
+            if fused_t1 is not None:
+                dz, T1_pre, dcoef, dca = fused_t1
+                dbv = None
+            else:
+                dz, dbv, dcoef, dca = bwd_prep(g, y=None if ysaved is None else ysaved[:, :, :Fout], act=act, mask=mask,
+                                               want_bias=chan_bias, dbias_out=ctx.gB, **bp_kw)
         if need_b and ctx.has_bias:
             if ctx.bias_mode == _lib.BIAS_VERTEX:
                 gb = ctx.gB                      # the bucket view of the [1, M, F] bias: written in place, no copy later
@@ -1497,7 +1565,9 @@ class ChebConvFn(torch.autograd.Function):
                 srcs = [(dz, ops.bwd[k]) for k in range(K)] + ([(g, ops.bwd[0])] if W_aff is not None else [])
                 todo = [i for i, (_, c) in enumerate(srcs) if not c.identity]
                 Ts = [t for t, _ in srcs]
-                if len(todo) == 1:
+                if len(todo) == 1 and todo[0] == 1 and T1_pre is not None:
+                    Ts[1] = T1_pre
+                elif len(todo) == 1:
                     Ts[todo[0]] = spmm(srcs[todo[0]][0], srcs[todo[0]][1])
                 elif todo:                         # every S^T application of this layer in one launch
                     for i, ti in zip(todo, spmm_multi([srcs[i][0] for i in todo], [srcs[i][1] for i in todo])):

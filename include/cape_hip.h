@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define CAPE_ABI_VERSION 12
+#define CAPE_ABI_VERSION 13
 #define CAPE_MAX_SRC 8
 
 /* error codes (negative = argument error; positive values are hipError_t) */
@@ -424,6 +424,29 @@ int32_t cape_spmm_multi_actgrad_chunks(const float *y, int64_t y_sample_stride, 
 int cape_spmm_multi_actgrad(const cape_spmm_term_t *terms, int32_t nterms, float *y, int64_t y_sample_stride, int32_t ldy,
                             int32_t N, int32_t Mo, int32_t C, float *rowmax_out, const float *act_x,
                             int64_t act_x_sample_stride, int32_t ld_act_x, int32_t act, float *bias_partials, void *stream);
+
+/*
+ * Backward-prep of an affine block fused with the operator application of its data gradient (fp32, vector form, square
+ * operator).  Reference: res_block_affine at one resolution, lib/models.py:776-793 (y = relu(conv_K(x)) + conv_1(x), K = 2),
+ * differentiated by tf.gradients (:460): with g the incoming gradient and mask the sign bits of conv_K(x) the forward launch
+ * wrote ([N, Mo, F/32] words, cape_gconv_fwd dual mode),
+ *     dz[n,r,c] = mask bit ? g[n,r,c] : 0                                   (what cape_bwd_prep writes)
+ *     t1[n,r,:] = sum_e vals[e] * dz[n,colidx[e],:]                          (what cape_spmm(dz) writes: T_1 = L~^T dz)
+ * t1 is bit-identical to the two-launch form (the gathered rows are masked first, then the same fma chain).  The rank-1
+ * condition sums go to `partials` in the layout cape_bwd_prep_finalize reads with cape_bwd_prep_item_t.chunks =
+ * cape_bwd_prep_spmm_chunks(...):  slot 1 + j: sum_r rowscale[j, r] dz[n,r,:] (j < R);  slot R + 1: sum_r rowscale[rg, r] g[n,r,:]
+ * (rg < 0: none);  slot 0 (the bias sum) is NOT written -- pass dbias = NULL to the finalisation.  partials:
+ * N * chunks * (R + 2) * F floats.  rowmax_g_out / rowmax_t1_out: NULL or [N, Mo, 4] row bounds of g (which bound dz) / of t1.
+ * Needs F % 32 == 0, 16-byte aligned views whose rows split into a power-of-two number (<= 64) of 4- or 8-channel work items;
+ * CAPE_EINVAL otherwise (the caller then takes cape_bwd_prep + cape_spmm).  dz and t1 must not alias g.
+ */
+int32_t cape_bwd_prep_spmm_chunks(const float *g, int64_t g_sample_stride, int32_t ldg, const float *dz, int64_t dz_sample_stride,
+                                  int32_t lddz, const float *t1, int64_t t1_sample_stride, int32_t ldt1, int32_t Mo, int32_t F);
+int cape_bwd_prep_spmm(const float *g, int64_t g_sample_stride, int32_t ldg, const uint32_t *mask, const int32_t *rowptr,
+                       const int32_t *colidx, const float *vals, int32_t ell_width, float *dz, int64_t dz_sample_stride,
+                       int32_t lddz, float *t1, int64_t t1_sample_stride, int32_t ldt1, const float *rowscale, int32_t R,
+                       int32_t rg, int32_t N, int32_t Mo, int32_t F, float *partials, int64_t partials_bytes,
+                       float *rowmax_g_out, float *rowmax_t1_out, void *stream);
 
 
 /*

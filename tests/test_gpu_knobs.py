@@ -27,6 +27,7 @@ KNOBS = [
     dict(CAPE_H2_TILE="64x64", CAPE_H2X="0"),
     dict(CAPE_H2X="2"),                                        # the wide 128 x 256 tile wherever its shape applies
     dict(CAPE_DW_V4="0"),                                      # weight gradient: the 4-byte operand loads of round 5
+    dict(CAPE_FUSE_PREP_SPMM="0"),                             # affine blocks: cape_bwd_prep + cape_spmm instead of the fused launch
     dict(CAPE_NARROW="0"),                                     # weight gradient of the 3-channel output layer on the tile kernels
 ]
 

@@ -169,6 +169,56 @@ def test_spmm_and_sparse_op(mesh_ops, dev):
         assert vertex_err(hx.grad.cpu().numpy(), refg) < TOL
 
 
+@pytest.mark.parametrize("case", [(3, 3, 256), (2, 2, 128), (2, 1, 64), (2, 0, 32), (16, 3, 256), (1, 4, 96)])
+def test_bwd_prep_spmm_equals_the_two_launches(case, mesh_ops, dev):
+    """cape_bwd_prep_spmm (backward-prep of an affine block fused with T_1 = L~^T dz, reference lib/models.py:776-793 under
+    tf.gradients :460) against the two launches it replaces, cape_bwd_prep + cape_spmm, on the same inputs: dz, T_1 and both
+    row-bound tensors bit for bit (the gathered rows are masked, then the same fma chain); the rank-1 condition sums (another
+    partial grouping of the same row sums) to 1e-5 of their norm and against float64."""
+    from cape_amd import ops
+    from cape_amd.graph import HostCSR
+    N, lvl, F = case
+    n64 = lambda v: v.detach().cpu().numpy().astype(np.float64)
+    Lm = sp.csr_matrix(mesh_ops["L"][2 * lvl], dtype=np.float64) if lvl < 4 else sp.csr_matrix(mesh_ops["L_d"][-1], dtype=np.float64)
+    Lt = sp.csr_matrix(Lm - sp.identity(Lm.shape[0]))                       # rescale_L with lmax = 2 (lib/mesh_sampling.py:31-38)
+    Mo = Lt.shape[0]
+    rng = np.random.default_rng(100 * lvl + F)
+    g = rng.standard_normal((N, Mo, F)) * np.exp2(rng.integers(-6, 6, size=(N, Mo, 1)))
+    g[0, 5] = 0.0                                                           # an all-zero row
+    bits = rng.random((N, Mo, F)) < 0.55
+    words = np.zeros((N, Mo, F // 32), dtype=np.uint32)
+    for b in range(32):
+        words |= bits[:, :, b::32].astype(np.uint32) << np.uint32(b)
+    rowscale = rng.standard_normal((3, Mo)).astype(np.float32)
+    csr = ops.DeviceCSR(HostCSR(sp.csr_matrix(Lt.T)), dev)
+    hg = torch.tensor(g, dtype=torch.float32, device=dev)
+    hm = torch.tensor(words.view(np.int32), device=dev)
+    hrs = torch.tensor(rowscale, device=dev)
+    if F == 96:               # 12 / 24 work items per row: not a power-of-two lane group -- the caller keeps the two launches
+        assert ops.bwd_prep_spmm(hg, hm, csr, rowscale=hrs, R=2, rg=2) is None
+        return
+    for joint in (False, True):
+        g1, g2 = hg.clone(), hg.clone()
+        dz_a, _, dc_a, dg_a = ops.bwd_prep(g1, mask=hm, rowscale=hrs, R=2, rg=2, joint=joint)
+        t1_a = ops.spmm(dz_a, csr)
+        out = ops.bwd_prep_spmm(g2, hm, csr, rowscale=hrs, R=2, rg=2, joint=joint)
+        assert out is not None
+        dz_b, t1_b, dc_b, dg_b = out
+        torch.cuda.synchronize()
+        assert torch.equal(dz_a, dz_b) and torch.equal(t1_a, t1_b)
+        assert np.array_equal(dz_b.cpu().numpy(), np.where(bits, hg.cpu().numpy(), 0.0))
+        for a, b in ((ops.rm_of(dz_a), ops.rm_of(dz_b)), (ops.rm_of(t1_a), ops.rm_of(t1_b))):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.equal(a[:, :, 0], b[:, :, 0])
+        dz64 = np.where(bits, hg.cpu().numpy().astype(np.float64), 0.0)
+        ref_c = np.einsum("jr,nrf->njf", rowscale[:2].astype(np.float64), dz64)
+        ref_g = np.einsum("r,nrf->nf", rowscale[2].astype(np.float64), hg.cpu().numpy().astype(np.float64))
+        for got, alt, ref in ((dc_b[:, :2], dc_a[:, :2], ref_c), (dg_b, dg_a, ref_g)):
+            assert mat_err(n64(got), ref) < 2e-6 and mat_err(n64(got), n64(alt)) < 1e-5
+        assert vertex_err(n64(t1_b), np.stack([Lt.T @ dz64[n] for n in range(N)])) < TOL
+
+
 @pytest.mark.parametrize("shape", [(2, 862, 544, 1), (2, 6890, 96, 1), (3, 1723, 64, 0),
                                    # channel counts outside the shipped YAMLs: G < C < 2G (one channel per group, 48 as in the
                                    # cmr_k3_res golden), C % 4 != 0 (24 + 8 + 6 condition channels), C // G = 2 with C % G != 0
