@@ -310,6 +310,7 @@ __global__ __launch_bounds__(256) void spmm_multi_kernel(SpmmTerms P, int sum, V
 // MASKED neighbour rows of g for T_1 (x_masked = bit ? x : 0, then the same fma chain as cape_spmm: T_1 is bit-identical to
 // the two-launch form), and the block reduces the weighted sums of its 256 / cq rows into the partial layout
 // cape_bwd_prep_finalize reads ([sample][block][R + 2][C]; slot 0, the bias sum, is not written -- these blocks have no bias).
+constexpr int PS_MAXR = 2;           // rank-1 terms of the fused form (K = 2); more: the caller keeps the two launches
 struct PrepSpmmP {
     const float *g; long long gs; int ldg;
     const unsigned *mask; int words;
@@ -404,74 +405,106 @@ __device__ __forceinline__ void cape_gather_row_ell_masked(const float *xb, long
     }
 }
 
+// rpb: consecutive groups of 256 work items a block handles one after the other (the weighted sums of all of them are reduced
+// ONCE: at 256 channels a group is only 8 rows, and one partial row per group and term would be a third of the tensor's bytes)
 template <int VW, int U>
-__global__ __launch_bounds__(256) void bwd_prep_spmm_kernel(PrepSpmmP P, int N, int Mo, int C) {
-    __shared__ float cs[4][64 * VW];
-    const int cq = C / VW;                                   // a power of two <= 64 (host check): the lanes of a row are one aligned group
-    const int bps = spmm_bps(Mo, cq);
+__global__ __launch_bounds__(256) void bwd_prep_spmm_kernel(PrepSpmmP P, int N, int Mo, int C, int rpb, int chunks) {
+    const int cq = C / VW;                                   // a power of two in 4 .. 64 (host check): the lanes of a row are one aligned group
     int n, t;
-    cape_map_block(blockIdx.x, N, bps, n, t);                // see spmm_kernel
-    const int i = t * 256 + (int)threadIdx.x;
-    const bool live = i < Mo * cq;                           // (whole blocks stay alive for the reductions)
-    const int ii = live ? i : Mo * cq - 1;
-    const int r = ii / cq;
-    const int c = (ii - r * cq) * VW;
-    const float *gb = P.g + (long long)n * P.gs + c;
-    const unsigned *mb = P.mask + (long long)n * Mo * P.words + (c >> 5);
-    const int sh = c & 31;
-    float gv[VW], d[VW], acc[VW];
-    cape_ldv<VW>(gb + (long long)r * P.ldg, gv);
-    const unsigned mw = mb[(long long)r * P.words] >> sh;
-    if (P.ew) cape_gather_row_ell_masked<VW>(gb, P.ldg, mb, P.words, sh, P.ci, P.va, P.ew, r, acc);
-    else cape_gather_row_masked<VW, U>(gb, P.ldg, mb, P.words, sh, P.rp, P.ci, P.va, r, acc);
+    cape_map_block(blockIdx.x, N, chunks, n, t);             // see spmm_kernel
+    const float *gbase = P.g + (long long)n * P.gs;
+    const unsigned *mbase = P.mask + (long long)n * Mo * P.words;
+    const int nterm = P.R + (P.rg >= 0 ? 1 : 0);
+    float racc[PS_MAXR + 1][VW];
 #pragma unroll
-    for (int u = 0; u < VW; ++u) d[u] = gv[u];
-    cape_mask_row<VW>(d, mw);
-    if (live) {
-        cape_stv<VW>(P.dz + (long long)n * P.dzs + (long long)r * P.lddz + c, d);
-        cape_stv<VW>(P.t1 + (long long)n * P.t1s + (long long)r * P.ldt1 + c, acc);
-    }
-    if (P.rm_t1) {
-        float m = 0.f;
+    for (int j = 0; j <= PS_MAXR; ++j)
 #pragma unroll
-        for (int u = 0; u < VW; ++u) m = fmaxf(m, fabsf(acc[u]));
-        m = cape_group_max(m, cq);
-        if (live && c == 0) cape_store_rowmax(P.rm_t1, (long long)n * Mo + r, m);
-    }
-    if (P.rm_g) {                                            // bounds g, and therefore dz
-        float m = 0.f;
+        for (int u = 0; u < VW; ++u) racc[j][u] = 0.f;
+    for (int it = 0; it < rpb; ++it) {
+        const int i = (t * rpb + it) * 256 + (int)threadIdx.x;
+        const bool live = i < Mo * cq;                       // (whole blocks stay alive for the reductions)
+        const int ii = live ? i : Mo * cq - 1;
+        const int r = ii / cq;
+        const int c = (ii - r * cq) * VW;
+        const float *gb = gbase + c;
+        const unsigned *mb = mbase + (c >> 5);
+        const int sh = c & 31;
+        float gv[VW], d[VW], acc[VW];
+        cape_ldv<VW>(gb + (long long)r * P.ldg, gv);
+        const unsigned mw = mb[(long long)r * P.words] >> sh;
+        // the row weights of the sums: loaded unconditionally on the clamped row, together with everything else (a guarded load
+        // compiles to a branch with a wait for ALL outstanding loads in front of it: one more dependent round trip, +5 us)
+        float sv[PS_MAXR + 1];
 #pragma unroll
-        for (int u = 0; u < VW; ++u) m = fmaxf(m, fabsf(gv[u]));
-        m = cape_group_max(m, cq);
-        if (live && c == 0) cape_store_rowmax(P.rm_g, (long long)n * Mo + r, m);
+        for (int j = 0; j <= PS_MAXR; ++j) sv[j] = P.rowscale ? P.rowscale[(long long)(j == P.R ? (P.rg >= 0 ? P.rg : 0) : (j < P.R ? j : 0)) * Mo + r] : 0.f;
+        if (P.ew) cape_gather_row_ell_masked<VW>(gb, P.ldg, mb, P.words, sh, P.ci, P.va, P.ew, r, acc);
+        else cape_gather_row_masked<VW, U>(gb, P.ldg, mb, P.words, sh, P.rp, P.ci, P.va, r, acc);
+#pragma unroll
+        for (int u = 0; u < VW; ++u) d[u] = gv[u];
+        cape_mask_row<VW>(d, mw);
+        if (live) {
+            cape_stv<VW>(P.dz + (long long)n * P.dzs + (long long)r * P.lddz + c, d);
+            cape_stv<VW>(P.t1 + (long long)n * P.t1s + (long long)r * P.ldt1 + c, acc);
+        }
+        if (P.rm_t1) {
+            float m = 0.f;
+#pragma unroll
+            for (int u = 0; u < VW; ++u) m = fmaxf(m, fabsf(acc[u]));
+            m = cape_group_max(m, cq);
+            if (live && c == 0) cape_store_rowmax(P.rm_t1, (long long)n * Mo + r, m);
+        }
+        if (P.rm_g) {                                        // bounds g, and therefore dz
+            float m = 0.f;
+#pragma unroll
+            for (int u = 0; u < VW; ++u) m = fmaxf(m, fabsf(gv[u]));
+            m = cape_group_max(m, cq);
+            if (live && c == 0) cape_store_rowmax(P.rm_g, (long long)n * Mo + r, m);
+        }
+#pragma unroll
+        for (int j = 0; j <= PS_MAXR; ++j)
+            if (j < nterm) {
+                const bool gterm = j == P.R;
+                const float w = live ? sv[j] : 0.f;
+#pragma unroll
+                for (int u = 0; u < VW; ++u) racc[j][u] = fmaf(w, gterm ? gv[u] : d[u], racc[j][u]);
+            }
     }
-    // weighted column sums over the block's 256 / cq rows, term by term: inside each wave over the lanes that hold the same
-    // column group (xor strides cq .. 32), then the four waves through LDS in a fixed order
+    // weighted column sums over the block's rows: inside each wave over the lanes that hold the same column group (a lane holds
+    // the same group in every pass: 256 % cq == 0) without the LDS crossbar -- DPP row rotations by 4 and 8 inside the 16-lane
+    // rows, the 16- and 32-lane swaps across them -- then the four waves through LDS in a fixed order, all terms behind ONE barrier
+    // (first version: ds_bpermute shuffles and a barrier pair per term: 5-7 us of a 21 us launch)
+    __shared__ float cs[4][PS_MAXR + 1][64 * VW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int T = P.R + 2;
-    float *pp = P.part + ((long long)n * bps + t) * T * C;
-    const int nterm = P.R + (P.rg >= 0 ? 1 : 0);
-    for (int j = 0; j < nterm; ++j) {
-        const bool gterm = j == P.R;
-        const float sv = live ? P.rowscale[(long long)(gterm ? P.rg : j) * Mo + r] : 0.f;
-        float v[VW];
+    float *pp = P.part + ((long long)n * chunks + t) * T * C;
 #pragma unroll
-        for (int u = 0; u < VW; ++u) v[u] = sv * (gterm ? gv[u] : d[u]);
-        for (int s = cq; s < 64; s <<= 1)
+    for (int j = 0; j <= PS_MAXR; ++j) {
+        if (j >= nterm) break;
 #pragma unroll
-            for (int u = 0; u < VW; ++u) v[u] += __shfl_xor(v[u], s);
+        for (int u = 0; u < VW; ++u) {
+            float v = racc[j][u];
+            if (cq <= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));   // row_ror:4
+            if (cq <= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));   // row_ror:8
+            if (cq <= 16) v = cape_sum_xor16(v);
+            if (cq <= 32) v = cape_sum_xor32(v);
+            racc[j][u] = v;
+        }
         if (lane < cq)
 #pragma unroll
-            for (int u = 0; u < VW; ++u) cs[wave][lane * VW + u] = v[u];
-        __syncthreads();
-        if ((int)threadIdx.x < cq) {
+            for (int u = 0; u < VW; ++u) cs[wave][j][lane * VW + u] = racc[j][u];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < cq) {
+#pragma unroll
+        for (int j = 0; j <= PS_MAXR; ++j) {
+            if (j >= nterm) break;
+            const bool gterm = j == P.R;
             float s4[VW];
 #pragma unroll
             for (int u = 0; u < VW; ++u)
-                s4[u] = ((cs[0][threadIdx.x * VW + u] + cs[1][threadIdx.x * VW + u]) + cs[2][threadIdx.x * VW + u]) + cs[3][threadIdx.x * VW + u];
+                s4[u] = ((cs[0][j][threadIdx.x * VW + u] + cs[1][j][threadIdx.x * VW + u]) + cs[2][j][threadIdx.x * VW + u]) + cs[3][j][threadIdx.x * VW + u];
             cape_stv<VW>(pp + (long long)(gterm ? P.R + 1 : 1 + j) * C + (int)threadIdx.x * VW, s4);
         }
-        __syncthreads();
     }
 }
 
@@ -1643,14 +1676,23 @@ static int prep_spmm_cq(const float *g, int64_t gs, int32_t ldg, const float *dz
     if ((F & 31) || !aligned4(g, gs, ldg, F, 4) || !aligned4(dz, dzs, lddz, F, 4) || !aligned4(t1, t1s, ldt1, F, 4)) return 0;
     const bool wide = spmm_wide() && aligned8(g, gs, ldg, F, 4) && aligned8(dz, dzs, lddz, F, 4) && aligned8(t1, t1s, ldt1, F, 4);
     const int cq = F / (wide ? 8 : 4);
-    return rm_fused(cq) ? cq : 0;
+    return (rm_fused(cq) && cq >= 4) ? cq : 0;
+}
+// groups of 256 work items a block handles in turn (its weighted sums are reduced once): measured on the five affine-block
+// shapes of the benchmarked step (16 samples, 108 groups each; tools/experiments/prep_spmm_bench.py under rocprofv3):
+// 21.4 / 20.9 / 19.9 / 20.9 us at 1 / 2 / 3 / 4 -- three keeps 576 blocks for the 256 CUs
+static int prep_spmm_rpb(int N, int bps) {
+    const long long groups = (long long)N * bps;
+    return groups >= 1536 ? 3 : groups >= 1024 ? 2 : 1;
 }
 
 extern "C" int32_t cape_bwd_prep_spmm_chunks(const float *g, int64_t g_sample_stride, int32_t ldg, const float *dz,
                                              int64_t dz_sample_stride, int32_t lddz, const float *t1, int64_t t1_sample_stride,
-                                             int32_t ldt1, int32_t Mo, int32_t F) {
+                                             int32_t ldt1, int32_t N, int32_t Mo, int32_t F) {
     const int cq = prep_spmm_cq(g, g_sample_stride, ldg, dz, dz_sample_stride, lddz, t1, t1_sample_stride, ldt1, F);
-    return (cq && Mo > 0) ? spmm_bps(Mo, cq) : 0;
+    if (!cq || Mo < 1 || N < 1) return 0;
+    const int bps = spmm_bps(Mo, cq), rpb = prep_spmm_rpb(N, bps);
+    return (bps + rpb - 1) / rpb;
 }
 
 extern "C" int cape_bwd_prep_spmm(const float *g, int64_t g_sample_stride, int32_t ldg, const uint32_t *mask, const int32_t *rowptr,
@@ -1660,13 +1702,14 @@ extern "C" int cape_bwd_prep_spmm(const float *g, int64_t g_sample_stride, int32
                                   float *rowmax_g_out, float *rowmax_t1_out, void *stream) {
     if (!g || !mask || !rowptr || !colidx || !vals || !dz || !t1 || N < 1 || Mo < 1 || F < 1 || ldg < F || lddz < F || ldt1 < F)
         return CAPE_EINVAL;
-    if (R < 0 || R > RSR_MAXR || ((R > 0 || rg >= 0) && (!rowscale || !partials))) return CAPE_EINVAL;
+    if (R < 0 || R > PS_MAXR || ((R > 0 || rg >= 0) && (!rowscale || !partials))) return CAPE_EINVAL;
     if (!ell_ok(ell_width, colidx, vals)) return CAPE_EINVAL;
     if ((long long)Mo * F >= (1LL << 31)) return CAPE_EINVAL;
     const int cq = prep_spmm_cq(g, g_sample_stride, ldg, dz, dz_sample_stride, lddz, t1, t1_sample_stride, ldt1, F);
     if (!cq) return CAPE_EINVAL;
-    const int bps = spmm_bps(Mo, cq);
-    if ((R > 0 || rg >= 0) && partials_bytes < (int64_t)N * bps * (R + 2) * F * (int64_t)sizeof(float)) return CAPE_EWORKSPACE;
+    const int bps = spmm_bps(Mo, cq), rpb = prep_spmm_rpb(N, bps);
+    const int chunks = (bps + rpb - 1) / rpb;
+    if ((R > 0 || rg >= 0) && partials_bytes < (int64_t)N * chunks * (R + 2) * F * (int64_t)sizeof(float)) return CAPE_EWORKSPACE;
     PrepSpmmP P;
     P.g = g; P.gs = g_sample_stride; P.ldg = ldg;
     P.mask = mask; P.words = (F + 31) / 32;
@@ -1677,17 +1720,17 @@ extern "C" int cape_bwd_prep_spmm(const float *g, int64_t g_sample_stride, int32
     P.part = partials;
     P.rm_g = rowmax_g_out; P.rm_t1 = rowmax_t1_out;
     const bool wide = cq * 8 == F;
-    const dim3 grid((unsigned)(N * bps));
+    const dim3 grid((unsigned)(N * chunks));
     hipStream_t st = (hipStream_t)stream;
     const int u = spmm_unroll();
     if (wide) {
-        if (u == 8) CAPE_LAUNCH((bwd_prep_spmm_kernel<8, 8>), grid, dim3(256), 0, st, P, N, Mo, F);
-        else if (u == 4) CAPE_LAUNCH((bwd_prep_spmm_kernel<8, 4>), grid, dim3(256), 0, st, P, N, Mo, F);
-        else CAPE_LAUNCH((bwd_prep_spmm_kernel<8, 0>), grid, dim3(256), 0, st, P, N, Mo, F);
+        if (u == 8) CAPE_LAUNCH((bwd_prep_spmm_kernel<8, 8>), grid, dim3(256), 0, st, P, N, Mo, F, rpb, chunks);
+        else if (u == 4) CAPE_LAUNCH((bwd_prep_spmm_kernel<8, 4>), grid, dim3(256), 0, st, P, N, Mo, F, rpb, chunks);
+        else CAPE_LAUNCH((bwd_prep_spmm_kernel<8, 0>), grid, dim3(256), 0, st, P, N, Mo, F, rpb, chunks);
     } else {
-        if (u == 8) CAPE_LAUNCH((bwd_prep_spmm_kernel<4, 8>), grid, dim3(256), 0, st, P, N, Mo, F);
-        else if (u == 4) CAPE_LAUNCH((bwd_prep_spmm_kernel<4, 4>), grid, dim3(256), 0, st, P, N, Mo, F);
-        else CAPE_LAUNCH((bwd_prep_spmm_kernel<4, 0>), grid, dim3(256), 0, st, P, N, Mo, F);
+        if (u == 8) CAPE_LAUNCH((bwd_prep_spmm_kernel<4, 8>), grid, dim3(256), 0, st, P, N, Mo, F, rpb, chunks);
+        else if (u == 4) CAPE_LAUNCH((bwd_prep_spmm_kernel<4, 4>), grid, dim3(256), 0, st, P, N, Mo, F, rpb, chunks);
+        else CAPE_LAUNCH((bwd_prep_spmm_kernel<4, 0>), grid, dim3(256), 0, st, P, N, Mo, F, rpb, chunks);
     }
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;

@@ -1120,7 +1120,7 @@ def bwd_prep_spmm(g, mask, csr, rowscale=None, R=0, rg=None, joint=False, defer=
     the arguments do not allow the fused form (the caller then takes the two launches)."""
     _lib.require_gpu()
     N, Mo, F = g.shape
-    if not (FUSE_PREP_SPMM and g.dtype == torch.float32 and mask is not None and F % 32 == 0 and csr.shape[0] == Mo and csr.shape[1] == Mo):
+    if not (FUSE_PREP_SPMM and g.dtype == torch.float32 and mask is not None and F % 32 == 0 and R <= 2 and csr.shape[0] == Mo and csr.shape[1] == Mo):
         return None
     dev = g.device
     dz = alloc_act(N, Mo, F, dev)
@@ -1128,7 +1128,7 @@ def bwd_prep_spmm(g, mask, csr, rowscale=None, R=0, rg=None, joint=False, defer=
     gp, gs, gl = _v(g)
     zp, zs, zl = _v(dz)
     tp, ts, tl = _v(t1)
-    chunks = int(lib.cape_bwd_prep_spmm_chunks(gp, gs, gl, zp, zs, zl, tp, ts, tl, Mo, F))
+    chunks = int(lib.cape_bwd_prep_spmm_chunks(gp, gs, gl, zp, zs, zl, tp, ts, tl, N, Mo, F))
     if chunks <= 0:
         return None
     cstride = 0

@@ -436,12 +436,13 @@ int cape_spmm_multi_actgrad(const cape_spmm_term_t *terms, int32_t nterms, float
  * condition sums go to `partials` in the layout cape_bwd_prep_finalize reads with cape_bwd_prep_item_t.chunks =
  * cape_bwd_prep_spmm_chunks(...):  slot 1 + j: sum_r rowscale[j, r] dz[n,r,:] (j < R);  slot R + 1: sum_r rowscale[rg, r] g[n,r,:]
  * (rg < 0: none);  slot 0 (the bias sum) is NOT written -- pass dbias = NULL to the finalisation.  partials:
- * N * chunks * (R + 2) * F floats.  rowmax_g_out / rowmax_t1_out: NULL or [N, Mo, 4] row bounds of g (which bound dz) / of t1.
+ * N * chunks * (R + 2) * F floats; R <= 2.  rowmax_g_out / rowmax_t1_out: NULL or [N, Mo, 4] row bounds of g (which bound dz) / of t1.
  * Needs F % 32 == 0, 16-byte aligned views whose rows split into a power-of-two number (<= 64) of 4- or 8-channel work items;
  * CAPE_EINVAL otherwise (the caller then takes cape_bwd_prep + cape_spmm).  dz and t1 must not alias g.
  */
 int32_t cape_bwd_prep_spmm_chunks(const float *g, int64_t g_sample_stride, int32_t ldg, const float *dz, int64_t dz_sample_stride,
-                                  int32_t lddz, const float *t1, int64_t t1_sample_stride, int32_t ldt1, int32_t Mo, int32_t F);
+                                  int32_t lddz, const float *t1, int64_t t1_sample_stride, int32_t ldt1, int32_t N, int32_t Mo,
+                                  int32_t F);
 int cape_bwd_prep_spmm(const float *g, int64_t g_sample_stride, int32_t ldg, const uint32_t *mask, const int32_t *rowptr,
                        const int32_t *colidx, const float *vals, int32_t ell_width, float *dz, int64_t dz_sample_stride,
                        int32_t lddz, float *t1, int64_t t1_sample_stride, int32_t ldt1, const float *rowscale, int32_t R,
