@@ -138,6 +138,8 @@ SIGNATURES = {
     "cape_spmm_multi_actgrad_chunks": (_i32, [_p, _i64, _i32, _p, _i64, _i32, _i32, _i32]),
     "cape_spmm_multi_actgrad": (C.c_int, [C.POINTER(CapeSpmmTerm), _i32, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _i64, _i32, _i32, _p, _p]),
     "cape_bwd_prep_spmm_chunks": (_i32, [_p, _i64, _i32, _p, _i64, _i32, _p, _i64, _i32, _i32, _i32, _i32]),
+    "cape_spmm_multi_prep_chunks": (_i32, [C.POINTER(CapeSpmmTerm), _i32, _i32, _i32, _i32]),
+    "cape_spmm_multi_prep": (C.c_int, [C.POINTER(CapeSpmmTerm), _i32, C.c_uint32, _p, _i32, _i32, _i32, _i32, _p, _i64, _p]),
     "cape_bwd_prep_spmm": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _i64, _i32, _p, _i64, _i32, _p, _i32, _i32, _i32, _i32, _i32,
                                      _p, _i64, _p, _p, _p]),
     "cape_spmm_combine": (C.c_int, [C.POINTER(CapeSpmmTerm), _i32, C.c_uint32, C.POINTER(CapeRank), _p, _i32, _i32, _i32, _p, _p,

@@ -508,6 +508,93 @@ __global__ __launch_bounds__(256) void bwd_prep_spmm_kernel(PrepSpmmP P, int N, 
     }
 }
 
+// The same idea for the affine block that ALSO up-samples (reference lib/models.py:776-793 with an unpool in front, :147-151): its
+// data gradient needs T_k = S_k^T dz (k < K) and T_aff = S_0^T g at the COARSE input rows, its weight gradient contracts those
+// T_k (ChebConvFn coarse_dw), and the rank-1 condition sums are column sums of them:
+//     sum_r (S_k 1)[r] dz[n,r,:] = sum_j (S_k^T dz)[n,j,:]
+// so dz itself is needed by nobody.  cape_bwd_prep + cape_spmm_multi (separate mode) become ONE launch: every term gathers the
+// fine rows of g, the terms flagged in `masked` multiply each gathered row by its sign bits first, and the block leaves the column
+// sums of every term as partials in the cape_bwd_prep_finalize layout (term k -> slot 1 + k).
+template <int VW, int U>
+__global__ __launch_bounds__(256) void spmm_multi_prep_kernel(SpmmTerms P, unsigned masked, const unsigned *mask, int words, int Mfine,
+                                                              int N, int Mo, int C, float *part, int T, int rpb, int chunks) {
+    const int cq = C / VW;                                   // a power of two in 4 .. 64 (host check)
+    int n, t;
+    cape_map_block(blockIdx.x, N, chunks, n, t);             // see spmm_kernel
+    const unsigned *mbase = mask + (long long)n * Mfine * words;
+    float racc[CAPE_MAX_SPMM_TERMS][VW];
+#pragma unroll
+    for (int k = 0; k < CAPE_MAX_SPMM_TERMS; ++k)
+#pragma unroll
+        for (int u = 0; u < VW; ++u) racc[k][u] = 0.f;
+    for (int it = 0; it < rpb; ++it) {
+        const int i = (t * rpb + it) * 256 + (int)threadIdx.x;
+        const bool live = i < Mo * cq;                       // (whole blocks stay alive for the reductions)
+        const int ii = live ? i : Mo * cq - 1;
+        const int r = ii / cq;
+        const int c = (ii - r * cq) * VW;
+        const unsigned *mb = mbase + (c >> 5);
+        const int sh = c & 31;
+#pragma unroll
+        for (int k = 0; k < CAPE_MAX_SPMM_TERMS; ++k) {
+            if (k >= P.n) break;
+            const SpmmTerms::T &Tm = P.t[k];
+            const float *xb = reinterpret_cast<const float *>(Tm.x) + (long long)n * Tm.xs + c;
+            float acc[VW];
+            if ((masked >> k) & 1u) {
+                if (Tm.ew) cape_gather_row_ell_masked<VW>(xb, Tm.ldx, mb, words, sh, Tm.ci, Tm.va, Tm.ew, r, acc);
+                else cape_gather_row_masked<VW, U>(xb, Tm.ldx, mb, words, sh, Tm.rp, Tm.ci, Tm.va, r, acc);
+            } else {
+                cape_gather<VW, U>(xb, Tm.ldx, Tm.rp, Tm.ci, Tm.va, Tm.ew, r, acc);
+            }
+            if (live) cape_stv<VW>(reinterpret_cast<float *>(Tm.y) + (long long)n * Tm.ys + (long long)r * Tm.ldy + c, acc);
+            if (Tm.rm) {
+                float m = 0.f;
+#pragma unroll
+                for (int u = 0; u < VW; ++u) m = fmaxf(m, fabsf(acc[u]));
+                m = cape_group_max(m, cq);
+                if (live && c == 0) cape_store_rowmax(Tm.rm, (long long)n * Mo + r, m);
+            }
+#pragma unroll
+            for (int u = 0; u < VW; ++u) racc[k][u] += live ? acc[u] : 0.f;
+        }
+    }
+    if (!part) return;
+    // column sums over the block's rows (see bwd_prep_spmm_kernel): DPP rotations / lane swaps inside the wave, the four waves
+    // through LDS in a fixed order, all terms behind one barrier
+    __shared__ float cs[4][CAPE_MAX_SPMM_TERMS][64 * VW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *pp = part + ((long long)n * chunks + t) * T * C;
+#pragma unroll
+    for (int k = 0; k < CAPE_MAX_SPMM_TERMS; ++k) {
+        if (k >= P.n) break;
+#pragma unroll
+        for (int u = 0; u < VW; ++u) {
+            float v = racc[k][u];
+            if (cq <= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));   // row_ror:4
+            if (cq <= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));   // row_ror:8
+            if (cq <= 16) v = cape_sum_xor16(v);
+            if (cq <= 32) v = cape_sum_xor32(v);
+            racc[k][u] = v;
+        }
+        if (lane < cq)
+#pragma unroll
+            for (int u = 0; u < VW; ++u) cs[wave][k][lane * VW + u] = racc[k][u];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < cq) {
+#pragma unroll
+        for (int k = 0; k < CAPE_MAX_SPMM_TERMS; ++k) {
+            if (k >= P.n) break;
+            float s4[VW];
+#pragma unroll
+            for (int u = 0; u < VW; ++u)
+                s4[u] = ((cs[0][k][threadIdx.x * VW + u] + cs[1][k][threadIdx.x * VW + u]) + cs[2][k][threadIdx.x * VW + u]) + cs[3][k][threadIdx.x * VW + u];
+            cape_stv<VW>(pp + (long long)(1 + k) * C + (int)threadIdx.x * VW, s4);
+        }
+    }
+}
+
 // ---- operator applications AFTER the dense contraction (up-sampling layers) ----------------------------------
 // (S_k x) W_k = S_k (x W_k): on an up-sampling layer the contraction runs on the coarse input rows (half the
 // GEMM work) and this kernel applies the operators to the F-channel products Z_k, adds the rank-1 condition terms
@@ -1732,6 +1819,71 @@ extern "C" int cape_bwd_prep_spmm(const float *g, int64_t g_sample_stride, int32
         else if (u == 4) CAPE_LAUNCH((bwd_prep_spmm_kernel<4, 4>), grid, dim3(256), 0, st, P, N, Mo, F, rpb, chunks);
         else CAPE_LAUNCH((bwd_prep_spmm_kernel<4, 0>), grid, dim3(256), 0, st, P, N, Mo, F, rpb, chunks);
     }
+    CAPE_LAUNCH_CHECK();
+    return CAPE_OK;
+}
+
+// work items per row of cape_spmm_multi_prep (8 channels where every view allows it, else 4); 0 = not possible
+static int multi_prep_cq(const cape_spmm_term_t *terms, int32_t nterms, int32_t C) {
+    if (!terms || nterms < 1 || nterms > CAPE_MAX_SPMM_TERMS || (C & 31)) return 0;
+    bool wide = spmm_wide();
+    for (int k = 0; k < nterms; ++k) {
+        const cape_spmm_term_t &t = terms[k];
+        if (!t.x || !t.y || !t.rowptr || !t.colidx || !t.vals || t.ldx < C || t.ldy < C || t.scale != 1.0f) return 0;
+        if (!aligned4(t.x, t.x_sample_stride, t.ldx, C, 4) || !aligned4(t.y, t.y_sample_stride, t.ldy, C, 4)) return 0;
+        if (!ell_ok(t.ell_width, t.colidx, t.vals)) return 0;
+        wide = wide && aligned8(t.x, t.x_sample_stride, t.ldx, C, 4) && aligned8(t.y, t.y_sample_stride, t.ldy, C, 4);
+    }
+    const int cq = C / (wide ? 8 : 4);
+    return (rm_fused(cq) && cq >= 4) ? cq : 0;
+}
+
+extern "C" int32_t cape_spmm_multi_prep_chunks(const cape_spmm_term_t *terms, int32_t nterms, int32_t N, int32_t Mo, int32_t C) {
+    const int cq = multi_prep_cq(terms, nterms, C);
+    if (!cq || Mo < 1 || N < 1) return 0;
+    const int bps = spmm_bps(Mo, cq), rpb = prep_spmm_rpb(N, bps);
+    return (bps + rpb - 1) / rpb;
+}
+
+extern "C" int cape_spmm_multi_prep(const cape_spmm_term_t *terms, int32_t nterms, uint32_t masked_terms, const uint32_t *mask,
+                                    int32_t mask_rows, int32_t N, int32_t Mo, int32_t C, float *partials, int64_t partials_bytes,
+                                    void *stream) {
+    const int cq = multi_prep_cq(terms, nterms, C);
+    if (!cq || N < 1 || Mo < 1 || mask_rows < 1 || (masked_terms && !mask) || (masked_terms >> nterms)) return CAPE_EINVAL;
+    if ((long long)Mo * C >= (1LL << 31)) return CAPE_EINVAL;
+    const int bps = spmm_bps(Mo, cq), rpb = prep_spmm_rpb(N, bps);
+    const int chunks = (bps + rpb - 1) / rpb;
+    const int T = nterms + 1;
+    if (partials && partials_bytes < (int64_t)N * chunks * T * C * (int64_t)sizeof(float)) return CAPE_EWORKSPACE;
+    SpmmTerms P;
+    P.n = nterms;
+    for (int k = 0; k < nterms; ++k) {
+        const cape_spmm_term_t &t = terms[k];
+        P.t[k].x = t.x; P.t[k].xs = t.x_sample_stride; P.t[k].ldx = t.ldx;
+        P.t[k].rp = t.rowptr; P.t[k].ci = t.colidx; P.t[k].va = t.vals;
+        P.t[k].y = t.y; P.t[k].ys = t.y_sample_stride; P.t[k].ldy = t.ldy;
+        P.t[k].scale = 1.0f;
+        P.t[k].ew = t.ell_width;
+        P.t[k].rm = t.rowmax_out;
+    }
+    const bool wide = cq * 8 == C;
+    const dim3 grid((unsigned)(N * chunks));
+    hipStream_t st = (hipStream_t)stream;
+    const int words = (C + 31) / 32;
+    const int u = spmm_unroll();
+#define CAPE_MP_LAUNCH(VW_, U_)                                                                                                 \
+    CAPE_LAUNCH((spmm_multi_prep_kernel<VW_, U_>), grid, dim3(256), 0, st, P, masked_terms, mask, words, mask_rows, N, Mo, C,   \
+                partials, T, rpb, chunks)
+    if (wide) {
+        if (u == 8) CAPE_MP_LAUNCH(8, 8);
+        else if (u == 4) CAPE_MP_LAUNCH(8, 4);
+        else CAPE_MP_LAUNCH(8, 0);
+    } else {
+        if (u == 8) CAPE_MP_LAUNCH(4, 8);
+        else if (u == 4) CAPE_MP_LAUNCH(4, 4);
+        else CAPE_MP_LAUNCH(4, 0);
+    }
+#undef CAPE_MP_LAUNCH
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }

@@ -1170,6 +1170,68 @@ def bwd_prep_spmm(g, mask, csr, rowscale=None, R=0, rg=None, joint=False, defer=
     return dz, t1, dcoef, dcoef_g
 
 
+def spmm_multi_prep(g, mask, csrs, masked, want_sums=True, joint=False, defer=False):
+    """All operator applications of an up-sampling affine block's data gradient in ONE launch (cape_spmm_multi_prep):
+    ``T_k = csrs[k] @ (g * sign bits)`` for the terms flagged in ``masked``, ``csrs[k] @ g`` for the others, and -- ``want_sums`` --
+    the column sums of every T_k as the rank-1 condition gradients (dcoef [N, n-1, F] from the first n-1 terms, dcoef_g [N, F]
+    from the last; ``joint``: slices of one [N, n, F] buffer).  ``dz = g * sign bits`` is never written.  Returns
+    (Ts, dcoef, dcoef_g) or None when the arguments do not allow the fused form."""
+    _lib.require_gpu()
+    N, Mf, F = g.shape
+    n = len(csrs)
+    if not (FUSE_PREP_SPMM and g.dtype == torch.float32 and mask is not None and F % 32 == 0 and 2 <= n <= 4
+            and all(c is not None and not c.identity and c.shape[1] == Mf for c in csrs)):
+        return None
+    Mo = csrs[0].shape[0]
+    dev = g.device
+    arr = (_lib.CapeSpmmTerm * n)()
+    outs = []
+    gp, gs, gl = _v(g)
+    bits = 0
+    for k in range(n):
+        assert csrs[k].shape[0] == Mo
+        t = arr[k]
+        t.x, t.x_sample_stride, t.ldx = gp.value, gs, gl
+        t.scale = 1.0
+        t.rowptr, t.colidx, t.vals, t.ell_width = csrs[k].operands()
+        yk = alloc_act(N, Mo, F, dev)
+        yp, t.y_sample_stride, t.ldy = _v(yk)
+        t.y = yp.value
+        if _want_rm(yk):
+            rmk = _new_rm(yk)
+            t.rowmax_out = rmk.data_ptr()
+            set_rm(yk, rmk)
+        outs.append(yk)
+        bits |= (1 << k) if masked[k] else 0
+    chunks = int(lib.cape_spmm_multi_prep_chunks(arr, n, N, Mo, F))
+    if chunks <= 0:
+        return None
+    R = n - 1
+    dcoef = dcoef_g = part = None
+    cstride = 0
+    if want_sums:
+        if joint:
+            dcoef = torch.empty((N, R + 1, F), device=dev, dtype=torch.float32)
+            dcoef_g = dcoef[:, R]
+            cstride = (R + 1) * F
+        else:
+            dcoef = torch.empty((N, R, F), device=dev, dtype=torch.float32)
+            dcoef_g = torch.empty((N, F), device=dev, dtype=torch.float32)
+        part = torch.empty((N, chunks, n + 1, F), device=dev, dtype=torch.float32)
+    flops = sum(2 * N * c.nnz * F for c in csrs)
+    byts = 4 * N * F * (Mf + n * Mo) + N * Mf * (F // 32) * 4 + sum(_csr_bytes(c) for c in csrs)
+    _log_launch("spmm_multi_prep", flops, byts,
+                lambda: check(lib.cape_spmm_multi_prep(arr, n, bits, _ptr(mask), Mf, N, Mo, F, _ptr(part),
+                                                       0 if part is None else part.numel() * 4, _stream()), "cape_spmm_multi_prep"))
+    if want_sums:
+        item = dict(ws=part, N=N, Mo=Mo, F=F, R=R, dbias=None, dcoef=dcoef, dcoef_g=dcoef_g, cstride=cstride, chunks=chunks)
+        if defer and DEFERRED is not None:
+            DEFERRED.append(item)
+        else:
+            _finalize_bwd_prep([item])
+    return outs, dcoef, dcoef_g
+
+
 def rowscale_reduce(dz, rowscale, R):
     """out[n, j, f] = sum_r rowscale[j, r] * dz[n, r, f]  for j < R."""
     _lib.require_gpu()
@@ -1408,6 +1470,7 @@ class ChebConvFn(torch.autograd.Function):
             need_w = need_b = need_wa = False       # data-gradient-only sweep through this layer (see NO_WEIGHT_GRAD)
         dW = dB = dWa = dci = dco = dx = dcoef_out = None
         T1_pre = None                      # T_1 = S_1^T dz when the backward-prep launch already produced it (bwd_prep_spmm)
+        Ts_pre = None                      # all T_k of an up-sampling affine block (spmm_multi_prep): dz is then None
         # one pass over g: dz (activation / ReLU-mask gradient), channel-bias gradient and the rank-1
         # condition-term gradients
         chan_bias = need_b and ctx.has_bias and ctx.bias_mode != _lib.BIAS_VERTEX
@@ -1439,9 +1502,20 @@ class ChebConvFn(torch.autograd.Function):
                     and ops.bwd[0].identity and not ops.bwd[1].identity and not ctx.coarse_dw):
                 # affine block at one resolution: dz, T_1 = L~^T dz and the condition sums in one launch
                 fused_t1 = bwd_prep_spmm(g, mask, ops.bwd[1], **bp_kw)
+            fused_ts = None
+            if (fused_t1 is None and W_aff is not None and mask is not None and not ctx.has_bias and need_x and K == 2 and ctx.coarse_dw
+                    and twopass and not any(ops.bwd[k].identity for k in range(K))):
+                # up-sampling affine block: T_0, T_1 (from dz = g * sign bits, formed while gathering) and T_aff (from g) in one
+                # launch, the condition sums as their column sums; dz itself is needed by nobody (the weight gradient contracts
+                # the T_k: coarse_dw)
+                fused_ts = spmm_multi_prep(g, mask, [ops.bwd[0], ops.bwd[1], ops.bwd[0]], [True, True, False], want_sums=bool(Cc),
+                                           joint=ctx.banked, defer=bp_kw["defer"])
             if fused_t1 is not None:
                 dz, T1_pre, dcoef, dca = fused_t1
                 dbv = None
+            elif fused_ts is not None:
+                Ts_pre, dcoef, dca = fused_ts
+                dz, dbv = None, None
             else:
                 dz, dbv, dcoef, dca = bwd_prep(g, y=None if ysaved is None else ysaved[:, :, :Fout], act=act, mask=mask,
                                                want_bias=chan_bias, dbias_out=ctx.gB, **bp_kw)
@@ -1453,7 +1527,7 @@ class ChebConvFn(torch.autograd.Function):
                 colsum(dz, dB, per_vertex=True)
             else:
                 dB = dbv.view(1, 1, Fout)
-        if H2 and twopass and dz.dtype == torch.float32 and rm_of(dz) is None and Fout % 32 == 0 and Fout >= 64 and (need_w or need_x):
+        if dz is not None and H2 and twopass and dz.dtype == torch.float32 and rm_of(dz) is None and Fout % 32 == 0 and Fout >= 64 and (need_w or need_x):
             rowmax(dz)      # (a gradient without bounds, e.g. from a group norm: one pass now serves the weight AND the data gradient)
         csr_of = lambda k: None
         if need_w:
@@ -1505,7 +1579,7 @@ class ChebConvFn(torch.autograd.Function):
             # contraction length of the shortest launch of the branch taken: one order per launch (contract_first) or all
             # orders (+ the affine term) as sources of one launch
             ktot_bw = Fout if contract_first else Fout * (K + (1 if W_aff is not None else 0))
-            bw_ok = P is not None and Fout % 32 == 0 and Ch >= 64 and dz.dtype == torch.float32 and h2_shape_ok(ktot_bw, Ch)
+            bw_ok = P is not None and Fout % 32 == 0 and Ch >= 64 and g.dtype == torch.float32 and h2_shape_ok(ktot_bw, Ch)
 
             def src(xk, k, aff=False):
                 e = dict(x=xk, csr=None, w=waT if aff else wT(k))
@@ -1565,7 +1639,9 @@ class ChebConvFn(torch.autograd.Function):
                 srcs = [(dz, ops.bwd[k]) for k in range(K)] + ([(g, ops.bwd[0])] if W_aff is not None else [])
                 todo = [i for i, (_, c) in enumerate(srcs) if not c.identity]
                 Ts = [t for t, _ in srcs]
-                if len(todo) == 1 and todo[0] == 1 and T1_pre is not None:
+                if Ts_pre is not None:
+                    Ts = list(Ts_pre)
+                elif len(todo) == 1 and todo[0] == 1 and T1_pre is not None:
                     Ts[1] = T1_pre
                 elif len(todo) == 1:
                     Ts[todo[0]] = spmm(srcs[todo[0]][0], srcs[todo[0]][1])

@@ -449,6 +449,24 @@ int cape_bwd_prep_spmm(const float *g, int64_t g_sample_stride, int32_t ldg, con
                        int32_t rg, int32_t N, int32_t Mo, int32_t F, float *partials, int64_t partials_bytes,
                        float *rowmax_g_out, float *rowmax_t1_out, void *stream);
 
+/*
+ * The up-sampling form of the same block (res_block_affine behind an unpool, lib/models.py:776-793 + :147-151, under
+ * tf.gradients :460): all operator applications of its data gradient, T_k = S_k^T dz (k < K) and T_aff = S_0^T g at the coarse
+ * input rows, with dz = mask bit ? g : 0 formed on the fly from the gathered FINE rows of g (terms whose bit is set in
+ * masked_terms; mask [N, mask_rows, C/32] words, mask_rows = rows of the terms' inputs), and the column sums of every output
+ *     partials[n, block, 1 + k, :] = sum over the block's rows j of terms[k].y[n, j, :]
+ * in the layout cape_bwd_prep_finalize reads (chunks = cape_spmm_multi_prep_chunks(...), R = nterms - 1, dcoef_g = the last
+ * term; slot 0 not written): sum_r (S_k 1)[r] dz[n,r,:] = sum_j (S_k^T dz)[n,j,:], so the rank-1 condition gradients need no
+ * pass over dz, and dz is never written -- the weight gradient of such a block contracts the T_k.  Replaces cape_bwd_prep +
+ * cape_spmm_multi(sum = 0).  Every term: a CSR / ELL operator with Mo rows, scale 1, y != NULL (rowmax_out optional); fp32,
+ * C % 32 == 0, 16-byte aligned views with a power-of-two number (4 .. 64) of work items per row, else CAPE_EINVAL.
+ * partials (NULL: no sums): N * chunks * (nterms + 1) * C floats.
+ */
+int32_t cape_spmm_multi_prep_chunks(const cape_spmm_term_t *terms, int32_t nterms, int32_t N, int32_t Mo, int32_t C);
+int cape_spmm_multi_prep(const cape_spmm_term_t *terms, int32_t nterms, uint32_t masked_terms, const uint32_t *mask,
+                         int32_t mask_rows, int32_t N, int32_t Mo, int32_t C, float *partials, int64_t partials_bytes,
+                         void *stream);
+
 
 /*
  * Operators applied AFTER the dense contraction, with the layer epilogue -- for up-sampling layers, where

@@ -219,6 +219,56 @@ def test_bwd_prep_spmm_equals_the_two_launches(case, mesh_ops, dev):
         assert vertex_err(n64(t1_b), np.stack([Lt.T @ dz64[n] for n in range(N)])) < TOL
 
 
+@pytest.mark.parametrize("case", [(3, 2, 128), (2, 1, 64), (16, 0, 32), (2, 2, 96)])
+def test_spmm_multi_prep_equals_the_two_launches(case, mesh_ops, dev):
+    """cape_spmm_multi_prep (every operator application of an UP-SAMPLING affine block's data gradient, dz formed from the gathered
+    rows, condition sums as column sums of the outputs; reference lib/models.py:776-793 behind the unpool of :147-151) against
+    cape_bwd_prep + cape_spmm_multi: the three T_k and their row bounds bit for bit, the condition sums -- here column sums
+    of the T_k, there row-weighted sums of dz, equal in exact arithmetic -- to 1e-5 of their norm and against float64."""
+    from cape_amd import ops
+    from cape_amd.graph import HostCSR
+    N, lvl, F = case
+    n64 = lambda v: v.detach().cpu().numpy().astype(np.float64)
+    # S_0 = U, S_1 = L~ U of the block that up-samples level lvl+1 -> lvl  (rescale_L with lmax = 2: L~ = L - I)
+    U = sp.csr_matrix(mesh_ops["U"][2 * lvl + 1], dtype=np.float64)
+    Lm = sp.csr_matrix(mesh_ops["L"][2 * lvl], dtype=np.float64)
+    Lt = sp.csr_matrix(Lm - sp.identity(Lm.shape[0]))
+    S = [U, sp.csr_matrix(Lt @ U)]
+    Mo, Mi = U.shape
+    rng = np.random.default_rng(10 * lvl + F)
+    g = rng.standard_normal((N, Mo, F)) * np.exp2(rng.integers(-6, 6, size=(N, Mo, 1)))
+    bits = rng.random((N, Mo, F)) < 0.5
+    words = np.zeros((N, Mo, (F + 31) // 32), dtype=np.uint32)
+    for b in range(32):
+        sl = bits[:, :, b::32]
+        words[:, :, :sl.shape[2]] |= sl.astype(np.uint32) << np.uint32(b)
+    rowscale = np.stack([np.asarray(S[0].sum(axis=1)).ravel(), np.asarray(S[1].sum(axis=1)).ravel(), np.asarray(S[0].sum(axis=1)).ravel()]).astype(np.float32)
+    bwd = [ops.DeviceCSR(HostCSR(sp.csr_matrix(s.T)), dev) for s in S]
+    hg = torch.tensor(g, dtype=torch.float32, device=dev)
+    hm = torch.tensor(words.view(np.int32), device=dev)
+    hrs = torch.tensor(rowscale, device=dev)
+    out = ops.spmm_multi_prep(hg, hm, [bwd[0], bwd[1], bwd[0]], [True, True, False], joint=True)
+    if F == 96:
+        assert out is None
+        return
+    assert out is not None
+    Ts_b, dc_b, dg_b = out
+    dz_a, _, dc_a, dg_a = ops.bwd_prep(hg.clone(), mask=hm, rowscale=hrs, R=2, rg=2, joint=True)
+    Ts_a = ops.spmm_multi([dz_a, dz_a, hg], [bwd[0], bwd[1], bwd[0]])
+    torch.cuda.synchronize()
+    for a, b in zip(Ts_a, Ts_b):
+        assert torch.equal(a, b)
+        ra, rb = ops.rm_of(a), ops.rm_of(b)
+        assert (ra is None) == (rb is None) and (ra is None or torch.equal(ra[:, :, 0], rb[:, :, 0]))
+    g64 = hg.cpu().numpy().astype(np.float64)
+    dz64 = np.where(bits, g64, 0.0)
+    ref_c = np.stack([np.stack([(S[k].T @ dz64[n]).sum(axis=0) for k in range(2)]) for n in range(N)])
+    ref_g = np.stack([(S[0].T @ g64[n]).sum(axis=0) for n in range(N)])
+    assert mat_err(n64(dc_b[:, :2]), ref_c) < 2e-6 and mat_err(n64(dc_b[:, :2]), n64(dc_a[:, :2])) < 1e-5
+    assert mat_err(n64(dg_b), ref_g) < 2e-6 and mat_err(n64(dg_b), n64(dg_a)) < 1e-5
+    assert vertex_err(n64(Ts_b[1]), np.stack([S[1].T @ dz64[n] for n in range(N)])) < TOL
+
+
 @pytest.mark.parametrize("shape", [(2, 862, 544, 1), (2, 6890, 96, 1), (3, 1723, 64, 0),
                                    # channel counts outside the shipped YAMLs: G < C < 2G (one channel per group, 48 as in the
                                    # cmr_k3_res golden), C % 4 != 0 (24 + 8 + 6 condition channels), C // G = 2 with C % G != 0
