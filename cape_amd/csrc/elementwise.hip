@@ -405,6 +405,88 @@ __device__ __forceinline__ void cape_gather_row_ell_masked(const float *xb, long
     }
 }
 
+// one operator row applied to the masked AND to the plain rows from ONE set of loads (an up-sampling affine block applies S_0^T to
+// dz and to g): acc_m as cape_gather_row*_masked, acc_p as cape_gather_row* -- same fma chains, bit-identical results
+template <int VW, int U>
+__device__ __forceinline__ void cape_gather_row_both(const float *xb, long long ldx, const unsigned *mb, int words, int sh, const int *rp,
+                                                     const int *ci, const float *va, int r, float (&acc_m)[VW], float (&acc_p)[VW]) {
+#pragma unroll
+    for (int u = 0; u < VW; ++u) acc_m[u] = acc_p[u] = 0.f;
+    int e = rp[r];
+    const int e1 = rp[r + 1];
+    constexpr int G = U > 0 ? U : 1;
+    for (; e < e1; e += G) {
+        int cols[G];
+        float vals[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const bool ok = e + j < e1;
+            const int ee = ok ? e + j : e;
+            cols[j] = ci[ee];
+            vals[j] = ok ? va[ee] : 0.f;
+        }
+        float xv[G][VW];
+        unsigned mk[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            cape_ldv<VW>(xb + (long long)cols[j] * ldx, xv[j]);
+            mk[j] = mb[(long long)cols[j] * words] >> sh;
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+#pragma unroll
+            for (int u = 0; u < VW; ++u) acc_p[u] = fmaf(vals[j], xv[j][u], acc_p[u]);
+            cape_mask_row<VW>(xv[j], mk[j]);
+#pragma unroll
+            for (int u = 0; u < VW; ++u) acc_m[u] = fmaf(vals[j], xv[j][u], acc_m[u]);
+        }
+    }
+}
+
+template <int VW>
+__device__ __forceinline__ void cape_gather_row_ell_both(const float *xb, long long ldx, const unsigned *mb, int words, int sh,
+                                                         const int *ec, const float *ev, int ew, int r, float (&acc_m)[VW], float (&acc_p)[VW]) {
+#pragma unroll
+    for (int u = 0; u < VW; ++u) acc_m[u] = acc_p[u] = 0.f;
+    const int4 *c4 = reinterpret_cast<const int4 *>(ec + (long long)r * ew);
+    const float4 *v4 = reinterpret_cast<const float4 *>(ev + (long long)r * ew);
+    int4 c0 = c4[0], c1 = c0, c2 = c0;
+    float4 v0 = v4[0], v1 = make_float4(0.f, 0.f, 0.f, 0.f), v2 = v1;
+    if (ew > 4) { c1 = c4[1]; v1 = v4[1]; }
+    if (ew > 8) { c2 = c4[2]; v2 = v4[2]; }
+    auto live = [](const float4 &v) { return v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f; };
+    auto gather4 = [&](const int4 &c, float (&xv)[4][VW], unsigned (&mk)[4]) __attribute__((always_inline)) {
+        cape_ldv<VW>(xb + (long long)c.x * ldx, xv[0]); cape_ldv<VW>(xb + (long long)c.y * ldx, xv[1]);
+        cape_ldv<VW>(xb + (long long)c.z * ldx, xv[2]); cape_ldv<VW>(xb + (long long)c.w * ldx, xv[3]);
+        mk[0] = mb[(long long)c.x * words] >> sh; mk[1] = mb[(long long)c.y * words] >> sh;
+        mk[2] = mb[(long long)c.z * words] >> sh; mk[3] = mb[(long long)c.w * words] >> sh;
+    };
+    auto fma4 = [&](const float4 &v, float (&xv)[4][VW], const unsigned (&mk)[4]) __attribute__((always_inline)) {
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int u = 0; u < VW; ++u) acc_p[u] = fmaf(vv[j], xv[j][u], acc_p[u]);
+            cape_mask_row<VW>(xv[j], mk[j]);
+#pragma unroll
+            for (int u = 0; u < VW; ++u) acc_m[u] = fmaf(vv[j], xv[j][u], acc_m[u]);
+        }
+    };
+    float xa[4][VW], xb2[4][VW];
+    unsigned ma[4], mb2[4];
+    const bool g1 = live(v1);
+    gather4(c0, xa, ma);
+    if (g1) gather4(c1, xb2, mb2);                // both groups in flight together
+    fma4(v0, xa, ma);
+    if (g1) {
+        fma4(v1, xb2, mb2);
+        if (live(v2)) {
+            gather4(c2, xa, ma);
+            fma4(v2, xa, ma);
+        }
+    }
+}
+
 // rpb: consecutive groups of 256 work items a block handles one after the other (the weighted sums of all of them are reduced
 // ONCE: at 256 channels a group is only 8 rows, and one partial row per group and term would be a third of the tensor's bytes)
 template <int VW, int U>
@@ -515,16 +597,17 @@ __global__ __launch_bounds__(256) void bwd_prep_spmm_kernel(PrepSpmmP P, int N, 
 // so dz itself is needed by nobody.  cape_bwd_prep + cape_spmm_multi (separate mode) become ONE launch: every term gathers the
 // fine rows of g, the terms flagged in `masked` multiply each gathered row by its sign bits first, and the block leaves the column
 // sums of every term as partials in the cape_bwd_prep_finalize layout (term k -> slot 1 + k).
+constexpr int MP_MAXT = 3;            // terms of cape_spmm_multi_prep (K = 2 orders + the affine term)
 template <int VW, int U>
-__global__ __launch_bounds__(256) void spmm_multi_prep_kernel(SpmmTerms P, unsigned masked, const unsigned *mask, int words, int Mfine,
+__global__ __launch_bounds__(256) void spmm_multi_prep_kernel(SpmmTerms P, unsigned masked, int pair, const unsigned *mask, int words, int Mfine,
                                                               int N, int Mo, int C, float *part, int T, int rpb, int chunks) {
     const int cq = C / VW;                                   // a power of two in 4 .. 64 (host check)
     int n, t;
     cape_map_block(blockIdx.x, N, chunks, n, t);             // see spmm_kernel
     const unsigned *mbase = mask + (long long)n * Mfine * words;
-    float racc[CAPE_MAX_SPMM_TERMS][VW];
+    float racc[MP_MAXT][VW];
 #pragma unroll
-    for (int k = 0; k < CAPE_MAX_SPMM_TERMS; ++k)
+    for (int k = 0; k < MP_MAXT; ++k)
 #pragma unroll
         for (int u = 0; u < VW; ++u) racc[k][u] = 0.f;
     for (int it = 0; it < rpb; ++it) {
@@ -535,13 +618,22 @@ __global__ __launch_bounds__(256) void spmm_multi_prep_kernel(SpmmTerms P, unsig
         const int c = (ii - r * cq) * VW;
         const unsigned *mb = mbase + (c >> 5);
         const int sh = c & 31;
+        // `pair`: the last term applies the operator of term 0 to the same input, unmasked (T_aff = S_0^T g next to T_0 = S_0^T dz):
+        // both from one set of gathered rows
+        float accp[VW];
 #pragma unroll
-        for (int k = 0; k < CAPE_MAX_SPMM_TERMS; ++k) {
+        for (int k = 0; k < MP_MAXT; ++k) {
             if (k >= P.n) break;
             const SpmmTerms::T &Tm = P.t[k];
             const float *xb = reinterpret_cast<const float *>(Tm.x) + (long long)n * Tm.xs + c;
             float acc[VW];
-            if ((masked >> k) & 1u) {
+            if (pair && k == P.n - 1) {
+#pragma unroll
+                for (int u = 0; u < VW; ++u) acc[u] = accp[u];
+            } else if (pair && k == 0) {
+                if (Tm.ew) cape_gather_row_ell_both<VW>(xb, Tm.ldx, mb, words, sh, Tm.ci, Tm.va, Tm.ew, r, acc, accp);
+                else cape_gather_row_both<VW, U>(xb, Tm.ldx, mb, words, sh, Tm.rp, Tm.ci, Tm.va, r, acc, accp);
+            } else if ((masked >> k) & 1u) {
                 if (Tm.ew) cape_gather_row_ell_masked<VW>(xb, Tm.ldx, mb, words, sh, Tm.ci, Tm.va, Tm.ew, r, acc);
                 else cape_gather_row_masked<VW, U>(xb, Tm.ldx, mb, words, sh, Tm.rp, Tm.ci, Tm.va, r, acc);
             } else {
@@ -562,11 +654,11 @@ __global__ __launch_bounds__(256) void spmm_multi_prep_kernel(SpmmTerms P, unsig
     if (!part) return;
     // column sums over the block's rows (see bwd_prep_spmm_kernel): DPP rotations / lane swaps inside the wave, the four waves
     // through LDS in a fixed order, all terms behind one barrier
-    __shared__ float cs[4][CAPE_MAX_SPMM_TERMS][64 * VW];
+    __shared__ float cs[4][MP_MAXT][64 * VW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *pp = part + ((long long)n * chunks + t) * T * C;
 #pragma unroll
-    for (int k = 0; k < CAPE_MAX_SPMM_TERMS; ++k) {
+    for (int k = 0; k < MP_MAXT; ++k) {
         if (k >= P.n) break;
 #pragma unroll
         for (int u = 0; u < VW; ++u) {
@@ -584,7 +676,7 @@ __global__ __launch_bounds__(256) void spmm_multi_prep_kernel(SpmmTerms P, unsig
     __syncthreads();
     if ((int)threadIdx.x < cq) {
 #pragma unroll
-        for (int k = 0; k < CAPE_MAX_SPMM_TERMS; ++k) {
+        for (int k = 0; k < MP_MAXT; ++k) {
             if (k >= P.n) break;
             float s4[VW];
 #pragma unroll
@@ -1825,7 +1917,7 @@ extern "C" int cape_bwd_prep_spmm(const float *g, int64_t g_sample_stride, int32
 
 // work items per row of cape_spmm_multi_prep (8 channels where every view allows it, else 4); 0 = not possible
 static int multi_prep_cq(const cape_spmm_term_t *terms, int32_t nterms, int32_t C) {
-    if (!terms || nterms < 1 || nterms > CAPE_MAX_SPMM_TERMS || (C & 31)) return 0;
+    if (!terms || nterms < 1 || nterms > MP_MAXT || (C & 31)) return 0;
     bool wide = spmm_wide();
     for (int k = 0; k < nterms; ++k) {
         const cape_spmm_term_t &t = terms[k];
@@ -1871,8 +1963,13 @@ extern "C" int cape_spmm_multi_prep(const cape_spmm_term_t *terms, int32_t nterm
     hipStream_t st = (hipStream_t)stream;
     const int words = (C + 31) / 32;
     const int u = spmm_unroll();
+    // the last term is the first one without its mask (same operator arrays, same input): one set of gathers serves both
+    const cape_spmm_term_t &ta = terms[0], &tb = terms[nterms - 1];
+    const int pair = nterms >= 2 && (masked_terms & 1u) && !((masked_terms >> (nterms - 1)) & 1u) && ta.x == tb.x &&
+                     ta.x_sample_stride == tb.x_sample_stride && ta.ldx == tb.ldx && ta.rowptr == tb.rowptr && ta.colidx == tb.colidx &&
+                     ta.vals == tb.vals && ta.ell_width == tb.ell_width;
 #define CAPE_MP_LAUNCH(VW_, U_)                                                                                                 \
-    CAPE_LAUNCH((spmm_multi_prep_kernel<VW_, U_>), grid, dim3(256), 0, st, P, masked_terms, mask, words, mask_rows, N, Mo, C,   \
+    CAPE_LAUNCH((spmm_multi_prep_kernel<VW_, U_>), grid, dim3(256), 0, st, P, masked_terms, pair, mask, words, mask_rows, N, Mo, C,   \
                 partials, T, rpb, chunks)
     if (wide) {
         if (u == 8) CAPE_MP_LAUNCH(8, 8);

@@ -1179,7 +1179,7 @@ def spmm_multi_prep(g, mask, csrs, masked, want_sums=True, joint=False, defer=Fa
     _lib.require_gpu()
     N, Mf, F = g.shape
     n = len(csrs)
-    if not (FUSE_PREP_SPMM and g.dtype == torch.float32 and mask is not None and F % 32 == 0 and 2 <= n <= 4
+    if not (FUSE_PREP_SPMM and g.dtype == torch.float32 and mask is not None and F % 32 == 0 and 2 <= n <= 3
             and all(c is not None and not c.identity and c.shape[1] == Mf for c in csrs)):
         return None
     Mo = csrs[0].shape[0]

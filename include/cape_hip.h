@@ -459,7 +459,7 @@ int cape_bwd_prep_spmm(const float *g, int64_t g_sample_stride, int32_t ldg, con
  * term; slot 0 not written): sum_r (S_k 1)[r] dz[n,r,:] = sum_j (S_k^T dz)[n,j,:], so the rank-1 condition gradients need no
  * pass over dz, and dz is never written -- the weight gradient of such a block contracts the T_k.  Replaces cape_bwd_prep +
  * cape_spmm_multi(sum = 0).  Every term: a CSR / ELL operator with Mo rows, scale 1, y != NULL (rowmax_out optional); fp32,
- * C % 32 == 0, 16-byte aligned views with a power-of-two number (4 .. 64) of work items per row, else CAPE_EINVAL.
+ * nterms <= 3, C % 32 == 0, 16-byte aligned views with a power-of-two number (4 .. 64) of work items per row, else CAPE_EINVAL.
  * partials (NULL: no sums): N * chunks * (nterms + 1) * C floats.
  */
 int32_t cape_spmm_multi_prep_chunks(const cape_spmm_term_t *terms, int32_t nterms, int32_t N, int32_t Mo, int32_t C);
