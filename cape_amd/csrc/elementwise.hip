@@ -1093,7 +1093,7 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(CViewT<AT> g, CViewT<AT> 
                 if (mask) d = ((mask[((long long)n * Mo + r) * words + (f >> 5)] >> (f & 31)) & 1u) ? gv : 0.f;
                 else if (act != CAPE_ACT_NONE) d = gv * cape_act_grad_from_out(cape_ld(y.p + (long long)n * y.ss + (long long)r * y.ld + f), act);
                 else d = gv;
-                cape_st(dz.p + (long long)n * dz.ss + (long long)r * dz.ld + f, d);
+                if (!((const void *)dz.p == (const void *)g.p && act == CAPE_ACT_NONE && !mask)) cape_st(dz.p + (long long)n * dz.ss + (long long)r * dz.ld + f, d);
                 acc[0] += d;
 #pragma unroll
                 for (int j = 0; j < RSR_MAXR; ++j)
@@ -1147,7 +1147,7 @@ __global__ __launch_bounds__(256) void bwd_prep_narrow_kernel(CViewT<AT> g, CVie
             if (mask) d = ((mw >> f) & 1u) ? gv[f] : 0.f;
             else if (act != CAPE_ACT_NONE) d = gv[f] * cape_act_grad_from_out(cape_ld(y.p + (long long)n * y.ss + (long long)r * y.ld + f), act);
             else d = gv[f];
-            cape_st(dz.p + (long long)n * dz.ss + (long long)r * dz.ld + f, d);
+            if (!((const void *)dz.p == (const void *)g.p && act == CAPE_ACT_NONE && !mask)) cape_st(dz.p + (long long)n * dz.ss + (long long)r * dz.ld + f, d);
             acc[0][f] += d;
 #pragma unroll
             for (int j = 0; j < RSR_MAXR; ++j) acc[1 + j][f] = fmaf(rs[j], d, acc[1 + j][f]);
@@ -1194,6 +1194,7 @@ __global__ __launch_bounds__(256) void bwd_prep_vec_kernel(CViewT<AT> g, CViewT<
     const AT *gb = g.p + (long long)n * g.ss;
     const AT *yb = y.p ? y.p + (long long)n * y.ss : nullptr;
     AT *zb = dz.p + (long long)n * dz.ss;
+    const bool wr = !((const void *)dz.p == (const void *)g.p && act == CAPE_ACT_NONE && !mask);      // dz == g unchanged: the caller wants the sums only
     const unsigned *mb = mask ? mask + (long long)n * Mo * words : nullptr;
     for (int fbase = 0; fbase < F; fbase += FB) {
         const int fw = min(FB, F - fbase);
@@ -1228,7 +1229,7 @@ __global__ __launch_bounds__(256) void bwd_prep_vec_kernel(CViewT<AT> g, CViewT<
                         else if (act != CAPE_ACT_NONE) d[u] = gv[k][u] * cape_act_grad_from_out(ov[k][u], act);
                         else d[u] = gv[k][u];
                     }
-                    cape_stv<VW>(zb + (long long)r * dz.ld + f, d);
+                    if (wr) cape_stv<VW>(zb + (long long)r * dz.ld + f, d);
                     if (rm) {
                         // row bound of g -- and therefore of dz (|dz| <= |g| element by element): the affine block's backward
                         // contracts BOTH, one reduction serves the two.  Entry = column pass (F <= 4 * FB); the cvn lanes of a row

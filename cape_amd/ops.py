@@ -1066,7 +1066,11 @@ def bwd_prep(g, y=None, act="none", mask=None, want_bias=False, rowscale=None, R
     _lib.require_gpu()
     N, Mo, F = g.shape
     dev = g.device
-    dz = alloc_act(N, Mo, F, dev, dtype=g.dtype)
+    # no activation and no mask: dz IS g -- the pass is made for its sums alone and writes nothing (dz aliases g; the kernels skip
+    # the store when the two pointers are equal)
+    alias = act == "none" and mask is None and _vec_ok(g)     # (an unaligned gradient still gets its row-padded copy: the
+    #                                                            weight-gradient kernels choose their staging by dz's alignment)
+    dz = g if alias else alloc_act(N, Mo, F, dev, dtype=g.dtype)
     assert y is None or y.dtype == g.dtype
     dbias = None
     if want_bias:
@@ -1107,7 +1111,7 @@ def bwd_prep(g, y=None, act="none", mask=None, want_bias=False, rowscale=None, R
         check(rc, "cape_bwd_prep")
 
     # one pass: read g (+ y or the 1-bit mask), write dz
-    _log_launch("bwd_prep", 0, g.element_size() * N * Mo * F * (3 if yp is not None else 2) + (N * Mo * ((F + 31) // 32) * 4 if mask is not None else 0),
+    _log_launch("bwd_prep", 0, g.element_size() * N * Mo * F * (1 if alias else 3 if yp is not None else 2) + (N * Mo * ((F + 31) // 32) * 4 if mask is not None else 0),
                 launch)
     if defer and DEFERRED is not None and (dbias is not None or R or rg is not None):
         DEFERRED.append(dict(ws=ws, N=N, Mo=Mo, F=F, R=R, dbias=dbias, dcoef=dcoef, dcoef_g=dcoef_g, cstride=cstride))

@@ -342,7 +342,8 @@ int cape_gconv_dw_plan(const cape_src_t *srcs, int32_t nsrc, const float *dz, in
  *   dcoef_g[n,f]   = sum_r rowscale[rg,r] * g[n,r,f]              (dcoef_g != NULL: affine branch)
  * dcoef_sample_stride: elements between samples of BOTH dcoef and dcoef_g (so that the two can be slices of one
  * [N, R+1, F] buffer, the layout cape_cond_coef_bwd reads); 0 = contiguous (R*F and F).
- * dz may alias g.  Deterministic two-stage reductions; workspace >= cape_bwd_prep_workspace_bytes.
+ * dz may alias g (in place); with act = CAPE_ACT_NONE and mask = NULL an aliased dz is not even stored (dz IS g: the call
+ * is made for its sums).  Deterministic two-stage reductions; workspace >= cape_bwd_prep_workspace_bytes.
  */
 int64_t cape_bwd_prep_workspace_bytes(int32_t N, int32_t Mo, int32_t F, int32_t R);
 int cape_bwd_prep(const float *g, int64_t g_sample_stride, int32_t ldg, const float *y,
