@@ -41,7 +41,7 @@ python $R/tools/dp_selftest.py 2>&1 | grep -v "UserWarning\|run_backward\|amdgpu
 # the library's two-piece / six-product forward kernels side by side over the layer shapes of the benchmarked model
 (cd $R/tools/ubench && timeout 180 ./h2_bench) > $O/${TAG}_h2_bench_final.txt 2>&1
 # same-box A/B of this round's switches on the replayed step
-for kv in "CAPE_H2=1" "CAPE_H2X=0" "CAPE_DW_V4=0" "CAPE_H2=0" "CAPE_FUSE_ACT_GRAD=0" "CAPE_FC_MFMA=0" "CAPE_H2=1"; do
+for kv in "CAPE_H2=1" "CAPE_FUSE_PREP_SPMM=0" "CAPE_H2X=0" "CAPE_DW_V4=0" "CAPE_H2=0" "CAPE_FUSE_ACT_GRAD=0" "CAPE_FC_MFMA=0" "CAPE_H2=1"; do
   echo "$kv $(env $kv python $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-extras --no-ab --no-roofline 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"], "ms/step")')"
 done > $O/${TAG}_switch_ab.txt
 cd $R && timeout 120 python tools/cheb_fused_phases.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_cheb_fused_phases.txt
