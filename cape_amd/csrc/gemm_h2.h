@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256 * H2_DW_KG, 1) void dw_h2_kernel(DwParams p) {
     const int t_op = tid & 127;
     const int qn = is_b ? QB : QA;
     const int cq = t_op % qn, rgi = t_op / qn;
-    float v4[V4 ? RPM : 1][4];
+    float v4[RPM][4];                                                     // (dead in the !V4 instantiations)
     int voff4 = 0;
 
     // ---- operand streams through buffer resources (one per operand and sample: base = the sample, num_records = the bytes
