@@ -37,6 +37,10 @@
  *   cape_bias_act_fwd / cape_act_bwd / cape_colsum
  *                       lib/models.py:105-127 standalone and their gradients.
  *   cape_mask_mul       gradient of tf.nn.relu in res_block_affine (lib/models.py:785).
+ *   cape_bwd_prep / cape_bwd_prep_spmm / cape_spmm_multi_prep
+ *                       the non-GEMM part of a conv layer's backward under tf.gradients (:460): activation / ReLU-mask
+ *                       gradient (:105-127, :785), bias and rank-1 condition sums, and -- the two fused forms, for
+ *                       res_block_affine (:776-793) -- the operator applications S_k^T dz of its data gradient.
  *   cape_fill_cond      lib/models.py:813-832 fit_cond_dim + tf.concat (:535,593,608,665).
  *   cape_groupnorm_fwd / cape_groupnorm_bwd
  *                       lib/models.py:681-712 gn (norm_type='group') and its gradient.
