@@ -137,7 +137,14 @@ SIGNATURES = {
     "cape_spmm_multi": (C.c_int, [C.POINTER(CapeSpmmTerm), _i32, _i32, _p, _i64, _i32, _i32, _i32, _i32, _p, _p]),
     "cape_spmm_multi_actgrad_chunks": (_i32, [_p, _i64, _i32, _p, _i64, _i32, _i32, _i32]),
     "cape_spmm_multi_actgrad": (C.c_int, [C.POINTER(CapeSpmmTerm), _i32, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _i64, _i32, _i32, _p, _p]),
+    "cape_spmm_multi_actgrad_chunks_bf16": (_i32, [_p, _i64, _i32, _p, _i64, _i32, _i32, _i32]),
+    "cape_spmm_multi_actgrad_bf16": (C.c_int, [C.POINTER(CapeSpmmTerm), _i32, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _i64, _i32, _i32, _p, _p]),
     "cape_bwd_prep_spmm_chunks": (_i32, [_p, _i64, _i32, _p, _i64, _i32, _p, _i64, _i32, _i32, _i32, _i32]),
+    "cape_spmm_multi_prep_chunks_bf16": (_i32, [C.POINTER(CapeSpmmTerm), _i32, _i32, _i32, _i32]),
+    "cape_spmm_multi_prep_bf16": (C.c_int, [C.POINTER(CapeSpmmTerm), _i32, C.c_uint32, _p, _i32, _i32, _i32, _i32, _p, _i64, _p]),
+    "cape_bwd_prep_spmm_chunks_bf16": (_i32, [_p, _i64, _i32, _p, _i64, _i32, _p, _i64, _i32, _i32, _i32, _i32]),
+    "cape_bwd_prep_spmm_bf16": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _i64, _i32, _p, _i64, _i32, _p, _i32, _i32, _i32, _i32, _i32,
+                                          _p, _i64, _p, _p, _p]),
     "cape_spmm_multi_prep_chunks": (_i32, [C.POINTER(CapeSpmmTerm), _i32, _i32, _i32, _i32]),
     "cape_spmm_multi_prep": (C.c_int, [C.POINTER(CapeSpmmTerm), _i32, C.c_uint32, _p, _i32, _i32, _i32, _i32, _p, _i64, _p]),
     "cape_bwd_prep_spmm": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _i64, _i32, _p, _i64, _i32, _p, _i32, _i32, _i32, _i32, _i32,

@@ -311,12 +311,12 @@ __global__ __launch_bounds__(256) void spmm_multi_kernel(SpmmTerms P, int sum, V
 // the two-launch form), and the block reduces the weighted sums of its 256 / cq rows into the partial layout
 // cape_bwd_prep_finalize reads ([sample][block][R + 2][C]; slot 0, the bias sum, is not written -- these blocks have no bias).
 constexpr int PS_MAXR = 2;           // rank-1 terms of the fused form (K = 2); more: the caller keeps the two launches
-struct PrepSpmmP {
-    const float *g; long long gs; int ldg;
+struct PrepSpmmP {                      // g / dz / t1: elements of the launch's storage type (fp32 or bf16)
+    const void *g; long long gs; int ldg;
     const unsigned *mask; int words;
     const int *rp; const int *ci; const float *va; int ew;
-    float *dz; long long dzs; int lddz;
-    float *t1; long long t1s; int ldt1;
+    void *dz; long long dzs; int lddz;
+    void *t1; long long t1s; int ldt1;
     const float *rowscale; int R, rg;               // rg < 0: no g-weighted sum
     float *part;
     float *rm_g, *rm_t1;
@@ -329,8 +329,8 @@ __device__ __forceinline__ void cape_mask_row(float (&x)[VW], unsigned bits) {
 }
 
 // masked forms of cape_gather_row / cape_gather_row_ell: every gathered row is multiplied by its own sign bits first
-template <int VW, int U>
-__device__ __forceinline__ void cape_gather_row_masked(const float *xb, long long ldx, const unsigned *mb, int words, int sh, const int *rp,
+template <int VW, int U, typename T>
+__device__ __forceinline__ void cape_gather_row_masked(const T *xb, long long ldx, const unsigned *mb, int words, int sh, const int *rp,
                                                        const int *ci, const float *va, int r, float (&acc)[VW]) {
 #pragma unroll
     for (int u = 0; u < VW; ++u) acc[u] = 0.f;
@@ -363,8 +363,8 @@ __device__ __forceinline__ void cape_gather_row_masked(const float *xb, long lon
     }
 }
 
-template <int VW>
-__device__ __forceinline__ void cape_gather_row_ell_masked(const float *xb, long long ldx, const unsigned *mb, int words, int sh,
+template <int VW, typename T>
+__device__ __forceinline__ void cape_gather_row_ell_masked(const T *xb, long long ldx, const unsigned *mb, int words, int sh,
                                                            const int *ec, const float *ev, int ew, int r, float (&acc)[VW]) {
 #pragma unroll
     for (int u = 0; u < VW; ++u) acc[u] = 0.f;
@@ -407,8 +407,8 @@ __device__ __forceinline__ void cape_gather_row_ell_masked(const float *xb, long
 
 // one operator row applied to the masked AND to the plain rows from ONE set of loads (an up-sampling affine block applies S_0^T to
 // dz and to g): acc_m as cape_gather_row*_masked, acc_p as cape_gather_row* -- same fma chains, bit-identical results
-template <int VW, int U>
-__device__ __forceinline__ void cape_gather_row_both(const float *xb, long long ldx, const unsigned *mb, int words, int sh, const int *rp,
+template <int VW, int U, typename T>
+__device__ __forceinline__ void cape_gather_row_both(const T *xb, long long ldx, const unsigned *mb, int words, int sh, const int *rp,
                                                      const int *ci, const float *va, int r, float (&acc_m)[VW], float (&acc_p)[VW]) {
 #pragma unroll
     for (int u = 0; u < VW; ++u) acc_m[u] = acc_p[u] = 0.f;
@@ -443,8 +443,8 @@ __device__ __forceinline__ void cape_gather_row_both(const float *xb, long long 
     }
 }
 
-template <int VW>
-__device__ __forceinline__ void cape_gather_row_ell_both(const float *xb, long long ldx, const unsigned *mb, int words, int sh,
+template <int VW, typename T>
+__device__ __forceinline__ void cape_gather_row_ell_both(const T *xb, long long ldx, const unsigned *mb, int words, int sh,
                                                          const int *ec, const float *ev, int ew, int r, float (&acc_m)[VW], float (&acc_p)[VW]) {
 #pragma unroll
     for (int u = 0; u < VW; ++u) acc_m[u] = acc_p[u] = 0.f;
@@ -489,12 +489,12 @@ __device__ __forceinline__ void cape_gather_row_ell_both(const float *xb, long l
 
 // rpb: consecutive groups of 256 work items a block handles one after the other (the weighted sums of all of them are reduced
 // ONCE: at 256 channels a group is only 8 rows, and one partial row per group and term would be a third of the tensor's bytes)
-template <int VW, int U>
+template <int VW, int U, typename AT = float>
 __global__ __launch_bounds__(256) void bwd_prep_spmm_kernel(PrepSpmmP P, int N, int Mo, int C, int rpb, int chunks) {
     const int cq = C / VW;                                   // a power of two in 4 .. 64 (host check): the lanes of a row are one aligned group
     int n, t;
     cape_map_block(blockIdx.x, N, chunks, n, t);             // see spmm_kernel
-    const float *gbase = P.g + (long long)n * P.gs;
+    const AT *gbase = reinterpret_cast<const AT *>(P.g) + (long long)n * P.gs;
     const unsigned *mbase = P.mask + (long long)n * Mo * P.words;
     const int nterm = P.R + (P.rg >= 0 ? 1 : 0);
     float racc[PS_MAXR + 1][VW];
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void bwd_prep_spmm_kernel(PrepSpmmP P, int N, 
         const int ii = live ? i : Mo * cq - 1;
         const int r = ii / cq;
         const int c = (ii - r * cq) * VW;
-        const float *gb = gbase + c;
+        const AT *gb = gbase + c;
         const unsigned *mb = mbase + (c >> 5);
         const int sh = c & 31;
         float gv[VW], d[VW], acc[VW];
@@ -519,14 +519,14 @@ __global__ __launch_bounds__(256) void bwd_prep_spmm_kernel(PrepSpmmP P, int N, 
         float sv[PS_MAXR + 1];
 #pragma unroll
         for (int j = 0; j <= PS_MAXR; ++j) sv[j] = P.rowscale ? P.rowscale[(long long)(j == P.R ? (P.rg >= 0 ? P.rg : 0) : (j < P.R ? j : 0)) * Mo + r] : 0.f;
-        if (P.ew) cape_gather_row_ell_masked<VW>(gb, P.ldg, mb, P.words, sh, P.ci, P.va, P.ew, r, acc);
-        else cape_gather_row_masked<VW, U>(gb, P.ldg, mb, P.words, sh, P.rp, P.ci, P.va, r, acc);
+        if (P.ew) cape_gather_row_ell_masked<VW, AT>(gb, P.ldg, mb, P.words, sh, P.ci, P.va, P.ew, r, acc);
+        else cape_gather_row_masked<VW, U, AT>(gb, P.ldg, mb, P.words, sh, P.rp, P.ci, P.va, r, acc);
 #pragma unroll
         for (int u = 0; u < VW; ++u) d[u] = gv[u];
         cape_mask_row<VW>(d, mw);
         if (live) {
-            cape_stv<VW>(P.dz + (long long)n * P.dzs + (long long)r * P.lddz + c, d);
-            cape_stv<VW>(P.t1 + (long long)n * P.t1s + (long long)r * P.ldt1 + c, acc);
+            cape_stv<VW>(reinterpret_cast<AT *>(P.dz) + (long long)n * P.dzs + (long long)r * P.lddz + c, d);
+            cape_stv<VW>(reinterpret_cast<AT *>(P.t1) + (long long)n * P.t1s + (long long)r * P.ldt1 + c, acc);
         }
         if (P.rm_t1) {
             float m = 0.f;
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256) void bwd_prep_spmm_kernel(PrepSpmmP P, int N, 
 // fine rows of g, the terms flagged in `masked` multiply each gathered row by its sign bits first, and the block leaves the column
 // sums of every term as partials in the cape_bwd_prep_finalize layout (term k -> slot 1 + k).
 constexpr int MP_MAXT = 3;            // terms of cape_spmm_multi_prep (K = 2 orders + the affine term)
-template <int VW, int U>
+template <int VW, int U, typename AT = float>
 __global__ __launch_bounds__(256) void spmm_multi_prep_kernel(SpmmTerms P, unsigned masked, int pair, const unsigned *mask, int words, int Mfine,
                                                               int N, int Mo, int C, float *part, int T, int rpb, int chunks) {
     const int cq = C / VW;                                   // a power of two in 4 .. 64 (host check)
@@ -625,21 +625,21 @@ __global__ __launch_bounds__(256) void spmm_multi_prep_kernel(SpmmTerms P, unsig
         for (int k = 0; k < MP_MAXT; ++k) {
             if (k >= P.n) break;
             const SpmmTerms::T &Tm = P.t[k];
-            const float *xb = reinterpret_cast<const float *>(Tm.x) + (long long)n * Tm.xs + c;
+            const AT *xb = reinterpret_cast<const AT *>(Tm.x) + (long long)n * Tm.xs + c;
             float acc[VW];
             if (pair && k == P.n - 1) {
 #pragma unroll
                 for (int u = 0; u < VW; ++u) acc[u] = accp[u];
             } else if (pair && k == 0) {
-                if (Tm.ew) cape_gather_row_ell_both<VW>(xb, Tm.ldx, mb, words, sh, Tm.ci, Tm.va, Tm.ew, r, acc, accp);
-                else cape_gather_row_both<VW, U>(xb, Tm.ldx, mb, words, sh, Tm.rp, Tm.ci, Tm.va, r, acc, accp);
+                if (Tm.ew) cape_gather_row_ell_both<VW, AT>(xb, Tm.ldx, mb, words, sh, Tm.ci, Tm.va, Tm.ew, r, acc, accp);
+                else cape_gather_row_both<VW, U, AT>(xb, Tm.ldx, mb, words, sh, Tm.rp, Tm.ci, Tm.va, r, acc, accp);
             } else if ((masked >> k) & 1u) {
-                if (Tm.ew) cape_gather_row_ell_masked<VW>(xb, Tm.ldx, mb, words, sh, Tm.ci, Tm.va, Tm.ew, r, acc);
-                else cape_gather_row_masked<VW, U>(xb, Tm.ldx, mb, words, sh, Tm.rp, Tm.ci, Tm.va, r, acc);
+                if (Tm.ew) cape_gather_row_ell_masked<VW, AT>(xb, Tm.ldx, mb, words, sh, Tm.ci, Tm.va, Tm.ew, r, acc);
+                else cape_gather_row_masked<VW, U, AT>(xb, Tm.ldx, mb, words, sh, Tm.rp, Tm.ci, Tm.va, r, acc);
             } else {
                 cape_gather<VW, U>(xb, Tm.ldx, Tm.rp, Tm.ci, Tm.va, Tm.ew, r, acc);
             }
-            if (live) cape_stv<VW>(reinterpret_cast<float *>(Tm.y) + (long long)n * Tm.ys + (long long)r * Tm.ldy + c, acc);
+            if (live) cape_stv<VW>(reinterpret_cast<AT *>(Tm.y) + (long long)n * Tm.ys + (long long)r * Tm.ldy + c, acc);
             if (Tm.rm) {
                 float m = 0.f;
 #pragma unroll
@@ -1536,8 +1536,8 @@ extern "C" int cape_spmm_multi_bf16(const cape_spmm_term_t *terms, int32_t nterm
 }
 
 // blocks per sample (= partial-sum chunks of the fused form) for a launch of C channels in the vector form it will take
-static int actgrad_cq(const void *y, int64_t ys, int32_t ldy, const void *ax, int64_t axs, int32_t ldax, int32_t C) {
-    const bool wide = spmm_wide() && aligned8(y, ys, ldy, C, 4) && aligned8(ax, axs, ldax, C, 4);
+static int actgrad_cq(const void *y, int64_t ys, int32_t ldy, const void *ax, int64_t axs, int32_t ldax, int32_t C, int es = 4) {
+    const bool wide = spmm_wide() && aligned8(y, ys, ldy, C, es) && aligned8(ax, axs, ldax, C, es);
     return C / (wide ? 8 : 4);
 }
 
@@ -1547,17 +1547,40 @@ extern "C" int32_t cape_spmm_multi_actgrad_chunks(const float *y, int64_t y_samp
     return spmm_bps(Mo, actgrad_cq(y, y_sample_stride, ldy, act_x, act_x_sample_stride, ld_act_x, C));
 }
 
-extern "C" int cape_spmm_multi_actgrad(const cape_spmm_term_t *terms, int32_t nterms, float *y, int64_t y_sample_stride, int32_t ldy,
-                                       int32_t N, int32_t Mo, int32_t C, float *rowmax_out, const float *act_x,
-                                       int64_t act_x_sample_stride, int32_t ld_act_x, int32_t act, float *bias_partials, void *stream) {
+extern "C" int32_t cape_spmm_multi_actgrad_chunks_bf16(const void *y, int64_t y_sample_stride, int32_t ldy, const void *act_x,
+                                                       int64_t act_x_sample_stride, int32_t ld_act_x, int32_t Mo, int32_t C) {
+    if (!y || !act_x || Mo < 1 || C < 4 || (C & 3)) return CAPE_EINVAL;
+    return spmm_bps(Mo, actgrad_cq(y, y_sample_stride, ldy, act_x, act_x_sample_stride, ld_act_x, C, 2));
+}
+
+namespace {
+template <typename T>
+int spmm_multi_actgrad_impl(const cape_spmm_term_t *terms, int32_t nterms, T *y, int64_t y_sample_stride, int32_t ldy, int32_t N, int32_t Mo,
+                            int32_t C, float *rowmax_out, const T *act_x, int64_t act_x_sample_stride, int32_t ld_act_x, int32_t act,
+                            float *bias_partials, void *stream) {
     if (!act_x || !bias_partials || ld_act_x < C || (act != CAPE_ACT_LEAKY && act != CAPE_ACT_RELU)) return CAPE_EINVAL;
     // every term must allow the 8-wide form exactly when y and act_x do (the chunk count above assumes it)
     SpmmActGrad G;
     G.ax = act_x; G.axs = act_x_sample_stride; G.ldax = ld_act_x; G.act = act; G.part = bias_partials;
-    const int cq = actgrad_cq(y, y_sample_stride, ldy, act_x, act_x_sample_stride, ld_act_x, C);
+    const int cq = actgrad_cq(y, y_sample_stride, ldy, act_x, act_x_sample_stride, ld_act_x, C, (int)sizeof(T));
     for (int k = 0; k < nterms && terms; ++k)
-        if (cq == C / 8 && !aligned8(terms[k].x, terms[k].x_sample_stride, terms[k].ldx, C, 4)) return CAPE_EINVAL;
-    return spmm_multi_impl<float>(terms, nterms, 1, y, y_sample_stride, ldy, N, Mo, C, rowmax_out, stream, &G);
+        if (cq == C / 8 && !aligned8(terms[k].x, terms[k].x_sample_stride, terms[k].ldx, C, (int)sizeof(T))) return CAPE_EINVAL;
+    return spmm_multi_impl<T>(terms, nterms, 1, y, y_sample_stride, ldy, N, Mo, C, rowmax_out, stream, &G);
+}
+}  // namespace
+
+extern "C" int cape_spmm_multi_actgrad(const cape_spmm_term_t *terms, int32_t nterms, float *y, int64_t y_sample_stride, int32_t ldy,
+                                       int32_t N, int32_t Mo, int32_t C, float *rowmax_out, const float *act_x,
+                                       int64_t act_x_sample_stride, int32_t ld_act_x, int32_t act, float *bias_partials, void *stream) {
+    return spmm_multi_actgrad_impl<float>(terms, nterms, y, y_sample_stride, ldy, N, Mo, C, rowmax_out, act_x, act_x_sample_stride, ld_act_x,
+                                          act, bias_partials, stream);
+}
+
+extern "C" int cape_spmm_multi_actgrad_bf16(const cape_spmm_term_t *terms, int32_t nterms, void *y, int64_t y_sample_stride, int32_t ldy,
+                                            int32_t N, int32_t Mo, int32_t C, float *rowmax_out, const void *act_x,
+                                            int64_t act_x_sample_stride, int32_t ld_act_x, int32_t act, float *bias_partials, void *stream) {
+    return spmm_multi_actgrad_impl<cape_bf16>(terms, nterms, (cape_bf16 *)y, y_sample_stride, ldy, N, Mo, C, rowmax_out,
+                                              (const cape_bf16 *)act_x, act_x_sample_stride, ld_act_x, act, bias_partials, stream);
 }
 
 namespace {
@@ -1850,11 +1873,11 @@ extern "C" int cape_bwd_prep_bf16(const void *g, int64_t g_sample_stride, int32_
 }
 
 // work items per row of the fused backward-prep + operator application: 8 channels each where every view allows it, else 4;
-// 0 = the arguments do not allow the fused form at all
-static int prep_spmm_cq(const float *g, int64_t gs, int32_t ldg, const float *dz, int64_t dzs, int32_t lddz, const float *t1,
-                        int64_t t1s, int32_t ldt1, int32_t F) {
-    if ((F & 31) || !aligned4(g, gs, ldg, F, 4) || !aligned4(dz, dzs, lddz, F, 4) || !aligned4(t1, t1s, ldt1, F, 4)) return 0;
-    const bool wide = spmm_wide() && aligned8(g, gs, ldg, F, 4) && aligned8(dz, dzs, lddz, F, 4) && aligned8(t1, t1s, ldt1, F, 4);
+// 0 = the arguments do not allow the fused form at all.  es = bytes per element (4: fp32, 2: bf16 storage)
+static int prep_spmm_cq(const void *g, int64_t gs, int32_t ldg, const void *dz, int64_t dzs, int32_t lddz, const void *t1,
+                        int64_t t1s, int32_t ldt1, int32_t F, int es) {
+    if ((F & 31) || !aligned4(g, gs, ldg, F, es) || !aligned4(dz, dzs, lddz, F, es) || !aligned4(t1, t1s, ldt1, F, es)) return 0;
+    const bool wide = spmm_wide() && aligned8(g, gs, ldg, F, es) && aligned8(dz, dzs, lddz, F, es) && aligned8(t1, t1s, ldt1, F, es);
     const int cq = F / (wide ? 8 : 4);
     return (rm_fused(cq) && cq >= 4) ? cq : 0;
 }
@@ -1865,27 +1888,39 @@ static int prep_spmm_rpb(int N, int bps) {
     const long long groups = (long long)N * bps;
     return groups >= 1536 ? 3 : groups >= 1024 ? 2 : 1;
 }
-
-extern "C" int32_t cape_bwd_prep_spmm_chunks(const float *g, int64_t g_sample_stride, int32_t ldg, const float *dz,
-                                             int64_t dz_sample_stride, int32_t lddz, const float *t1, int64_t t1_sample_stride,
-                                             int32_t ldt1, int32_t N, int32_t Mo, int32_t F) {
-    const int cq = prep_spmm_cq(g, g_sample_stride, ldg, dz, dz_sample_stride, lddz, t1, t1_sample_stride, ldt1, F);
+static int32_t prep_spmm_chunks(const void *g, int64_t gs, int32_t ldg, const void *dz, int64_t dzs, int32_t lddz, const void *t1, int64_t t1s,
+                                int32_t ldt1, int32_t N, int32_t Mo, int32_t F, int es) {
+    const int cq = prep_spmm_cq(g, gs, ldg, dz, dzs, lddz, t1, t1s, ldt1, F, es);
     if (!cq || Mo < 1 || N < 1) return 0;
     const int bps = spmm_bps(Mo, cq), rpb = prep_spmm_rpb(N, bps);
     return (bps + rpb - 1) / rpb;
 }
 
-extern "C" int cape_bwd_prep_spmm(const float *g, int64_t g_sample_stride, int32_t ldg, const uint32_t *mask, const int32_t *rowptr,
-                                  const int32_t *colidx, const float *vals, int32_t ell_width, float *dz, int64_t dz_sample_stride,
-                                  int32_t lddz, float *t1, int64_t t1_sample_stride, int32_t ldt1, const float *rowscale, int32_t R,
-                                  int32_t rg, int32_t N, int32_t Mo, int32_t F, float *partials, int64_t partials_bytes,
-                                  float *rowmax_g_out, float *rowmax_t1_out, void *stream) {
+extern "C" int32_t cape_bwd_prep_spmm_chunks(const float *g, int64_t g_sample_stride, int32_t ldg, const float *dz,
+                                             int64_t dz_sample_stride, int32_t lddz, const float *t1, int64_t t1_sample_stride,
+                                             int32_t ldt1, int32_t N, int32_t Mo, int32_t F) {
+    return prep_spmm_chunks(g, g_sample_stride, ldg, dz, dz_sample_stride, lddz, t1, t1_sample_stride, ldt1, N, Mo, F, 4);
+}
+extern "C" int32_t cape_bwd_prep_spmm_chunks_bf16(const void *g, int64_t g_sample_stride, int32_t ldg, const void *dz,
+                                                  int64_t dz_sample_stride, int32_t lddz, const void *t1, int64_t t1_sample_stride,
+                                                  int32_t ldt1, int32_t N, int32_t Mo, int32_t F) {
+    return prep_spmm_chunks(g, g_sample_stride, ldg, dz, dz_sample_stride, lddz, t1, t1_sample_stride, ldt1, N, Mo, F, 2);
+}
+
+namespace {
+template <typename T>
+int bwd_prep_spmm_impl(const T *g, int64_t g_sample_stride, int32_t ldg, const uint32_t *mask, const int32_t *rowptr, const int32_t *colidx,
+                       const float *vals, int32_t ell_width, T *dz, int64_t dz_sample_stride, int32_t lddz, T *t1, int64_t t1_sample_stride,
+                       int32_t ldt1, const float *rowscale, int32_t R, int32_t rg, int32_t N, int32_t Mo, int32_t F, float *partials,
+                       int64_t partials_bytes, float *rowmax_g_out, float *rowmax_t1_out, void *stream) {
+    constexpr int es = (int)sizeof(T);
     if (!g || !mask || !rowptr || !colidx || !vals || !dz || !t1 || N < 1 || Mo < 1 || F < 1 || ldg < F || lddz < F || ldt1 < F)
         return CAPE_EINVAL;
+    if ((rowmax_g_out || rowmax_t1_out) && es != 4) return CAPE_EINVAL;
     if (R < 0 || R > PS_MAXR || ((R > 0 || rg >= 0) && (!rowscale || !partials))) return CAPE_EINVAL;
     if (!ell_ok(ell_width, colidx, vals)) return CAPE_EINVAL;
     if ((long long)Mo * F >= (1LL << 31)) return CAPE_EINVAL;
-    const int cq = prep_spmm_cq(g, g_sample_stride, ldg, dz, dz_sample_stride, lddz, t1, t1_sample_stride, ldt1, F);
+    const int cq = prep_spmm_cq(g, g_sample_stride, ldg, dz, dz_sample_stride, lddz, t1, t1_sample_stride, ldt1, F, es);
     if (!cq) return CAPE_EINVAL;
     const int bps = spmm_bps(Mo, cq), rpb = prep_spmm_rpb(N, bps);
     const int chunks = (bps + rpb - 1) / rpb;
@@ -1904,50 +1939,78 @@ extern "C" int cape_bwd_prep_spmm(const float *g, int64_t g_sample_stride, int32
     hipStream_t st = (hipStream_t)stream;
     const int u = spmm_unroll();
     if (wide) {
-        if (u == 8) CAPE_LAUNCH((bwd_prep_spmm_kernel<8, 8>), grid, dim3(256), 0, st, P, N, Mo, F, rpb, chunks);
-        else if (u == 4) CAPE_LAUNCH((bwd_prep_spmm_kernel<8, 4>), grid, dim3(256), 0, st, P, N, Mo, F, rpb, chunks);
-        else CAPE_LAUNCH((bwd_prep_spmm_kernel<8, 0>), grid, dim3(256), 0, st, P, N, Mo, F, rpb, chunks);
+        if (u == 8) CAPE_LAUNCH((bwd_prep_spmm_kernel<8, 8, T>), grid, dim3(256), 0, st, P, N, Mo, F, rpb, chunks);
+        else if (u == 4) CAPE_LAUNCH((bwd_prep_spmm_kernel<8, 4, T>), grid, dim3(256), 0, st, P, N, Mo, F, rpb, chunks);
+        else CAPE_LAUNCH((bwd_prep_spmm_kernel<8, 0, T>), grid, dim3(256), 0, st, P, N, Mo, F, rpb, chunks);
     } else {
-        if (u == 8) CAPE_LAUNCH((bwd_prep_spmm_kernel<4, 8>), grid, dim3(256), 0, st, P, N, Mo, F, rpb, chunks);
-        else if (u == 4) CAPE_LAUNCH((bwd_prep_spmm_kernel<4, 4>), grid, dim3(256), 0, st, P, N, Mo, F, rpb, chunks);
-        else CAPE_LAUNCH((bwd_prep_spmm_kernel<4, 0>), grid, dim3(256), 0, st, P, N, Mo, F, rpb, chunks);
+        if (u == 8) CAPE_LAUNCH((bwd_prep_spmm_kernel<4, 8, T>), grid, dim3(256), 0, st, P, N, Mo, F, rpb, chunks);
+        else if (u == 4) CAPE_LAUNCH((bwd_prep_spmm_kernel<4, 4, T>), grid, dim3(256), 0, st, P, N, Mo, F, rpb, chunks);
+        else CAPE_LAUNCH((bwd_prep_spmm_kernel<4, 0, T>), grid, dim3(256), 0, st, P, N, Mo, F, rpb, chunks);
     }
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
 }
+}  // namespace
+
+extern "C" int cape_bwd_prep_spmm(const float *g, int64_t g_sample_stride, int32_t ldg, const uint32_t *mask, const int32_t *rowptr,
+                                  const int32_t *colidx, const float *vals, int32_t ell_width, float *dz, int64_t dz_sample_stride,
+                                  int32_t lddz, float *t1, int64_t t1_sample_stride, int32_t ldt1, const float *rowscale, int32_t R,
+                                  int32_t rg, int32_t N, int32_t Mo, int32_t F, float *partials, int64_t partials_bytes,
+                                  float *rowmax_g_out, float *rowmax_t1_out, void *stream) {
+    return bwd_prep_spmm_impl<float>(g, g_sample_stride, ldg, mask, rowptr, colidx, vals, ell_width, dz, dz_sample_stride, lddz, t1,
+                                     t1_sample_stride, ldt1, rowscale, R, rg, N, Mo, F, partials, partials_bytes, rowmax_g_out, rowmax_t1_out,
+                                     stream);
+}
+extern "C" int cape_bwd_prep_spmm_bf16(const void *g, int64_t g_sample_stride, int32_t ldg, const uint32_t *mask, const int32_t *rowptr,
+                                       const int32_t *colidx, const float *vals, int32_t ell_width, void *dz, int64_t dz_sample_stride,
+                                       int32_t lddz, void *t1, int64_t t1_sample_stride, int32_t ldt1, const float *rowscale, int32_t R,
+                                       int32_t rg, int32_t N, int32_t Mo, int32_t F, float *partials, int64_t partials_bytes,
+                                       float *rowmax_g_out, float *rowmax_t1_out, void *stream) {
+    return bwd_prep_spmm_impl<cape_bf16>((const cape_bf16 *)g, g_sample_stride, ldg, mask, rowptr, colidx, vals, ell_width, (cape_bf16 *)dz,
+                                         dz_sample_stride, lddz, (cape_bf16 *)t1, t1_sample_stride, ldt1, rowscale, R, rg, N, Mo, F, partials,
+                                         partials_bytes, rowmax_g_out, rowmax_t1_out, stream);
+}
 
 // work items per row of cape_spmm_multi_prep (8 channels where every view allows it, else 4); 0 = not possible
-static int multi_prep_cq(const cape_spmm_term_t *terms, int32_t nterms, int32_t C) {
+static int multi_prep_cq(const cape_spmm_term_t *terms, int32_t nterms, int32_t C, int es) {
     if (!terms || nterms < 1 || nterms > MP_MAXT || (C & 31)) return 0;
     bool wide = spmm_wide();
     for (int k = 0; k < nterms; ++k) {
         const cape_spmm_term_t &t = terms[k];
         if (!t.x || !t.y || !t.rowptr || !t.colidx || !t.vals || t.ldx < C || t.ldy < C || t.scale != 1.0f) return 0;
-        if (!aligned4(t.x, t.x_sample_stride, t.ldx, C, 4) || !aligned4(t.y, t.y_sample_stride, t.ldy, C, 4)) return 0;
+        if (t.rowmax_out && es != 4) return 0;
+        if (!aligned4(t.x, t.x_sample_stride, t.ldx, C, es) || !aligned4(t.y, t.y_sample_stride, t.ldy, C, es)) return 0;
         if (!ell_ok(t.ell_width, t.colidx, t.vals)) return 0;
-        wide = wide && aligned8(t.x, t.x_sample_stride, t.ldx, C, 4) && aligned8(t.y, t.y_sample_stride, t.ldy, C, 4);
+        wide = wide && aligned8(t.x, t.x_sample_stride, t.ldx, C, es) && aligned8(t.y, t.y_sample_stride, t.ldy, C, es);
     }
     const int cq = C / (wide ? 8 : 4);
     return (rm_fused(cq) && cq >= 4) ? cq : 0;
 }
-
-extern "C" int32_t cape_spmm_multi_prep_chunks(const cape_spmm_term_t *terms, int32_t nterms, int32_t N, int32_t Mo, int32_t C) {
-    const int cq = multi_prep_cq(terms, nterms, C);
+static int32_t multi_prep_chunks(const cape_spmm_term_t *terms, int32_t nterms, int32_t N, int32_t Mo, int32_t C, int es) {
+    const int cq = multi_prep_cq(terms, nterms, C, es);
     if (!cq || Mo < 1 || N < 1) return 0;
     const int bps = spmm_bps(Mo, cq), rpb = prep_spmm_rpb(N, bps);
     return (bps + rpb - 1) / rpb;
 }
 
-extern "C" int cape_spmm_multi_prep(const cape_spmm_term_t *terms, int32_t nterms, uint32_t masked_terms, const uint32_t *mask,
-                                    int32_t mask_rows, int32_t N, int32_t Mo, int32_t C, float *partials, int64_t partials_bytes,
-                                    void *stream) {
-    const int cq = multi_prep_cq(terms, nterms, C);
+extern "C" int32_t cape_spmm_multi_prep_chunks(const cape_spmm_term_t *terms, int32_t nterms, int32_t N, int32_t Mo, int32_t C) {
+    return multi_prep_chunks(terms, nterms, N, Mo, C, 4);
+}
+extern "C" int32_t cape_spmm_multi_prep_chunks_bf16(const cape_spmm_term_t *terms, int32_t nterms, int32_t N, int32_t Mo, int32_t C) {
+    return multi_prep_chunks(terms, nterms, N, Mo, C, 2);
+}
+
+namespace {
+template <typename T>
+int spmm_multi_prep_impl(const cape_spmm_term_t *terms, int32_t nterms, uint32_t masked_terms, const uint32_t *mask, int32_t mask_rows,
+                         int32_t N, int32_t Mo, int32_t C, float *partials, int64_t partials_bytes, void *stream) {
+    const int cq = multi_prep_cq(terms, nterms, C, (int)sizeof(T));
     if (!cq || N < 1 || Mo < 1 || mask_rows < 1 || (masked_terms && !mask) || (masked_terms >> nterms)) return CAPE_EINVAL;
     if ((long long)Mo * C >= (1LL << 31)) return CAPE_EINVAL;
     const int bps = spmm_bps(Mo, cq), rpb = prep_spmm_rpb(N, bps);
     const int chunks = (bps + rpb - 1) / rpb;
-    const int T = nterms + 1;
-    if (partials && partials_bytes < (int64_t)N * chunks * T * C * (int64_t)sizeof(float)) return CAPE_EWORKSPACE;
+    const int T_ = nterms + 1;
+    if (partials && partials_bytes < (int64_t)N * chunks * T_ * C * (int64_t)sizeof(float)) return CAPE_EWORKSPACE;
     SpmmTerms P;
     P.n = nterms;
     for (int k = 0; k < nterms; ++k) {
@@ -1969,9 +2032,9 @@ extern "C" int cape_spmm_multi_prep(const cape_spmm_term_t *terms, int32_t nterm
     const int pair = nterms >= 2 && (masked_terms & 1u) && !((masked_terms >> (nterms - 1)) & 1u) && ta.x == tb.x &&
                      ta.x_sample_stride == tb.x_sample_stride && ta.ldx == tb.ldx && ta.rowptr == tb.rowptr && ta.colidx == tb.colidx &&
                      ta.vals == tb.vals && ta.ell_width == tb.ell_width;
-#define CAPE_MP_LAUNCH(VW_, U_)                                                                                                 \
-    CAPE_LAUNCH((spmm_multi_prep_kernel<VW_, U_>), grid, dim3(256), 0, st, P, masked_terms, pair, mask, words, mask_rows, N, Mo, C,   \
-                partials, T, rpb, chunks)
+#define CAPE_MP_LAUNCH(VW_, U_)                                                                                                          \
+    CAPE_LAUNCH((spmm_multi_prep_kernel<VW_, U_, T>), grid, dim3(256), 0, st, P, masked_terms, pair, mask, words, mask_rows, N, Mo, C,   \
+                partials, T_, rpb, chunks)
     if (wide) {
         if (u == 8) CAPE_MP_LAUNCH(8, 8);
         else if (u == 4) CAPE_MP_LAUNCH(8, 4);
@@ -1984,6 +2047,18 @@ extern "C" int cape_spmm_multi_prep(const cape_spmm_term_t *terms, int32_t nterm
 #undef CAPE_MP_LAUNCH
     CAPE_LAUNCH_CHECK();
     return CAPE_OK;
+}
+}  // namespace
+
+extern "C" int cape_spmm_multi_prep(const cape_spmm_term_t *terms, int32_t nterms, uint32_t masked_terms, const uint32_t *mask,
+                                    int32_t mask_rows, int32_t N, int32_t Mo, int32_t C, float *partials, int64_t partials_bytes,
+                                    void *stream) {
+    return spmm_multi_prep_impl<float>(terms, nterms, masked_terms, mask, mask_rows, N, Mo, C, partials, partials_bytes, stream);
+}
+extern "C" int cape_spmm_multi_prep_bf16(const cape_spmm_term_t *terms, int32_t nterms, uint32_t masked_terms, const uint32_t *mask,
+                                         int32_t mask_rows, int32_t N, int32_t Mo, int32_t C, float *partials, int64_t partials_bytes,
+                                         void *stream) {
+    return spmm_multi_prep_impl<cape_bf16>(terms, nterms, masked_terms, mask, mask_rows, N, Mo, C, partials, partials_bytes, stream);
 }
 
 extern "C" int cape_bwd_prep_finalize(const cape_bwd_prep_item_t *items, int32_t nitems, void *stream) {

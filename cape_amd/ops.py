@@ -849,13 +849,13 @@ def spmm_multi(xs, csrs, sum=False, scales=None, act_x=None, act=None):
         flops += 2 * N * (Mo if ident[k] else csrs[k].nnz) * Cn
         byts += es * N * Cn * xs[k].shape[1] + (0 if ident[k] else _csr_bytes(csrs[k]))
     if act_x is not None:
-        assert sum and y.dtype == torch.float32 and act in ("leaky", "relu") and act_x.shape == y.shape
+        assert sum and y.dtype == act_x.dtype and act in ("leaky", "relu") and act_x.shape == y.shape
         ap, as_, al = _v(act_x)
-        chunks = int(lib.cape_spmm_multi_actgrad_chunks(yp, ys, yl, ap, as_, al, Mo, Cn))
+        chunks = int(_fn("cape_spmm_multi_actgrad_chunks", y)(yp, ys, yl, ap, as_, al, Mo, Cn))
         part = torch.empty((N, chunks, 2, Cn), device=y.device, dtype=torch.float32)
         _log_launch("spmm_multi_kernel", flops, byts + es * N * Mo * Cn,
-                    lambda: check(lib.cape_spmm_multi_actgrad(arr, n, yp, ys, yl, N, Mo, Cn, _ptr(rm), ap, as_, al, _lib.ACT[act],
-                                                              _ptr(part), _stream()), "cape_spmm_multi_actgrad"))
+                    lambda: check(_fn("cape_spmm_multi_actgrad", y)(arr, n, yp, ys, yl, N, Mo, Cn, _ptr(rm), ap, as_, al, _lib.ACT[act],
+                                                                    _ptr(part), _stream()), "cape_spmm_multi_actgrad"))
         return y, part, chunks
     _log_launch("spmm_multi_kernel", flops, byts,
                 lambda: check(_fn("cape_spmm_multi", xs[0])(arr, n, 1 if sum else 0, yp, ys, yl, N, Mo, Cn, _ptr(rm), _stream()), "cape_spmm_multi"))
@@ -864,12 +864,13 @@ def spmm_multi(xs, csrs, sum=False, scales=None, act_x=None, act=None):
 
 def actgrad_fusable(xs, act_x, Cn):
     """The fused activation-gradient form of spmm_multi needs the 8-wide vector kernel with the lanes of a row forming one
-    power-of-two group of at most 64: 64..512 channels in powers of two, every operand 32-byte aligned (fresh outputs are)."""
+    power-of-two group of at most 64: 64..512 channels in powers of two, every operand aligned for 8-element accesses (fresh
+    outputs are).  fp32 or bf16 storage (all operands the same)."""
     if not (FUSE_ACT_GRAD and Cn in (64, 128, 256, 512)) or _os.environ.get("CAPE_SPMM_WIDE", "1") == "0":
         return False
     for t in list(xs) + [act_x]:
         p, ss, ld = _v(t)
-        if t.dtype != torch.float32 or (p.value % 32) or (ss % 8) or (ld % 8):
+        if t.dtype != act_x.dtype or t.dtype not in ACT_DTYPES or (p.value % (32 if t.dtype == torch.float32 else 16)) or (ss % 8) or (ld % 8):
             return False
     return True
 
@@ -1124,15 +1125,15 @@ def bwd_prep_spmm(g, mask, csr, rowscale=None, R=0, rg=None, joint=False, defer=
     the arguments do not allow the fused form (the caller then takes the two launches)."""
     _lib.require_gpu()
     N, Mo, F = g.shape
-    if not (FUSE_PREP_SPMM and g.dtype == torch.float32 and mask is not None and F % 32 == 0 and R <= 2 and csr.shape[0] == Mo and csr.shape[1] == Mo):
+    if not (FUSE_PREP_SPMM and g.dtype in ACT_DTYPES and mask is not None and F % 32 == 0 and R <= 2 and csr.shape[0] == Mo and csr.shape[1] == Mo):
         return None
     dev = g.device
-    dz = alloc_act(N, Mo, F, dev)
-    t1 = alloc_act(N, Mo, F, dev)
+    dz = alloc_act(N, Mo, F, dev, dtype=g.dtype)
+    t1 = alloc_act(N, Mo, F, dev, dtype=g.dtype)
     gp, gs, gl = _v(g)
     zp, zs, zl = _v(dz)
     tp, ts, tl = _v(t1)
-    chunks = int(lib.cape_bwd_prep_spmm_chunks(gp, gs, gl, zp, zs, zl, tp, ts, tl, N, Mo, F))
+    chunks = int(_fn("cape_bwd_prep_spmm_chunks", g)(gp, gs, gl, zp, zs, zl, tp, ts, tl, N, Mo, F))
     if chunks <= 0:
         return None
     cstride = 0
@@ -1157,13 +1158,13 @@ def bwd_prep_spmm(g, mask, csr, rowscale=None, R=0, rg=None, joint=False, defer=
     rm_t1 = _new_rm(t1) if _want_rm(t1) else None
 
     def launch():
-        rc = lib.cape_bwd_prep_spmm(gp, gs, gl, _ptr(mask), C.c_void_p(rp_), C.c_void_p(ci_), C.c_void_p(va_), ew_, zp, zs, zl, tp, ts, tl,
+        rc = _fn("cape_bwd_prep_spmm", g)(gp, gs, gl, _ptr(mask), C.c_void_p(rp_), C.c_void_p(ci_), C.c_void_p(va_), ew_, zp, zs, zl, tp, ts, tl,
                                     _ptr(rowscale), R, -1 if rg is None else int(rg), N, Mo, F, _ptr(part),
                                     0 if part is None else part.numel() * 4, _ptr(rm_g_new), _ptr(rm_t1), _stream())
         check(rc, "cape_bwd_prep_spmm")
 
     # one pass: read g (+ sign words, + the gathered neighbour rows: cache hits), write dz and T1
-    _log_launch("bwd_prep_spmm", 2 * N * csr.nnz * F, 4 * N * Mo * F * 3 + N * Mo * (F // 32) * 4 + 8 * csr.nnz, launch)
+    _log_launch("bwd_prep_spmm", 2 * N * csr.nnz * F, g.element_size() * N * Mo * F * 3 + N * Mo * (F // 32) * 4 + 8 * csr.nnz, launch)
     set_rm(t1, rm_t1)
     if need_part:
         item = dict(ws=part, N=N, Mo=Mo, F=F, R=R, dbias=None, dcoef=dcoef, dcoef_g=dcoef_g, cstride=cstride, chunks=chunks)
@@ -1183,7 +1184,7 @@ def spmm_multi_prep(g, mask, csrs, masked, want_sums=True, joint=False, defer=Fa
     _lib.require_gpu()
     N, Mf, F = g.shape
     n = len(csrs)
-    if not (FUSE_PREP_SPMM and g.dtype == torch.float32 and mask is not None and F % 32 == 0 and 2 <= n <= 3
+    if not (FUSE_PREP_SPMM and g.dtype in ACT_DTYPES and mask is not None and F % 32 == 0 and 2 <= n <= 3
             and all(c is not None and not c.identity and c.shape[1] == Mf for c in csrs)):
         return None
     Mo = csrs[0].shape[0]
@@ -1198,7 +1199,7 @@ def spmm_multi_prep(g, mask, csrs, masked, want_sums=True, joint=False, defer=Fa
         t.x, t.x_sample_stride, t.ldx = gp.value, gs, gl
         t.scale = 1.0
         t.rowptr, t.colidx, t.vals, t.ell_width = csrs[k].operands()
-        yk = alloc_act(N, Mo, F, dev)
+        yk = alloc_act(N, Mo, F, dev, dtype=g.dtype)
         yp, t.y_sample_stride, t.ldy = _v(yk)
         t.y = yp.value
         if _want_rm(yk):
@@ -1207,7 +1208,7 @@ def spmm_multi_prep(g, mask, csrs, masked, want_sums=True, joint=False, defer=Fa
             set_rm(yk, rmk)
         outs.append(yk)
         bits |= (1 << k) if masked[k] else 0
-    chunks = int(lib.cape_spmm_multi_prep_chunks(arr, n, N, Mo, F))
+    chunks = int(_fn("cape_spmm_multi_prep_chunks", g)(arr, n, N, Mo, F))
     if chunks <= 0:
         return None
     R = n - 1
@@ -1223,9 +1224,9 @@ def spmm_multi_prep(g, mask, csrs, masked, want_sums=True, joint=False, defer=Fa
             dcoef_g = torch.empty((N, F), device=dev, dtype=torch.float32)
         part = torch.empty((N, chunks, n + 1, F), device=dev, dtype=torch.float32)
     flops = sum(2 * N * c.nnz * F for c in csrs)
-    byts = 4 * N * F * (Mf + n * Mo) + N * Mf * (F // 32) * 4 + sum(_csr_bytes(c) for c in csrs)
+    byts = g.element_size() * N * F * (Mf + n * Mo) + N * Mf * (F // 32) * 4 + sum(_csr_bytes(c) for c in csrs)
     _log_launch("spmm_multi_prep", flops, byts,
-                lambda: check(lib.cape_spmm_multi_prep(arr, n, bits, _ptr(mask), Mf, N, Mo, F, _ptr(part),
+                lambda: check(_fn("cape_spmm_multi_prep", g)(arr, n, bits, _ptr(mask), Mf, N, Mo, F, _ptr(part),
                                                        0 if part is None else part.numel() * 4, _stream()), "cape_spmm_multi_prep"))
     if want_sums:
         item = dict(ws=part, N=N, Mo=Mo, F=F, R=R, dbias=None, dcoef=dcoef, dcoef_g=dcoef_g, cstride=cstride, chunks=chunks)
@@ -1369,7 +1370,7 @@ class ChebConvFn(torch.autograd.Function):
         # layer's backward may differentiate for it; our own output is tagged the same way for the layer above
         ctx.prev_act = getattr(x, "_cape_act_out", None) if (_CHAIN[0] and FUSE_ACT_GRAD and twopass) else None
         ctx.offers_dz = bool(W_aff is None and Co == 0 and Cc == 0 and bias is not None and bias_mode == _lib.BIAS_CHANNEL
-                             and act in ("leaky", "relu") and y.dtype == torch.float32 and gB is not None)
+                             and act in ("leaky", "relu") and y.dtype in ACT_DTYPES and gB is not None)
         ctx.offer = None
         if ctx.offers_dz:
             ctx.offer = yfull._cape_act_out = _ActOffer(act, gB)

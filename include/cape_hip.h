@@ -429,6 +429,13 @@ int32_t cape_spmm_multi_actgrad_chunks(const float *y, int64_t y_sample_stride, 
 int cape_spmm_multi_actgrad(const cape_spmm_term_t *terms, int32_t nterms, float *y, int64_t y_sample_stride, int32_t ldy,
                             int32_t N, int32_t Mo, int32_t C, float *rowmax_out, const float *act_x,
                             int64_t act_x_sample_stride, int32_t ld_act_x, int32_t act, float *bias_partials, void *stream);
+/* the same for bf16 activation storage (x_k, y, act_x bf16; act' applied and the bias sums taken in fp32 before the one rounding
+ * of y; rowmax_out must be NULL) */
+int32_t cape_spmm_multi_actgrad_chunks_bf16(const void *y, int64_t y_sample_stride, int32_t ldy, const void *act_x,
+                                            int64_t act_x_sample_stride, int32_t ld_act_x, int32_t Mo, int32_t C);
+int cape_spmm_multi_actgrad_bf16(const cape_spmm_term_t *terms, int32_t nterms, void *y, int64_t y_sample_stride, int32_t ldy,
+                                 int32_t N, int32_t Mo, int32_t C, float *rowmax_out, const void *act_x,
+                                 int64_t act_x_sample_stride, int32_t ld_act_x, int32_t act, float *bias_partials, void *stream);
 
 /*
  * Backward-prep of an affine block fused with the operator application of its data gradient (fp32, vector form, square
@@ -471,6 +478,20 @@ int32_t cape_spmm_multi_prep_chunks(const cape_spmm_term_t *terms, int32_t nterm
 int cape_spmm_multi_prep(const cape_spmm_term_t *terms, int32_t nterms, uint32_t masked_terms, const uint32_t *mask,
                          int32_t mask_rows, int32_t N, int32_t Mo, int32_t C, float *partials, int64_t partials_bytes,
                          void *stream);
+/* both fused forms for bf16 activation storage (g, dz, t1 / the terms' x and y bf16; sums in fp32; no row bounds: the rowmax
+ * arguments must be NULL) */
+int32_t cape_bwd_prep_spmm_chunks_bf16(const void *g, int64_t g_sample_stride, int32_t ldg, const void *dz, int64_t dz_sample_stride,
+                                       int32_t lddz, const void *t1, int64_t t1_sample_stride, int32_t ldt1, int32_t N, int32_t Mo,
+                                       int32_t F);
+int cape_bwd_prep_spmm_bf16(const void *g, int64_t g_sample_stride, int32_t ldg, const uint32_t *mask, const int32_t *rowptr,
+                            const int32_t *colidx, const float *vals, int32_t ell_width, void *dz, int64_t dz_sample_stride,
+                            int32_t lddz, void *t1, int64_t t1_sample_stride, int32_t ldt1, const float *rowscale, int32_t R,
+                            int32_t rg, int32_t N, int32_t Mo, int32_t F, float *partials, int64_t partials_bytes,
+                            float *rowmax_g_out, float *rowmax_t1_out, void *stream);
+int32_t cape_spmm_multi_prep_chunks_bf16(const cape_spmm_term_t *terms, int32_t nterms, int32_t N, int32_t Mo, int32_t C);
+int cape_spmm_multi_prep_bf16(const cape_spmm_term_t *terms, int32_t nterms, uint32_t masked_terms, const uint32_t *mask,
+                              int32_t mask_rows, int32_t N, int32_t Mo, int32_t C, float *partials, int64_t partials_bytes,
+                              void *stream);
 
 
 /*

@@ -169,8 +169,9 @@ def test_spmm_and_sparse_op(mesh_ops, dev):
         assert vertex_err(hx.grad.cpu().numpy(), refg) < TOL
 
 
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", [(3, 3, 256), (2, 2, 128), (2, 1, 64), (2, 0, 32), (16, 3, 256), (1, 4, 96)])
-def test_bwd_prep_spmm_equals_the_two_launches(case, mesh_ops, dev):
+def test_bwd_prep_spmm_equals_the_two_launches(case, storage, mesh_ops, dev):
     """cape_bwd_prep_spmm (backward-prep of an affine block fused with T_1 = L~^T dz, reference lib/models.py:776-793 under
     tf.gradients :460) against the two launches it replaces, cape_bwd_prep + cape_spmm, on the same inputs: dz, T_1 and both
     row-bound tensors bit for bit (the gathered rows are masked, then the same fma chain); the rank-1 condition sums (another
@@ -191,7 +192,8 @@ def test_bwd_prep_spmm_equals_the_two_launches(case, mesh_ops, dev):
         words |= bits[:, :, b::32].astype(np.uint32) << np.uint32(b)
     rowscale = rng.standard_normal((3, Mo)).astype(np.float32)
     csr = ops.DeviceCSR(HostCSR(sp.csr_matrix(Lt.T)), dev)
-    hg = torch.tensor(g, dtype=torch.float32, device=dev)
+    # (bf16 storage: the same comparisons on bf16-rounded inputs -- dz is an exact copy, T_1 one rounding of the same fp32 sum)
+    hg = torch.tensor(g, dtype=torch.float32, device=dev).to(torch.bfloat16 if storage == "bf16" else torch.float32)
     hm = torch.tensor(words.view(np.int32), device=dev)
     hrs = torch.tensor(rowscale, device=dev)
     if F == 96:               # 12 / 24 work items per row: not a power-of-two lane group -- the caller keeps the two launches
@@ -206,21 +208,22 @@ def test_bwd_prep_spmm_equals_the_two_launches(case, mesh_ops, dev):
         dz_b, t1_b, dc_b, dg_b = out
         torch.cuda.synchronize()
         assert torch.equal(dz_a, dz_b) and torch.equal(t1_a, t1_b)
-        assert np.array_equal(dz_b.cpu().numpy(), np.where(bits, hg.cpu().numpy(), 0.0))
+        assert np.array_equal(dz_b.float().cpu().numpy(), np.where(bits, hg.float().cpu().numpy(), 0.0))
         for a, b in ((ops.rm_of(dz_a), ops.rm_of(dz_b)), (ops.rm_of(t1_a), ops.rm_of(t1_b))):
             assert (a is None) == (b is None)
             if a is not None:
                 assert torch.equal(a[:, :, 0], b[:, :, 0])
-        dz64 = np.where(bits, hg.cpu().numpy().astype(np.float64), 0.0)
+        dz64 = np.where(bits, hg.float().cpu().numpy().astype(np.float64), 0.0)
         ref_c = np.einsum("jr,nrf->njf", rowscale[:2].astype(np.float64), dz64)
-        ref_g = np.einsum("r,nrf->nf", rowscale[2].astype(np.float64), hg.cpu().numpy().astype(np.float64))
+        ref_g = np.einsum("r,nrf->nf", rowscale[2].astype(np.float64), hg.float().cpu().numpy().astype(np.float64))
         for got, alt, ref in ((dc_b[:, :2], dc_a[:, :2], ref_c), (dg_b, dg_a, ref_g)):
             assert mat_err(n64(got), ref) < 2e-6 and mat_err(n64(got), n64(alt)) < 1e-5
-        assert vertex_err(n64(t1_b), np.stack([Lt.T @ dz64[n] for n in range(N)])) < TOL
+        assert vertex_err(n64(t1_b.float()), np.stack([Lt.T @ dz64[n] for n in range(N)])) < (TOL if storage == "fp32" else 8e-3)
 
 
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", [(3, 2, 128), (2, 1, 64), (16, 0, 32), (2, 2, 96)])
-def test_spmm_multi_prep_equals_the_two_launches(case, mesh_ops, dev):
+def test_spmm_multi_prep_equals_the_two_launches(case, storage, mesh_ops, dev):
     """cape_spmm_multi_prep (every operator application of an UP-SAMPLING affine block's data gradient, dz formed from the gathered
     rows, condition sums as column sums of the outputs; reference lib/models.py:776-793 behind the unpool of :147-151) against
     cape_bwd_prep + cape_spmm_multi: the three T_k and their row bounds bit for bit, the condition sums -- here column sums
@@ -244,7 +247,7 @@ def test_spmm_multi_prep_equals_the_two_launches(case, mesh_ops, dev):
         words[:, :, :sl.shape[2]] |= sl.astype(np.uint32) << np.uint32(b)
     rowscale = np.stack([np.asarray(S[0].sum(axis=1)).ravel(), np.asarray(S[1].sum(axis=1)).ravel(), np.asarray(S[0].sum(axis=1)).ravel()]).astype(np.float32)
     bwd = [ops.DeviceCSR(HostCSR(sp.csr_matrix(s.T)), dev) for s in S]
-    hg = torch.tensor(g, dtype=torch.float32, device=dev)
+    hg = torch.tensor(g, dtype=torch.float32, device=dev).to(torch.bfloat16 if storage == "bf16" else torch.float32)
     hm = torch.tensor(words.view(np.int32), device=dev)
     hrs = torch.tensor(rowscale, device=dev)
     out = ops.spmm_multi_prep(hg, hm, [bwd[0], bwd[1], bwd[0]], [True, True, False], joint=True)
@@ -260,13 +263,13 @@ def test_spmm_multi_prep_equals_the_two_launches(case, mesh_ops, dev):
         assert torch.equal(a, b)
         ra, rb = ops.rm_of(a), ops.rm_of(b)
         assert (ra is None) == (rb is None) and (ra is None or torch.equal(ra[:, :, 0], rb[:, :, 0]))
-    g64 = hg.cpu().numpy().astype(np.float64)
+    g64 = hg.float().cpu().numpy().astype(np.float64)
     dz64 = np.where(bits, g64, 0.0)
     ref_c = np.stack([np.stack([(S[k].T @ dz64[n]).sum(axis=0) for k in range(2)]) for n in range(N)])
     ref_g = np.stack([(S[0].T @ g64[n]).sum(axis=0) for n in range(N)])
     assert mat_err(n64(dc_b[:, :2]), ref_c) < 2e-6 and mat_err(n64(dc_b[:, :2]), n64(dc_a[:, :2])) < 1e-5
     assert mat_err(n64(dg_b), ref_g) < 2e-6 and mat_err(n64(dg_b), n64(dg_a)) < 1e-5
-    assert vertex_err(n64(Ts_b[1]), np.stack([S[1].T @ dz64[n] for n in range(N)])) < TOL
+    assert vertex_err(n64(Ts_b[1].float()), np.stack([S[1].T @ dz64[n] for n in range(N)])) < (TOL if storage == "fp32" else 8e-3)
 
 
 @pytest.mark.parametrize("shape", [(2, 862, 544, 1), (2, 6890, 96, 1), (3, 1723, 64, 0),
